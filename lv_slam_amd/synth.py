@@ -1,0 +1,153 @@
+"""Seeded synthetic HDL-64E scan pairs (no KITTI data exists in the build or GPU box).
+
+Sensor model: 64 beams, elevation linear from +2.0 deg to -24.9 deg (the reference hard-codes the
+same fan, include/ndt_pca/voxel_grid_covariance_pca.h:97), mounted 1.73 m above a ground plane;
+`n_azimuth` firings per revolution (1024 -> 65,536 points, 2048 -> 131,072 points).
+Scene: a procedural street along +x (buildings both sides, poles, parked vehicles), generated per
+24 m slot from a hash of (seed, slot) so any frame position sees a deterministic neighbourhood.
+Pair k: target = scan at pose P_k = trans(k * 1.0 m, 0, 0); source = scan at P_k * dT_k with
+dT_k ~ (x~U(0.6,1.4), y~N(0,0.03), z~N(0,0.01), yaw~N(0,1deg), pitch/roll~N(0,0.2deg)); both scans
+are expressed in their own sensor frames, so the true source->target transform is dT_k.
+Range noise N(0, 0.02 m).  RNG seed = 0x5EED0000 + pair index.  Points are ordered ring-major
+(beam, azimuth).  This is data plumbing for tests/bench, not part of the measured path.
+"""
+from __future__ import annotations
+
+import math
+import numpy as np
+import torch
+
+SENSOR_H = 1.73
+SLOT = 24.0
+BASE_SEED = 0x5EED0000
+
+
+def _slot_primitives(seed: int, slot: int):
+    rng = np.random.default_rng([seed & 0xFFFFFFFF, slot & 0xFFFFFFFF, 0xC0FFEE])
+    x0 = slot * SLOT
+    boxes, cyls = [], []
+    for side in (1.0, -1.0):
+        w = rng.uniform(6.0, 20.0)
+        depth = rng.uniform(10.0, 15.0)
+        h = rng.uniform(4.0, 15.0)
+        setback = rng.uniform(8.0, 14.0)
+        bx = x0 + rng.uniform(0.0, SLOT - w)
+        y_in, y_out = side * setback, side * (setback + depth)
+        boxes.append([bx, min(y_in, y_out), 0.0, bx + w, max(y_in, y_out), h])
+    for _ in range(4):  # poles / trunks
+        cyls.append([x0 + rng.uniform(0.0, SLOT), rng.choice([-1.0, 1.0]) * rng.uniform(5.0, 7.5),
+                     rng.uniform(0.15, 0.4), rng.uniform(3.0, 8.0)])
+    if rng.uniform() < 0.6:  # parked vehicle
+        cx = x0 + rng.uniform(2.5, SLOT - 2.5)
+        cy = rng.choice([-1.0, 1.0]) * rng.uniform(2.8, 4.5)
+        boxes.append([cx - 2.1, cy - 0.9, 0.0, cx + 2.1, cy + 0.9, 1.5])
+    return boxes, cyls
+
+
+def street_primitives(x_center: float, seed: int = BASE_SEED, reach: float = 130.0):
+    s0 = int(math.floor((x_center - reach) / SLOT))
+    s1 = int(math.floor((x_center + reach) / SLOT))
+    boxes, cyls = [], []
+    for s in range(s0, s1 + 1):
+        b, c = _slot_primitives(seed, s)
+        boxes += b
+        cyls += c
+    return np.asarray(boxes, dtype=np.float64), np.asarray(cyls, dtype=np.float64)
+
+
+def beam_directions(n_azimuth: int, device, n_beams: int = 64):
+    el = torch.deg2rad(torch.linspace(2.0, -24.9, n_beams, dtype=torch.float64, device=device))
+    az = torch.arange(n_azimuth, dtype=torch.float64, device=device) * (2.0 * math.pi / n_azimuth)
+    ce, se = torch.cos(el)[:, None], torch.sin(el)[:, None]
+    d = torch.stack([ce * torch.cos(az)[None, :], ce * torch.sin(az)[None, :], se.expand(-1, n_azimuth)], dim=-1)
+    return d.reshape(-1, 3)  # ring-major (beam, azimuth)
+
+
+def rot_zyx(yaw, pitch, roll):
+    cy, sy, cp, sp, cr, sr = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch), math.cos(roll), math.sin(roll)
+    return np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+                     [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+                     [-sp, cp * sr, cp * cr]], dtype=np.float64)
+
+
+def cast_scan(pose: np.ndarray, n_azimuth: int, noise: torch.Tensor, ring_u: torch.Tensor, device,
+              seed: int = BASE_SEED, n_beams: int = 64) -> torch.Tensor:
+    """Ray-cast one scan.  pose = 4x4 sensor->world (world z=0 is the ground; sensor origin at z=1.73
+    is folded in here).  Returns float32 [N,3] in the sensor frame."""
+    R = torch.as_tensor(pose[:3, :3], dtype=torch.float64, device=device)
+    o = torch.as_tensor(pose[:3, 3] + np.array([0, 0, SENSOR_H]), dtype=torch.float64, device=device)
+    ds = beam_directions(n_azimuth, device, n_beams)          # sensor-frame unit rays
+    d = ds @ R.T                                              # world-frame
+    boxes_np, cyls_np = street_primitives(float(pose[0, 3]), seed)
+    inf = torch.full((d.shape[0],), float("inf"), dtype=torch.float64, device=device)
+    # ground z = 0
+    t = torch.where(d[:, 2] < -1e-9, -o[2] / d[:, 2], inf)
+    # boxes (slab test)
+    if len(boxes_np):
+        B = torch.as_tensor(boxes_np, device=device)
+        inv = 1.0 / torch.where(d.abs() < 1e-12, torch.full_like(d, 1e-12), d)
+        t0 = (B[None, :, 0:3] - o[None, None, :]) * inv[:, None, :]
+        t1 = (B[None, :, 3:6] - o[None, None, :]) * inv[:, None, :]
+        tn = torch.minimum(t0, t1).amax(dim=-1)
+        tf = torch.maximum(t0, t1).amin(dim=-1)
+        hit = (tf >= tn) & (tf > 0)
+        tb = torch.where(hit, torch.where(tn > 0, tn, tf), inf[:, None].expand(-1, B.shape[0]))
+        t = torch.minimum(t, tb.amin(dim=1))
+    # vertical cylinders of finite height
+    if len(cyls_np):
+        C = torch.as_tensor(cyls_np, device=device)
+        ox, oy = o[0] - C[None, :, 0], o[1] - C[None, :, 1]
+        a = (d[:, 0] ** 2 + d[:, 1] ** 2)[:, None]
+        b = 2.0 * (ox * d[:, 0:1] + oy * d[:, 1:2])
+        c = ox * ox + oy * oy - C[None, :, 2] ** 2
+        disc = b * b - 4 * a * c
+        tc = (-b - torch.sqrt(disc.clamp_min(0))) / (2 * a.clamp_min(1e-12))
+        zc = o[2] + tc * d[:, 2:3]
+        ok = (disc > 0) & (tc > 0) & (zc >= 0) & (zc <= C[None, :, 3])
+        tc = torch.where(ok, tc, inf[:, None].expand(-1, C.shape[0]))
+        t = torch.minimum(t, tc.amin(dim=1))
+    rng_ok = (t > 0.5) & (t < 100.0)
+    t_noisy = t + noise.to(device)
+    pts = ds * torch.where(rng_ok, t_noisy, torch.zeros_like(t))[:, None]
+    # fallback: a ground point at horizontal range 4..60 m along the ray's world azimuth
+    rr = 4.0 + 56.0 * ring_u.to(device)
+    azw = torch.atan2(d[:, 1], d[:, 0])
+    pw = torch.stack([o[0] + rr * torch.cos(azw), o[1] + rr * torch.sin(azw), torch.zeros_like(rr)], dim=-1)
+    ps = (pw - o[None, :]) @ R                                # R^T (p - o)
+    pts = torch.where(rng_ok[:, None], pts, ps)
+    return pts.to(torch.float32)
+
+
+def pair_motion(pair: int, seed: int = BASE_SEED):
+    """True source->target transform dT_k (4x4 f64) for pair k."""
+    rng = np.random.default_rng([seed & 0xFFFFFFFF, pair & 0xFFFFFFFF, 0xD7])
+    fwd = rng.uniform(0.6, 1.4)
+    y, z = rng.normal(0, 0.03), rng.normal(0, 0.01)
+    yaw, pitch, roll = rng.normal(0, math.radians(1.0)), rng.normal(0, math.radians(0.2)), rng.normal(0, math.radians(0.2))
+    T = np.eye(4)
+    T[:3, :3] = rot_zyx(yaw, pitch, roll)
+    T[:3, 3] = [fwd, y, z]
+    return T
+
+
+def make_pair(pair: int, n_azimuth: int = 1024, device="cpu", seed: int = BASE_SEED, n_beams: int = 64,
+              noise_sigma: float = 0.02):
+    """Returns (target[N,3] f32, source[N,3] f32, dT[4,4] f64 true source->target)."""
+    n = n_azimuth * n_beams
+    g = torch.Generator(device="cpu")
+    g.manual_seed((seed + pair) & 0x7FFFFFFFFFFFFFFF)
+    noise = torch.randn(2, n, generator=g, dtype=torch.float64) * noise_sigma
+    ring = torch.rand(2, n, generator=g, dtype=torch.float64)
+    P = np.eye(4)
+    P[0, 3] = 1.0 * pair
+    dT = pair_motion(pair, seed)
+    tgt = cast_scan(P, n_azimuth, noise[0], ring[0], device, seed, n_beams)
+    src = cast_scan(P @ dT, n_azimuth, noise[1], ring[1], device, seed, n_beams)
+    return tgt, src, dT
+
+
+def default_guess() -> np.ndarray:
+    """Per-pair fixed initial guess: identity with x = +1.0 m, 4x4 f32."""
+    G = np.eye(4, dtype=np.float32)
+    G[0, 3] = 1.0
+    return G

@@ -1,0 +1,748 @@
+/*
+ * oracle/ndt_oracle.c -- CPU restatement of lv_slam's NDT scan-matching path
+ * (pclomp::NormalDistributionsTransform / pclpca::NormalDistributionsTransform,
+ * the *_impl2.hpp Lie-algebra variant that src/ndt_omp/ndt_omp.cpp:1-2 compiles).
+ *
+ * TEST INFRASTRUCTURE ONLY -- see ndt_oracle.h.  PARITY UNPINNED (no reference build,
+ * no reference golden vectors exist; pinned against tests/golden/make_golden.py).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC (oracle/Makefile).
+ * -ffp-contract=off is REQUIRED: the reference is built -msse4.2 without FMA
+ * (CMakeLists.txt:6,11) and every f32 step below is a separately rounded op.
+ *
+ * Third-party arithmetic restated here (sources are not under /root/reference):
+ *   Sophus a621ff2 (README.md:61-66): non-templated SE3/SO3 exp, log, operator*.
+ *   Eigen 3.3: 3x3 inverse (cofactors), JacobiSVD::solve semantics (thresholded
+ *   pseudo-inverse, threshold = 6*eps), SelfAdjointEigenSolver (lower triangle,
+ *   ascending) -- the eigen/SVD *algorithms* here are cyclic Jacobi, results agree
+ *   with Eigen's to rounding.
+ *   PCL 1.8: transformPointCloud scalar form, getMinMax3D, VoxelGrid leaf-size
+ *   members, getAllNeighborCellIndices order.
+ */
+#include "ndt_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define SMALL_EPS 1e-10 /* Sophus so3.h */
+
+static int g_threads = 0;
+void ora_set_threads(int n) { g_threads = n; }
+
+/* ------------------------------------------------------------------ params */
+void ora_default_params(ora_params* p) {
+  /* ndt_omp_impl2.hpp:53-83 (ctor); voxel_grid_covariance_omp.h:202-205 */
+  p->resolution = 1.0f;
+  p->step_size = 0.1;
+  p->outlier_ratio = 0.55;
+  p->trans_epsilon = 0.1;
+  p->max_iterations = 35;
+  p->neighbor_mode = ORA_DIRECT7;
+  p->variant = ORA_VARIANT_OMP;
+  p->min_points_per_voxel = 6;
+  p->min_covar_eigvalue_mult = 0.01;
+}
+
+void ora_gauss_constants(double outlier_ratio, float resolution, double out[3]) {
+  /* ndt_omp_impl2.hpp:93-100 */
+  double c1 = 10 * (1 - outlier_ratio);
+  double c2 = outlier_ratio / pow((double)resolution, 3);
+  double d3 = -log(c2);
+  double d1 = -log(c1 + c2) - d3;
+  double d2 = -2 * log((-log(c1 * exp(-0.5) + c2) - d3) / d1);
+  out[0] = d1; out[1] = d2; out[2] = d3;
+}
+
+/* ------------------------------------------------------- small linear algebra */
+static void mat3_mul(const double A[9], const double B[9], double C[9]) {
+  /* Eigen lazy coefficient product, k ascending */
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      C[i * 3 + j] = (A[i * 3 + 0] * B[0 * 3 + j] + A[i * 3 + 1] * B[1 * 3 + j]) + A[i * 3 + 2] * B[2 * 3 + j];
+}
+
+/* Eigen 3.3 InverseImpl.h compute_inverse<Matrix3d>: cofactor expansion. */
+static double cof3(const double* m, int i, int j) {
+  int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return m[i1 * 3 + j1] * m[i2 * 3 + j2] - m[i1 * 3 + j2] * m[i2 * 3 + j1];
+}
+static void mat3_inverse(const double m[9], double r[9]) {
+  double c0 = cof3(m, 0, 0), c1 = cof3(m, 1, 0), c2 = cof3(m, 2, 0);
+  double det = (c0 * m[0] + c1 * m[3]) + c2 * m[6]; /* cofactors_col0 . matrix.col(0) */
+  double invdet = 1.0 / det;
+  r[0] = c0 * invdet; r[1] = c1 * invdet; r[2] = c2 * invdet; /* result.row(0) */
+  r[3] = cof3(m, 0, 1) * invdet; r[4] = cof3(m, 1, 1) * invdet; r[5] = cof3(m, 2, 1) * invdet;
+  r[6] = cof3(m, 0, 2) * invdet; r[7] = cof3(m, 1, 2) * invdet; r[8] = cof3(m, 2, 2) * invdet;
+}
+
+/* Symmetric 3x3 eigen-decomposition, cyclic Jacobi; reads the LOWER triangle only
+ * (as Eigen::SelfAdjointEigenSolver::compute does, voxel_grid_covariance_omp_impl.hpp:333).
+ * Eigenvalues ascending; eigenvectors are the columns of evecs (row-major storage).
+ * Uses only + - * / sqrt so a device restatement can be bit-identical. */
+void ora_eigen_sym3(const double Ain[9], double evals[3], double evecs[9]) {
+  double a[3][3], v[3][3];
+  a[0][0] = Ain[0]; a[1][1] = Ain[4]; a[2][2] = Ain[8];
+  a[0][1] = a[1][0] = Ain[3]; a[0][2] = a[2][0] = Ain[6]; a[1][2] = a[2][1] = Ain[7];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) v[i][j] = (i == j) ? 1.0 : 0.0;
+  static const int P[3] = {0, 0, 1}, Q[3] = {1, 2, 2};
+  for (int sweep = 0; sweep < 64; sweep++) {
+    double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+    if (off == 0.0) break;
+    for (int k = 0; k < 3; k++) {
+      int p = P[k], q = Q[k];
+      double apq = a[p][q];
+      if (apq == 0.0) continue;
+      double g = 100.0 * fabs(apq);
+      /* after 4 sweeps drop entries that no longer change the diagonal */
+      if (sweep > 3 && fabs(a[p][p]) + g == fabs(a[p][p]) && fabs(a[q][q]) + g == fabs(a[q][q])) {
+        a[p][q] = a[q][p] = 0.0;
+        continue;
+      }
+      double h = a[q][q] - a[p][p];
+      double t;
+      if (fabs(h) + g == fabs(h)) {
+        t = apq / h;
+      } else {
+        double theta = 0.5 * h / apq;
+        t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+        if (theta < 0.0) t = -t;
+      }
+      double c = 1.0 / sqrt(1.0 + t * t);
+      double s = t * c;
+      double tau = s / (1.0 + c);
+      double hh = t * apq;
+      a[p][p] -= hh;
+      a[q][q] += hh;
+      a[p][q] = a[q][p] = 0.0;
+      int r = 3 - p - q; /* the remaining index */
+      double arp = a[r][p], arq = a[r][q];
+      a[r][p] = a[p][r] = arp - s * (arq + arp * tau);
+      a[r][q] = a[q][r] = arq + s * (arp - arq * tau);
+      for (int i = 0; i < 3; i++) {
+        double vip = v[i][p], viq = v[i][q];
+        v[i][p] = vip - s * (viq + vip * tau);
+        v[i][q] = viq + s * (vip - viq * tau);
+      }
+    }
+  }
+  int o[3] = {0, 1, 2};
+  double d[3] = {a[0][0], a[1][1], a[2][2]};
+  /* stable 3-element sort, ascending */
+  if (d[o[1]] < d[o[0]]) { int t = o[0]; o[0] = o[1]; o[1] = t; }
+  if (d[o[2]] < d[o[1]]) { int t = o[1]; o[1] = o[2]; o[2] = t; }
+  if (d[o[1]] < d[o[0]]) { int t = o[0]; o[0] = o[1]; o[1] = t; }
+  for (int j = 0; j < 3; j++) {
+    evals[j] = d[o[j]];
+    for (int i = 0; i < 3; i++) evecs[i * 3 + j] = v[i][o[j]];
+  }
+}
+
+/* Eigen::JacobiSVD<Matrix6d>(H, FullU|FullV).solve(b): x = V S^+ U^T b with
+ * rank = #{ sigma_i >= max(sigma_max * 6*eps, DBL_MIN) } (ndt_omp_impl2.hpp:138-140).
+ * Algorithm here: one-sided (Hestenes) Jacobi. */
+void ora_svd_solve6(const double H[36], const double b[6], double x[6]) {
+  double A[6][6], V[6][6];
+  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { A[i][j] = H[i * 6 + j]; V[i][j] = (i == j); }
+  for (int sweep = 0; sweep < 60; sweep++) {
+    int rotated = 0;
+    for (int p = 0; p < 5; p++) {
+      for (int q = p + 1; q < 6; q++) {
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int i = 0; i < 6; i++) { alpha += A[i][p] * A[i][p]; beta += A[i][q] * A[i][q]; gamma += A[i][p] * A[i][q]; }
+        if (gamma == 0.0 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
+        rotated = 1;
+        double zeta = (beta - alpha) / (2.0 * gamma);
+        double t = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        if (zeta < 0) t = -t;
+        double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        for (int i = 0; i < 6; i++) {
+          double aip = A[i][p], aiq = A[i][q];
+          A[i][p] = c * aip - s * aiq;
+          A[i][q] = s * aip + c * aiq;
+          double vip = V[i][p], viq = V[i][q];
+          V[i][p] = c * vip - s * viq;
+          V[i][q] = s * vip + c * viq;
+        }
+      }
+    }
+    if (!rotated) break;
+  }
+  double sig[6], smax = 0;
+  for (int j = 0; j < 6; j++) {
+    double s2 = 0;
+    for (int i = 0; i < 6; i++) s2 += A[i][j] * A[i][j];
+    sig[j] = sqrt(s2);
+    if (sig[j] > smax) smax = sig[j];
+  }
+  double thr = smax * (6.0 * DBL_EPSILON);
+  if (thr < DBL_MIN) thr = DBL_MIN;
+  for (int i = 0; i < 6; i++) x[i] = 0;
+  for (int j = 0; j < 6; j++) {
+    if (!(sig[j] >= thr) || sig[j] == 0.0) continue;
+    double ub = 0;
+    for (int i = 0; i < 6; i++) ub += (A[i][j] / sig[j]) * b[i];
+    double w = ub / sig[j];
+    for (int i = 0; i < 6; i++) x[i] += V[i][j] * w;
+  }
+}
+
+/* ------------------------------------------------------------ Sophus a621ff2 */
+typedef struct { double w, x, y, z; } quat;
+
+static quat quat_normalized(quat q) {
+  double n = sqrt(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
+  quat r = {q.w / n, q.x / n, q.y / n, q.z / n};
+  return r;
+}
+/* Eigen Quaternion::operator= (Matrix3) -- quaternionbase_assign_impl<3,3> */
+static quat quat_from_matrix(const double m[9]) {
+  quat q;
+  double t = m[0] + m[4] + m[8];
+  if (t > 0) {
+    t = sqrt(t + 1.0);
+    q.w = 0.5 * t;
+    t = 0.5 / t;
+    q.x = (m[2 * 3 + 1] - m[1 * 3 + 2]) * t;
+    q.y = (m[0 * 3 + 2] - m[2 * 3 + 0]) * t;
+    q.z = (m[1 * 3 + 0] - m[0 * 3 + 1]) * t;
+  } else {
+    int i = 0;
+    if (m[4] > m[0]) i = 1;
+    if (m[8] > m[i * 3 + i]) i = 2;
+    int j = (i + 1) % 3, k = (j + 1) % 3;
+    double qv[3];
+    t = sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
+    qv[i] = 0.5 * t;
+    t = 0.5 / t;
+    q.w = (m[k * 3 + j] - m[j * 3 + k]) * t;
+    qv[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
+    qv[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+    q.x = qv[0]; q.y = qv[1]; q.z = qv[2];
+  }
+  return q;
+}
+/* Eigen QuaternionBase::toRotationMatrix */
+static void quat_to_matrix(quat q, double r[9]) {
+  double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+  double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  r[0] = 1 - (tyy + tzz); r[1] = txy - twz; r[2] = txz + twy;
+  r[3] = txy + twz; r[4] = 1 - (txx + tzz); r[5] = tyz - twx;
+  r[6] = txz - twy; r[7] = tyz + twx; r[8] = 1 - (txx + tyy);
+}
+static quat quat_mul(quat a, quat b) {
+  quat r;
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+  r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+  return r;
+}
+/* QuaternionBase::_transformVector: v + w*uv + q.vec x uv, uv = 2 (q.vec x v) */
+static void quat_rotate(quat q, const double v[3], double out[3]) {
+  double uv[3] = {q.y * v[2] - q.z * v[1], q.z * v[0] - q.x * v[2], q.x * v[1] - q.y * v[0]};
+  uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+  double c[3] = {q.y * uv[2] - q.z * uv[1], q.z * uv[0] - q.x * uv[2], q.x * uv[1] - q.y * uv[0]};
+  for (int i = 0; i < 3; i++) out[i] = (v[i] + q.w * uv[i]) + c[i];
+}
+
+typedef struct { quat q; double t[3]; } se3;
+
+/* SO3::expAndTheta */
+static quat so3_exp(const double om[3], double* theta) {
+  *theta = sqrt((om[0] * om[0] + om[1] * om[1]) + om[2] * om[2]);
+  double half = 0.5 * (*theta);
+  double imag, real = cos(half);
+  if (*theta < SMALL_EPS) {
+    double th2 = (*theta) * (*theta), th4 = th2 * th2;
+    imag = 0.5 - 0.0208333 * th2 + 0.000260417 * th4;
+  } else {
+    imag = sin(half) / (*theta);
+  }
+  quat q = {real, imag * om[0], imag * om[1], imag * om[2]};
+  return quat_normalized(q); /* SO3(Quaterniond) normalises */
+}
+/* SO3::logAndTheta (atan-based) */
+static void so3_log(quat q, double om[3], double* theta) {
+  double n = sqrt((q.x * q.x + q.y * q.y) + q.z * q.z);
+  double w = q.w, f;
+  if (n < SMALL_EPS) {
+    f = 2. / w - 2. * (n * n) / (w * (w * w));
+  } else {
+    /* the |w|<eps special-case in the source is overwritten by the next line (kept) */
+    f = 2 * atan(n / w) / n;
+  }
+  *theta = f * n;
+  om[0] = f * q.x; om[1] = f * q.y; om[2] = f * q.z;
+}
+static void hat(const double o[3], double O[9]) {
+  O[0] = 0; O[1] = -o[2]; O[2] = o[1];
+  O[3] = o[2]; O[4] = 0; O[5] = -o[0];
+  O[6] = -o[1]; O[7] = o[0]; O[8] = 0;
+}
+/* SE3::exp */
+static se3 se3_exp(const double p[6]) {
+  se3 r;
+  double theta;
+  const double* ups = p; const double* om = p + 3;
+  r.q = so3_exp(om, &theta);
+  double Om[9], Om2[9], V[9];
+  hat(om, Om);
+  mat3_mul(Om, Om, Om2);
+  if (theta < SMALL_EPS) {
+    quat_to_matrix(r.q, V);
+  } else {
+    double th2 = theta * theta;
+    double a = (1 - cos(theta)) / th2, b = (theta - sin(theta)) / (th2 * theta);
+    for (int i = 0; i < 9; i++) V[i] = (((i % 4) == 0 ? 1.0 : 0.0) + a * Om[i]) + b * Om2[i];
+  }
+  for (int i = 0; i < 3; i++) r.t[i] = (V[i * 3 + 0] * ups[0] + V[i * 3 + 1] * ups[1]) + V[i * 3 + 2] * ups[2];
+  return r;
+}
+/* SE3::log */
+static void se3_log(se3 s, double p[6]) {
+  double theta, om[3];
+  so3_log(s.q, om, &theta);
+  double Om[9], Om2[9], Vi[9];
+  hat(om, Om);
+  mat3_mul(Om, Om, Om2);
+  if (theta < SMALL_EPS) {
+    for (int i = 0; i < 9; i++) Vi[i] = (((i % 4) == 0 ? 1.0 : 0.0) - 0.5 * Om[i]) + (1. / 12.) * Om2[i];
+  } else {
+    double c = (1 - theta / (2 * tan(theta / 2))) / (theta * theta);
+    for (int i = 0; i < 9; i++) Vi[i] = (((i % 4) == 0 ? 1.0 : 0.0) - 0.5 * Om[i]) + c * Om2[i];
+  }
+  for (int i = 0; i < 3; i++) p[i] = (Vi[i * 3 + 0] * s.t[0] + Vi[i * 3 + 1] * s.t[1]) + Vi[i * 3 + 2] * s.t[2];
+  p[3] = om[0]; p[4] = om[1]; p[5] = om[2];
+}
+/* SE3::operator* */
+static se3 se3_mul(se3 a, se3 b) {
+  se3 r;
+  double rt[3];
+  quat_rotate(a.q, b.t, rt);
+  for (int i = 0; i < 3; i++) r.t[i] = a.t[i] + rt[i];
+  r.q = quat_normalized(quat_mul(a.q, b.q));
+  return r;
+}
+static void se3_matrix(se3 s, double M[16]) { /* row-major 4x4 */
+  double R[9];
+  quat_to_matrix(s.q, R);
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) M[i * 4 + j] = R[i * 3 + j];
+    M[i * 4 + 3] = s.t[i];
+  }
+  M[12] = M[13] = M[14] = 0; M[15] = 1;
+}
+static se3 se3_from_Rt(const double R[9], const double t[3]) { /* SE3(R,t): SO3(R) normalises */
+  se3 s;
+  s.q = quat_normalized(quat_from_matrix(R));
+  s.t[0] = t[0]; s.t[1] = t[1]; s.t[2] = t[2];
+  return s;
+}
+void ora_se3_exp(const double p[6], double M[16]) { se3_matrix(se3_exp(p), M); }
+void ora_se3_log(const double M[16], double p[6]) {
+  double R[9] = {M[0], M[1], M[2], M[4], M[5], M[6], M[8], M[9], M[10]};
+  double t[3] = {M[3], M[7], M[11]};
+  se3_log(se3_from_Rt(R, t), p);
+}
+void ora_se3_compose_log(const double dp[6], const double p[6], double out[6]) {
+  se3_log(se3_mul(se3_exp(dp), se3_exp(p)), out);
+}
+
+/* ------------------------------------------------------------------ voxel grid */
+struct ora_grid {
+  int min_b[3], max_b[3], div_b[3], mul[3];
+  float leaf[3], inv_leaf[3];
+  size_t n_leaves, n_valid;
+  ora_leaf* leaves;        /* ascending idx */
+  int64_t ncells;
+  int32_t* dense;          /* cell -> leaf index or -1 (when ncells small) */
+  int min_points;
+};
+
+typedef struct { int32_t idx; uint32_t pos; } keypos;
+static int cmp_keypos(const void* a, const void* b) {
+  const keypos* A = (const keypos*)a; const keypos* B = (const keypos*)b;
+  if (A->idx != B->idx) return A->idx < B->idx ? -1 : 1;
+  return A->pos < B->pos ? -1 : (A->pos > B->pos);
+}
+
+static int finite3(float x, float y, float z) { return isfinite(x) && isfinite(y) && isfinite(z); }
+
+ora_grid* ora_grid_build(const float* x, const float* y, const float* z, size_t n, const ora_params* prm) {
+  if (n == 0) return NULL;
+  ora_grid* g = (ora_grid*)calloc(1, sizeof(ora_grid));
+  g->min_points = prm->min_points_per_voxel;
+  /* pcl::VoxelGrid::setLeafSize: leaf_size_, inverse_leaf_size_ = 1/leaf (f32) */
+  for (int a = 0; a < 3; a++) { g->leaf[a] = prm->resolution; g->inv_leaf[a] = 1.0f / prm->resolution; }
+  /* getMinMax3D (impl:72) over finite points */
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  size_t nfinite = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (!finite3(x[i], y[i], z[i])) continue;
+    nfinite++;
+    if (x[i] < mn[0]) mn[0] = x[i]; if (x[i] > mx[0]) mx[0] = x[i];
+    if (y[i] < mn[1]) mn[1] = y[i]; if (y[i] > mx[1]) mx[1] = y[i];
+    if (z[i] < mn[2]) mn[2] = z[i]; if (z[i] > mx[2]) mx[2] = z[i];
+  }
+  if (nfinite == 0) { free(g); return NULL; }
+  /* overflow guard impl:75-84 (f32 arithmetic, then int64) */
+  int64_t d[3];
+  for (int a = 0; a < 3; a++) d[a] = (int64_t)((mx[a] - mn[a]) * g->inv_leaf[a]) + 1;
+  if (d[0] * d[1] * d[2] > (int64_t)INT32_MAX) { free(g); return NULL; }
+  /* impl:87-103 */
+  for (int a = 0; a < 3; a++) {
+    g->min_b[a] = (int)floorf(mn[a] * g->inv_leaf[a]);
+    g->max_b[a] = (int)floorf(mx[a] * g->inv_leaf[a]);
+    g->div_b[a] = g->max_b[a] - g->min_b[a] + 1;
+  }
+  g->mul[0] = 1; g->mul[1] = g->div_b[0]; g->mul[2] = g->div_b[0] * g->div_b[1];
+  g->ncells = (int64_t)g->div_b[0] * g->div_b[1] * g->div_b[2];
+
+  /* first pass impl:209-263: cell index per point; group with a stable sort so the
+   * f64 sums run in input order exactly as leaves_[idx] accumulation does. */
+  keypos* kp = (keypos*)malloc(nfinite * sizeof(keypos));
+  size_t m = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (!finite3(x[i], y[i], z[i])) continue;
+    int ijk0 = (int)(floorf(x[i] * g->inv_leaf[0]) - (float)g->min_b[0]);
+    int ijk1 = (int)(floorf(y[i] * g->inv_leaf[1]) - (float)g->min_b[1]);
+    int ijk2 = (int)(floorf(z[i] * g->inv_leaf[2]) - (float)g->min_b[2]);
+    kp[m].idx = ijk0 * g->mul[0] + ijk1 * g->mul[1] + ijk2 * g->mul[2];
+    kp[m].pos = (uint32_t)i;
+    m++;
+  }
+  qsort(kp, m, sizeof(keypos), cmp_keypos);
+  size_t nl = 0;
+  for (size_t i = 0; i < m; i++) if (i == 0 || kp[i].idx != kp[i - 1].idx) nl++;
+  g->n_leaves = nl;
+  g->leaves = (ora_leaf*)calloc(nl, sizeof(ora_leaf));
+
+  size_t li = 0;
+  for (size_t s = 0; s < m;) {
+    size_t e = s;
+    while (e < m && kp[e].idx == kp[s].idx) e++;
+    ora_leaf* L = &g->leaves[li++];
+    L->idx = kp[s].idx;
+    /* Leaf ctor: mean_ = 0, cov_ = Identity, icov_ = 0 (voxel_grid_covariance_omp.h:97-106) */
+    double S[3] = {0, 0, 0};
+    double C[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    int cnt = 0;
+    for (size_t k = s; k < e; k++) {
+      size_t i = kp[k].pos;
+      double p3[3] = {(double)x[i], (double)y[i], (double)z[i]};
+      for (int a = 0; a < 3; a++) S[a] += p3[a];                       /* impl:235 */
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) C[a * 3 + b] += p3[a] * p3[b]; /* impl:237 */
+      cnt++;
+    }
+    L->n = cnt;
+    double mu[3];
+    for (int a = 0; a < 3; a++) mu[a] = S[a] / (double)cnt;            /* impl:293 */
+    memcpy(L->mean, mu, sizeof mu);
+    if (cnt >= prm->min_points_per_voxel) {                            /* impl:297 */
+      double cov[9];
+      /* impl:329-330 */
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++)
+          cov[a * 3 + b] = (C[a * 3 + b] - 2 * (S[a] * mu[b])) / (double)cnt + mu[a] * mu[b];
+      double f = ((double)cnt - 1.0) / (double)cnt;
+      for (int a = 0; a < 9; a++) cov[a] *= f;
+      double ev[3], V[9];
+      ora_eigen_sym3(cov, ev, V);                                      /* impl:333-335 */
+      memcpy(L->evecs, V, sizeof V);
+      if (ev[0] < 0 || ev[1] < 0 || ev[2] <= 0) {                      /* impl:337-341 */
+        L->n = -1;
+        memcpy(L->cov, cov, sizeof cov);
+        memcpy(L->evals, ev, sizeof ev);
+        s = e;
+        continue;
+      }
+      double minev = prm->min_covar_eigvalue_mult * ev[2];             /* impl:345 */
+      if (ev[0] < minev) {
+        ev[0] = minev;
+        if (ev[1] < minev) ev[1] = minev;
+        /* cov = evecs * diag * evecs.inverse()  impl:355 */
+        double VD[9], Vi[9];
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) VD[a * 3 + b] = V[a * 3 + b] * ev[b];
+        mat3_inverse(V, Vi);
+        mat3_mul(VD, Vi, cov);
+      }
+      memcpy(L->evals, ev, sizeof ev);
+      memcpy(L->cov, cov, sizeof cov);
+      if (prm->variant == ORA_VARIANT_PCA) {                           /* pca impl:364-397 */
+        double sg[3] = {sqrt(ev[0]), sqrt(ev[1]), sqrt(ev[2])};
+        double ft[3] = {(sg[2] - sg[1]) / sg[2], (sg[1] - sg[0]) / sg[2], sg[0] / sg[2]};
+        int dmax = 0;
+        if (ft[1] > ft[dmax]) dmax = 1;
+        if (ft[2] > ft[dmax]) dmax = 2;
+        L->label = dmax + 1;
+        double scale = 1;
+        if (L->label == 2) scale = 1.25; else if (L->label == 3) scale = 1; else if (L->label == 1) scale = 0.75;
+        L->dim2d = scale * sqrt((mu[0] * mu[0] + mu[1] * mu[1]) + mu[2] * mu[2]);
+        L->weight = (int)L->dim2d;                                     /* pca.h:222-226 returns int */
+      }
+      mat3_inverse(cov, L->icov);                                      /* impl:359 */
+      int bad = 0;
+      for (int a = 0; a < 9; a++) if (!isfinite(L->icov[a])) bad = 1;  /* impl:360-364 (NaN treated as inf) */
+      if (bad) L->n = -1;
+    }
+    s = e;
+  }
+  free(kp);
+  g->n_valid = 0;
+  for (size_t i = 0; i < nl; i++) if (g->leaves[i].n >= prm->min_points_per_voxel) g->n_valid++;
+  if (g->ncells <= ((int64_t)1 << 27)) {
+    g->dense = (int32_t*)malloc((size_t)g->ncells * sizeof(int32_t));
+    memset(g->dense, 0xff, (size_t)g->ncells * sizeof(int32_t));
+    for (size_t i = 0; i < nl; i++) g->dense[g->leaves[i].idx] = (int32_t)i;
+  }
+  return g;
+}
+
+void ora_grid_free(ora_grid* g) { if (!g) return; free(g->leaves); free(g->dense); free(g); }
+size_t ora_grid_num_leaves(const ora_grid* g) { return g->n_leaves; }
+size_t ora_grid_num_valid(const ora_grid* g) { return g->n_valid; }
+const ora_leaf* ora_grid_leaves(const ora_grid* g) { return g->leaves; }
+void ora_grid_bounds(const ora_grid* g, int min_b[3], int max_b[3], int div_b[3]) {
+  for (int a = 0; a < 3; a++) { min_b[a] = g->min_b[a]; max_b[a] = g->max_b[a]; div_b[a] = g->div_b[a]; }
+}
+
+static const ora_leaf* grid_find(const ora_grid* g, int32_t idx) {
+  if (g->dense) { int32_t l = g->dense[idx]; return l < 0 ? NULL : &g->leaves[l]; }
+  size_t lo = 0, hi = g->n_leaves;
+  while (lo < hi) { size_t mid = (lo + hi) / 2; if (g->leaves[mid].idx < idx) lo = mid + 1; else hi = mid; }
+  return (lo < g->n_leaves && g->leaves[lo].idx == idx) ? &g->leaves[lo] : NULL;
+}
+
+/* neighbour offset tables: DIRECT7 impl:423-430; DIRECT1 impl:441;
+ * DIRECT26 = pcl::getAllNeighborCellIndices() (PCL 1.8 voxel_grid.h): 13 "half" offsets then their negation */
+static int build_offsets(int mode, int off[26][3]) {
+  if (mode == ORA_DIRECT1) { off[0][0] = off[0][1] = off[0][2] = 0; return 1; }
+  if (mode == ORA_DIRECT7) {
+    static const int o7[7][3] = {{0,0,0},{1,0,0},{-1,0,0},{0,1,0},{0,-1,0},{0,0,1},{0,0,-1}};
+    memcpy(off, o7, sizeof o7);
+    return 7;
+  }
+  if (mode == ORA_DIRECT26) {
+    int k = 0;
+    for (int i = -1; i < 2; i++) for (int j = -1; j < 2; j++) { off[k][0] = i; off[k][1] = j; off[k][2] = -1; k++; }
+    for (int i = -1; i < 2; i++) { off[k][0] = i; off[k][1] = -1; off[k][2] = 0; k++; }
+    off[k][0] = -1; off[k][1] = 0; off[k][2] = 0; k++;
+    for (int i = 0; i < 13; i++) { off[13 + i][0] = -off[i][0]; off[13 + i][1] = -off[i][1]; off[13 + i][2] = -off[i][2]; }
+    return 26;
+  }
+  return 0; /* KDTREE: not restated (dead in shipped configs) */
+}
+
+/* -------------------------------------------------- one (point, voxel) evaluation */
+/* updateDerivatives (ndt_omp_impl2.hpp:566-619) with J/Hp of
+ * computePointDerivatives_AngleAxisd (impl2:503-532) folded in.  All f32 ops are
+ * single, left-to-right, uncontracted.  Returns score_inc (0 if the validity gate fires). */
+static double eval_hit(const float u[3], const float r[3], const float C[9], double d1, float d2f,
+                       double g[6], double H[36]) {
+  /* y = x_trans4 * c_inv4 (impl2:600) */
+  float y[3];
+  for (int j = 0; j < 3; j++) y[j] = (u[0] * C[0 * 3 + j] + u[1] * C[1 * 3 + j]) + u[2] * C[2 * 3 + j];
+  float qf = (u[0] * y[0] + u[1] * y[1]) + u[2] * y[2];
+  /* impl2:581 -- exp evaluated in double on the f32 argument, rounded to f32 (canonical choice) */
+  float e0 = (float)exp((double)((-d2f * qf) * 0.5f));
+  float s_inc = (float)(-d1 * (double)e0);                       /* impl2:583 */
+  float e1 = d2f * e0;                                           /* impl2:585 */
+  if (e1 > 1 || e1 < 0 || e1 != e1) return 0;                    /* impl2:588-589 */
+  float e = (float)((double)e1 * d1);                            /* impl2:592 */
+  /* CJ = c_inv4 * point_gradient4 (impl2:594); J = [I | -[r]x] */
+  float CJ[3][6];
+  for (int a = 0; a < 3; a++) {
+    CJ[a][0] = C[a * 3 + 0]; CJ[a][1] = C[a * 3 + 1]; CJ[a][2] = C[a * 3 + 2];
+    CJ[a][3] = C[a * 3 + 1] * (-r[2]) + C[a * 3 + 2] * r[1];
+    CJ[a][4] = C[a * 3 + 0] * r[2] + C[a * 3 + 2] * (-r[0]);
+    CJ[a][5] = C[a * 3 + 0] * (-r[1]) + C[a * 3 + 1] * r[0];
+  }
+  float v[6];
+  for (int k = 0; k < 6; k++) v[k] = (u[0] * CJ[0][k] + u[1] * CJ[1][k]) + u[2] * CJ[2][k];   /* impl2:595 */
+  for (int k = 0; k < 6; k++) g[k] += (double)(e * v[k]);                                     /* impl2:597 */
+  /* JCJ = J^T * CJ (impl2:601) */
+  float JCJ[6][6];
+  for (int j = 0; j < 6; j++) {
+    JCJ[0][j] = CJ[0][j]; JCJ[1][j] = CJ[1][j]; JCJ[2][j] = CJ[2][j];
+    JCJ[3][j] = (-r[2]) * CJ[1][j] + r[1] * CJ[2][j];
+    JCJ[4][j] = r[2] * CJ[0][j] + (-r[0]) * CJ[2][j];
+    JCJ[5][j] = (-r[1]) * CJ[0][j] + r[0] * CJ[1][j];
+  }
+  /* z_i[j] = y * Hp_block_i (impl2:607), Hp of impl2:522-530 */
+  float Z[6][6];
+  memset(Z, 0, sizeof Z);
+  Z[3][3] = y[1] * (-r[1]) + y[2] * (-r[2]);
+  Z[4][3] = y[0] * r[1];
+  Z[5][3] = y[0] * r[2];
+  Z[3][4] = y[1] * r[0];
+  Z[4][4] = y[0] * (-r[0]) + y[2] * (-r[2]);
+  Z[5][4] = y[1] * r[2];
+  Z[3][5] = y[2] * r[0];
+  Z[4][5] = y[2] * r[1];
+  Z[5][5] = y[0] * (-r[0]) + y[1] * (-r[1]);
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++)
+      H[i * 6 + j] += (double)(e * ((((-d2f) * v[i]) * v[j] + Z[i][j]) + JCJ[j][i]));          /* impl2:611-613 */
+  return (double)s_inc;
+}
+
+#define CHUNK 256
+
+long ora_derivatives(const ora_grid* g, const ora_params* prm,
+                     const float* x, const float* y, const float* z, size_t n,
+                     const float T[16], const float Rj[9],
+                     double* score, double grad[6], double hess[36]) {
+  double gc[3];
+  ora_gauss_constants(prm->outlier_ratio, prm->resolution, gc);
+  const double d1 = gc[0];
+  const float d2f = (float)gc[1];                                 /* impl2:578 */
+  int off[26][3];
+  const int K = build_offsets(prm->neighbor_mode, off);
+  const int pca = prm->variant == ORA_VARIANT_PCA;
+  size_t nchunks = (n + CHUNK - 1) / CHUNK;
+  double* part = (double*)calloc(nchunks ? nchunks : 1, 44 * sizeof(double));
+#ifdef _OPENMP
+  int nt = g_threads > 0 ? g_threads : omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nt)
+#endif
+  for (long c = 0; c < (long)nchunks; c++) {
+    double* acc = part + (size_t)c * 44; /* [0]=score [1..6]=g [7..42]=H [43]=hits */
+    size_t i0 = (size_t)c * CHUNK, i1 = i0 + CHUNK < n ? i0 + CHUNK : n;
+    for (size_t i = i0; i < i1; i++) {
+      float px = x[i], py = y[i], pz = z[i];
+      if (!finite3(px, py, pz)) continue;
+      /* PCL 1.8 transformPointCloud scalar form */
+      float xt[3];
+      for (int a = 0; a < 3; a++) xt[a] = ((T[0 * 4 + a] * px + T[1 * 4 + a] * py) + T[2 * 4 + a] * pz) + T[3 * 4 + a];
+      /* impl2:507-508 : x_t = float(exp(p).matrix()) * (x,0) */
+      float r[3];
+      for (int a = 0; a < 3; a++) r[a] = (Rj[a * 3 + 0] * px + Rj[a * 3 + 1] * py) + Rj[a * 3 + 2] * pz;
+      /* getNeighborhoodAtPoint, voxel_grid_covariance_omp_impl.hpp:379-399 */
+      int ijk[3] = {(int)floorf(xt[0] / g->leaf[0]), (int)floorf(xt[1] / g->leaf[1]), (int)floorf(xt[2] / g->leaf[2])};
+      double s_pt = 0, g_pt[6] = {0}, H_pt[36] = {0};
+      for (int k = 0; k < K; k++) {
+        int c3[3] = {ijk[0] + off[k][0], ijk[1] + off[k][1], ijk[2] + off[k][2]};
+        if (c3[0] < g->min_b[0] || c3[0] > g->max_b[0] || c3[1] < g->min_b[1] || c3[1] > g->max_b[1] ||
+            c3[2] < g->min_b[2] || c3[2] > g->max_b[2]) continue;
+        int32_t idx = (c3[0] - g->min_b[0]) * g->mul[0] + (c3[1] - g->min_b[1]) * g->mul[1] + (c3[2] - g->min_b[2]) * g->mul[2];
+        const ora_leaf* L = grid_find(g, idx);
+        if (!L || L->n < g->min_points) continue;
+        /* impl2:276-281, 574-576 */
+        float u[3], Cf[9];
+        for (int a = 0; a < 3; a++) u[a] = (float)((double)xt[a] - L->mean[a]);
+        for (int a = 0; a < 9; a++) Cf[a] = (float)L->icov[a];
+        s_pt += eval_hit(u, r, Cf, d1, d2f, g_pt, H_pt);
+        if (pca) {                                                  /* ndt_pca_impl2.hpp:295-296 */
+          double w = (double)L->weight;
+          s_pt *= w;
+          for (int a = 0; a < 6; a++) g_pt[a] *= w;
+          for (int a = 0; a < 36; a++) H_pt[a] *= w;
+        }
+        acc[43] += 1;
+      }
+      acc[0] += s_pt;                                               /* impl2:293-295 */
+      for (int a = 0; a < 6; a++) acc[1 + a] += g_pt[a];
+      for (int a = 0; a < 36; a++) acc[7 + a] += H_pt[a];
+    }
+  }
+  double tot[44] = {0};
+  for (size_t c = 0; c < nchunks; c++) for (int a = 0; a < 44; a++) tot[a] += part[c * 44 + a];  /* impl2:298-302 (fixed order) */
+  free(part);
+  *score = tot[0];
+  memcpy(grad, tot + 1, 6 * sizeof(double));
+  memcpy(hess, tot + 7, 36 * sizeof(double));
+  return (long)tot[43];
+}
+
+static void pose_to_f32(const double p[6], float T[16], float Rj[9]) {
+  double M[16];
+  ora_se3_exp(p, M);
+  for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) T[c * 4 + r] = (float)M[r * 4 + c];   /* .cast<float>() */
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Rj[r * 3 + c] = (float)M[r * 4 + c];
+}
+
+long ora_derivatives_at(const ora_grid* g, const ora_params* prm,
+                        const float* x, const float* y, const float* z, size_t n,
+                        const double p[6], double* score, double grad[6], double hess[36]) {
+  float T[16], Rj[9];
+  pose_to_f32(p, T, Rj);
+  return ora_derivatives(g, prm, x, y, z, n, T, Rj, score, grad, hess);
+}
+
+/* computeTransformation, ndt_omp_impl2.hpp:87-188, with computeStepLengthMT's live
+ * prefix (impl2:841-907) inlined.  `g` may be NULL (no target cells => zero hits). */
+int ora_align(const ora_grid* g, const ora_params* prm,
+              const float* x, const float* y, const float* z, size_t n,
+              const float guess[16], ora_result* out) {
+  memset(out, 0, sizeof *out);
+  const double eps = prm->trans_epsilon;
+  const double step_max = prm->step_size, step_min = eps / 2;
+  if (!((step_max - step_min) > 0)) return -2;                     /* impl2:888: MT loop would be live */
+  if (!g) return -3;
+  /* final_transformation_ = guess (or Identity, same thing) impl2:102-108 */
+  float T[16], Rj[9];
+  memcpy(T, guess, sizeof T);
+  memcpy(out->final_colmajor, guess, sizeof T);
+  /* p = SE3(R,t).log() impl2:120-121 */
+  double p[6];
+  {
+    double M[16];
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) M[r * 4 + c] = (double)guess[c * 4 + r];
+    ora_se3_log(M, p);
+    float Tdummy[16];
+    pose_to_f32(p, Tdummy, Rj);                                    /* Jacobian uses exp(p), impl2:508 */
+  }
+  double score, grad[6], H[36];
+  long hits = ora_derivatives(g, prm, x, y, z, n, T, Rj, &score, grad, H);   /* impl2:129 */
+  int sweeps = 1, it = 0, converged = 0;
+  while (!converged) {
+    double neg[6], dp[6];
+    for (int a = 0; a < 6; a++) neg[a] = -grad[a];
+    ora_svd_solve6(H, neg, dp);                                    /* impl2:138-140 */
+    double nrm = 0;
+    for (int a = 0; a < 6; a++) nrm += dp[a] * dp[a];
+    nrm = sqrt(nrm);
+    if (nrm == 0 || nrm != nrm) {                                  /* impl2:147-152 */
+      out->trans_probability = score / (double)n;
+      out->converged = (nrm == nrm);
+      out->iterations = it; out->score = score; out->hits_last = hits; out->sweeps = sweeps;
+      return 0;
+    }
+    for (int a = 0; a < 6; a++) dp[a] /= nrm;                      /* normalize() impl2:154 */
+    /* computeStepLengthMT impl2:846-907 */
+    double dphi0 = 0;
+    for (int a = 0; a < 6; a++) dphi0 += grad[a] * dp[a];
+    dphi0 = -dphi0;
+    double a_t;
+    if (dphi0 >= 0 && dphi0 == 0) {
+      a_t = 0;                                                     /* impl2:856-857: return 0, nothing re-evaluated */
+    } else {
+      if (dphi0 >= 0) { for (int a = 0; a < 6; a++) dp[a] *= -1; } /* impl2:861-862 */
+      a_t = nrm;
+      a_t = a_t < step_max ? a_t : step_max;                       /* impl2:890-892 */
+      a_t = a_t > step_min ? a_t : step_min;
+      double xt[6];
+      for (int a = 0; a < 6; a++) xt[a] = p[a] + dp[a] * a_t;      /* impl2:894 */
+      pose_to_f32(xt, T, Rj);                                      /* impl2:900 */
+      memcpy(out->final_colmajor, T, sizeof T);
+      hits = ora_derivatives(g, prm, x, y, z, n, T, Rj, &score, grad, H);  /* impl2:903-907 */
+      sweeps++;
+    }
+    for (int a = 0; a < 6; a++) dp[a] *= a_t;                      /* impl2:156 */
+    double pn[6];
+    ora_se3_compose_log(dp, p, pn);                                /* impl2:166 */
+    memcpy(p, pn, sizeof pn);
+    if (it > prm->max_iterations || (it && (fabs(a_t) < eps))) converged = 1;   /* impl2:175-179 */
+    it++;
+  }
+  out->trans_probability = score / (double)n;                      /* impl2:187 */
+  out->converged = 1; out->iterations = it; out->score = score; out->hits_last = hits; out->sweeps = sweeps;
+  return 0;
+}

@@ -1,0 +1,122 @@
+/*
+ * oracle/ndt_oracle.h -- CPU restatement of lv_slam's NDT scan-matching path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (lv_slam_amd/, include/)
+ * may include, link or call this.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg use it, and only as the checker.
+ *
+ * PARITY UNPINNED: the reference (PCL + Eigen + Sophus + FLANN) cannot be built in
+ * this environment and ships no golden vectors for this path, so this
+ * restatement is pinned only against an independent NumPy restatement of the same
+ * cited lines (tests/golden/make_golden.py) and analytic anchors.
+ *
+ * Every function cites the reference file:line it follows (paths relative to the
+ * lv_slam tree).  Matrices crossing this API are 4x4 float, COLUMN-MAJOR
+ * (Eigen::Matrix4f native layout): M(r,c) = m[c*4+r].
+ */
+#ifndef NDT_ORACLE_H_
+#define NDT_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* enum order of include/ndt_omp/ndt_omp.h:51-56 */
+enum { ORA_KDTREE = 0, ORA_DIRECT26 = 1, ORA_DIRECT7 = 2, ORA_DIRECT1 = 3 };
+enum { ORA_VARIANT_OMP = 0, ORA_VARIANT_PCA = 1 };
+
+typedef struct {
+  float  resolution;              /* ndt_omp_impl2.hpp:56   (1.0f) */
+  double step_size;               /* ndt_omp_impl2.hpp:57   (0.1)  */
+  double outlier_ratio;           /* ndt_omp_impl2.hpp:58   (0.55) */
+  double trans_epsilon;           /* ndt_omp_impl2.hpp:78   (0.1)  */
+  int    max_iterations;          /* ndt_omp_impl2.hpp:79   (35)   */
+  int    neighbor_mode;           /* ndt_omp_impl2.hpp:81   (DIRECT7) */
+  int    variant;                 /* 0 = pclomp (ndt_omp), 1 = pclpca (ndt_pca) */
+  int    min_points_per_voxel;    /* voxel_grid_covariance_omp.h:204 (6) */
+  double min_covar_eigvalue_mult; /* voxel_grid_covariance_omp.h:205 (0.01) */
+} ora_params;
+
+/* One searchable-or-not leaf of the voxel grid (voxel_grid_covariance_omp.h:92-187). */
+typedef struct {
+  int32_t idx;        /* linear cell index (voxel_grid_covariance_omp_impl.hpp:223) */
+  int32_t n;          /* nr_points; -1 = eigen/inverse failure (impl:339,363) */
+  double  mean[3];
+  double  cov[9];     /* row-major */
+  double  icov[9];    /* row-major */
+  double  evals[3];   /* ascending, after inflation */
+  double  evecs[9];   /* columns = eigenvectors, row-major storage */
+  int32_t label;      /* ndt_pca dimension_label_ (1/2/3), 0 if not computed */
+  int32_t weight;     /* ndt_pca (int)dimension_2d_  */
+  double  dim2d;      /* ndt_pca dimension_2d_ */
+} ora_leaf;
+
+typedef struct ora_grid ora_grid;
+
+void ora_default_params(ora_params* p);
+
+/* Gauss constants, ndt_omp_impl2.hpp:93-100.  out = {d1,d2,d3}. */
+void ora_gauss_constants(double outlier_ratio, float resolution, double out[3]);
+
+/* Target build: voxel_grid_covariance_omp_impl.hpp:48-370 (+pca impl:364-397).
+ * Points with non-finite coordinates are skipped (the !is_dense branch, impl:211-216).
+ * Returns NULL on the int32-overflow guard (impl:75-84) or n==0. */
+ora_grid* ora_grid_build(const float* x, const float* y, const float* z, size_t n,
+                         const ora_params* prm);
+void   ora_grid_free(ora_grid* g);
+size_t ora_grid_num_leaves(const ora_grid* g);          /* all occupied cells */
+size_t ora_grid_num_valid(const ora_grid* g);           /* leaves with n >= min_points */
+const ora_leaf* ora_grid_leaves(const ora_grid* g);     /* ascending idx (std::map order) */
+void   ora_grid_bounds(const ora_grid* g, int min_b[3], int max_b[3], int div_b[3]);
+
+/* One computeDerivatives sweep (ndt_omp_impl2.hpp:196-305, 503-532, 566-619; pca :294-296).
+ *   T_colmajor : 4x4 f32 used to transform the points (PCL transformPointCloud form)
+ *   Rj         : 3x3 f32 row-major rotation used for the point Jacobian (impl2:508)
+ * Outputs score, g[6], H[36] (row-major, NOT symmetric).  Returns number of (point,voxel) hits. */
+long ora_derivatives(const ora_grid* g, const ora_params* prm,
+                     const float* x, const float* y, const float* z, size_t n,
+                     const float T_colmajor[16], const float Rj[9],
+                     double* score, double grad[6], double hess[36]);
+
+/* Convenience: sweep at tangent p: T = f32(exp(p)), Rj = its rotation block (impl2:900-907). */
+long ora_derivatives_at(const ora_grid* g, const ora_params* prm,
+                        const float* x, const float* y, const float* z, size_t n,
+                        const double p[6], double* score, double grad[6], double hess[36]);
+
+typedef struct {
+  float  final_colmajor[16];   /* final_transformation_ */
+  double trans_probability;    /* impl2:187 */
+  double score;                /* last sweep score */
+  int    iterations;           /* nr_iterations_ */
+  int    converged;            /* converged_ */
+  long   hits_last;            /* hits in last sweep */
+  int    sweeps;               /* number of computeDerivatives calls */
+} ora_result;
+
+/* computeTransformation (ndt_omp_impl2.hpp:87-188) + the live part of
+ * computeStepLengthMT (impl2:841-907).  Returns 0, or -2 if step_size <= eps/2
+ * (the More-Thuente refinement would be live; not restated). */
+int ora_align(const ora_grid* g, const ora_params* prm,
+              const float* x, const float* y, const float* z, size_t n,
+              const float guess_colmajor[16], ora_result* out);
+
+/* Sophus a621ff2 (non-templated) SE3 exp/log, tangent order [upsilon; omega]. */
+void ora_se3_exp(const double p[6], double M_rowmajor[16]);
+void ora_se3_log(const double M_rowmajor[16], double p[6]);   /* SE3(R,t).log() incl. quaternion normalise */
+void ora_se3_compose_log(const double dp[6], const double p[6], double out[6]); /* (exp(dp)*exp(p)).log() impl2:166 */
+
+/* Eigen::JacobiSVD<6x6>(H, FullU|FullV).solve(b) semantics (thresholded pseudo-inverse). */
+void ora_svd_solve6(const double H[36], const double b[6], double x[6]);
+
+/* symmetric 3x3 eigen (lower triangle read), ascending; evecs row-major with eigenvectors as columns */
+void ora_eigen_sym3(const double A[9], double evals[3], double evecs[9]);
+
+void ora_set_threads(int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
