@@ -1,0 +1,172 @@
+/*
+ * mi355_ndt.h -- C-ABI of the MI355X-native NDT scan-matching engine (libmi355ndt.so).
+ *
+ * Drop-in boundary for the one hot path of BurryChen/lv_slam: the pcl::Registration-style
+ * setInputTarget / setInputSource / align surface implemented by
+ *   pclomp::NormalDistributionsTransform  (include/ndt_omp/ndt_omp.h, ndt_omp_impl2.hpp)
+ *   pclpca::NormalDistributionsTransform  (include/ndt_pca/ndt_pca.h,  ndt_pca_impl2.hpp)
+ * and their VoxelGridCovariance target grids, as called from
+ *   src/lidar_odometry/scan_matching_odom_nodelet.cpp:109-119,197,220-226,243  and
+ *   include/global_graph/loop_detector.hpp:219,249-262.
+ * Everything behind these entry points runs as hand-written HIP kernels on gfx950; there is
+ * no CPU fallback: every call fails with MI355NDT_ERR_NO_DEVICE / MI355NDT_ERR_HIP when no GPU
+ * is usable.
+ *
+ * Conventions
+ *   - plain C types only; no exceptions cross the boundary; every call returns an int status.
+ *   - 4x4 transforms are float[16] COLUMN-MAJOR (Eigen::Matrix4f's native layout):
+ *     M(r,c) = m[c*4+r].
+ *   - host point clouds are arrays of records whose first three floats are x,y,z, `stride_bytes`
+ *     apart (16 for pcl::PointXYZ, 32 for pcl::PointXYZI / PointXYZRGBL).  The engine copies
+ *     x,y,z out during the call; caller memory is never referenced afterwards.
+ *   - a handle is bound to one HIP device and one stream and is NOT thread-safe (the reference
+ *     object is driven by one thread at a time, scan_matching_odom_nodelet.cpp:56;
+ *     global_graph_nodelet.cpp:672); distinct handles are independent.
+ */
+#ifndef MI355_NDT_H_
+#define MI355_NDT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355NDT_OK               0
+#define MI355NDT_ERR_BAD_HANDLE  (-1)
+#define MI355NDT_ERR_BAD_ARG     (-2)
+#define MI355NDT_ERR_HIP         (-3)  /* a HIP runtime call failed; see mi355ndt_last_error() */
+#define MI355NDT_ERR_GRID        (-4)  /* target grid unusable: reference int32 guard
+                                          (voxel_grid_covariance_omp_impl.hpp:75-84) or engine cell cap */
+#define MI355NDT_ERR_NO_DEVICE   (-5)
+#define MI355NDT_ERR_UNSUPPORTED (-6)  /* KDTREE search, or step_size <= trans_epsilon/2 (live More-Thuente loop) */
+#define MI355NDT_ERR_STATE       (-7)  /* align/derivatives before target+source were set */
+
+/* pclomp::NeighborSearchMethod, include/ndt_omp/ndt_omp.h:51-56 (same enum order) */
+enum mi355ndt_neighbor { MI355NDT_KDTREE = 0, MI355NDT_DIRECT26 = 1, MI355NDT_DIRECT7 = 2, MI355NDT_DIRECT1 = 3 };
+/* which reference class is emulated */
+enum mi355ndt_variant { MI355NDT_VARIANT_OMP = 0 /* pclomp:: */, MI355NDT_VARIANT_PCA = 1 /* pclpca:: */ };
+
+typedef struct mi355ndt_params {
+  float  resolution;              /* setResolution            ndt_omp.h:126-136; ctor default 1.0f (ndt_omp_impl2.hpp:56) */
+  double step_size;               /* setStepSize              ndt_omp.h:163;     default 0.1  (impl2:57) */
+  double outlier_ratio;           /* setOulierRatio [sic]     ndt_omp.h:181;     default 0.55 (impl2:58) */
+  double trans_epsilon;           /* setTransformationEpsilon (pcl::Registration); default 0.1 (impl2:78) */
+  int    max_iterations;          /* setMaximumIterations     (pcl::Registration); default 35  (impl2:79) */
+  int    neighbor_mode;           /* setNeighborhoodSearchMethod ndt_omp.h:186;  default DIRECT7 (impl2:81) */
+  int    variant;                 /* 0 = ndt_omp, 1 = ndt_pca (integer voxel weight, ndt_pca_impl2.hpp:294-296) */
+  int    min_points_per_voxel;    /* voxel_grid_covariance_omp.h:204 (6) */
+  double min_covar_eigvalue_mult; /* voxel_grid_covariance_omp.h:205 (0.01) */
+} mi355ndt_params;
+
+typedef struct mi355ndt_result {
+  float     final_colmajor[16];   /* getFinalTransformation()          (final_transformation_, impl2:900) */
+  double    trans_probability;    /* getTransformationProbability()    (impl2:187) */
+  double    score;                /* score of the last derivative sweep */
+  int       iterations;           /* getFinalNumIteration()            (nr_iterations_) */
+  int       converged;            /* hasConverged()                    (converged_) */
+  int       sweeps;               /* number of computeDerivatives passes executed (1 + steps taken) */
+  int       status;               /* per-pair status: MI355NDT_OK or MI355NDT_ERR_GRID */
+  long long hits_last;            /* (point,voxel) evaluations in the last sweep */
+} mi355ndt_result;
+
+/* one searchable voxel as the sweep sees it (parity hook for VoxelGridCovariance::Leaf,
+ * voxel_grid_covariance_omp.h:92-187) */
+typedef struct mi355ndt_voxel {
+  int32_t idx;        /* linear cell index (voxel_grid_covariance_omp_impl.hpp:223) */
+  int32_t n;          /* nr_points; -1 = eigen / inverse failure (impl:339,363) -> never hit */
+  double  mean[3];    /* mean_ */
+  float   icov[9];    /* float(icov_), row-major (ndt_omp_impl2.hpp:576) */
+  int32_t weight;     /* ndt_pca (int)dimension_2d_ (voxel_grid_covariance_pca.h:222-226); 1 for ndt_omp */
+} mi355ndt_voxel;
+
+typedef struct mi355ndt_profile {
+  double    sweep_ms;        /* sum of derivative-sweep kernel durations (HIP events on the engine's stream) */
+  long long sweep_launches;
+  double    sweep_alg_bytes; /* algorithmic bytes of those launches: sum over active pairs of N*(12+4K) + 64*hits */
+  long long sweep_hits;      /* (point,voxel) evaluations in those launches */
+  long long sweep_points;    /* source points swept in those launches */
+  double    build_ms;        /* sum of target-build durations (all voxelisation kernels + sort) */
+  long long build_launches;  /* number of batch builds */
+  double    build_alg_bytes; /* algorithmic bytes of the builds (DESIGN.md B_build) */
+  double    update_ms;       /* sum of Newton-update kernel durations */
+  long long update_launches;
+} mi355ndt_profile;
+
+typedef struct mi355ndt_handle mi355ndt_handle;
+
+const char* mi355ndt_version(void);
+int mi355ndt_device_count(void);                       /* number of usable HIP devices (0 on a CPU-only box) */
+
+/* ctor defaults of NormalDistributionsTransform() (ndt_omp_impl2.hpp:53-83) */
+int mi355ndt_default_params(mi355ndt_params* p);
+
+/* replaces: `pclomp::NormalDistributionsTransform<PS,PT> reg;` (scan_matching_odom_nodelet.cpp:328,
+ * registrations.cpp:78).  `params` may be NULL (defaults). */
+int mi355ndt_create(const mi355ndt_params* params, int device, mi355ndt_handle** out);
+int mi355ndt_destroy(mi355ndt_handle* h);
+
+/* replaces the setters of ndt_omp.h:109-203.  A change of `resolution` (or variant / min points /
+ * eigenvalue multiplier) re-voxelises the current targets, as setResolution does (ndt_omp.h:126-136). */
+int mi355ndt_set_params(mi355ndt_handle* h, const mi355ndt_params* params);
+int mi355ndt_get_params(const mi355ndt_handle* h, mi355ndt_params* out);
+
+/* bind the engine to a caller-owned hipStream_t (NULL = the engine's own stream) */
+int mi355ndt_set_stream(mi355ndt_handle* h, void* hip_stream);
+const char* mi355ndt_last_error(const mi355ndt_handle* h);
+
+/* ---- single registration: the pcl::Registration surface (pair slot 0) --------------------------- */
+
+/* replaces setInputTarget(cloud) -> init() -> VoxelGridCovariance::filter(true)
+ * (ndt_omp.h:116-121, 270-277; voxel_grid_covariance_omp_impl.hpp:48-370) */
+int mi355ndt_set_target(mi355ndt_handle* h, const void* pts, size_t n, size_t stride_bytes);
+/* replaces pcl::Registration::setInputSource(cloud) */
+int mi355ndt_set_source(mi355ndt_handle* h, const void* pts, size_t n, size_t stride_bytes);
+/* replaces align(output, guess) -> computeTransformation(output, guess) (ndt_omp_impl2.hpp:87-188) */
+int mi355ndt_align(mi355ndt_handle* h, const float guess_colmajor[16], mi355ndt_result* out);
+/* the `output` cloud of align(): source transformed by the final pose (f32, PCL 1.8 scalar form).
+ * Writes x,y,z into records `stride_bytes` apart. */
+int mi355ndt_get_aligned(mi355ndt_handle* h, void* out_pts, size_t stride_bytes);
+
+/* parity hooks ------------------------------------------------------------------------------------ */
+/* one computeDerivatives sweep (ndt_omp_impl2.hpp:196-305) at tangent p = [upsilon; omega]:
+ * points transformed by float(exp(p)), Jacobian from the same matrix (impl2:900-907).
+ * H is 6x6 row-major and NOT symmetric. */
+int mi355ndt_derivatives(mi355ndt_handle* h, const double p[6], double* score, double g[6], double H[36], long long* hits);
+/* same sweep with an explicit point transform (column-major 4x4) and Jacobian rotation (row-major 3x3),
+ * i.e. the first sweep of align() where the cloud is moved by the caller's guess (impl2:102-129) */
+int mi355ndt_derivatives_T(mi355ndt_handle* h, const float T_colmajor[16], const float Rj_rowmajor[9],
+                           double* score, double g[6], double H[36], long long* hits);
+/* target grid of pair `pair`: bounds (min_b_, max_b_, div_b_) and searchable voxels in ascending idx order */
+int mi355ndt_get_grid(mi355ndt_handle* h, int pair, int min_b[3], int max_b[3], int div_b[3], int* n_voxels);
+int mi355ndt_get_voxels(mi355ndt_handle* h, int pair, mi355ndt_voxel* out, size_t capacity);
+
+/* ---- batch: n independent (target, source, guess) triples on one GPU ---------------------------- */
+/* (BASELINE.json configs 3-5; the single-registration calls above are the n = 1 case) */
+
+int mi355ndt_batch_reserve(mi355ndt_handle* h, int n_pairs, size_t max_target_pts, size_t max_source_pts);
+/* host uploads into pair slot `pair` (same record convention as set_target / set_source) */
+int mi355ndt_batch_set_target(mi355ndt_handle* h, int pair, const void* pts, size_t n, size_t stride_bytes);
+int mi355ndt_batch_set_source(mi355ndt_handle* h, int pair, const void* pts, size_t n, size_t stride_bytes);
+/* zero-copy: use device-resident SoA buffers laid out [pair][3][pitch] (x row, y row, z row of `pitch`
+ * floats each).  counts are HOST arrays of n_pairs ints.  The buffers must stay valid until replaced. */
+int mi355ndt_batch_bind_device(mi355ndt_handle* h, int n_pairs,
+                               const float* d_targets, const int* target_counts, size_t target_pitch,
+                               const float* d_sources, const int* source_counts, size_t source_pitch);
+/* voxelise every target (setInputTarget for all pairs); asynchronous on the engine's stream */
+int mi355ndt_batch_build_targets(mi355ndt_handle* h);
+/* align every pair; guesses = n_pairs x 16 floats column-major; out = n_pairs results. Synchronous. */
+int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses_colmajor, mi355ndt_result* out);
+int mi355ndt_batch_size(const mi355ndt_handle* h);
+
+/* profiling: HIP-event timing of the engine's own kernels on the engine's stream */
+int mi355ndt_profile_enable(mi355ndt_handle* h, int on);
+int mi355ndt_profile_reset(mi355ndt_handle* h);
+int mi355ndt_profile_get(mi355ndt_handle* h, mi355ndt_profile* out);
+int mi355ndt_synchronize(mi355ndt_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_NDT_H_ */

@@ -1,0 +1,1345 @@
+// mi355_ndt.hip -- MI355X (gfx950) NDT scan-matching engine behind the C-ABI of include/mi355_ndt.h.
+//
+// What runs where (all on the GPU; the host only enqueues):
+//   target build  : k_minmax -> k_griddesc -> k_keys -> radix sort (cell, input order) -> k_mark
+//                   -> k_rank -> k_voxels          (VoxelGridCovariance::applyFilter,
+//                   include/ndt_omp/voxel_grid_covariance_omp_impl.hpp:48-370)
+//   align         : k_init_state -> k_sweep -> [k_update -> k_sweep]*      (computeTransformation +
+//                   computeDerivatives + the live prefix of computeStepLengthMT,
+//                   include/ndt_omp/ndt_omp_impl2.hpp:87-188, 196-305, 841-907)
+// Data layout in HBM: DESIGN.md.  Built with -ffp-contract=off: every f32/f64 step of the
+// reference recipe is a separately rounded operation.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include <cmath>
+
+#include "mi355_ndt.h"
+#include "ndt_math.hpp"
+
+// ------------------------------------------------------------------------------------ constants
+#define CHUNK_PTS      1024          // source points per reduction chunk (fixed => results independent of launch geometry)
+#define SWEEP_THREADS  256
+#define NACC           44            // score, g[6], H[36], hits
+#define IDX_BITS       26            // sort key = pair << 26 | cell ; cell < 2^25 ; bit 25 = "not binned"
+#define MAX_CELLS      (1 << 25)
+#define INVALID_CELL   (1u << 25)
+
+enum { GRID_OK = 0, GRID_EMPTY = 1, GRID_OVERFLOW = 2, GRID_CAP = 3 };
+enum { PH_SWEEP0 = 0, PH_STEP = 1, PH_DONE = 2 };
+
+struct GridDesc {              // one per target
+  int   min_b[3], max_b[3], div_b[3];
+  int   mul1, mul2;            // divb_mul_ = (1, mul1, mul2)
+  float leaf, inv_leaf;
+  int   ncells, nwords;
+  int   status;
+  int   n_voxels;              // searchable leaves (n >= min_points), including eigen-failed ones
+  unsigned word_off;           // into the BitWord pool
+  unsigned rec_off;            // into the VoxelRec pool
+};
+
+struct BitWord {               // occupancy of 64 consecutive cells + rank of the first one
+  unsigned long long bits;
+  unsigned prefix;
+  unsigned pad;
+};
+
+struct VoxelRec {              // 64 B, what one (point, voxel) evaluation reads
+  double mean[3];
+  float  icov[9];
+  int    weight;               // ndt_pca integer weight; 1 for ndt_omp; INT_MIN = dead (eigen/inverse failure)
+};
+#define VOX_DEAD INT_MIN
+
+struct PairState {
+  float  T[12];                // 3x4 row-major point transform (f32)
+  float  Rj[9];                // rotation used for the point Jacobian (f32)
+  double p[6];                 // current tangent [upsilon; omega]
+  double dir[6];               // pending step direction
+  double a_t;                  // pending step length
+  double score, g[6], H[36];
+  double trans_probability;
+  long long hits;
+  float  final_cm[16];
+  int    it, phase, converged, sweeps, n_src, grid_status;
+};
+
+struct SweepConst {
+  double d1;
+  float  d2f;
+  int    K;                    // neighbour probes
+  int    pca;
+  int    off[26][3];
+};
+
+// ------------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
+__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+__device__ __forceinline__ bool finite3(float x, float y, float z) { return isfinite(x) && isfinite(y) && isfinite(z); }
+
+// ------------------------------------------------------------------------------------ target build
+__global__ void k_minmax_init(int* mm, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n * 6) mm[i] = (i % 6) < 3 ? INT_MAX : INT_MIN;
+}
+
+// getMinMax3D over finite points (voxel_grid_covariance_omp_impl.hpp:72, 211-216)
+__global__ void __launch_bounds__(256) k_minmax(const float* __restrict__ tgt, size_t pitch, const int* __restrict__ cnt, int* mm) {
+  const int b = blockIdx.y;
+  const int n = cnt[b];
+  const float* X = tgt + (size_t)b * 3 * pitch;
+  int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float x = X[i], y = X[pitch + i], z = X[2 * pitch + i];
+    if (!finite3(x, y, z)) continue;
+    int ox = f2ord(x), oy = f2ord(y), oz = f2ord(z);
+    mn[0] = min(mn[0], ox); mx[0] = max(mx[0], ox);
+    mn[1] = min(mn[1], oy); mx[1] = max(mx[1], oy);
+    mn[2] = min(mn[2], oz); mx[2] = max(mx[2], oz);
+  }
+  for (int a = 0; a < 3; a++) {
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[a] = min(mn[a], __shfl_xor(mn[a], o));
+      mx[a] = max(mx[a], __shfl_xor(mx[a], o));
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+    for (int a = 0; a < 3; a++) {
+      if (mn[a] != INT_MAX) atomicMin(&mm[b * 6 + a], mn[a]);
+      if (mx[a] != INT_MIN) atomicMax(&mm[b * 6 + 3 + a], mx[a]);
+    }
+  }
+}
+
+// min_b_/max_b_/div_b_/divb_mul_ (voxel_grid_covariance_omp_impl.hpp:75-103)
+__global__ void k_griddesc(const int* __restrict__ mm, GridDesc* gd, unsigned* nwords, float leaf, int n_pairs, unsigned recs_per_pair) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_pairs) return;
+  GridDesc g;
+  memset(&g, 0, sizeof g);
+  g.leaf = leaf;
+  g.inv_leaf = 1.0f / leaf;                      // pcl::VoxelGrid::setLeafSize
+  g.rec_off = (unsigned)b * recs_per_pair;
+  if (mm[b * 6] == INT_MAX) {
+    g.status = GRID_EMPTY;
+  } else {
+    float mn[3], mx[3];
+    for (int a = 0; a < 3; a++) { mn[a] = ord2f(mm[b * 6 + a]); mx[a] = ord2f(mm[b * 6 + 3 + a]); }
+    long long d0 = (long long)((mx[0] - mn[0]) * g.inv_leaf) + 1;
+    long long d1 = (long long)((mx[1] - mn[1]) * g.inv_leaf) + 1;
+    long long d2 = (long long)((mx[2] - mn[2]) * g.inv_leaf) + 1;
+    if (d0 * d1 * d2 > (long long)INT_MAX) {
+      g.status = GRID_OVERFLOW;                  // impl:79-84: empty grid
+    } else {
+      for (int a = 0; a < 3; a++) {
+        g.min_b[a] = (int)floorf(mn[a] * g.inv_leaf);
+        g.max_b[a] = (int)floorf(mx[a] * g.inv_leaf);
+        g.div_b[a] = g.max_b[a] - g.min_b[a] + 1;
+      }
+      long long nc = (long long)g.div_b[0] * g.div_b[1] * g.div_b[2];
+      if (nc > MAX_CELLS) {
+        g.status = GRID_CAP;
+      } else {
+        g.mul1 = g.div_b[0];
+        g.mul2 = g.div_b[0] * g.div_b[1];
+        g.ncells = (int)nc;
+        g.nwords = (int)((nc + 63) >> 6);
+      }
+    }
+  }
+  gd[b] = g;
+  nwords[b] = (unsigned)g.nwords;
+}
+
+__global__ void k_set_word_off(GridDesc* gd, const unsigned* __restrict__ off, int n_pairs) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < n_pairs) gd[b].word_off = off[b];
+}
+
+// first pass of applyFilter: cell index per point (impl:218-223)
+__global__ void __launch_bounds__(256) k_keys(const float* __restrict__ tgt, size_t pitch, const int* __restrict__ cnt,
+                                               const GridDesc* __restrict__ gd, unsigned long long* keys, unsigned* vals) {
+  const int b = blockIdx.y;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pitch) return;
+  const GridDesc& g = gd[b];
+  unsigned cell = INVALID_CELL;
+  if ((int)i < cnt[b] && g.status == GRID_OK) {
+    const float* X = tgt + (size_t)b * 3 * pitch;
+    float x = X[i], y = X[pitch + i], z = X[2 * pitch + i];
+    if (finite3(x, y, z)) {
+      int i0 = (int)(floorf(x * g.inv_leaf) - (float)g.min_b[0]);
+      int i1 = (int)(floorf(y * g.inv_leaf) - (float)g.min_b[1]);
+      int i2 = (int)(floorf(z * g.inv_leaf) - (float)g.min_b[2]);
+      cell = (unsigned)(i0 + i1 * g.mul1 + i2 * g.mul2);
+    }
+  }
+  keys[(size_t)b * pitch + i] = ((unsigned long long)b << IDX_BITS) | cell;
+  vals[(size_t)b * pitch + i] = (unsigned)i;
+}
+
+// mark cells that hold >= min_points points (impl:297) in the occupancy bitmap
+__global__ void __launch_bounds__(256) k_mark(const unsigned long long* __restrict__ keys, size_t pitch, const GridDesc* __restrict__ gd,
+                                               BitWord* words, int min_points) {
+  const int b = blockIdx.y;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pitch) return;
+  const unsigned long long* K = keys + (size_t)b * pitch;
+  const unsigned long long key = K[i];
+  const unsigned cell = (unsigned)(key & ((1u << IDX_BITS) - 1));
+  if (cell & INVALID_CELL) return;
+  if (i != 0 && K[i - 1] == key) return;                       // not the head of its segment
+  const size_t last = i + (size_t)(min_points > 0 ? min_points - 1 : 0);
+  if (last >= pitch || K[last] != key) return;                 // fewer than min_points points
+  atomicOr(&words[gd[b].word_off + (cell >> 6)].bits, 1ull << (cell & 63));
+}
+
+// exclusive popcount prefix over the bitmap words of each target: voxel id = rank in ascending cell order
+__global__ void __launch_bounds__(256) k_rank(GridDesc* gd, BitWord* words) {
+  typedef hipcub::BlockScan<unsigned, 256> Scan;
+  __shared__ typename Scan::TempStorage tmp;
+  const int b = blockIdx.x;
+  BitWord* W = words + gd[b].word_off;
+  const int nw = gd[b].nwords;
+  unsigned base = 0;
+  for (int w0 = 0; w0 < nw; w0 += 256) {
+    int w = w0 + threadIdx.x;
+    unsigned c = (w < nw) ? (unsigned)__popcll(W[w].bits) : 0u, ex, tot;
+    Scan(tmp).ExclusiveSum(c, ex, tot);
+    if (w < nw) W[w].prefix = base + ex;
+    base += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) gd[b].n_voxels = (int)base;
+}
+
+// second pass of applyFilter (impl:282-367; pca impl:364-397): one thread per searchable leaf
+__global__ void __launch_bounds__(256) k_voxels(const float* __restrict__ tgt, size_t pitch,
+                                                 const unsigned long long* __restrict__ keys, const unsigned* __restrict__ vals,
+                                                 const GridDesc* __restrict__ gd, const BitWord* __restrict__ words,
+                                                 VoxelRec* recs, int* vox_idx, int* vox_n,
+                                                 int min_points, double eig_mult, int pca) {
+  const int b = blockIdx.y;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pitch) return;
+  const unsigned long long* K = keys + (size_t)b * pitch;
+  const unsigned long long key = K[i];
+  const unsigned cell = (unsigned)(key & ((1u << IDX_BITS) - 1));
+  if (cell & INVALID_CELL) return;
+  if (i != 0 && K[i - 1] == key) return;
+  const size_t last = i + (size_t)(min_points > 0 ? min_points - 1 : 0);
+  if (last >= pitch || K[last] != key) return;
+  const GridDesc& g = gd[b];
+  const BitWord bw = words[g.word_off + (cell >> 6)];
+  const unsigned id = bw.prefix + (unsigned)__popcll(bw.bits & ((1ull << (cell & 63)) - 1ull));
+
+  // leaf.mean_ += pt ; leaf.cov_ += pt pt^T  in input order (the sort is stable); cov_ seeded with Identity
+  const float* X = tgt + (size_t)b * 3 * pitch;
+  const unsigned* V = vals + (size_t)b * pitch;
+  double S0 = 0, S1 = 0, S2 = 0, C00 = 1, C01 = 0, C02 = 0, C11 = 1, C12 = 0, C22 = 1;
+  int cnt = 0;
+  for (size_t j = i; j < pitch && K[j] == key; j++) {
+    unsigned pi = V[j];
+    double x = (double)X[pi], y = (double)X[pitch + pi], z = (double)X[2 * pitch + pi];
+    S0 += x; S1 += y; S2 += z;
+    C00 += x * x; C01 += x * y; C02 += x * z; C11 += y * y; C12 += y * z; C22 += z * z;
+    cnt++;
+  }
+  const double S[3] = {S0, S1, S2};
+  const double C[9] = {C00, C01, C02, C01, C11, C12, C02, C12, C22};
+  const double dn = (double)cnt;
+  double mu[3] = {S0 / dn, S1 / dn, S2 / dn};                                    // impl:293
+  double cov[9];
+  for (int a = 0; a < 3; a++)
+    for (int c = 0; c < 3; c++) cov[a * 3 + c] = (C[a * 3 + c] - 2 * (S[a] * mu[c])) / dn + mu[a] * mu[c];   // impl:329
+  const double f = (dn - 1.0) / dn;
+  for (int a = 0; a < 9; a++) cov[a] *= f;                                       // impl:330
+  double ev[3], Vm[9];
+  ndtm::eigen_sym3(cov, ev, Vm);                                                 // impl:333-335
+  VoxelRec r;
+  r.mean[0] = mu[0]; r.mean[1] = mu[1]; r.mean[2] = mu[2];
+  for (int a = 0; a < 9; a++) r.icov[a] = 0.f;
+  r.weight = 1;
+  int n_out = cnt;
+  if (ev[0] < 0 || ev[1] < 0 || ev[2] <= 0) {                                    // impl:337-341
+    n_out = -1;
+    r.weight = VOX_DEAD;
+  } else {
+    const double minev = eig_mult * ev[2];                                       // impl:345
+    if (ev[0] < minev) {
+      ev[0] = minev;
+      if (ev[1] < minev) ev[1] = minev;
+      double VD[9], Vi[9];
+      for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) VD[a * 3 + c] = Vm[a * 3 + c] * ev[c];
+      ndtm::mat3_inverse(Vm, Vi);
+      ndtm::mat3_mul(VD, Vi, cov);                                               // impl:355
+    }
+    if (pca) {                                                                   // pca impl:364-397
+      double s0 = sqrt(ev[0]), s1 = sqrt(ev[1]), s2 = sqrt(ev[2]);
+      double f0 = (s2 - s1) / s2, f1 = (s1 - s0) / s2, f2 = s0 / s2;
+      int label = 1;
+      double fm = f0;
+      if (f1 > fm) { fm = f1; label = 2; }
+      if (f2 > fm) { label = 3; }
+      double scale = (label == 2) ? 1.25 : ((label == 1) ? 0.75 : 1.0);
+      double d2d = scale * sqrt((mu[0] * mu[0] + mu[1] * mu[1]) + mu[2] * mu[2]);
+      r.weight = (int)d2d;                                                       // getDimension2d() returns int (pca.h:222-226)
+    }
+    double ic[9];
+    ndtm::mat3_inverse(cov, ic);                                                 // impl:359
+    bool bad = false;
+    for (int a = 0; a < 9; a++) { if (!isfinite(ic[a])) bad = true; r.icov[a] = (float)ic[a]; }
+    if (bad) { n_out = -1; r.weight = VOX_DEAD; }                                // impl:360-364
+  }
+  recs[g.rec_off + id] = r;
+  vox_idx[g.rec_off + id] = (int)cell;
+  vox_n[g.rec_off + id] = n_out;
+}
+
+// ------------------------------------------------------------------------------------ derivative sweep
+// One (point, voxel) evaluation: updateDerivatives (ndt_omp_impl2.hpp:566-619) with the Jacobian /
+// Hessian patterns of computePointDerivatives_AngleAxisd (impl2:503-532) folded in (J and Hp are never
+// materialised).  f32 ops single, left to right; f64 accumulation.  `w` = weight multiplier
+// (ndt_pca compounding, applied as a suffix product; 1.0 for ndt_omp).
+__device__ __forceinline__ void eval_hit(const float u[3], const float r[3], const float C[9],
+                                         const double d1, const float d2f, const double w, double acc[NACC]) {
+  float y[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) y[j] = (u[0] * C[j] + u[1] * C[3 + j]) + u[2] * C[6 + j];
+  const float qf = (u[0] * y[0] + u[1] * y[1]) + u[2] * y[2];
+  const float e0 = (float)exp((double)((-d2f * qf) * 0.5f));                     // impl2:581
+  const float s_inc = (float)(-d1 * (double)e0);                                 // impl2:583
+  const float e1 = d2f * e0;                                                     // impl2:585
+  if (e1 > 1.f || e1 < 0.f || e1 != e1) return;                                  // impl2:588-589
+  const float e = (float)((double)e1 * d1);                                      // impl2:592
+  float CJ[3][6];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    CJ[a][0] = C[a * 3 + 0]; CJ[a][1] = C[a * 3 + 1]; CJ[a][2] = C[a * 3 + 2];
+    CJ[a][3] = C[a * 3 + 1] * (-r[2]) + C[a * 3 + 2] * r[1];
+    CJ[a][4] = C[a * 3 + 0] * r[2] + C[a * 3 + 2] * (-r[0]);
+    CJ[a][5] = C[a * 3 + 0] * (-r[1]) + C[a * 3 + 1] * r[0];
+  }
+  float v[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) v[k] = (u[0] * CJ[0][k] + u[1] * CJ[1][k]) + u[2] * CJ[2][k];   // impl2:595
+  acc[0] += w * (double)s_inc;
+#pragma unroll
+  for (int k = 0; k < 6; k++) acc[1 + k] += w * (double)(e * v[k]);                           // impl2:597
+  float Z[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j < 6; j++) Z[i][j] = 0.f;
+  Z[3][3] = y[1] * (-r[1]) + y[2] * (-r[2]);
+  Z[4][3] = y[0] * r[1];
+  Z[5][3] = y[0] * r[2];
+  Z[3][4] = y[1] * r[0];
+  Z[4][4] = y[0] * (-r[0]) + y[2] * (-r[2]);
+  Z[5][4] = y[1] * r[2];
+  Z[3][5] = y[2] * r[0];
+  Z[4][5] = y[2] * r[1];
+  Z[5][5] = y[0] * (-r[0]) + y[1] * (-r[1]);
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      // JCJ[j][i] = (J^T CJ)(j,i)
+      float jcj;
+      if (j < 3) jcj = CJ[j][i];
+      else if (j == 3) jcj = (-r[2]) * CJ[1][i] + r[1] * CJ[2][i];
+      else if (j == 4) jcj = r[2] * CJ[0][i] + (-r[0]) * CJ[2][i];
+      else jcj = (-r[1]) * CJ[0][i] + r[0] * CJ[1][i];
+      const float h = e * ((((-d2f) * v[i]) * v[j] + Z[i][j]) + jcj);                         // impl2:611-613
+      acc[7 + i * 6 + j] += w * (double)h;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(SWEEP_THREADS)
+k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict__ st,
+        const GridDesc* __restrict__ gd, const BitWord* __restrict__ words, const VoxelRec* __restrict__ recs,
+        double* partials, int chunks_per_pair, SweepConst sc) {
+  const int b = blockIdx.y;
+  const PairState& S = st[b];
+  if (S.phase == PH_DONE) return;
+  const int n = S.n_src;
+  const GridDesc& g = gd[b];
+  const float* X = src + (size_t)b * 3 * pitch;
+  const BitWord* W = words + g.word_off;
+  const VoxelRec* R = recs + g.rec_off;
+  const bool grid_ok = (g.status == GRID_OK);
+  float T[12], Rj[9];
+#pragma unroll
+  for (int a = 0; a < 12; a++) T[a] = S.T[a];
+#pragma unroll
+  for (int a = 0; a < 9; a++) Rj[a] = S.Rj[a];
+  __shared__ double red[SWEEP_THREADS / 64][NACC];
+
+  for (int chunk = blockIdx.x; chunk < chunks_per_pair; chunk += gridDim.x) {
+    double acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; a++) acc[a] = 0.0;
+    const int base = chunk * CHUNK_PTS;
+    if (base < n && grid_ok) {
+#pragma unroll 1
+      for (int k = 0; k < CHUNK_PTS / SWEEP_THREADS; k++) {
+        const int i = base + k * SWEEP_THREADS + threadIdx.x;
+        if (i >= n) continue;
+        const float px = X[i], py = X[pitch + i], pz = X[2 * pitch + i];
+        if (!finite3(px, py, pz)) continue;
+        // PCL 1.8 transformPointCloud scalar form
+        float xt[3], r[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          xt[a] = ((T[a * 4 + 0] * px + T[a * 4 + 1] * py) + T[a * 4 + 2] * pz) + T[a * 4 + 3];
+          r[a] = (Rj[a * 3 + 0] * px + Rj[a * 3 + 1] * py) + Rj[a * 3 + 2] * pz;               // impl2:507-508
+        }
+        // getNeighborhoodAtPoint (voxel_grid_covariance_omp_impl.hpp:379-399)
+        const int c0 = (int)floorf(xt[0] / g.leaf), c1 = (int)floorf(xt[1] / g.leaf), c2 = (int)floorf(xt[2] / g.leaf);
+        // pass 1: collect hits (needed up front for the ndt_pca suffix-product weights)
+        unsigned hit_id[26];
+        double hit_w[26];
+        int nh = 0;
+#pragma unroll 1
+        for (int q = 0; q < sc.K; q++) {
+          const int a0 = c0 + sc.off[q][0], a1 = c1 + sc.off[q][1], a2 = c2 + sc.off[q][2];
+          if (a0 < g.min_b[0] || a0 > g.max_b[0] || a1 < g.min_b[1] || a1 > g.max_b[1] || a2 < g.min_b[2] || a2 > g.max_b[2]) continue;
+          const unsigned cell = (unsigned)((a0 - g.min_b[0]) + (a1 - g.min_b[1]) * g.mul1 + (a2 - g.min_b[2]) * g.mul2);
+          const BitWord bw = W[cell >> 6];
+          const unsigned long long bit = 1ull << (cell & 63);
+          if (!(bw.bits & bit)) continue;
+          const unsigned id = bw.prefix + (unsigned)__popcll(bw.bits & (bit - 1ull));
+          const int wi = R[id].weight;
+          if (wi == VOX_DEAD) continue;                         // nr_points == -1: not a neighbour (impl:395)
+          hit_id[nh] = id;
+          hit_w[nh] = (double)wi;
+          nh++;
+        }
+        acc[43] += (double)nh;
+        // ndt_pca multiplies the running per-point sums by the weight of the current and of every later hit
+        // (ndt_pca_impl2.hpp:295-296) => hit q carries the product of weights q..last (exact: small integers).
+        if (sc.pca) { double suf = 1.0; for (int q = nh - 1; q >= 0; q--) { suf *= hit_w[q]; hit_w[q] = suf; } }
+        // pass 2: evaluate
+#pragma unroll 1
+        for (int q = 0; q < nh; q++) {
+          const VoxelRec& vr = R[hit_id[q]];
+          float u[3], Cf[9];
+#pragma unroll
+          for (int a = 0; a < 3; a++) u[a] = (float)((double)xt[a] - vr.mean[a]);               // impl2:276-279, 574
+#pragma unroll
+          for (int a = 0; a < 9; a++) Cf[a] = vr.icov[a];
+          eval_hit(u, r, Cf, sc.d1, sc.d2f, sc.pca ? hit_w[q] : 1.0, acc);
+        }
+      }
+    }
+    // fixed-order block reduction: wave butterfly, then waves 0..3
+#pragma unroll
+    for (int a = 0; a < NACC; a++) {
+      double v = acc[a];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      acc[a] = v;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int a = 0; a < NACC; a++) red[threadIdx.x >> 6][a] = acc[a];
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+      double v = red[0][threadIdx.x];
+      for (int wv = 1; wv < SWEEP_THREADS / 64; wv++) v += red[wv][threadIdx.x];
+      partials[((size_t)b * chunks_per_pair + chunk) * NACC + threadIdx.x] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ Newton control
+__device__ void finalize_pair(PairState& S, mi355ndt_result* res, int converged) {
+  S.converged = converged;
+  S.phase = PH_DONE;
+  S.trans_probability = S.score / (double)S.n_src;                                // impl2:149 / 187
+  mi355ndt_result o;
+  for (int a = 0; a < 16; a++) o.final_colmajor[a] = S.final_cm[a];
+  o.trans_probability = S.trans_probability;
+  o.score = S.score;
+  o.iterations = S.it;
+  o.converged = converged;
+  o.sweeps = S.sweeps;
+  o.status = (S.grid_status == GRID_OK || S.grid_status == GRID_EMPTY) ? MI355NDT_OK : MI355NDT_ERR_GRID;
+  o.hits_last = S.hits;
+  *res = o;
+}
+
+// p = SE3(R,t).log(); first sweep moves the cloud by the caller's f32 guess itself (impl2:102-129)
+__global__ void k_init_state(PairState* st, const float* __restrict__ guess_cm, const int* __restrict__ src_cnt,
+                             const GridDesc* __restrict__ gd, int n_pairs) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_pairs) return;
+  PairState& S = st[b];
+  const float* G = guess_cm + (size_t)b * 16;
+  double R[9], t[3];
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) { S.T[r * 4 + c] = G[c * 4 + r]; R[r * 3 + c] = (double)G[c * 4 + r]; }
+    S.T[r * 4 + 3] = G[12 + r];
+    t[r] = (double)G[12 + r];
+  }
+  for (int a = 0; a < 16; a++) S.final_cm[a] = G[a];
+  ndtm::se3_log(ndtm::se3_from_Rt(R, t), S.p);
+  float Tdummy[12];
+  ndtm::pose_to_f32(S.p, Tdummy, S.Rj);
+  S.it = 0; S.phase = PH_SWEEP0; S.converged = 0; S.sweeps = 1; S.a_t = 0; S.hits = 0; S.score = 0;
+  S.n_src = src_cnt[b];
+  S.grid_status = gd[b].status;
+}
+
+// explicit sweep pose (parity hooks)
+__global__ void k_set_pose(PairState* st, int b, const float* __restrict__ T_cm, const float* __restrict__ Rj, const int* __restrict__ src_cnt,
+                           const GridDesc* __restrict__ gd) {
+  PairState& S = st[b];
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) S.T[r * 4 + c] = T_cm[c * 4 + r];
+  for (int a = 0; a < 9; a++) S.Rj[a] = Rj[a];
+  S.phase = PH_SWEEP0; S.n_src = src_cnt[b]; S.grid_status = gd[b].status; S.it = 0; S.sweeps = 1;
+}
+__global__ void k_set_pose_p(PairState* st, int b, const double* __restrict__ p, const int* __restrict__ src_cnt, const GridDesc* __restrict__ gd) {
+  PairState& S = st[b];
+  double pp[6];
+  for (int a = 0; a < 6; a++) pp[a] = p[a];
+  ndtm::pose_to_f32(pp, S.T, S.Rj);
+  S.phase = PH_SWEEP0; S.n_src = src_cnt[b]; S.grid_status = gd[b].status; S.it = 0; S.sweeps = 1;
+}
+
+// One wave per pair: fixed-order reduction of the chunk partials, then the body of the while loop of
+// computeTransformation (impl2:131-183) with computeStepLengthMT's live prefix (impl2:846-907).
+__global__ void __launch_bounds__(64)
+k_update(PairState* st, const double* __restrict__ partials, int chunks_per_pair, mi355ndt_result* results,
+         int* active_counter, unsigned long long* hits_total, double step_max, double eps, int max_iterations, int reduce_only) {
+  const int b = blockIdx.x;
+  PairState& S = st[b];
+  if (S.phase == PH_DONE) return;
+  const int lane = threadIdx.x;
+  const int nchunks = (S.n_src + CHUNK_PTS - 1) / CHUNK_PTS;
+  if (lane < NACC) {
+    double v = 0.0;
+    const double* P = partials + (size_t)b * chunks_per_pair * NACC + lane;
+    for (int c = 0; c < nchunks; c++) v += P[(size_t)c * NACC];                  // impl2:298-302 (fixed order)
+    if (lane == 0) S.score = v;
+    else if (lane < 7) S.g[lane - 1] = v;
+    else if (lane < 43) S.H[lane - 7] = v;
+    else { S.hits = (long long)v; if (hits_total) atomicAdd(hits_total, (unsigned long long)v); }
+  }
+  __syncthreads();
+  if (lane != 0 || reduce_only) return;
+
+  const double step_min = eps / 2;
+  if (S.phase == PH_STEP) {
+    double dp[6], pn[6];
+    for (int a = 0; a < 6; a++) dp[a] = S.dir[a] * S.a_t;                        // impl2:156
+    ndtm::se3_log(ndtm::se3_mul(ndtm::se3_exp(dp), ndtm::se3_exp(S.p)), pn);     // impl2:166
+    for (int a = 0; a < 6; a++) S.p[a] = pn[a];
+    const bool conv = (S.it > max_iterations) || (S.it && (fabs(S.a_t) < eps));  // impl2:175-179
+    S.it++;
+    if (conv) { finalize_pair(S, &results[b], 1); return; }
+  }
+  for (int guard = 0; guard < 4; guard++) {
+    double neg[6], d[6];
+    for (int a = 0; a < 6; a++) neg[a] = -S.g[a];
+    ndtm::svd_solve6(S.H, neg, d);                                               // impl2:138-140
+    double nrm = 0;
+    for (int a = 0; a < 6; a++) nrm += d[a] * d[a];
+    nrm = sqrt(nrm);
+    if (nrm == 0 || nrm != nrm) { finalize_pair(S, &results[b], nrm == nrm); return; }   // impl2:147-152
+    for (int a = 0; a < 6; a++) d[a] /= nrm;                                     // impl2:154
+    double dphi0 = 0;
+    for (int a = 0; a < 6; a++) dphi0 += S.g[a] * d[a];
+    dphi0 = -dphi0;                                                              // impl2:849
+    if (dphi0 >= 0 && dphi0 == 0) {
+      // impl2:856-857: step length 0, nothing re-evaluated
+      double z[6] = {0, 0, 0, 0, 0, 0}, pn[6];
+      ndtm::se3_log(ndtm::se3_mul(ndtm::se3_exp(z), ndtm::se3_exp(S.p)), pn);
+      for (int a = 0; a < 6; a++) S.p[a] = pn[a];
+      const bool conv = (S.it > max_iterations) || (S.it && (0.0 < eps));
+      S.it++;
+      if (conv) { finalize_pair(S, &results[b], 1); return; }
+      continue;
+    }
+    if (dphi0 >= 0) { for (int a = 0; a < 6; a++) d[a] = -d[a]; }                // impl2:861-862
+    double a_t = nrm;
+    a_t = a_t < step_max ? a_t : step_max;                                       // impl2:890-892
+    a_t = a_t > step_min ? a_t : step_min;
+    double xt[6];
+    for (int a = 0; a < 6; a++) { S.dir[a] = d[a]; xt[a] = S.p[a] + d[a] * a_t; }   // impl2:894
+    S.a_t = a_t;
+    ndtm::pose_to_f32(xt, S.T, S.Rj);                                            // impl2:900
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 4; c++) S.final_cm[c * 4 + r] = S.T[r * 4 + c];
+      S.final_cm[r * 4 + 3] = 0.f;
+    }
+    S.final_cm[15] = 1.f;
+    S.phase = PH_STEP;
+    S.sweeps++;
+    atomicAdd(active_counter, 1);
+    return;
+  }
+  finalize_pair(S, &results[b], 1);
+}
+
+// output cloud of align(): source moved by final_transformation_ (f32)
+__global__ void k_transform(const float* __restrict__ src, size_t pitch, const PairState* __restrict__ st, int b, float* out, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* X = src + (size_t)b * 3 * pitch;
+  const float* F = st[b].final_cm;
+  float px = X[i], py = X[pitch + i], pz = X[2 * pitch + i];
+  for (int a = 0; a < 3; a++) out[(size_t)a * n + i] = ((F[0 * 4 + a] * px + F[1 * 4 + a] * py) + F[2 * 4 + a] * pz) + F[3 * 4 + a];
+}
+
+// ------------------------------------------------------------------------------------ host side
+struct mi355ndt_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  mi355ndt_params prm;
+  std::string err;
+
+  int n_pairs = 0, cap_pairs = 0;
+  size_t tgt_pitch = 0, src_pitch = 0;          // geometry in use
+  size_t own_tgt_pitch = 0, own_src_pitch = 0;  // geometry of the owned buffers
+  int own_tgt_pairs = 0, own_src_pairs = 0;
+  float *d_tgt_own = nullptr, *d_src_own = nullptr;
+  const float *d_tgt = nullptr, *d_src = nullptr;
+  int *d_tgt_cnt = nullptr, *d_src_cnt = nullptr;
+  std::vector<int> h_tgt_cnt, h_src_cnt;
+  bool targets_built = false, have_target = false, have_source = false;
+
+  // build workspace
+  int* d_minmax = nullptr;
+  GridDesc* d_grid = nullptr;
+  unsigned *d_nwords = nullptr, *d_word_off = nullptr;
+  unsigned long long *d_keys_a = nullptr, *d_keys_b = nullptr;
+  unsigned *d_vals_a = nullptr, *d_vals_b = nullptr;
+  void* d_tmp = nullptr; size_t tmp_bytes = 0;
+  size_t keys_cap = 0;
+  BitWord* d_words = nullptr; size_t words_cap = 0;
+  VoxelRec* d_recs = nullptr; int *d_vox_idx = nullptr, *d_vox_n = nullptr;
+  size_t recs_per_pair = 0, recs_cap = 0;
+  unsigned* h_pin_u = nullptr;                  // pinned scratch (2 unsigned)
+
+  // align workspace
+  PairState* d_state = nullptr;
+  double* d_partials = nullptr; size_t partials_cap = 0;
+  int chunks_per_pair = 0;
+  float* d_guess = nullptr;
+  mi355ndt_result* d_results = nullptr;
+  int* d_active = nullptr;                      // per-round active counters
+  int* h_pin_active = nullptr;
+  unsigned long long* d_hits = nullptr;         // (point,voxel) evaluations, all sweeps
+  float* d_hook = nullptr;                      // 16 + 9 floats, 6 doubles
+  float* d_aligned = nullptr; size_t aligned_cap = 0;
+  std::vector<float> h_stage;
+
+  // profiling
+  bool prof = false;
+  mi355ndt_profile P{};
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_sweep, ev_update, ev_build;
+  std::vector<double> ev_sweep_bytes_static;    // N*(12+4K) part per launch (hits added at collection)
+  hipEvent_t ev_pool_unused = nullptr;
+};
+
+#define HIPCHK(h, call)                                                                          \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                              \
+      return MI355NDT_ERR_HIP;                                                                   \
+    }                                                                                            \
+  } while (0)
+
+static int ceil_log2(unsigned v) { int b = 0; while ((1u << b) < v) b++; return b; }
+
+template <typename T>
+static hipError_t grow(T*& p, size_t& cap, size_t need) {
+  if (need <= cap) return hipSuccess;
+  if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; }
+  hipError_t e = hipMalloc((void**)&p, need * sizeof(T));
+  if (e == hipSuccess) cap = need;
+  else cap = 0;
+  return e;
+}
+
+static void build_offsets(int mode, SweepConst& sc) {
+  // DIRECT7: voxel_grid_covariance_omp_impl.hpp:423-430; DIRECT1: impl:441;
+  // DIRECT26: pcl::getAllNeighborCellIndices() (PCL 1.8 voxel_grid.h): 13 half offsets, then their negation
+  memset(sc.off, 0, sizeof sc.off);
+  if (mode == MI355NDT_DIRECT1) { sc.K = 1; return; }
+  if (mode == MI355NDT_DIRECT7) {
+    static const int o7[7][3] = {{0,0,0},{1,0,0},{-1,0,0},{0,1,0},{0,-1,0},{0,0,1},{0,0,-1}};
+    memcpy(sc.off, o7, sizeof o7);
+    sc.K = 7;
+    return;
+  }
+  int k = 0;
+  for (int i = -1; i < 2; i++) for (int j = -1; j < 2; j++) { sc.off[k][0] = i; sc.off[k][1] = j; sc.off[k][2] = -1; k++; }
+  for (int i = -1; i < 2; i++) { sc.off[k][0] = i; sc.off[k][1] = -1; sc.off[k][2] = 0; k++; }
+  sc.off[k][0] = -1; sc.off[k][1] = 0; sc.off[k][2] = 0; k++;
+  for (int i = 0; i < 13; i++) for (int a = 0; a < 3; a++) sc.off[13 + i][a] = -sc.off[i][a];
+  sc.K = 26;
+}
+
+static void gauss_constants(const mi355ndt_params& p, double& d1, double& d2) {
+  // ndt_omp_impl2.hpp:93-100
+  double c1 = 10 * (1 - p.outlier_ratio);
+  double c2 = p.outlier_ratio / pow((double)p.resolution, 3);
+  double d3 = -log(c2);
+  d1 = -log(c1 + c2) - d3;
+  d2 = -2 * log((-log(c1 * exp(-0.5) + c2) - d3) / d1);
+}
+
+static int check_params(const mi355ndt_params& p) {
+  if (!(p.resolution > 0) || !std::isfinite(p.resolution)) return MI355NDT_ERR_BAD_ARG;
+  if (p.neighbor_mode < 0 || p.neighbor_mode > 3) return MI355NDT_ERR_BAD_ARG;
+  if (p.variant < 0 || p.variant > 1) return MI355NDT_ERR_BAD_ARG;
+  if (p.min_points_per_voxel < 1) return MI355NDT_ERR_BAD_ARG;
+  if (p.max_iterations < 0) return MI355NDT_ERR_BAD_ARG;
+  return MI355NDT_OK;
+}
+
+extern "C" {
+
+const char* mi355ndt_version(void) { return "mi355ndt 0.1 (gfx950)"; }
+
+int mi355ndt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int mi355ndt_default_params(mi355ndt_params* p) {
+  if (!p) return MI355NDT_ERR_BAD_ARG;
+  p->resolution = 1.0f;
+  p->step_size = 0.1;
+  p->outlier_ratio = 0.55;
+  p->trans_epsilon = 0.1;
+  p->max_iterations = 35;
+  p->neighbor_mode = MI355NDT_DIRECT7;
+  p->variant = MI355NDT_VARIANT_OMP;
+  p->min_points_per_voxel = 6;
+  p->min_covar_eigvalue_mult = 0.01;
+  return MI355NDT_OK;
+}
+
+int mi355ndt_create(const mi355ndt_params* params, int device, mi355ndt_handle** out) {
+  if (!out) return MI355NDT_ERR_BAD_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MI355NDT_ERR_NO_DEVICE;
+  if (device < 0 || device >= n) return MI355NDT_ERR_BAD_ARG;
+  mi355ndt_params p;
+  mi355ndt_default_params(&p);
+  if (params) p = *params;
+  int rc = check_params(p);
+  if (rc) return rc;
+  mi355ndt_handle* h = new mi355ndt_handle();
+  h->device = device;
+  h->prm = p;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return MI355NDT_ERR_HIP;
+  }
+  if (hipHostMalloc((void**)&h->h_pin_u, 4 * sizeof(unsigned)) != hipSuccess ||
+      hipHostMalloc((void**)&h->h_pin_active, 128 * sizeof(int)) != hipSuccess ||
+      hipMalloc((void**)&h->d_active, 128 * sizeof(int)) != hipSuccess ||
+      hipMalloc((void**)&h->d_hits, sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc((void**)&h->d_hook, 64 * sizeof(double)) != hipSuccess) {
+    delete h;
+    return MI355NDT_ERR_HIP;
+  }
+  *out = h;
+  return MI355NDT_OK;
+}
+
+int mi355ndt_destroy(mi355ndt_handle* h) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  void* ptrs[] = {h->d_tgt_own, h->d_src_own, h->d_tgt_cnt, h->d_src_cnt, h->d_minmax, h->d_grid, h->d_nwords, h->d_word_off,
+                  h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, h->d_tmp, h->d_words, h->d_recs, h->d_vox_idx, h->d_vox_n,
+                  h->d_state, h->d_partials, h->d_guess, h->d_results, h->d_active, h->d_hook, h->d_aligned, h->d_hits};
+  for (void* p : ptrs) if (p) hipFree(p);
+  if (h->h_pin_u) hipHostFree(h->h_pin_u);
+  if (h->h_pin_active) hipHostFree(h->h_pin_active);
+  for (auto& e : h->ev_sweep) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  for (auto& e : h->ev_update) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  for (auto& e : h->ev_build) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return MI355NDT_OK;
+}
+
+int mi355ndt_get_params(const mi355ndt_handle* h, mi355ndt_params* out) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (!out) return MI355NDT_ERR_BAD_ARG;
+  *out = h->prm;
+  return MI355NDT_OK;
+}
+
+int mi355ndt_set_stream(mi355ndt_handle* h, void* s) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  if (s) {
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    h->stream = (hipStream_t)s;
+    h->own_stream = false;
+  } else if (!h->own_stream) {
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+  }
+  return MI355NDT_OK;
+}
+
+const char* mi355ndt_last_error(const mi355ndt_handle* h) { return h ? h->err.c_str() : "bad handle"; }
+
+int mi355ndt_synchronize(mi355ndt_handle* h) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MI355NDT_OK;
+}
+
+int mi355ndt_batch_size(const mi355ndt_handle* h) { return h ? h->n_pairs : MI355NDT_ERR_BAD_HANDLE; }
+
+// ---- capacity management ----------------------------------------------------------------------
+static int ensure_pair_arrays(mi355ndt_handle* h, int n_pairs) {
+  if (n_pairs <= h->cap_pairs) return MI355NDT_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  auto re = [&](void** p, size_t bytes) -> hipError_t {
+    if (*p) { hipError_t e = hipFree(*p); *p = nullptr; if (e != hipSuccess) return e; }
+    return hipMalloc(p, bytes);
+  };
+  HIPCHK(h, re((void**)&h->d_tgt_cnt, n_pairs * sizeof(int)));
+  HIPCHK(h, re((void**)&h->d_src_cnt, n_pairs * sizeof(int)));
+  HIPCHK(h, re((void**)&h->d_minmax, n_pairs * 6 * sizeof(int)));
+  HIPCHK(h, re((void**)&h->d_grid, n_pairs * sizeof(GridDesc)));
+  HIPCHK(h, re((void**)&h->d_nwords, (n_pairs + 1) * sizeof(unsigned)));
+  HIPCHK(h, re((void**)&h->d_word_off, (n_pairs + 1) * sizeof(unsigned)));
+  HIPCHK(h, re((void**)&h->d_state, n_pairs * sizeof(PairState)));
+  HIPCHK(h, re((void**)&h->d_guess, n_pairs * 16 * sizeof(float)));
+  HIPCHK(h, re((void**)&h->d_results, n_pairs * sizeof(mi355ndt_result)));
+  HIPCHK(h, hipMemsetAsync(h->d_grid, 0, n_pairs * sizeof(GridDesc), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_state, 0, n_pairs * sizeof(PairState), h->stream));
+  h->cap_pairs = n_pairs;
+  h->h_tgt_cnt.assign(n_pairs, 0);
+  h->h_src_cnt.assign(n_pairs, 0);
+  return MI355NDT_OK;
+}
+
+static int alloc_side(mi355ndt_handle* h, bool tgt, int n_pairs, size_t pitch) {
+  float*& buf = tgt ? h->d_tgt_own : h->d_src_own;
+  size_t& own_pitch = tgt ? h->own_tgt_pitch : h->own_src_pitch;
+  int& own_pairs = tgt ? h->own_tgt_pairs : h->own_src_pairs;
+  if (buf && own_pitch == pitch && own_pairs == n_pairs) return MI355NDT_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (buf) { HIPCHK(h, hipFree(buf)); buf = nullptr; }
+  HIPCHK(h, hipMalloc((void**)&buf, (size_t)n_pairs * 3 * pitch * sizeof(float)));
+  own_pitch = pitch; own_pairs = n_pairs;
+  std::vector<int>& cnt = tgt ? h->h_tgt_cnt : h->h_src_cnt;
+  std::fill(cnt.begin(), cnt.end(), 0);
+  if (tgt) { h->targets_built = false; h->have_target = false; } else { h->have_source = false; }
+  return MI355NDT_OK;
+}
+
+int mi355ndt_batch_reserve(mi355ndt_handle* h, int n_pairs, size_t max_tgt, size_t max_src) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (n_pairs <= 0 || max_tgt == 0 || max_src == 0 || n_pairs > (1 << 20)) return MI355NDT_ERR_BAD_ARG;
+  if (max_tgt >= (1u << 31) || max_src >= (1u << 31)) return MI355NDT_ERR_BAD_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  // pitches padded to 64 floats so every row starts 256-B aligned
+  size_t tp = (max_tgt + 63) & ~(size_t)63, sp = (max_src + 63) & ~(size_t)63;
+  int rc = ensure_pair_arrays(h, n_pairs);
+  if (rc) return rc;
+  if (n_pairs != h->n_pairs || h->d_tgt != h->d_tgt_own || h->d_src != h->d_src_own) {
+    std::fill(h->h_tgt_cnt.begin(), h->h_tgt_cnt.end(), 0);
+    std::fill(h->h_src_cnt.begin(), h->h_src_cnt.end(), 0);
+    h->targets_built = false; h->have_target = false; h->have_source = false;
+  }
+  rc = alloc_side(h, true, n_pairs, tp);
+  if (rc) return rc;
+  rc = alloc_side(h, false, n_pairs, sp);
+  if (rc) return rc;
+  h->n_pairs = n_pairs;
+  h->tgt_pitch = tp; h->src_pitch = sp;
+  h->d_tgt = h->d_tgt_own; h->d_src = h->d_src_own;
+  return MI355NDT_OK;
+}
+
+static int upload_cloud(mi355ndt_handle* h, float* d_base, size_t pitch, int pair, const void* pts, size_t n, size_t stride) {
+  if (!pts && n) return MI355NDT_ERR_BAD_ARG;
+  if (stride < 12 || n > pitch) return MI355NDT_ERR_BAD_ARG;
+  h->h_stage.resize(3 * pitch);
+  const unsigned char* p = (const unsigned char*)pts;
+  float* sx = h->h_stage.data(); float* sy = sx + pitch; float* sz = sy + pitch;
+  for (size_t i = 0; i < n; i++) {
+    float v[3];
+    memcpy(v, p + i * stride, 12);
+    sx[i] = v[0]; sy[i] = v[1]; sz[i] = v[2];
+  }
+  for (size_t i = n; i < pitch; i++) sx[i] = sy[i] = sz[i] = 0.f;
+  HIPCHK(h, hipMemcpyAsync(d_base + (size_t)pair * 3 * pitch, h->h_stage.data(), 3 * pitch * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));   // staging buffer is reused
+  return MI355NDT_OK;
+}
+
+int mi355ndt_batch_set_target(mi355ndt_handle* h, int pair, const void* pts, size_t n, size_t stride) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (pair < 0 || pair >= h->n_pairs || h->d_tgt != h->d_tgt_own) return MI355NDT_ERR_BAD_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = upload_cloud(h, h->d_tgt_own, h->tgt_pitch, pair, pts, n, stride);
+  if (rc) return rc;
+  h->h_tgt_cnt[pair] = (int)n;
+  h->targets_built = false;
+  h->have_target = true;
+  return MI355NDT_OK;
+}
+
+int mi355ndt_batch_set_source(mi355ndt_handle* h, int pair, const void* pts, size_t n, size_t stride) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (pair < 0 || pair >= h->n_pairs || h->d_src != h->d_src_own) return MI355NDT_ERR_BAD_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = upload_cloud(h, h->d_src_own, h->src_pitch, pair, pts, n, stride);
+  if (rc) return rc;
+  h->h_src_cnt[pair] = (int)n;
+  h->have_source = true;
+  return MI355NDT_OK;
+}
+
+int mi355ndt_batch_bind_device(mi355ndt_handle* h, int n_pairs, const float* d_t, const int* tc, size_t tp,
+                               const float* d_s, const int* scnt, size_t sp) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (n_pairs <= 0 || !d_t || !d_s || !tc || !scnt || tp == 0 || sp == 0 || n_pairs > (1 << 20)) return MI355NDT_ERR_BAD_ARG;
+  if (tp >= (1u << 31) || sp >= (1u << 31)) return MI355NDT_ERR_BAD_ARG;
+  for (int b = 0; b < n_pairs; b++) if (tc[b] < 0 || (size_t)tc[b] > tp || scnt[b] < 0 || (size_t)scnt[b] > sp) return MI355NDT_ERR_BAD_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = ensure_pair_arrays(h, n_pairs);
+  if (rc) return rc;
+  h->n_pairs = n_pairs;
+  h->d_tgt = d_t; h->d_src = d_s;
+  h->tgt_pitch = tp; h->src_pitch = sp;
+  for (int b = 0; b < n_pairs; b++) { h->h_tgt_cnt[b] = tc[b]; h->h_src_cnt[b] = scnt[b]; }
+  h->targets_built = false;
+  h->have_target = h->have_source = true;
+  return MI355NDT_OK;
+}
+
+// ---- profiling helpers ------------------------------------------------------------------------
+static hipError_t ev_begin(mi355ndt_handle* h, std::vector<std::pair<hipEvent_t, hipEvent_t>>& v) {
+  hipEvent_t a, b;
+  hipError_t e = hipEventCreate(&a); if (e != hipSuccess) return e;
+  e = hipEventCreate(&b); if (e != hipSuccess) return e;
+  v.push_back({a, b});
+  return hipEventRecord(a, h->stream);
+}
+static hipError_t ev_end(mi355ndt_handle* h, std::vector<std::pair<hipEvent_t, hipEvent_t>>& v) {
+  return hipEventRecord(v.back().second, h->stream);
+}
+static void ev_collect(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, double& ms, long long& n) {
+  for (auto& e : v) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, e.first, e.second) == hipSuccess) { ms += t; n++; }
+    hipEventDestroy(e.first); hipEventDestroy(e.second);
+  }
+  v.clear();
+}
+
+int mi355ndt_profile_enable(mi355ndt_handle* h, int on) { if (!h) return MI355NDT_ERR_BAD_HANDLE; h->prof = on != 0; return MI355NDT_OK; }
+int mi355ndt_profile_reset(mi355ndt_handle* h) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  double d; long long n;
+  ev_collect(h->ev_sweep, d, n); ev_collect(h->ev_update, d, n); ev_collect(h->ev_build, d, n);
+  h->P = mi355ndt_profile{};
+  return MI355NDT_OK;
+}
+int mi355ndt_profile_get(mi355ndt_handle* h, mi355ndt_profile* out) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (!out) return MI355NDT_ERR_BAD_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  ev_collect(h->ev_sweep, h->P.sweep_ms, h->P.sweep_launches);
+  ev_collect(h->ev_update, h->P.update_ms, h->P.update_launches);
+  ev_collect(h->ev_build, h->P.build_ms, h->P.build_launches);
+  *out = h->P;
+  return MI355NDT_OK;
+}
+
+// ---- target build -----------------------------------------------------------------------------
+int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (h->n_pairs <= 0 || !h->d_tgt) return MI355NDT_ERR_STATE;
+  if (h->prm.neighbor_mode == MI355NDT_KDTREE) return MI355NDT_ERR_UNSUPPORTED;
+  HIPCHK(h, hipSetDevice(h->device));
+  const int B = h->n_pairs;
+  const size_t pitch = h->tgt_pitch;
+  const size_t total = (size_t)B * pitch;
+  hipStream_t s = h->stream;
+  HIPCHK(h, hipMemcpyAsync(h->d_tgt_cnt, h->h_tgt_cnt.data(), B * sizeof(int), hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipStreamSynchronize(s));   // h_tgt_cnt is pageable
+
+  // workspace
+  if (total > h->keys_cap) {
+    size_t c1 = h->keys_cap, c2 = h->keys_cap, c3 = h->keys_cap, c4 = h->keys_cap;
+    HIPCHK(h, grow(h->d_keys_a, c1, total)); HIPCHK(h, grow(h->d_keys_b, c2, total));
+    HIPCHK(h, grow(h->d_vals_a, c3, total)); HIPCHK(h, grow(h->d_vals_b, c4, total));
+    h->keys_cap = total;
+  }
+  const int minpts = h->prm.min_points_per_voxel;
+  const size_t rpp = pitch / (size_t)minpts + 1;
+  if ((size_t)B * rpp > h->recs_cap || rpp != h->recs_per_pair) {
+    size_t need = (size_t)B * rpp, c1 = 0, c2 = 0, c3 = 0;
+    if (h->d_recs) { HIPCHK(h, hipFree(h->d_recs)); h->d_recs = nullptr; }
+    if (h->d_vox_idx) { HIPCHK(h, hipFree(h->d_vox_idx)); h->d_vox_idx = nullptr; }
+    if (h->d_vox_n) { HIPCHK(h, hipFree(h->d_vox_n)); h->d_vox_n = nullptr; }
+    HIPCHK(h, grow(h->d_recs, c1, need)); HIPCHK(h, grow(h->d_vox_idx, c2, need)); HIPCHK(h, grow(h->d_vox_n, c3, need));
+    h->recs_cap = need; h->recs_per_pair = rpp;
+  }
+  const int end_bit = IDX_BITS + ceil_log2((unsigned)B);
+  size_t need_tmp = 0, need_scan = 0;
+  HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(nullptr, need_tmp, h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, (int)total, 0, end_bit, s));
+  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(nullptr, need_scan, h->d_nwords, h->d_word_off, B + 1, s));
+  need_tmp = std::max(need_tmp, need_scan);
+  if (need_tmp > h->tmp_bytes) {
+    if (h->d_tmp) { HIPCHK(h, hipFree(h->d_tmp)); h->d_tmp = nullptr; }
+    HIPCHK(h, hipMalloc(&h->d_tmp, need_tmp));
+    h->tmp_bytes = need_tmp;
+  }
+  if (total >= ((size_t)1 << 31)) { h->err = "batch too large for one radix sort"; return MI355NDT_ERR_BAD_ARG; }
+
+  if (h->prof) HIPCHK(h, ev_begin(h, h->ev_build));
+  const int gx = (int)((pitch + 255) / 256);
+  k_minmax_init<<<(B * 6 + 255) / 256, 256, 0, s>>>(h->d_minmax, B);
+  k_minmax<<<dim3(std::min(gx, 64), B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_minmax);
+  HIPCHK(h, hipMemsetAsync(h->d_nwords, 0, (B + 1) * sizeof(unsigned), s));
+  k_griddesc<<<(B + 63) / 64, 64, 0, s>>>(h->d_minmax, h->d_grid, h->d_nwords, h->prm.resolution, B, (unsigned)rpp);
+  size_t tb = h->tmp_bytes;
+  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(h->d_tmp, tb, h->d_nwords, h->d_word_off, B + 1, s));
+  k_set_word_off<<<(B + 63) / 64, 64, 0, s>>>(h->d_grid, h->d_word_off, B);
+  HIPCHK(h, hipMemcpyAsync(h->h_pin_u, h->d_word_off + B, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  k_keys<<<dim3(gx, B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_grid, h->d_keys_a, h->d_vals_a);
+  tb = h->tmp_bytes;
+  HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(h->d_tmp, tb, h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, (int)total, 0, end_bit, s));
+  HIPCHK(h, hipStreamSynchronize(s));           // total bitmap words -> size the pool
+  const size_t total_words = h->h_pin_u[0];
+  if (total_words > h->words_cap) {
+    size_t c = h->words_cap;
+    HIPCHK(h, grow(h->d_words, c, std::max(total_words, (size_t)1024)));
+    h->words_cap = c;
+  }
+  if (total_words) HIPCHK(h, hipMemsetAsync(h->d_words, 0, total_words * sizeof(BitWord), s));
+  k_mark<<<dim3(gx, B), 256, 0, s>>>(h->d_keys_b, pitch, h->d_grid, h->d_words, minpts);
+  k_rank<<<B, 256, 0, s>>>(h->d_grid, h->d_words);
+  k_voxels<<<dim3(gx, B), 256, 0, s>>>(h->d_tgt, pitch, h->d_keys_b, h->d_vals_b, h->d_grid, h->d_words,
+                                       h->d_recs, h->d_vox_idx, h->d_vox_n, minpts, h->prm.min_covar_eigvalue_mult,
+                                       h->prm.variant == MI355NDT_VARIANT_PCA);
+  HIPCHK(h, hipGetLastError());
+  if (h->prof) {
+    HIPCHK(h, ev_end(h, h->ev_build));
+    double pts = 0;
+    for (int b = 0; b < B; b++) pts += h->h_tgt_cnt[b];
+    // B_build: minmax 12 + binning 12 + key write 12 + sort r/w + grouped gather 16 per point (+ records)
+    h->P.build_alg_bytes += pts * (12 + 12 + 4 + 16);
+  }
+  h->targets_built = true;
+  return MI355NDT_OK;
+}
+
+// ---- sweeps -----------------------------------------------------------------------------------
+static int prep_align_ws(mi355ndt_handle* h) {
+  const int B = h->n_pairs;
+  int maxn = 0;
+  for (int b = 0; b < B; b++) maxn = std::max(maxn, h->h_src_cnt[b]);
+  h->chunks_per_pair = std::max(1, (maxn + CHUNK_PTS - 1) / CHUNK_PTS);
+  size_t need = (size_t)B * h->chunks_per_pair * NACC;
+  HIPCHK(h, grow(h->d_partials, h->partials_cap, need));
+  HIPCHK(h, hipMemcpyAsync(h->d_src_cnt, h->h_src_cnt.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MI355NDT_OK;
+}
+
+static void make_sweep_const(const mi355ndt_handle* h, SweepConst& sc) {
+  double d1, d2;
+  gauss_constants(h->prm, d1, d2);
+  sc.d1 = d1;
+  sc.d2f = (float)d2;                        // impl2:578
+  sc.pca = h->prm.variant == MI355NDT_VARIANT_PCA;
+  build_offsets(h->prm.neighbor_mode, sc);
+}
+
+static int launch_sweep(mi355ndt_handle* h, const SweepConst& sc, int first_pair, int n_pairs_launch) {
+  // grid.x = chunks handled round-robin by blocks; enough blocks to fill 256 CUs
+  int bx = h->chunks_per_pair;
+  const int want = 2048;
+  if ((long long)bx * n_pairs_launch > 4 * want) bx = std::max(1, std::min(bx, (4 * want) / n_pairs_launch));
+  if (h->prof) HIPCHK(h, ev_begin(h, h->ev_sweep));
+  k_sweep<<<dim3(bx, n_pairs_launch), SWEEP_THREADS, 0, h->stream>>>(
+      h->d_src + (size_t)first_pair * 3 * h->src_pitch, h->src_pitch, h->d_state + first_pair, h->d_grid + first_pair,
+      h->d_words, h->d_recs, h->d_partials + (size_t)first_pair * h->chunks_per_pair * NACC, h->chunks_per_pair, sc);
+  if (h->prof) HIPCHK(h, ev_end(h, h->ev_sweep));
+  return MI355NDT_OK;
+}
+
+int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_result* out) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (!guesses || !out) return MI355NDT_ERR_BAD_ARG;
+  if (h->n_pairs <= 0 || !h->d_tgt || !h->d_src) return MI355NDT_ERR_STATE;
+  if (h->prm.neighbor_mode == MI355NDT_KDTREE) return MI355NDT_ERR_UNSUPPORTED;
+  if (!((h->prm.step_size - h->prm.trans_epsilon / 2) > 0)) return MI355NDT_ERR_UNSUPPORTED;   // impl2:888: live More-Thuente loop
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->targets_built) { int rc = mi355ndt_batch_build_targets(h); if (rc) return rc; }
+  int rc = prep_align_ws(h);
+  if (rc) return rc;
+  const int B = h->n_pairs;
+  hipStream_t s = h->stream;
+  SweepConst sc;
+  make_sweep_const(h, sc);
+  HIPCHK(h, hipMemcpyAsync(h->d_guess, guesses, (size_t)B * 16 * sizeof(float), hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipStreamSynchronize(s));           // guesses may be pageable caller memory
+  k_init_state<<<(B + 63) / 64, 64, 0, s>>>(h->d_state, h->d_guess, h->d_src_cnt, h->d_grid, B);
+  rc = launch_sweep(h, sc, 0, B);
+  if (rc) return rc;
+  const int max_rounds = h->prm.max_iterations + 4;   // loop body runs for it = 0 .. max_iterations+1
+  double pts_total = 0;
+  for (int b = 0; b < B; b++) pts_total += h->h_src_cnt[b];
+  const double alg_static = pts_total * (12.0 + 4.0 * sc.K);   // every active pair streams its points + K table probes
+  if (h->prof) {
+    HIPCHK(h, hipMemsetAsync(h->d_hits, 0, sizeof(unsigned long long), s));
+    h->P.sweep_alg_bytes += alg_static;                          // the initial sweep covers all pairs
+    h->P.sweep_points += (long long)pts_total;
+  }
+  const int burst = 2;                                           // update+sweep rounds enqueued between host checks
+  int round = 0;
+  while (round < max_rounds) {
+    HIPCHK(h, hipMemsetAsync(h->d_active, 0, 128 * sizeof(int), s));
+    const int r0 = round;
+    for (int k = 0; k < burst && round < max_rounds; k++, round++) {
+      if (h->prof) HIPCHK(h, ev_begin(h, h->ev_update));
+      k_update<<<B, 64, 0, s>>>(h->d_state, h->d_partials, h->chunks_per_pair, h->d_results, h->d_active + (round - r0),
+                                h->prof ? h->d_hits : nullptr, h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations, 0);
+      if (h->prof) HIPCHK(h, ev_end(h, h->ev_update));
+      rc = launch_sweep(h, sc, 0, B);
+      if (rc) return rc;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->h_pin_active, h->d_active, burst * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    if (h->prof) {
+      // sweep k of this burst streamed the pairs that scheduled a step in update k (equal-size pairs assumed)
+      for (int k = 0; k < round - r0; k++) {
+        const double frac = (double)h->h_pin_active[k] / B;
+        h->P.sweep_alg_bytes += alg_static * frac;
+        h->P.sweep_points += (long long)(pts_total * frac);
+      }
+    }
+    if (h->h_pin_active[round - r0 - 1] == 0) break;
+  }
+  if (h->prof) {
+    // one more reduction so the hits of the very last sweeps are counted is not needed: every sweep is
+    // followed by an update (the loop only exits after an update scheduled no further sweep)
+    unsigned long long hh = 0;
+    HIPCHK(h, hipMemcpyAsync(&hh, h->d_hits, sizeof hh, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    h->P.sweep_hits += (long long)hh;
+    h->P.sweep_alg_bytes += 64.0 * (double)hh;
+  }
+  HIPCHK(h, hipMemcpyAsync(out, h->d_results, (size_t)B * sizeof(mi355ndt_result), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  HIPCHK(h, hipGetLastError());
+  return MI355NDT_OK;
+}
+
+// ---- single-registration surface (pair slot 0) ---------------------------------------------------
+static int ensure_single(mi355ndt_handle* h, bool tgt, size_t n) {
+  const size_t want = std::max(((n + 63) & ~(size_t)63), (size_t)64);
+  const bool single = h->n_pairs == 1 && h->d_tgt_own && h->d_src_own && h->d_tgt == h->d_tgt_own && h->d_src == h->d_src_own;
+  if (!single) {
+    // leaving batch / bound mode: start a fresh one-pair engine
+    return mi355ndt_batch_reserve(h, 1, tgt ? want : 64, tgt ? 64 : want);
+  }
+  // target and source buffers are independent: grow only the side being replaced
+  const size_t have = tgt ? h->own_tgt_pitch : h->own_src_pitch;
+  if (n <= have) return MI355NDT_OK;
+  int rc = alloc_side(h, tgt, 1, want);
+  if (rc) return rc;
+  if (tgt) h->tgt_pitch = want; else h->src_pitch = want;
+  h->d_tgt = h->d_tgt_own; h->d_src = h->d_src_own;
+  return MI355NDT_OK;
+}
+
+int mi355ndt_set_target(mi355ndt_handle* h, const void* pts, size_t n, size_t stride) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if ((!pts && n) || stride < 12 || n >= (1u << 31)) return MI355NDT_ERR_BAD_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = ensure_single(h, true, n);
+  if (rc) return rc;
+  rc = mi355ndt_batch_set_target(h, 0, pts, n, stride);
+  if (rc) return rc;
+  h->have_target = true;
+  return mi355ndt_batch_build_targets(h);      // init(): filter(true) (ndt_omp.h:270-277)
+}
+
+int mi355ndt_set_source(mi355ndt_handle* h, const void* pts, size_t n, size_t stride) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if ((!pts && n) || stride < 12 || n >= (1u << 31)) return MI355NDT_ERR_BAD_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = ensure_single(h, false, n);
+  if (rc) return rc;
+  rc = mi355ndt_batch_set_source(h, 0, pts, n, stride);
+  if (rc) return rc;
+  h->have_source = true;
+  return MI355NDT_OK;
+}
+
+int mi355ndt_set_params(mi355ndt_handle* h, const mi355ndt_params* p) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (!p) return MI355NDT_ERR_BAD_ARG;
+  int rc = check_params(*p);
+  if (rc) return rc;
+  const mi355ndt_params old = h->prm;
+  h->prm = *p;
+  const bool regrid = old.resolution != p->resolution || old.variant != p->variant ||
+                      old.min_points_per_voxel != p->min_points_per_voxel ||
+                      old.min_covar_eigvalue_mult != p->min_covar_eigvalue_mult;
+  if (regrid && h->targets_built) {
+    h->targets_built = false;
+    if (p->neighbor_mode != MI355NDT_KDTREE) return mi355ndt_batch_build_targets(h);   // setResolution -> init() (ndt_omp.h:126-136)
+  }
+  return MI355NDT_OK;
+}
+
+int mi355ndt_align(mi355ndt_handle* h, const float guess[16], mi355ndt_result* out) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (!guess || !out) return MI355NDT_ERR_BAD_ARG;
+  if (h->n_pairs < 1 || !h->have_target || !h->have_source) return MI355NDT_ERR_STATE;
+  if (h->n_pairs == 1) return mi355ndt_batch_align(h, guess, out);
+  return MI355NDT_ERR_STATE;                   // a batch is bound: use mi355ndt_batch_align
+}
+
+int mi355ndt_get_aligned(mi355ndt_handle* h, void* out_pts, size_t stride) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (!out_pts || stride < 12) return MI355NDT_ERR_BAD_ARG;
+  if (h->n_pairs < 1 || !h->d_src) return MI355NDT_ERR_STATE;
+  HIPCHK(h, hipSetDevice(h->device));
+  const int n = h->h_src_cnt[0];
+  if (n == 0) return MI355NDT_OK;
+  HIPCHK(h, grow(h->d_aligned, h->aligned_cap, (size_t)3 * n));
+  k_transform<<<(n + 255) / 256, 256, 0, h->stream>>>(h->d_src, h->src_pitch, h->d_state, 0, h->d_aligned, n);
+  std::vector<float> tmp((size_t)3 * n);
+  HIPCHK(h, hipMemcpyAsync(tmp.data(), h->d_aligned, (size_t)3 * n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  unsigned char* o = (unsigned char*)out_pts;
+  for (int i = 0; i < n; i++) {
+    float v[3] = {tmp[i], tmp[(size_t)n + i], tmp[(size_t)2 * n + i]};
+    memcpy(o + (size_t)i * stride, v, 12);
+  }
+  return MI355NDT_OK;
+}
+
+static int run_hook_sweep(mi355ndt_handle* h, double* score, double g[6], double H[36], long long* hits) {
+  SweepConst sc;
+  make_sweep_const(h, sc);
+  int rc = launch_sweep(h, sc, 0, 1);
+  if (rc) return rc;
+  k_update<<<1, 64, 0, h->stream>>>(h->d_state, h->d_partials, h->chunks_per_pair, h->d_results, h->d_active, nullptr, 0, 0, 0, 1);
+  PairState S;
+  HIPCHK(h, hipMemcpyAsync(&S, h->d_state, sizeof(PairState), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipGetLastError());
+  if (score) *score = S.score;
+  if (g) memcpy(g, S.g, sizeof S.g);
+  if (H) memcpy(H, S.H, sizeof S.H);
+  if (hits) *hits = S.hits;
+  return MI355NDT_OK;
+}
+
+static int hook_ready(mi355ndt_handle* h) {
+  if (h->n_pairs < 1 || !h->have_target || !h->have_source) return MI355NDT_ERR_STATE;
+  if (h->prm.neighbor_mode == MI355NDT_KDTREE) return MI355NDT_ERR_UNSUPPORTED;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->targets_built) { int rc = mi355ndt_batch_build_targets(h); if (rc) return rc; }
+  return prep_align_ws(h);
+}
+
+int mi355ndt_derivatives(mi355ndt_handle* h, const double p[6], double* score, double g[6], double H[36], long long* hits) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (!p) return MI355NDT_ERR_BAD_ARG;
+  int rc = hook_ready(h);
+  if (rc) return rc;
+  double* dp = (double*)h->d_hook;
+  HIPCHK(h, hipMemcpyAsync(dp, p, 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  k_set_pose_p<<<1, 1, 0, h->stream>>>(h->d_state, 0, dp, h->d_src_cnt, h->d_grid);
+  return run_hook_sweep(h, score, g, H, hits);
+}
+
+int mi355ndt_derivatives_T(mi355ndt_handle* h, const float T[16], const float Rj[9], double* score, double g[6], double H[36], long long* hits) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (!T || !Rj) return MI355NDT_ERR_BAD_ARG;
+  int rc = hook_ready(h);
+  if (rc) return rc;
+  float buf[25];
+  memcpy(buf, T, 16 * sizeof(float));
+  memcpy(buf + 16, Rj, 9 * sizeof(float));
+  HIPCHK(h, hipMemcpyAsync(h->d_hook, buf, sizeof buf, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  k_set_pose<<<1, 1, 0, h->stream>>>(h->d_state, 0, h->d_hook, h->d_hook + 16, h->d_src_cnt, h->d_grid);
+  return run_hook_sweep(h, score, g, H, hits);
+}
+
+int mi355ndt_get_grid(mi355ndt_handle* h, int pair, int min_b[3], int max_b[3], int div_b[3], int* n_voxels) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (pair < 0 || pair >= h->n_pairs) return MI355NDT_ERR_BAD_ARG;
+  if (!h->targets_built) return MI355NDT_ERR_STATE;
+  HIPCHK(h, hipSetDevice(h->device));
+  GridDesc g;
+  HIPCHK(h, hipMemcpyAsync(&g, h->d_grid + pair, sizeof g, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int a = 0; a < 3; a++) {
+    if (min_b) min_b[a] = g.min_b[a];
+    if (max_b) max_b[a] = g.max_b[a];
+    if (div_b) div_b[a] = g.div_b[a];
+  }
+  if (n_voxels) *n_voxels = g.n_voxels;
+  return (g.status == GRID_OVERFLOW || g.status == GRID_CAP) ? MI355NDT_ERR_GRID : MI355NDT_OK;
+}
+
+int mi355ndt_get_voxels(mi355ndt_handle* h, int pair, mi355ndt_voxel* out, size_t capacity) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (pair < 0 || pair >= h->n_pairs || (!out && capacity)) return MI355NDT_ERR_BAD_ARG;
+  if (!h->targets_built) return MI355NDT_ERR_STATE;
+  HIPCHK(h, hipSetDevice(h->device));
+  GridDesc g;
+  HIPCHK(h, hipMemcpyAsync(&g, h->d_grid + pair, sizeof g, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  size_t n = std::min((size_t)g.n_voxels, capacity);
+  if (n == 0) return MI355NDT_OK;
+  std::vector<VoxelRec> r(n);
+  std::vector<int> idx(n), cnt(n);
+  HIPCHK(h, hipMemcpy(r.data(), h->d_recs + g.rec_off, n * sizeof(VoxelRec), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(idx.data(), h->d_vox_idx + g.rec_off, n * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(cnt.data(), h->d_vox_n + g.rec_off, n * sizeof(int), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; i++) {
+    out[i].idx = idx[i];
+    out[i].n = cnt[i];
+    memcpy(out[i].mean, r[i].mean, sizeof r[i].mean);
+    memcpy(out[i].icov, r[i].icov, sizeof r[i].icov);
+    out[i].weight = (r[i].weight == VOX_DEAD) ? 0 : r[i].weight;
+  }
+  return MI355NDT_OK;
+}
+
+}  // extern "C"

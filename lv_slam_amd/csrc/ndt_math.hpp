@@ -1,0 +1,307 @@
+// ndt_math.hpp -- f64 control math of the NDT engine, device side (gfx950).
+//
+// Runs inside the Newton-update kernel (one pair per wave) so that the whole Gauss-Newton loop of
+// computeTransformation (include/ndt_omp/ndt_omp_impl2.hpp:87-188) stays on the GPU: no host
+// round-trip between derivative sweeps.
+//
+// Third-party arithmetic restated from its published form (sources are not in the lv_slam tree):
+//   Sophus a621ff2 (lv_slam README.md:61-66): non-templated SE3/SO3 exp, log, operator*
+//   Eigen 3.3: Quaternion<->Matrix3, 3x3 cofactor inverse, JacobiSVD::solve threshold semantics.
+// Compiled with -ffp-contract=off: no FMA contraction anywhere in this file.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+
+namespace ndtm {
+
+#define NDT_SMALL_EPS 1e-10
+
+struct Quat { double w, x, y, z; };
+struct SE3 { Quat q; double t[3]; };
+
+__device__ inline Quat q_normalized(Quat q) {
+  double n = sqrt(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
+  Quat r = {q.w / n, q.x / n, q.y / n, q.z / n};
+  return r;
+}
+
+// Eigen quaternionbase_assign_impl<Matrix3>
+__device__ inline Quat q_from_matrix(const double m[9]) {
+  Quat q;
+  double t = m[0] + m[4] + m[8];
+  if (t > 0) {
+    t = sqrt(t + 1.0);
+    q.w = 0.5 * t;
+    t = 0.5 / t;
+    q.x = (m[7] - m[5]) * t;
+    q.y = (m[2] - m[6]) * t;
+    q.z = (m[3] - m[1]) * t;
+  } else {
+    int i = 0;
+    if (m[4] > m[0]) i = 1;
+    if (m[8] > m[i * 3 + i]) i = 2;
+    int j = (i + 1) % 3, k = (j + 1) % 3;
+    double qv[3];
+    t = sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
+    qv[i] = 0.5 * t;
+    t = 0.5 / t;
+    q.w = (m[k * 3 + j] - m[j * 3 + k]) * t;
+    qv[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
+    qv[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+    q.x = qv[0]; q.y = qv[1]; q.z = qv[2];
+  }
+  return q;
+}
+
+// Eigen QuaternionBase::toRotationMatrix
+__device__ inline void q_to_matrix(Quat q, double r[9]) {
+  double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+  double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  r[0] = 1 - (tyy + tzz); r[1] = txy - twz; r[2] = txz + twy;
+  r[3] = txy + twz; r[4] = 1 - (txx + tzz); r[5] = tyz - twx;
+  r[6] = txz - twy; r[7] = tyz + twx; r[8] = 1 - (txx + tyy);
+}
+
+__device__ inline Quat q_mul(Quat a, Quat b) {
+  Quat r;
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+  r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+  return r;
+}
+
+// QuaternionBase::_transformVector
+__device__ inline void q_rotate(Quat q, const double v[3], double out[3]) {
+  double uv[3] = {q.y * v[2] - q.z * v[1], q.z * v[0] - q.x * v[2], q.x * v[1] - q.y * v[0]};
+  uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+  double c[3] = {q.y * uv[2] - q.z * uv[1], q.z * uv[0] - q.x * uv[2], q.x * uv[1] - q.y * uv[0]};
+  for (int i = 0; i < 3; i++) out[i] = (v[i] + q.w * uv[i]) + c[i];
+}
+
+__device__ inline void mat3_mul(const double A[9], const double B[9], double C[9]) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      C[i * 3 + j] = (A[i * 3 + 0] * B[j] + A[i * 3 + 1] * B[3 + j]) + A[i * 3 + 2] * B[6 + j];
+}
+
+__device__ inline double cof3(const double* m, int i, int j) {
+  int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return m[i1 * 3 + j1] * m[i2 * 3 + j2] - m[i1 * 3 + j2] * m[i2 * 3 + j1];
+}
+// Eigen 3.3 compute_inverse<Matrix3d> (cofactor expansion)
+__device__ inline void mat3_inverse(const double m[9], double r[9]) {
+  double c0 = cof3(m, 0, 0), c1 = cof3(m, 1, 0), c2 = cof3(m, 2, 0);
+  double det = (c0 * m[0] + c1 * m[3]) + c2 * m[6];
+  double invdet = 1.0 / det;
+  r[0] = c0 * invdet; r[1] = c1 * invdet; r[2] = c2 * invdet;
+  r[3] = cof3(m, 0, 1) * invdet; r[4] = cof3(m, 1, 1) * invdet; r[5] = cof3(m, 2, 1) * invdet;
+  r[6] = cof3(m, 0, 2) * invdet; r[7] = cof3(m, 1, 2) * invdet; r[8] = cof3(m, 2, 2) * invdet;
+}
+
+__device__ inline void hat3(const double o[3], double O[9]) {
+  O[0] = 0; O[1] = -o[2]; O[2] = o[1];
+  O[3] = o[2]; O[4] = 0; O[5] = -o[0];
+  O[6] = -o[1]; O[7] = o[0]; O[8] = 0;
+}
+
+// SO3::expAndTheta
+__device__ inline Quat so3_exp(const double om[3], double* theta) {
+  *theta = sqrt((om[0] * om[0] + om[1] * om[1]) + om[2] * om[2]);
+  double half = 0.5 * (*theta);
+  double imag, real = cos(half);
+  if (*theta < NDT_SMALL_EPS) {
+    double th2 = (*theta) * (*theta), th4 = th2 * th2;
+    imag = 0.5 - 0.0208333 * th2 + 0.000260417 * th4;
+  } else {
+    imag = sin(half) / (*theta);
+  }
+  Quat q = {real, imag * om[0], imag * om[1], imag * om[2]};
+  return q_normalized(q);
+}
+
+// SO3::logAndTheta
+__device__ inline void so3_log(Quat q, double om[3], double* theta) {
+  double n = sqrt((q.x * q.x + q.y * q.y) + q.z * q.z);
+  double w = q.w, f;
+  if (n < NDT_SMALL_EPS) {
+    f = 2. / w - 2. * (n * n) / (w * (w * w));
+  } else {
+    f = 2 * atan(n / w) / n;
+  }
+  *theta = f * n;
+  om[0] = f * q.x; om[1] = f * q.y; om[2] = f * q.z;
+}
+
+// SE3::exp, tangent [upsilon; omega]
+__device__ inline SE3 se3_exp(const double p[6]) {
+  SE3 r;
+  double theta;
+  r.q = so3_exp(p + 3, &theta);
+  double Om[9], Om2[9], V[9];
+  hat3(p + 3, Om);
+  mat3_mul(Om, Om, Om2);
+  if (theta < NDT_SMALL_EPS) {
+    q_to_matrix(r.q, V);
+  } else {
+    double th2 = theta * theta;
+    double a = (1 - cos(theta)) / th2, b = (theta - sin(theta)) / (th2 * theta);
+    for (int i = 0; i < 9; i++) V[i] = (((i % 4) == 0 ? 1.0 : 0.0) + a * Om[i]) + b * Om2[i];
+  }
+  for (int i = 0; i < 3; i++) r.t[i] = (V[i * 3 + 0] * p[0] + V[i * 3 + 1] * p[1]) + V[i * 3 + 2] * p[2];
+  return r;
+}
+
+// SE3::log
+__device__ inline void se3_log(SE3 s, double p[6]) {
+  double theta, om[3];
+  so3_log(s.q, om, &theta);
+  double Om[9], Om2[9], Vi[9];
+  hat3(om, Om);
+  mat3_mul(Om, Om, Om2);
+  double c = (theta < NDT_SMALL_EPS) ? (1. / 12.) : (1 - theta / (2 * tan(theta / 2))) / (theta * theta);
+  for (int i = 0; i < 9; i++) Vi[i] = (((i % 4) == 0 ? 1.0 : 0.0) - 0.5 * Om[i]) + c * Om2[i];
+  for (int i = 0; i < 3; i++) p[i] = (Vi[i * 3 + 0] * s.t[0] + Vi[i * 3 + 1] * s.t[1]) + Vi[i * 3 + 2] * s.t[2];
+  p[3] = om[0]; p[4] = om[1]; p[5] = om[2];
+}
+
+// SE3::operator*
+__device__ inline SE3 se3_mul(SE3 a, SE3 b) {
+  SE3 r;
+  double rt[3];
+  q_rotate(a.q, b.t, rt);
+  for (int i = 0; i < 3; i++) r.t[i] = a.t[i] + rt[i];
+  r.q = q_normalized(q_mul(a.q, b.q));
+  return r;
+}
+
+// SE3(R, t): SO3(R) goes through the (normalised) quaternion
+__device__ inline SE3 se3_from_Rt(const double R[9], const double t[3]) {
+  SE3 s;
+  s.q = q_normalized(q_from_matrix(R));
+  s.t[0] = t[0]; s.t[1] = t[1]; s.t[2] = t[2];
+  return s;
+}
+
+// float(exp(p).matrix()): T = 3x4 row-major [R|t], Rj = R (both f32)
+__device__ inline void pose_to_f32(const double p[6], float T[12], float Rj[9]) {
+  SE3 s = se3_exp(p);
+  double R[9];
+  q_to_matrix(s.q, R);
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) { T[r * 4 + c] = (float)R[r * 3 + c]; Rj[r * 3 + c] = (float)R[r * 3 + c]; }
+    T[r * 4 + 3] = (float)s.t[r];
+  }
+}
+
+// Symmetric 3x3 eigen-decomposition (cyclic Jacobi; lower triangle read, ascending eigenvalues,
+// eigenvectors = columns of V).  Stands in for Eigen::SelfAdjointEigenSolver
+// (voxel_grid_covariance_omp_impl.hpp:333-335).
+__device__ inline void eigen_sym3(const double Ain[9], double evals[3], double V[9]) {
+  double a[3][3], v[3][3];
+  a[0][0] = Ain[0]; a[1][1] = Ain[4]; a[2][2] = Ain[8];
+  a[0][1] = a[1][0] = Ain[3]; a[0][2] = a[2][0] = Ain[6]; a[1][2] = a[2][1] = Ain[7];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) v[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 64; sweep++) {
+    double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+    if (off == 0.0) break;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int p = (k == 2) ? 1 : 0, q = (k == 0) ? 1 : 2, r = 3 - p - q;
+      double apq = a[p][q];
+      if (apq == 0.0) continue;
+      double g = 100.0 * fabs(apq);
+      if (sweep > 3 && fabs(a[p][p]) + g == fabs(a[p][p]) && fabs(a[q][q]) + g == fabs(a[q][q])) {
+        a[p][q] = a[q][p] = 0.0;
+        continue;
+      }
+      double h = a[q][q] - a[p][p];
+      double t;
+      if (fabs(h) + g == fabs(h)) {
+        t = apq / h;
+      } else {
+        double theta = 0.5 * h / apq;
+        t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+        if (theta < 0.0) t = -t;
+      }
+      double c = 1.0 / sqrt(1.0 + t * t);
+      double s = t * c;
+      double tau = s / (1.0 + c);
+      double hh = t * apq;
+      a[p][p] -= hh;
+      a[q][q] += hh;
+      a[p][q] = a[q][p] = 0.0;
+      double arp = a[r][p], arq = a[r][q];
+      a[r][p] = a[p][r] = arp - s * (arq + arp * tau);
+      a[r][q] = a[q][r] = arq + s * (arp - arq * tau);
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        double vip = v[i][p], viq = v[i][q];
+        v[i][p] = vip - s * (viq + vip * tau);
+        v[i][q] = viq + s * (vip - viq * tau);
+      }
+    }
+  }
+  double d[3] = {a[0][0], a[1][1], a[2][2]};
+  int o0 = 0, o1 = 1, o2 = 2, t;
+  if (d[o1] < d[o0]) { t = o0; o0 = o1; o1 = t; }
+  if (d[o2] < d[o1]) { t = o1; o1 = o2; o2 = t; }
+  if (d[o1] < d[o0]) { t = o0; o0 = o1; o1 = t; }
+  const int o[3] = {o0, o1, o2};
+  for (int j = 0; j < 3; j++) {
+    evals[j] = d[o[j]];
+    for (int i = 0; i < 3; i++) V[i * 3 + j] = v[i][o[j]];
+  }
+}
+
+// x = pinv(H) b with Eigen::JacobiSVD<6x6>::solve semantics (ndt_omp_impl2.hpp:138-140):
+// rank = #{sigma_i >= max(sigma_max * 6 eps, DBL_MIN)}.  One-sided (Hestenes) Jacobi.
+__device__ inline void svd_solve6(const double* H, const double b[6], double x[6]) {
+  double A[6][6], V[6][6];
+  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { A[i][j] = H[i * 6 + j]; V[i][j] = (i == j) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 60; sweep++) {
+    int rotated = 0;
+    for (int p = 0; p < 5; p++) {
+      for (int q = p + 1; q < 6; q++) {
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int i = 0; i < 6; i++) { alpha += A[i][p] * A[i][p]; beta += A[i][q] * A[i][q]; gamma += A[i][p] * A[i][q]; }
+        if (gamma == 0.0 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
+        rotated = 1;
+        double zeta = (beta - alpha) / (2.0 * gamma);
+        double t = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        if (zeta < 0) t = -t;
+        double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        for (int i = 0; i < 6; i++) {
+          double aip = A[i][p], aiq = A[i][q];
+          A[i][p] = c * aip - s * aiq;
+          A[i][q] = s * aip + c * aiq;
+          double vip = V[i][p], viq = V[i][q];
+          V[i][p] = c * vip - s * viq;
+          V[i][q] = s * vip + c * viq;
+        }
+      }
+    }
+    if (!rotated) break;
+  }
+  double sig[6], smax = 0;
+  for (int j = 0; j < 6; j++) {
+    double s2 = 0;
+    for (int i = 0; i < 6; i++) s2 += A[i][j] * A[i][j];
+    sig[j] = sqrt(s2);
+    if (sig[j] > smax) smax = sig[j];
+  }
+  double thr = smax * (6.0 * DBL_EPSILON);
+  if (thr < DBL_MIN) thr = DBL_MIN;
+  for (int i = 0; i < 6; i++) x[i] = 0;
+  for (int j = 0; j < 6; j++) {
+    if (!(sig[j] >= thr) || sig[j] == 0.0) continue;
+    double ub = 0;
+    for (int i = 0; i < 6; i++) ub += (A[i][j] / sig[j]) * b[i];
+    double w = ub / sig[j];
+    for (int i = 0; i < 6; i++) x[i] += V[i][j] * w;
+  }
+}
+
+}  // namespace ndtm

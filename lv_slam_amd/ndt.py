@@ -1,0 +1,387 @@
+"""Host-side mirror of the reference registration interface over the C-ABI (include/mi355_ndt.h).
+
+`NormalDistributionsTransform` keeps the method names, argument meaning and error behaviour of
+pclomp::/pclpca::NormalDistributionsTransform (include/ndt_omp/ndt_omp.h:69-277,
+include/ndt_pca/ndt_pca.h) and of the pcl::Registration base it derives from, so a user of
+lv_slam's `reg.setInputTarget(..); reg.setInputSource(..); reg.align(out, guess)` sequence
+(src/lidar_odometry/scan_matching_odom_nodelet.cpp:109-119,197,220-226) finds the same surface.
+All computation happens in libmi355ndt.so (hand-written HIP, gfx950).  There is no CPU fallback:
+loading fails loudly if the library is missing, construction fails if no GPU is usable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355ndt.so")
+
+# pclomp::NeighborSearchMethod (include/ndt_omp/ndt_omp.h:51-56)
+KDTREE, DIRECT26, DIRECT7, DIRECT1 = 0, 1, 2, 3
+VARIANT_OMP, VARIANT_PCA = 0, 1
+
+OK = 0
+ERR = {-1: "bad handle", -2: "bad argument", -3: "HIP error", -4: "target grid unusable", -5: "no HIP device",
+       -6: "unsupported configuration", -7: "target/source not set"}
+
+
+class NDTError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        super().__init__(f"{where}: {ERR.get(code, code)}" + (f" ({detail})" if detail else ""))
+
+
+class Params(C.Structure):
+    _fields_ = [("resolution", C.c_float), ("step_size", C.c_double), ("outlier_ratio", C.c_double),
+                ("trans_epsilon", C.c_double), ("max_iterations", C.c_int), ("neighbor_mode", C.c_int),
+                ("variant", C.c_int), ("min_points_per_voxel", C.c_int), ("min_covar_eigvalue_mult", C.c_double)]
+
+
+class Result(C.Structure):
+    _fields_ = [("final_colmajor", C.c_float * 16), ("trans_probability", C.c_double), ("score", C.c_double),
+                ("iterations", C.c_int), ("converged", C.c_int), ("sweeps", C.c_int), ("status", C.c_int),
+                ("hits_last", C.c_longlong)]
+
+
+class Voxel(C.Structure):
+    _fields_ = [("idx", C.c_int32), ("n", C.c_int32), ("mean", C.c_double * 3), ("icov", C.c_float * 9),
+                ("weight", C.c_int32)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("sweep_ms", C.c_double), ("sweep_launches", C.c_longlong), ("sweep_alg_bytes", C.c_double),
+                ("sweep_hits", C.c_longlong), ("sweep_points", C.c_longlong), ("build_ms", C.c_double),
+                ("build_launches", C.c_longlong), ("build_alg_bytes", C.c_double), ("update_ms", C.c_double),
+                ("update_launches", C.c_longlong)]
+
+
+# every symbol include/mi355_ndt.h declares
+SYMBOLS = [
+    "mi355ndt_version", "mi355ndt_device_count", "mi355ndt_default_params", "mi355ndt_create", "mi355ndt_destroy",
+    "mi355ndt_set_params", "mi355ndt_get_params", "mi355ndt_set_stream", "mi355ndt_last_error",
+    "mi355ndt_set_target", "mi355ndt_set_source", "mi355ndt_align", "mi355ndt_get_aligned",
+    "mi355ndt_derivatives", "mi355ndt_derivatives_T", "mi355ndt_get_grid", "mi355ndt_get_voxels",
+    "mi355ndt_batch_reserve", "mi355ndt_batch_set_target", "mi355ndt_batch_set_source", "mi355ndt_batch_bind_device",
+    "mi355ndt_batch_build_targets", "mi355ndt_batch_align", "mi355ndt_batch_size",
+    "mi355ndt_profile_enable", "mi355ndt_profile_reset", "mi355ndt_profile_get", "mi355ndt_synchronize",
+]
+
+_LIB = None
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen libmi355ndt.so; raises (never falls back) when it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(path)
+    vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
+    L.mi355ndt_version.restype = C.c_char_p
+    L.mi355ndt_last_error.restype = C.c_char_p
+    L.mi355ndt_last_error.argtypes = [vp]
+    L.mi355ndt_default_params.argtypes = [C.POINTER(Params)]
+    L.mi355ndt_create.argtypes = [C.POINTER(Params), i, C.POINTER(vp)]
+    L.mi355ndt_destroy.argtypes = [vp]
+    L.mi355ndt_set_params.argtypes = [vp, C.POINTER(Params)]
+    L.mi355ndt_get_params.argtypes = [vp, C.POINTER(Params)]
+    L.mi355ndt_set_stream.argtypes = [vp, vp]
+    L.mi355ndt_set_target.argtypes = [vp, vp, sz, sz]
+    L.mi355ndt_set_source.argtypes = [vp, vp, sz, sz]
+    L.mi355ndt_align.argtypes = [vp, vp, C.POINTER(Result)]
+    L.mi355ndt_get_aligned.argtypes = [vp, vp, sz]
+    L.mi355ndt_derivatives.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.mi355ndt_derivatives_T.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.mi355ndt_get_grid.argtypes = [vp, i, vp, vp, vp, vp]
+    L.mi355ndt_get_voxels.argtypes = [vp, i, vp, sz]
+    L.mi355ndt_batch_reserve.argtypes = [vp, i, sz, sz]
+    L.mi355ndt_batch_set_target.argtypes = [vp, i, vp, sz, sz]
+    L.mi355ndt_batch_set_source.argtypes = [vp, i, vp, sz, sz]
+    L.mi355ndt_batch_bind_device.argtypes = [vp, i, vp, vp, sz, vp, vp, sz]
+    L.mi355ndt_batch_build_targets.argtypes = [vp]
+    L.mi355ndt_batch_align.argtypes = [vp, vp, vp]
+    L.mi355ndt_batch_size.argtypes = [vp]
+    L.mi355ndt_profile_enable.argtypes = [vp, i]
+    L.mi355ndt_profile_reset.argtypes = [vp]
+    L.mi355ndt_profile_get.argtypes = [vp, C.POINTER(Profile)]
+    L.mi355ndt_synchronize.argtypes = [vp]
+    _LIB = L
+    return L
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    load_library().mi355ndt_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def _as_points(cloud) -> np.ndarray:
+    """Accept [N,3]/[N,4+] float arrays (PCL-like records: x,y,z first); returns C-contiguous f32."""
+    a = np.asarray(cloud)
+    if a.ndim != 2 or a.shape[1] < 3:
+        raise ValueError("cloud must be [N,>=3] (x,y,z first)")
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _colmajor(M) -> np.ndarray:
+    M = np.asarray(M, dtype=np.float32)
+    if M.shape != (4, 4):
+        raise ValueError("transform must be 4x4")
+    return np.ascontiguousarray(M.T).ravel()      # column-major flattening (Eigen::Matrix4f layout)
+
+
+def _result_dict(r: Result) -> dict:
+    return dict(final=np.array(r.final_colmajor, np.float32).reshape(4, 4).T.copy(),
+                trans_probability=r.trans_probability, score=r.score, iterations=r.iterations,
+                converged=bool(r.converged), sweeps=r.sweeps, status=r.status, hits_last=r.hits_last)
+
+
+class Engine:
+    """Thin RAII wrapper of one mi355ndt_handle (one GPU, one stream)."""
+
+    def __init__(self, params: Params | None = None, device: int = 0):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        rc = self.lib.mi355ndt_create(C.byref(params) if params is not None else None, device, C.byref(self.h))
+        if rc != OK:
+            self.h = None
+            raise NDTError(rc, "mi355ndt_create")
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mi355ndt_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _chk(self, rc, where):
+        if rc != OK:
+            raise NDTError(rc, where, (self.lib.mi355ndt_last_error(self.h) or b"").decode())
+
+    # -- parameters
+    def get_params(self) -> Params:
+        p = Params()
+        self._chk(self.lib.mi355ndt_get_params(self.h, C.byref(p)), "get_params")
+        return p
+
+    def set_params(self, p: Params):
+        self._chk(self.lib.mi355ndt_set_params(self.h, C.byref(p)), "set_params")
+
+    def set_stream(self, stream_ptr: int | None):
+        self._chk(self.lib.mi355ndt_set_stream(self.h, C.c_void_p(stream_ptr or 0)), "set_stream")
+
+    # -- single registration
+    def set_target(self, cloud):
+        a = _as_points(cloud)
+        self._chk(self.lib.mi355ndt_set_target(self.h, a.ctypes.data_as(C.c_void_p), a.shape[0], a.strides[0]), "set_target")
+
+    def set_source(self, cloud):
+        a = _as_points(cloud)
+        self._n_src = a.shape[0]
+        self._chk(self.lib.mi355ndt_set_source(self.h, a.ctypes.data_as(C.c_void_p), a.shape[0], a.strides[0]), "set_source")
+
+    def align(self, guess) -> dict:
+        g = _colmajor(guess)
+        r = Result()
+        self._chk(self.lib.mi355ndt_align(self.h, g.ctypes.data_as(C.c_void_p), C.byref(r)), "align")
+        return _result_dict(r)
+
+    def get_aligned(self) -> np.ndarray:
+        out = np.zeros((self._n_src, 3), np.float32)
+        self._chk(self.lib.mi355ndt_get_aligned(self.h, out.ctypes.data_as(C.c_void_p), 12), "get_aligned")
+        return out
+
+    # -- parity hooks
+    def derivatives(self, p):
+        p = np.ascontiguousarray(p, np.float64)
+        s, hits = C.c_double(), C.c_longlong()
+        g, H = np.zeros(6), np.zeros(36)
+        self._chk(self.lib.mi355ndt_derivatives(self.h, p.ctypes.data_as(C.c_void_p), C.byref(s), g.ctypes.data_as(C.c_void_p),
+                                                H.ctypes.data_as(C.c_void_p), C.byref(hits)), "derivatives")
+        return s.value, g, H.reshape(6, 6), hits.value
+
+    def derivatives_T(self, T, Rj):
+        t = _colmajor(T)
+        r = np.ascontiguousarray(np.asarray(Rj, np.float32)).ravel()
+        s, hits = C.c_double(), C.c_longlong()
+        g, H = np.zeros(6), np.zeros(36)
+        self._chk(self.lib.mi355ndt_derivatives_T(self.h, t.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), C.byref(s),
+                                                  g.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p), C.byref(hits)), "derivatives_T")
+        return s.value, g, H.reshape(6, 6), hits.value
+
+    def get_grid(self, pair: int = 0):
+        mn, mx, dv = (np.zeros(3, np.int32) for _ in range(3))
+        nv = C.c_int()
+        self._chk(self.lib.mi355ndt_get_grid(self.h, pair, mn.ctypes.data_as(C.c_void_p), mx.ctypes.data_as(C.c_void_p),
+                                             dv.ctypes.data_as(C.c_void_p), C.byref(nv)), "get_grid")
+        return mn, mx, dv, nv.value
+
+    def get_voxels(self, pair: int = 0) -> np.ndarray:
+        nv = self.get_grid(pair)[3]
+        arr = (Voxel * max(nv, 1))()
+        self._chk(self.lib.mi355ndt_get_voxels(self.h, pair, C.cast(arr, C.c_void_p), nv), "get_voxels")
+        dt = np.dtype([("idx", "<i4"), ("n", "<i4"), ("mean", "<f8", 3), ("icov", "<f4", 9), ("weight", "<i4")], align=True)
+        assert dt.itemsize == C.sizeof(Voxel)
+        return np.frombuffer(bytes(arr), dtype=dt)[:nv].copy()
+
+    # -- batch
+    def batch_reserve(self, n_pairs, max_target_pts, max_source_pts):
+        self._chk(self.lib.mi355ndt_batch_reserve(self.h, n_pairs, max_target_pts, max_source_pts), "batch_reserve")
+
+    def batch_set_target(self, pair, cloud):
+        a = _as_points(cloud)
+        self._chk(self.lib.mi355ndt_batch_set_target(self.h, pair, a.ctypes.data_as(C.c_void_p), a.shape[0], a.strides[0]), "batch_set_target")
+
+    def batch_set_source(self, pair, cloud):
+        a = _as_points(cloud)
+        self._chk(self.lib.mi355ndt_batch_set_source(self.h, pair, a.ctypes.data_as(C.c_void_p), a.shape[0], a.strides[0]), "batch_set_source")
+
+    def batch_bind_device(self, d_targets_ptr: int, target_counts, target_pitch: int, d_sources_ptr: int, source_counts, source_pitch: int):
+        """Zero-copy device buffers laid out [pair][3][pitch] float32.  The caller keeps them alive."""
+        tc = np.ascontiguousarray(target_counts, np.int32)
+        sc = np.ascontiguousarray(source_counts, np.int32)
+        assert len(tc) == len(sc)
+        self._chk(self.lib.mi355ndt_batch_bind_device(self.h, len(tc), C.c_void_p(d_targets_ptr), tc.ctypes.data_as(C.c_void_p), target_pitch,
+                                                      C.c_void_p(d_sources_ptr), sc.ctypes.data_as(C.c_void_p), source_pitch), "batch_bind_device")
+
+    def batch_build_targets(self):
+        self._chk(self.lib.mi355ndt_batch_build_targets(self.h), "batch_build_targets")
+
+    def batch_align(self, guesses) -> list[dict]:
+        G = np.asarray(guesses, np.float32)
+        n = self.lib.mi355ndt_batch_size(self.h)
+        if G.shape == (4, 4):
+            G = np.broadcast_to(G, (n, 4, 4))
+        if G.shape != (n, 4, 4):
+            raise ValueError(f"guesses must be [{n},4,4]")
+        gc = np.ascontiguousarray(np.transpose(G, (0, 2, 1))).reshape(n, 16)
+        res = (Result * n)()
+        self._chk(self.lib.mi355ndt_batch_align(self.h, gc.ctypes.data_as(C.c_void_p), C.cast(res, C.c_void_p)), "batch_align")
+        return [_result_dict(r) for r in res]
+
+    def batch_align_raw(self, guesses_colmajor: np.ndarray, res_array):
+        """Allocation-free variant for timing loops: guesses [n,16] f32 C-contiguous, res_array = (Result*n)()."""
+        self._chk(self.lib.mi355ndt_batch_align(self.h, guesses_colmajor.ctypes.data_as(C.c_void_p), C.cast(res_array, C.c_void_p)), "batch_align")
+
+    def synchronize(self):
+        self._chk(self.lib.mi355ndt_synchronize(self.h), "synchronize")
+
+    # -- profiling
+    def profile_enable(self, on=True):
+        self._chk(self.lib.mi355ndt_profile_enable(self.h, int(on)), "profile_enable")
+
+    def profile_reset(self):
+        self._chk(self.lib.mi355ndt_profile_reset(self.h), "profile_reset")
+
+    def profile_get(self) -> dict:
+        p = Profile()
+        self._chk(self.lib.mi355ndt_profile_get(self.h, C.byref(p)), "profile_get")
+        return {k: getattr(p, k) for k, _ in Profile._fields_}
+
+
+class NormalDistributionsTransform:
+    """Drop-in mirror of pclomp::NormalDistributionsTransform / pclpca::NormalDistributionsTransform.
+
+    variant=VARIANT_OMP -> include/ndt_omp/ndt_omp.h ; variant=VARIANT_PCA -> include/ndt_pca/ndt_pca.h.
+    Method names (including the reference's `setOulierRatio` spelling) follow ndt_omp.h:109-203 and
+    pcl::Registration.  PCL-style error behaviour: no exceptions for a failed registration --
+    `hasConverged()` reports it; exceptions are reserved for API misuse and HIP failures.
+    """
+
+    def __init__(self, variant: int = VARIANT_OMP, device: int = 0):
+        self._prm = default_params(variant=variant)           # ctor defaults, ndt_omp_impl2.hpp:53-83
+        self._eng = Engine(self._prm, device)
+        self._final = np.eye(4, dtype=np.float32)
+        self._converged = False
+        self._nr_iterations = 0
+        self._trans_probability = 0.0
+        self._has_target = False
+        self._has_source = False
+        self._last = None
+
+    def _push(self):
+        self._eng.set_params(self._prm)
+
+    # ---- setters / getters of ndt_omp.h
+    def setNumThreads(self, n: int):            # ndt_omp.h:109 -- OpenMP thread count; meaningless on the GPU, accepted
+        self._num_threads = int(n)
+
+    def setResolution(self, resolution: float):  # ndt_omp.h:126-136 (re-voxelises only if changed and a target is set)
+        if np.float32(resolution) != np.float32(self._prm.resolution):
+            self._prm.resolution = float(resolution)
+            self._push()
+
+    def getResolution(self) -> float:
+        return float(self._prm.resolution)
+
+    def setStepSize(self, step_size: float):
+        self._prm.step_size = float(step_size)
+        self._push()
+
+    def getStepSize(self) -> float:
+        return self._prm.step_size
+
+    def setOulierRatio(self, outlier_ratio: float):   # [sic] ndt_omp.h:181
+        self._prm.outlier_ratio = float(outlier_ratio)
+        self._push()
+
+    def getOulierRatio(self) -> float:
+        return self._prm.outlier_ratio
+
+    def setNeighborhoodSearchMethod(self, method: int):
+        self._prm.neighbor_mode = int(method)
+        self._push()
+
+    def setTransformationEpsilon(self, eps: float):    # pcl::Registration
+        self._prm.trans_epsilon = float(eps)
+        self._push()
+
+    def setMaximumIterations(self, n: int):            # pcl::Registration
+        self._prm.max_iterations = int(n)
+        self._push()
+
+    def getTransformationProbability(self) -> float:
+        return self._trans_probability
+
+    def getFinalNumIteration(self) -> int:
+        return self._nr_iterations
+
+    # ---- pcl::Registration surface
+    def setInputTarget(self, cloud):             # ndt_omp.h:116-121 -> init()
+        self._eng.set_target(cloud)
+        self._has_target = True
+
+    def setInputSource(self, cloud):
+        self._eng.set_source(cloud)
+        self._has_source = True
+
+    def align(self, guess=None) -> np.ndarray:
+        """align(output, guess): returns the output cloud (source moved by the final pose, [N,3] f32)."""
+        if not (self._has_target and self._has_source):
+            # pcl::Registration::initCompute() fails -> PCL prints an error and returns with converged_ unchanged
+            self._converged = False
+            return np.zeros((0, 3), np.float32)
+        G = np.eye(4, dtype=np.float32) if guess is None else np.asarray(guess, np.float32)
+        r = self._eng.align(G)
+        self._last = r
+        self._final = r["final"]
+        self._converged = r["converged"]
+        self._nr_iterations = r["iterations"]
+        self._trans_probability = r["trans_probability"]
+        return self._eng.get_aligned()
+
+    def getFinalTransformation(self) -> np.ndarray:
+        return self._final.copy()
+
+    def hasConverged(self) -> bool:
+        return bool(self._converged)
+
+    @property
+    def engine(self) -> Engine:
+        return self._eng

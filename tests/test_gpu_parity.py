@@ -1,0 +1,280 @@
+"""GPU (-m gpu): the HIP path through the C-ABI vs the oracle and vs the committed golden fixtures.
+
+Bars: voxel grid -- cell indices / counts / pca weights bit-exact, mean and f32 icov bit-exact
+(same op order, IEEE f64 div/sqrt on both sides); sweep (score, g, H) -- rtol 1e-11 of the
+largest entry (only the f64 summation ORDER differs); align -- identical iteration count and
+SE(3) within the north-star tolerance trans < 1e-4 m, rot < 1e-5 rad."""
+import os
+import numpy as np
+import pytest
+
+from conftest import se3_err
+from lv_slam_amd import ndt, synth
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["omp_direct7_r1", "omp_direct1_r1", "omp_direct26_r2", "pca_direct7_r1", "pca_direct1_r05"]
+FIELDS = ["resolution", "step_size", "outlier_ratio", "trans_epsilon", "max_iterations", "neighbor_mode", "variant",
+          "min_points_per_voxel", "min_covar_eigvalue_mult"]
+
+
+def both_params(**kw):
+    return ndt.default_params(**kw), O.default_params(**kw)
+
+
+def golden(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    pv = z["params"]
+    kw = dict(resolution=float(pv[0]), step_size=float(pv[1]), outlier_ratio=float(pv[2]), trans_epsilon=float(pv[3]),
+              max_iterations=int(pv[4]), neighbor_mode=int(pv[5]), variant=int(pv[6]), min_points_per_voxel=int(pv[7]),
+              min_covar_eigvalue_mult=float(pv[8]))
+    return z, kw
+
+
+def check_voxels(eng, grid, exact=True):
+    mn, mx, dv, nv = eng.get_grid()
+    omn, omx, odv = grid.bounds()
+    assert np.array_equal(mn, omn) and np.array_equal(mx, omx) and np.array_equal(dv, odv)
+    lv = grid.leaves()
+    # searchable = every leaf that reached min_points (eigen failures keep their slot with n = -1)
+    minp = grid.prm.min_points_per_voxel
+    sel = lv[(lv["n"] >= minp) | (lv["n"] == -1)]
+    assert nv == len(sel)
+    v = eng.get_voxels()
+    assert np.array_equal(v["idx"], sel["idx"])
+    assert np.array_equal(v["n"], sel["n"])
+    live = sel["n"] >= minp
+    if exact:
+        assert np.array_equal(v["mean"], sel["mean"])
+        assert np.array_equal(v["icov"][live], sel["icov"][live].astype(np.float32))
+    else:
+        assert np.allclose(v["mean"], sel["mean"], rtol=1e-14, atol=0)
+        assert np.allclose(v["icov"][live], sel["icov"][live].astype(np.float32), rtol=1e-6)
+    if grid.prm.variant == O.VARIANT_PCA:
+        assert np.array_equal(v["weight"][live], sel["weight"][live])
+    return len(sel)
+
+
+def check_sweep(a, b, rtol=1e-11):
+    s1, g1, H1, h1 = a
+    s2, g2, H2, h2 = b
+    assert h1 == h2
+    scale = max(1.0, abs(s2), np.abs(g2).max(), np.abs(H2).max())
+    assert abs(s1 - s2) <= rtol * scale
+    assert np.abs(g1 - g2).max() <= rtol * scale
+    assert np.abs(H1 - H2).max() <= rtol * scale
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_voxels_sweep_align(golden_dir, name):
+    z, kw = golden(golden_dir, name)
+    gp, op = both_params(**kw)
+    eng = ndt.Engine(gp)
+    grid = O.Grid(z["target"], op)
+    eng.set_target(z["target"])
+    check_voxels(eng, grid)
+    # sweeps at the fixture poses: vs oracle (tight) and vs the independent NumPy restatement (fixture)
+    eng.set_source(z["src_sweep"])
+    for p, T, sc, gr, H, hits in zip(z["sweep_p"], z["sweep_T"], z["sweep_score"], z["sweep_g"], z["sweep_H"], z["sweep_hits"]):
+        got = eng.derivatives_T(T, T[:3, :3])
+        check_sweep(got, O.derivatives(grid, z["src_sweep"], T, T[:3, :3]))
+        check_sweep(got, (float(sc), gr, H, int(hits)), rtol=1e-8)
+        got_p = eng.derivatives(p)
+        check_sweep(got_p, O.derivatives_at(grid, z["src_sweep"], p), rtol=1e-9)
+    # align
+    eng.set_source(z["src_align"])
+    r = eng.align(z["guess"])
+    ro = O.align(grid, z["src_align"], z["guess"])
+    assert r["iterations"] == ro["iterations"] == int(z["align_iterations"])
+    assert r["converged"] == ro["converged"] and r["sweeps"] == ro["sweeps"]
+    for ref in (ro["final"], z["align_final"]):
+        dt, dr = se3_err(ref, r["final"])
+        assert dt < 1e-4 and dr < 1e-5, (dt, dr)
+    assert abs(r["score"] - ro["score"]) <= 1e-9 * max(1.0, abs(ro["score"]))
+    assert r["hits_last"] == ro["hits_last"]
+    assert abs(r["trans_probability"] - ro["trans_probability"]) <= 1e-9 * max(1.0, abs(ro["trans_probability"]))
+    # output cloud = source moved by the final pose (f32, PCL scalar form)
+    out = eng.get_aligned()
+    F = r["final"]
+    s = z["src_align"].astype(np.float32)
+    exp = np.stack([((F[a, 0] * s[:, 0] + F[a, 1] * s[:, 1]) + F[a, 2] * s[:, 2]) + F[a, 3] for a in range(3)], axis=1)
+    assert np.array_equal(out, exp.astype(np.float32))
+
+
+@pytest.mark.parametrize("mode,variant,res", [(ndt.DIRECT7, 0, 1.0), (ndt.DIRECT1, 1, 1.0), (ndt.DIRECT7, 1, 0.5)])
+def test_full_size_pair_vs_oracle(mode, variant, res):
+    """BASELINE config 2 (65,536-pt pair, HIP path, SE(3) checked against the CPU restatement) + the nodelet's
+    pca/DIRECT1 setting + config 5's 0.5 m pca grid."""
+    tgt, src, dT = synth.make_pair(0, 1024)
+    tgt, src = tgt.numpy(), src.numpy()
+    kw = dict(resolution=res, trans_epsilon=0.01, max_iterations=64, neighbor_mode=mode, variant=variant)
+    gp, op = both_params(**kw)
+    eng = ndt.Engine(gp)
+    grid = O.Grid(tgt, op)
+    eng.set_target(tgt)
+    nv = check_voxels(eng, grid)
+    assert nv > 500
+    eng.set_source(src)
+    G = synth.default_guess()
+    p0 = O.se3_log(G.astype(np.float64))
+    check_sweep(eng.derivatives(p0), O.derivatives_at(grid, src, p0))
+    r = eng.align(G)
+    ro = O.align(grid, src, G)
+    assert r["iterations"] == ro["iterations"] and r["converged"] == ro["converged"]
+    dt, dr = se3_err(ro["final"], r["final"])
+    assert dt < 1e-4 and dr < 1e-5, (dt, dr)
+    # and the registration is physically right: recovered motion ~ true motion (scene-noise level)
+    dt, dr = se3_err(dT, r["final"])
+    assert dt < 0.1 and dr < 0.01, (dt, dr)
+
+
+def test_identity_alignment_property():
+    """identical clouds + identity guess => nothing to do: |delta| -> 0 within the 3-sweep minimum."""
+    tgt, _, _ = synth.make_pair(2, 256)
+    tgt = tgt.numpy()
+    eng = ndt.Engine(ndt.default_params(trans_epsilon=0.01, max_iterations=64))
+    eng.set_target(tgt)
+    eng.set_source(tgt)
+    r = eng.align(np.eye(4, dtype=np.float32))
+    assert r["converged"] and r["iterations"] <= 3
+    dt, dr = se3_err(np.eye(4), r["final"])
+    assert dt < 0.02 and dr < 0.002       # steps are clamped to >= eps/2 = 0.005 each
+
+
+def test_edge_cases():
+    prm = ndt.default_params(trans_epsilon=0.01, max_iterations=64)
+    eng = ndt.Engine(prm)
+    rng = np.random.default_rng(3)
+    tgt = rng.uniform(-5, 5, (3000, 3)).astype(np.float32)
+    # align before any input: state error, not a crash
+    with pytest.raises(ndt.NDTError) as e:
+        eng.align(np.eye(4, dtype=np.float32))
+    assert e.value.code == -7
+    eng.set_target(tgt)
+    # zero hits: source far from every voxel -> delta == 0 -> converged, 0 iterations, final == guess (impl2:147-152)
+    src = (rng.uniform(-1, 1, (100, 3)) + 500).astype(np.float32)
+    eng.set_source(src)
+    G = np.eye(4, dtype=np.float32)
+    G[0, 3] = 0.25
+    r = eng.align(G)
+    assert r["converged"] and r["iterations"] == 0 and r["sweeps"] == 1 and np.array_equal(r["final"], G) and r["hits_last"] == 0
+    # non-finite points are skipped on both sides (the !is_dense branches)
+    tgt2 = tgt.copy()
+    tgt2[::7] = np.nan
+    src2 = rng.uniform(-4, 4, (777, 3)).astype(np.float32)
+    src2[::5, 1] = np.inf
+    op = O.default_params(trans_epsilon=0.01, max_iterations=64)
+    grid = O.Grid(tgt2, op)
+    eng.set_target(tgt2)
+    check_voxels(eng, grid)
+    eng.set_source(src2)
+    p = np.array([0.1, -0.05, 0.02, 0.01, 0.02, -0.03])
+    check_sweep(eng.derivatives(p), O.derivatives_at(grid, src2, p))
+    # ragged sizes: 1-point source, source not a multiple of the 1024-pt chunk
+    for n in (1, 1023, 1025):
+        s = rng.uniform(-4, 4, (n, 3)).astype(np.float32)
+        eng.set_source(s)
+        check_sweep(eng.derivatives(p), O.derivatives_at(grid, s, p))
+    # unsupported configurations fail loudly
+    with pytest.raises(ndt.NDTError) as e:
+        ndt.Engine(ndt.default_params(trans_epsilon=0.5, step_size=0.1)).align(G) if False else \
+            _align_with(ndt.default_params(trans_epsilon=0.5, step_size=0.1), tgt, src, G)
+    assert e.value.code == -6
+    with pytest.raises(ndt.NDTError) as e:
+        _align_with(ndt.default_params(neighbor_mode=ndt.KDTREE), tgt, src, G)
+    assert e.value.code == -6
+    # stride: PointXYZI-style 32-byte records
+    rec = np.zeros((len(tgt), 8), np.float32)
+    rec[:, :3] = tgt
+    rec[:, 4] = 77.0
+    eng.set_target(rec)
+    check_voxels(eng, O.Grid(tgt, op))
+
+
+def _align_with(prm, tgt, src, G):
+    e = ndt.Engine(prm)
+    e.set_target(tgt)
+    e.set_source(src)
+    return e.align(G)
+
+
+def test_set_resolution_revoxelises():
+    tgt, src, _ = synth.make_pair(4, 256, n_beams=32)
+    tgt, src = tgt.numpy(), src.numpy()
+    reg = ndt.NormalDistributionsTransform()
+    reg.setTransformationEpsilon(0.01)
+    reg.setMaximumIterations(64)
+    reg.setInputTarget(tgt)
+    n1 = reg.engine.get_grid()[3]
+    reg.setResolution(2.0)                     # ndt_omp.h:126-136: re-init because a target is set
+    n2 = reg.engine.get_grid()[3]
+    assert n1 != n2
+    check_voxels(reg.engine, O.Grid(tgt, O.default_params(resolution=2.0)))
+    reg.setInputSource(src)
+    out = reg.align(synth.default_guess())
+    ro = O.align(O.Grid(tgt, O.default_params(resolution=2.0, trans_epsilon=0.01, max_iterations=64)), src, synth.default_guess())
+    assert reg.getFinalNumIteration() == ro["iterations"] and reg.hasConverged() == ro["converged"]
+    dt, dr = se3_err(ro["final"], reg.getFinalTransformation())
+    assert dt < 1e-4 and dr < 1e-5
+    assert out.shape == src.shape
+    assert abs(reg.getTransformationProbability() - ro["trans_probability"]) < 1e-9
+
+
+def test_batch_matches_single_and_oracle():
+    """configs 3/4 in miniature: a batch of independent pairs == the same pairs run one at a time (bit-identical),
+    and == the oracle to tolerance; ragged cloud sizes inside one batch."""
+    prm_kw = dict(trans_epsilon=0.01, max_iterations=64)
+    pairs = []
+    for k in range(5):
+        t, s, dT = synth.make_pair(10 + k, 128 if k % 2 else 192, n_beams=32)
+        pairs.append((t.numpy(), s.numpy()[: len(s) - 37 * k], dT))
+    G = synth.default_guess()
+    eng = ndt.Engine(ndt.default_params(**prm_kw))
+    eng.batch_reserve(len(pairs), max(len(p[0]) for p in pairs), max(len(p[1]) for p in pairs))
+    for k, (t, s, _) in enumerate(pairs):
+        eng.batch_set_target(k, t)
+        eng.batch_set_source(k, s)
+    eng.batch_build_targets()
+    res = eng.batch_align(np.broadcast_to(G, (len(pairs), 4, 4)))
+    single = ndt.Engine(ndt.default_params(**prm_kw))
+    for k, (t, s, _) in enumerate(pairs):
+        single.set_target(t)
+        single.set_source(s)
+        r1 = single.align(G)
+        assert np.array_equal(res[k]["final"], r1["final"])           # bit-identical: fixed reduction tree
+        assert res[k]["score"] == r1["score"] and res[k]["iterations"] == r1["iterations"]
+        ro = O.align(O.Grid(t, O.default_params(**prm_kw)), s, G)
+        assert res[k]["iterations"] == ro["iterations"] and res[k]["converged"] == ro["converged"]
+        dt, dr = se3_err(ro["final"], res[k]["final"])
+        assert dt < 1e-4 and dr < 1e-5
+    # run-to-run determinism
+    res2 = eng.batch_align(np.broadcast_to(G, (len(pairs), 4, 4)))
+    for a, b in zip(res, res2):
+        assert np.array_equal(a["final"], b["final"]) and a["score"] == b["score"]
+
+
+def test_device_resident_batch_zero_copy():
+    import torch
+    dev = torch.device("cuda:0")
+    B, naz = 4, 256
+    T = torch.zeros(B, 3, naz * 64, device=dev)
+    S = torch.zeros(B, 3, naz * 64, device=dev)
+    host = []
+    for k in range(B):
+        t, s, dT = synth.make_pair(20 + k, naz, device=dev)
+        T[k] = t.T
+        S[k] = s.T
+        host.append((t.cpu().numpy(), s.cpu().numpy()))
+    torch.cuda.synchronize()
+    eng = ndt.Engine(ndt.default_params(trans_epsilon=0.01, max_iterations=64))
+    n = naz * 64
+    eng.batch_bind_device(T.data_ptr(), [n] * B, n, S.data_ptr(), [n] * B, n)
+    eng.batch_build_targets()
+    G = synth.default_guess()
+    res = eng.batch_align(G)
+    for k in range(B):
+        ro = O.align(O.Grid(host[k][0], O.default_params(trans_epsilon=0.01, max_iterations=64)), host[k][1], G)
+        assert res[k]["iterations"] == ro["iterations"]
+        dt, dr = se3_err(ro["final"], res[k]["final"])
+        assert dt < 1e-4 and dr < 1e-5
