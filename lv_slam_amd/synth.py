@@ -3,7 +3,7 @@
 Sensor model: 64 beams, elevation linear from +2.0 deg to -24.9 deg (the reference hard-codes the
 same fan, include/ndt_pca/voxel_grid_covariance_pca.h:97), mounted 1.73 m above a ground plane;
 `n_azimuth` firings per revolution (1024 -> 65,536 points, 2048 -> 131,072 points).
-Scene: a procedural street along +x (buildings both sides, poles, parked vehicles), generated per
+Scene: a procedural street along +x (buildings both sides, poles, tree crowns, bushes, parked vehicles), generated per
 24 m slot from a hash of (seed, slot) so any frame position sees a deterministic neighbourhood.
 Pair k: target = scan at pose P_k = trans(k * 1.0 m, 0, 0); source = scan at P_k * dT_k with
 dT_k ~ (x~U(0.6,1.4), y~N(0,0.03), z~N(0,0.01), yaw~N(0,1deg), pitch/roll~N(0,0.2deg)); both scans
@@ -25,7 +25,7 @@ BASE_SEED = 0x5EED0000
 def _slot_primitives(seed: int, slot: int):
     rng = np.random.default_rng([seed & 0xFFFFFFFF, slot & 0xFFFFFFFF, 0xC0FFEE])
     x0 = slot * SLOT
-    boxes, cyls = [], []
+    boxes, cyls, sph = [], [], []
     for side in (1.0, -1.0):
         w = rng.uniform(6.0, 20.0)
         depth = rng.uniform(10.0, 15.0)
@@ -34,25 +34,32 @@ def _slot_primitives(seed: int, slot: int):
         bx = x0 + rng.uniform(0.0, SLOT - w)
         y_in, y_out = side * setback, side * (setback + depth)
         boxes.append([bx, min(y_in, y_out), 0.0, bx + w, max(y_in, y_out), h])
-    for _ in range(4):  # poles / trunks
-        cyls.append([x0 + rng.uniform(0.0, SLOT), rng.choice([-1.0, 1.0]) * rng.uniform(5.0, 7.5),
-                     rng.uniform(0.15, 0.4), rng.uniform(3.0, 8.0)])
+    for _ in range(4):  # poles / trunks, every second one carries a tree crown
+        cx, cy = x0 + rng.uniform(0.0, SLOT), rng.choice([-1.0, 1.0]) * rng.uniform(5.0, 7.5)
+        r, hgt = rng.uniform(0.15, 0.4), rng.uniform(3.0, 8.0)
+        cyls.append([cx, cy, r, hgt])
+        if rng.uniform() < 0.5:
+            sph.append([cx, cy, hgt + 0.5, rng.uniform(1.5, 3.0)])
+    for _ in range(6):  # bushes / clutter on the verge
+        sph.append([x0 + rng.uniform(0.0, SLOT), rng.choice([-1.0, 1.0]) * rng.uniform(4.5, 8.0), rng.uniform(0.2, 0.6),
+                    rng.uniform(0.5, 1.4)])
     if rng.uniform() < 0.6:  # parked vehicle
         cx = x0 + rng.uniform(2.5, SLOT - 2.5)
         cy = rng.choice([-1.0, 1.0]) * rng.uniform(2.8, 4.5)
         boxes.append([cx - 2.1, cy - 0.9, 0.0, cx + 2.1, cy + 0.9, 1.5])
-    return boxes, cyls
+    return boxes, cyls, sph
 
 
 def street_primitives(x_center: float, seed: int = BASE_SEED, reach: float = 130.0):
     s0 = int(math.floor((x_center - reach) / SLOT))
     s1 = int(math.floor((x_center + reach) / SLOT))
-    boxes, cyls = [], []
+    boxes, cyls, sph = [], [], []
     for s in range(s0, s1 + 1):
-        b, c = _slot_primitives(seed, s)
+        b, c, p = _slot_primitives(seed, s)
         boxes += b
         cyls += c
-    return np.asarray(boxes, dtype=np.float64), np.asarray(cyls, dtype=np.float64)
+        sph += p
+    return np.asarray(boxes, dtype=np.float64), np.asarray(cyls, dtype=np.float64), np.asarray(sph, dtype=np.float64)
 
 
 def beam_directions(n_azimuth: int, device, n_beams: int = 64):
@@ -78,7 +85,7 @@ def cast_scan(pose: np.ndarray, n_azimuth: int, noise: torch.Tensor, ring_u: tor
     o = torch.as_tensor(pose[:3, 3] + np.array([0, 0, SENSOR_H]), dtype=torch.float64, device=device)
     ds = beam_directions(n_azimuth, device, n_beams)          # sensor-frame unit rays
     d = ds @ R.T                                              # world-frame
-    boxes_np, cyls_np = street_primitives(float(pose[0, 3]), seed)
+    boxes_np, cyls_np, sph_np = street_primitives(float(pose[0, 3]), seed)
     inf = torch.full((d.shape[0],), float("inf"), dtype=torch.float64, device=device)
     # ground z = 0
     t = torch.where(d[:, 2] < -1e-9, -o[2] / d[:, 2], inf)
@@ -106,6 +113,17 @@ def cast_scan(pose: np.ndarray, n_azimuth: int, noise: torch.Tensor, ring_u: tor
         ok = (disc > 0) & (tc > 0) & (zc >= 0) & (zc <= C[None, :, 3])
         tc = torch.where(ok, tc, inf[:, None].expand(-1, C.shape[0]))
         t = torch.minimum(t, tc.amin(dim=1))
+    # spheres (tree crowns, bushes)
+    if len(sph_np):
+        Sp = torch.as_tensor(sph_np, device=device)
+        oc = o[None, :] - Sp[:, 0:3]                           # [S,3]
+        bq = d @ oc.T                                          # [N,S]  (d . oc)
+        cq = (oc * oc).sum(dim=1)[None, :] - Sp[None, :, 3] ** 2
+        disc = bq * bq - cq
+        ts = -bq - torch.sqrt(disc.clamp_min(0))
+        ok = (disc > 0) & (ts > 0)
+        ts = torch.where(ok, ts, inf[:, None].expand(-1, Sp.shape[0]))
+        t = torch.minimum(t, ts.amin(dim=1))
     rng_ok = (t > 0.5) & (t < 100.0)
     t_noisy = t + noise.to(device)
     pts = ds * torch.where(rng_ok, t_noisy, torch.zeros_like(t))[:, None]
