@@ -23,8 +23,11 @@
 #include "ndt_math.hpp"
 
 // ------------------------------------------------------------------------------------ constants
-#define CHUNK_PTS      1024          // source points per reduction chunk (fixed => results independent of launch geometry)
+#define CHUNK_PTS      2048          // source points per reduction chunk (fixed => results independent of launch geometry)
 #define SWEEP_THREADS  256
+#ifndef SWEEP_WPE
+#define SWEEP_WPE       3             // waves per SIMD the sweep is register-allocated for (3: 168 VGPRs, measured faster than 2)
+#endif
 #define NACC           44            // score, g[6], H[36], hits
 #define IDX_BITS       26            // sort key = pair << 26 | cell ; cell < 2^25 ; bit 25 = "not binned"
 #define MAX_CELLS      (1 << 25)
@@ -305,19 +308,25 @@ __global__ void __launch_bounds__(256) k_voxels(const float* __restrict__ tgt, s
 // ------------------------------------------------------------------------------------ derivative sweep
 // One (point, voxel) evaluation: updateDerivatives (ndt_omp_impl2.hpp:566-619) with the Jacobian /
 // Hessian patterns of computePointDerivatives_AngleAxisd (impl2:503-532) folded in (J and Hp are never
-// materialised).  f32 ops single, left to right; f64 accumulation.  `w` = weight multiplier
-// (ndt_pca compounding, applied as a suffix product; 1.0 for ndt_omp).
+// materialised).  f32 ops single, left to right; f64 accumulation.  `w` = weight multiplier of the hit
+// (ndt_pca compounding, applied as a suffix product; unused for ndt_omp).
+template <bool PCA>
 __device__ __forceinline__ void eval_hit(const float u[3], const float r[3], const float C[9],
-                                         const double d1, const float d2f, const double w, double acc[NACC]) {
+                                         const double d1, const float d2f, const double w, const bool ok_in, double acc[43]) {
   float y[3];
 #pragma unroll
   for (int j = 0; j < 3; j++) y[j] = (u[0] * C[j] + u[1] * C[3 + j]) + u[2] * C[6 + j];
   const float qf = (u[0] * y[0] + u[1] * y[1]) + u[2] * y[2];
   const float e0 = (float)exp((double)((-d2f * qf) * 0.5f));                     // impl2:581
-  const float s_inc = (float)(-d1 * (double)e0);                                 // impl2:583
+  float s_inc = (float)(-d1 * (double)e0);                                       // impl2:583
   const float e1 = d2f * e0;                                                     // impl2:585
-  if (e1 > 1.f || e1 < 0.f || e1 != e1) return;                                  // impl2:588-589
-  const float e = (float)((double)e1 * d1);                                      // impl2:592
+  // impl2:588-589, branch-free: a rejected hit (or an idle lane, ok_in = false) multiplies every term by e = 0 and so
+  // adds +0 to all 43 sums (all operands are finite here: dead voxels never enter the queue).
+  const bool ok = ok_in && !(e1 > 1.f || e1 < 0.f || e1 != e1);
+  float e = (float)((double)e1 * d1);                                            // impl2:592
+  e = ok ? e : 0.f;
+  s_inc = ok ? s_inc : 0.f;
+  // CJ = c_inv4 * point_gradient4 (impl2:594): columns 0..2 are C itself
   float CJ[3][6];
 #pragma unroll
   for (int a = 0; a < 3; a++) {
@@ -329,44 +338,72 @@ __device__ __forceinline__ void eval_hit(const float u[3], const float r[3], con
   float v[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) v[k] = (u[0] * CJ[0][k] + u[1] * CJ[1][k]) + u[2] * CJ[2][k];   // impl2:595
-  acc[0] += w * (double)s_inc;
+  // w * term: the product is a single rounding away from the reference's nested multiplies (both ~1e-16)
+#define NDT_ACC(slot, val) do { if (PCA) acc[slot] = fma(w, (double)(val), acc[slot]); else acc[slot] += (double)(val); } while (0)
+  NDT_ACC(0, s_inc);
 #pragma unroll
-  for (int k = 0; k < 6; k++) acc[1 + k] += w * (double)(e * v[k]);                           // impl2:597
-  float Z[6][6];
-#pragma unroll
-  for (int i = 0; i < 6; i++)
-#pragma unroll
-    for (int j = 0; j < 6; j++) Z[i][j] = 0.f;
-  Z[3][3] = y[1] * (-r[1]) + y[2] * (-r[2]);
-  Z[4][3] = y[0] * r[1];
-  Z[5][3] = y[0] * r[2];
-  Z[3][4] = y[1] * r[0];
-  Z[4][4] = y[0] * (-r[0]) + y[2] * (-r[2]);
-  Z[5][4] = y[1] * r[2];
-  Z[3][5] = y[2] * r[0];
-  Z[4][5] = y[2] * r[1];
-  Z[5][5] = y[0] * (-r[0]) + y[1] * (-r[1]);
+  for (int k = 0; k < 6; k++) NDT_ACC(1 + k, e * v[k]);                                        // impl2:597
+  // z_i[j] = y * Hp_block_i (impl2:607) -- nine non-zero entries (impl2:522-530)
+  float Z[3][3];
+  Z[0][0] = y[1] * (-r[1]) + y[2] * (-r[2]);
+  Z[1][0] = y[0] * r[1];
+  Z[2][0] = y[0] * r[2];
+  Z[0][1] = y[1] * r[0];
+  Z[1][1] = y[0] * (-r[0]) + y[2] * (-r[2]);
+  Z[2][1] = y[1] * r[2];
+  Z[0][2] = y[2] * r[0];
+  Z[1][2] = y[2] * r[1];
+  Z[2][2] = y[0] * (-r[0]) + y[1] * (-r[1]);
 #pragma unroll
   for (int i = 0; i < 6; i++) {
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-      // JCJ[j][i] = (J^T CJ)(j,i)
+      // JCJ[j][i] = (J^T CJ)(j,i) (impl2:601)
       float jcj;
       if (j < 3) jcj = CJ[j][i];
       else if (j == 3) jcj = (-r[2]) * CJ[1][i] + r[1] * CJ[2][i];
       else if (j == 4) jcj = r[2] * CJ[0][i] + (-r[0]) * CJ[2][i];
       else jcj = (-r[1]) * CJ[0][i] + r[0] * CJ[1][i];
-      const float h = e * ((((-d2f) * v[i]) * v[j] + Z[i][j]) + jcj);                         // impl2:611-613
-      acc[7 + i * 6 + j] += w * (double)h;
+      const float z = (i >= 3 && j >= 3) ? Z[i - 3][j - 3] : 0.f;
+      const float h = e * ((((-d2f) * v[i]) * v[j] + z) + jcj);                                // impl2:611-613
+      NDT_ACC(7 + i * 6 + j, h);
     }
   }
+#undef NDT_ACC
 }
 
-__global__ void __launch_bounds__(SWEEP_THREADS)
+#define Q_CAP   512                       // per-wave hit queue (entries); >= 63 + 7*64
+#define Q_GROUP 7                         // probes between queue drains
+#define ID_BITS 25                        // queue entry = slot << 25 | voxel id
+#define WAVES   (SWEEP_THREADS / 64)
+
+// The sweep.  Work decomposition (MI355X-first):
+//   block = 4 waves = one CHUNK_PTS chunk of one pair at a time; each wave owns CHUNK_PTS/4 consecutive points.
+//   phase A (probe, lane = point): transform the point (f32), probe its K neighbour cells in the rank-bitmap,
+//     and push every hit as a 4-byte entry into the wave's LDS queue (ballot + popcount compaction).
+//   phase B (evaluate, lane = hit): lanes pull 64 queue entries at a time -- every lane busy no matter how the
+//     hits were distributed over points -- read the staged point (LDS) and the 64-B voxel record, and add the
+//     43 f64 terms into per-lane accumulators.
+//   chunk end: flush the queue tail, wave butterfly + fixed-order wave sum -> one 44-double partial row per chunk.
+// The partial rows depend only on (CHUNK_PTS, input order), never on the launch geometry, so single and batched
+// runs of one pair are bit-identical.
+template <bool PCA>
+__global__ void __launch_bounds__(SWEEP_THREADS, SWEEP_WPE)
 k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict__ st,
         const GridDesc* __restrict__ gd, const BitWord* __restrict__ words, const VoxelRec* __restrict__ recs,
-        double* partials, int chunks_per_pair, SweepConst sc) {
-  const int b = blockIdx.y;
+        double* partials, int chunks_per_pair, int n_pairs, int bx, int xcd_map, SweepConst sc) {
+  // XCD-aware mapping: workgroup L runs on XCD L % 8 (observed dispatch order, MI355X_MICROARCH.md); keep all
+  // blocks of one pair on one XCD so its voxel records / bitmap / points stay in that XCD's L2.
+  int b, bxi;
+  if (xcd_map) {
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    b = (j / bx) * 8 + xcd;
+    bxi = j % bx;
+    if (b >= n_pairs) return;
+  } else {
+    b = blockIdx.x / bx;
+    bxi = blockIdx.x % bx;
+  }
   const PairState& S = st[b];
   if (S.phase == PH_DONE) return;
   const int n = S.n_src;
@@ -375,86 +412,135 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
   const BitWord* W = words + g.word_off;
   const VoxelRec* R = recs + g.rec_off;
   const bool grid_ok = (g.status == GRID_OK);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+  __shared__ unsigned q_ent[WAVES][Q_CAP];
+  __shared__ double q_w[PCA ? WAVES : 1][PCA ? Q_CAP : 1];
+  __shared__ float stage[WAVES][128][6];           // two tiles of staged points: x'(3), R x (3)
+  __shared__ double red[WAVES][NACC];
+
   float T[12], Rj[9];
 #pragma unroll
   for (int a = 0; a < 12; a++) T[a] = S.T[a];
 #pragma unroll
   for (int a = 0; a < 9; a++) Rj[a] = S.Rj[a];
-  __shared__ double red[SWEEP_THREADS / 64][NACC];
+  const float leaf = g.leaf;
+  const int mb0 = g.min_b[0], mb1 = g.min_b[1], mb2 = g.min_b[2];
+  const int xb0 = g.max_b[0], xb1 = g.max_b[1], xb2 = g.max_b[2];
+  const int mul1 = g.mul1, mul2 = g.mul2;
 
-  for (int chunk = blockIdx.x; chunk < chunks_per_pair; chunk += gridDim.x) {
-    double acc[NACC];
+  for (int chunk = bxi; chunk < chunks_per_pair; chunk += bx) {
+    double acc[43];
 #pragma unroll
-    for (int a = 0; a < NACC; a++) acc[a] = 0.0;
-    const int base = chunk * CHUNK_PTS;
-    if (base < n && grid_ok) {
+    for (int a = 0; a < 43; a++) acc[a] = 0.0;
+    unsigned nhits = 0;                              // wave-uniform
+    int qhead = 0, qcount = 0;                       // wave-uniform
+    int q_old = 0;                                   // queued entries that reference the OTHER staging half (older tile)
+    const int wbase = chunk * CHUNK_PTS + wv * (CHUNK_PTS / WAVES);
+
+    // evaluate `m` queued hits (m <= 64), one per lane; lanes >= m re-read the last entry and contribute +0
+    auto drain = [&](int m) {
+      const int k = lane < m ? lane : m - 1;
+      const unsigned ent = q_ent[wv][(qhead + k) & (Q_CAP - 1)];
+      const unsigned slot = ent >> ID_BITS, id = ent & ((1u << ID_BITS) - 1);
+      const float* sp = stage[wv][slot];
+      const float xt0 = sp[0], xt1 = sp[1], xt2 = sp[2];
+      float r[3] = {sp[3], sp[4], sp[5]};
+      const VoxelRec& vr = R[id];
+      const double m0 = vr.mean[0], m1 = vr.mean[1], m2 = vr.mean[2];
+      float Cf[9];
+#pragma unroll
+      for (int a = 0; a < 9; a++) Cf[a] = vr.icov[a];
+      double w = 1.0;
+      if (PCA) w = q_w[wv][(qhead + k) & (Q_CAP - 1)];
+      float u[3] = {(float)((double)xt0 - m0), (float)((double)xt1 - m1), (float)((double)xt2 - m2)};   // impl2:276-279, 574
+      eval_hit<PCA>(u, r, Cf, sc.d1, sc.d2f, w, lane < m, acc);
+      nhits += (unsigned)m;
+      qhead = (qhead + m) & (Q_CAP - 1);
+      qcount -= m;
+      q_old = q_old > m ? q_old - m : 0;
+    };
+
+    if (wbase < n && grid_ok) {
 #pragma unroll 1
-      for (int k = 0; k < CHUNK_PTS / SWEEP_THREADS; k++) {
-        const int i = base + k * SWEEP_THREADS + threadIdx.x;
-        if (i >= n) continue;
-        const float px = X[i], py = X[pitch + i], pz = X[2 * pitch + i];
-        if (!finite3(px, py, pz)) continue;
-        // PCL 1.8 transformPointCloud scalar form
+      for (int t = 0; t < CHUNK_PTS / WAVES / 64; t++) {
+        const int i = wbase + t * 64 + lane;
+        if (wbase + t * 64 >= n) break;              // wave-uniform
+        // the staging area holds two tiles: entries of tile t-2 must be gone before tile t overwrites their half
+        // (only happens when hits are sparse; dense tiles are consumed by the regular 64-wide drains)
+        if (q_old > 0) { __builtin_amdgcn_wave_barrier(); drain(q_old); }
+        q_old = qcount;
+        const int slot = (t & 1) * 64 + lane;
+        bool valid = i < n;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (valid) { px = X[i]; py = X[pitch + i]; pz = X[2 * pitch + i]; }
+        valid = valid && finite3(px, py, pz);
+        // PCL 1.8 transformPointCloud scalar form; Jacobian point r = R x (impl2:507-508)
         float xt[3], r[3];
 #pragma unroll
         for (int a = 0; a < 3; a++) {
           xt[a] = ((T[a * 4 + 0] * px + T[a * 4 + 1] * py) + T[a * 4 + 2] * pz) + T[a * 4 + 3];
-          r[a] = (Rj[a * 3 + 0] * px + Rj[a * 3 + 1] * py) + Rj[a * 3 + 2] * pz;               // impl2:507-508
+          r[a] = (Rj[a * 3 + 0] * px + Rj[a * 3 + 1] * py) + Rj[a * 3 + 2] * pz;
         }
+        float* sp = stage[wv][slot];
+        sp[0] = xt[0]; sp[1] = xt[1]; sp[2] = xt[2]; sp[3] = r[0]; sp[4] = r[1]; sp[5] = r[2];
         // getNeighborhoodAtPoint (voxel_grid_covariance_omp_impl.hpp:379-399)
-        const int c0 = (int)floorf(xt[0] / g.leaf), c1 = (int)floorf(xt[1] / g.leaf), c2 = (int)floorf(xt[2] / g.leaf);
-        // pass 1: collect hits (needed up front for the ndt_pca suffix-product weights)
-        unsigned hit_id[26];
-        double hit_w[26];
-        int nh = 0;
+        const int c0 = (int)floorf(xt[0] / leaf), c1 = (int)floorf(xt[1] / leaf), c2 = (int)floorf(xt[2] / leaf);
+        // probes run last-to-first so the ndt_pca weight of a hit (product of its own and all LATER hits' weights,
+        // ndt_pca_impl2.hpp:295-296) is a running product; the order of the f64 additions is free anyway.
+        double suf = 1.0;
 #pragma unroll 1
-        for (int q = 0; q < sc.K; q++) {
+        for (int q = sc.K - 1; q >= 0; q--) {
           const int a0 = c0 + sc.off[q][0], a1 = c1 + sc.off[q][1], a2 = c2 + sc.off[q][2];
-          if (a0 < g.min_b[0] || a0 > g.max_b[0] || a1 < g.min_b[1] || a1 > g.max_b[1] || a2 < g.min_b[2] || a2 > g.max_b[2]) continue;
-          const unsigned cell = (unsigned)((a0 - g.min_b[0]) + (a1 - g.min_b[1]) * g.mul1 + (a2 - g.min_b[2]) * g.mul2);
-          const BitWord bw = W[cell >> 6];
-          const unsigned long long bit = 1ull << (cell & 63);
-          if (!(bw.bits & bit)) continue;
-          const unsigned id = bw.prefix + (unsigned)__popcll(bw.bits & (bit - 1ull));
-          const int wi = R[id].weight;
-          if (wi == VOX_DEAD) continue;                         // nr_points == -1: not a neighbour (impl:395)
-          hit_id[nh] = id;
-          hit_w[nh] = (double)wi;
-          nh++;
-        }
-        acc[43] += (double)nh;
-        // ndt_pca multiplies the running per-point sums by the weight of the current and of every later hit
-        // (ndt_pca_impl2.hpp:295-296) => hit q carries the product of weights q..last (exact: small integers).
-        if (sc.pca) { double suf = 1.0; for (int q = nh - 1; q >= 0; q--) { suf *= hit_w[q]; hit_w[q] = suf; } }
-        // pass 2: evaluate
-#pragma unroll 1
-        for (int q = 0; q < nh; q++) {
-          const VoxelRec& vr = R[hit_id[q]];
-          float u[3], Cf[9];
-#pragma unroll
-          for (int a = 0; a < 3; a++) u[a] = (float)((double)xt[a] - vr.mean[a]);               // impl2:276-279, 574
-#pragma unroll
-          for (int a = 0; a < 9; a++) Cf[a] = vr.icov[a];
-          eval_hit(u, r, Cf, sc.d1, sc.d2f, sc.pca ? hit_w[q] : 1.0, acc);
+          bool hit = valid && a0 >= mb0 && a0 <= xb0 && a1 >= mb1 && a1 <= xb1 && a2 >= mb2 && a2 <= xb2;
+          unsigned id = 0;
+          if (hit) {
+            const unsigned cell = (unsigned)((a0 - mb0) + (a1 - mb1) * mul1 + (a2 - mb2) * mul2);
+            const BitWord bw = W[cell >> 6];
+            const unsigned long long bit = 1ull << (cell & 63);
+            hit = (bw.bits & bit) != 0ull;
+            id = bw.prefix + (unsigned)__popcll(bw.bits & (bit - 1ull));
+          }
+          if (hit) {
+            const int wi = R[id].weight;             // also pulls the record's line towards this CU for phase B
+            hit = wi != VOX_DEAD;                    // nr_points == -1: not a neighbour (impl:395)
+            if (PCA && hit) suf *= (double)wi;
+          }
+          const unsigned long long mask = __ballot(hit);
+          if (hit) {
+            const int pos = (qhead + qcount + (int)__popcll(mask & lt_mask)) & (Q_CAP - 1);
+            q_ent[wv][pos] = ((unsigned)slot << ID_BITS) | id;
+            if (PCA) q_w[wv][pos] = suf;
+          }
+          qcount += (int)__popcll(mask);
+          if (((sc.K - 1 - q) % Q_GROUP) == Q_GROUP - 1 || q == 0) {
+            __builtin_amdgcn_wave_barrier();
+            while (qcount >= 64) drain(64);
+          }
         }
       }
+      __builtin_amdgcn_wave_barrier();
+      if (qcount > 0) drain(qcount);
     }
     // fixed-order block reduction: wave butterfly, then waves 0..3
 #pragma unroll
-    for (int a = 0; a < NACC; a++) {
+    for (int a = 0; a < 43; a++) {
       double v = acc[a];
+#pragma unroll
       for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
       acc[a] = v;
     }
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) {
+    if (lane == 0) {
 #pragma unroll
-      for (int a = 0; a < NACC; a++) red[threadIdx.x >> 6][a] = acc[a];
+      for (int a = 0; a < 43; a++) red[wv][a] = acc[a];
+      red[wv][43] = (double)nhits;
     }
     __syncthreads();
     if (threadIdx.x < NACC) {
       double v = red[0][threadIdx.x];
-      for (int wv = 1; wv < SWEEP_THREADS / 64; wv++) v += red[wv][threadIdx.x];
+      for (int k = 1; k < WAVES; k++) v += red[k][threadIdx.x];
       partials[((size_t)b * chunks_per_pair + chunk) * NACC + threadIdx.x] = v;
     }
   }
@@ -1082,14 +1168,22 @@ static void make_sweep_const(const mi355ndt_handle* h, SweepConst& sc) {
 }
 
 static int launch_sweep(mi355ndt_handle* h, const SweepConst& sc, int first_pair, int n_pairs_launch) {
-  // grid.x = chunks handled round-robin by blocks; enough blocks to fill 256 CUs
+  // bx blocks walk the chunks of one pair round-robin; enough blocks overall to fill 256 CUs several times
   int bx = h->chunks_per_pair;
-  const int want = 2048;
-  if ((long long)bx * n_pairs_launch > 4 * want) bx = std::max(1, std::min(bx, (4 * want) / n_pairs_launch));
+  const int want = 8192;
+  if ((long long)bx * n_pairs_launch > want) bx = std::max(1, std::min(bx, want / n_pairs_launch));
+  const int xcd_map = n_pairs_launch >= 8;
+  const int groups = xcd_map ? ((n_pairs_launch + 7) / 8) * 8 : n_pairs_launch;
+  const dim3 grid((unsigned)(groups * bx));
   if (h->prof) HIPCHK(h, ev_begin(h, h->ev_sweep));
-  k_sweep<<<dim3(bx, n_pairs_launch), SWEEP_THREADS, 0, h->stream>>>(
-      h->d_src + (size_t)first_pair * 3 * h->src_pitch, h->src_pitch, h->d_state + first_pair, h->d_grid + first_pair,
-      h->d_words, h->d_recs, h->d_partials + (size_t)first_pair * h->chunks_per_pair * NACC, h->chunks_per_pair, sc);
+  const float* src = h->d_src + (size_t)first_pair * 3 * h->src_pitch;
+  double* part = h->d_partials + (size_t)first_pair * h->chunks_per_pair * NACC;
+  if (sc.pca)
+    k_sweep<true><<<grid, SWEEP_THREADS, 0, h->stream>>>(src, h->src_pitch, h->d_state + first_pair, h->d_grid + first_pair,
+        h->d_words, h->d_recs, part, h->chunks_per_pair, n_pairs_launch, bx, xcd_map, sc);
+  else
+    k_sweep<false><<<grid, SWEEP_THREADS, 0, h->stream>>>(src, h->src_pitch, h->d_state + first_pair, h->d_grid + first_pair,
+        h->d_words, h->d_recs, part, h->chunks_per_pair, n_pairs_launch, bx, xcd_map, sc);
   if (h->prof) HIPCHK(h, ev_end(h, h->ev_sweep));
   return MI355NDT_OK;
 }
