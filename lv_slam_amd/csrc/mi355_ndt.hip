@@ -2,7 +2,7 @@
 //
 // What runs where (all on the GPU; the host only enqueues):
 //   target build  : k_minmax -> k_griddesc -> k_keys -> radix sort (cell, input order) -> k_mark
-//                   -> k_rank -> k_voxels          (VoxelGridCovariance::applyFilter,
+//                   -> k_rank -> k_segstart -> k_leafsum -> k_voxels          (VoxelGridCovariance::applyFilter,
 //                   include/ndt_omp/voxel_grid_covariance_omp_impl.hpp:48-370)
 //   align         : k_init_state -> k_sweep -> [k_update -> k_sweep]*      (computeTransformation +
 //                   computeDerivatives + the live prefix of computeStepLengthMT,
@@ -222,12 +222,9 @@ __global__ void __launch_bounds__(256) k_rank(GridDesc* gd, BitWord* words) {
   if (threadIdx.x == 0) gd[b].n_voxels = (int)base;
 }
 
-// second pass of applyFilter (impl:282-367; pca impl:364-397): one thread per searchable leaf
-__global__ void __launch_bounds__(256) k_voxels(const float* __restrict__ tgt, size_t pitch,
-                                                 const unsigned long long* __restrict__ keys, const unsigned* __restrict__ vals,
-                                                 const GridDesc* __restrict__ gd, const BitWord* __restrict__ words,
-                                                 VoxelRec* recs, int* vox_idx, int* vox_n,
-                                                 int min_points, double eig_mult, int pca) {
+// where does the point run of searchable leaf `id` start in the sorted order?
+__global__ void __launch_bounds__(256) k_segstart(const unsigned long long* __restrict__ keys, size_t pitch, const GridDesc* __restrict__ gd,
+                                                   const BitWord* __restrict__ words, unsigned* seg_start, int min_points) {
   const int b = blockIdx.y;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= pitch) return;
@@ -241,23 +238,69 @@ __global__ void __launch_bounds__(256) k_voxels(const float* __restrict__ tgt, s
   const GridDesc& g = gd[b];
   const BitWord bw = words[g.word_off + (cell >> 6)];
   const unsigned id = bw.prefix + (unsigned)__popcll(bw.bits & ((1ull << (cell & 63)) - 1ull));
+  seg_start[g.rec_off + id] = (unsigned)i;
+}
 
-  // leaf.mean_ += pt ; leaf.cov_ += pt pt^T  in input order (the sort is stable); cov_ seeded with Identity
-  const float* X = tgt + (size_t)b * 3 * pitch;
+// leaf.mean_ += pt ; leaf.cov_ += pt pt^T (impl:233-237) for every searchable leaf: one WAVE per leaf.
+// The wave gathers 64 points of the leaf's run at a time (the radix sort is stable, so the run is in input
+// order), parks the nine f64 terms of each point in LDS, and lanes 0..8 -- one per accumulator -- add them
+// strictly in input order, which keeps the sums bit-identical to the reference's sequential accumulation.
+#define LS_WAVES 4
+__global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restrict__ tgt, size_t pitch,
+                                                           const unsigned long long* __restrict__ keys, const unsigned* __restrict__ vals,
+                                                           const GridDesc* __restrict__ gd, const unsigned* __restrict__ seg_start,
+                                                           double* sums, int* vox_idx, int* vox_n) {
+  __shared__ double term[LS_WAVES][64][9];
+  const int b = blockIdx.y;
+  const GridDesc& g = gd[b];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const unsigned long long* K = keys + (size_t)b * pitch;
   const unsigned* V = vals + (size_t)b * pitch;
-  double S0 = 0, S1 = 0, S2 = 0, C00 = 1, C01 = 0, C02 = 0, C11 = 1, C12 = 0, C22 = 1;
-  int cnt = 0;
-  for (size_t j = i; j < pitch && K[j] == key; j++) {
-    unsigned pi = V[j];
-    double x = (double)X[pi], y = (double)X[pitch + pi], z = (double)X[2 * pitch + pi];
-    S0 += x; S1 += y; S2 += z;
-    C00 += x * x; C01 += x * y; C02 += x * z; C11 += y * y; C12 += y * z; C22 += z * z;
-    cnt++;
+  const float* X = tgt + (size_t)b * 3 * pitch;
+  for (int id = blockIdx.x * LS_WAVES + wv; id < g.n_voxels; id += gridDim.x * LS_WAVES) {
+    const size_t start = seg_start[g.rec_off + id];
+    const unsigned long long key = K[start];
+    // accumulator order: S0 S1 S2 C00 C01 C02 C11 C12 C22 ; cov_ is seeded with Identity (voxel_grid_covariance_omp.h:101)
+    double acc = (lane == 3 || lane == 6 || lane == 8) ? 1.0 : 0.0;
+    int cnt = 0;
+    for (size_t j0 = start;; j0 += 64) {
+      const size_t j = j0 + lane;
+      const bool in = j < pitch && K[j] == key;
+      const int m = (int)__popcll(__ballot(in));
+      if (in) {
+        const unsigned pi = V[j];
+        const double x = (double)X[pi], y = (double)X[pitch + pi], z = (double)X[2 * pitch + pi];
+        double* t = term[wv][lane];
+        t[0] = x; t[1] = y; t[2] = z;
+        t[3] = x * x; t[4] = x * y; t[5] = x * z; t[6] = y * y; t[7] = y * z; t[8] = z * z;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 9) for (int l = 0; l < m; l++) acc += term[wv][l][lane];
+      __builtin_amdgcn_wave_barrier();
+      cnt += m;
+      if (m < 64) break;
+    }
+    if (lane < 9) sums[(size_t)(g.rec_off + id) * 9 + lane] = acc;
+    if (lane == 0) {
+      vox_idx[g.rec_off + id] = (int)(key & ((1u << IDX_BITS) - 1));
+      vox_n[g.rec_off + id] = cnt;
+    }
   }
-  const double S[3] = {S0, S1, S2};
-  const double C[9] = {C00, C01, C02, C01, C11, C12, C02, C12, C22};
+}
+
+// second pass of applyFilter (impl:282-367; pca impl:364-397): one thread per searchable leaf
+__global__ void __launch_bounds__(256) k_voxels(const GridDesc* __restrict__ gd, const double* __restrict__ sums,
+                                                 VoxelRec* recs, int* vox_n, double eig_mult, int pca) {
+  const int b = blockIdx.y;
+  const GridDesc& g = gd[b];
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= g.n_voxels) return;
+  const double* A = sums + (size_t)(g.rec_off + id) * 9;
+  const double S[3] = {A[0], A[1], A[2]};
+  const double C[9] = {A[3], A[4], A[5], A[4], A[6], A[7], A[5], A[7], A[8]};
+  const int cnt = vox_n[g.rec_off + id];
   const double dn = (double)cnt;
-  double mu[3] = {S0 / dn, S1 / dn, S2 / dn};                                    // impl:293
+  double mu[3] = {S[0] / dn, S[1] / dn, S[2] / dn};                              // impl:293
   double cov[9];
   for (int a = 0; a < 3; a++)
     for (int c = 0; c < 3; c++) cov[a * 3 + c] = (C[a * 3 + c] - 2 * (S[a] * mu[c])) / dn + mu[a] * mu[c];   // impl:329
@@ -301,7 +344,6 @@ __global__ void __launch_bounds__(256) k_voxels(const float* __restrict__ tgt, s
     if (bad) { n_out = -1; r.weight = VOX_DEAD; }                                // impl:360-364
   }
   recs[g.rec_off + id] = r;
-  vox_idx[g.rec_off + id] = (int)cell;
   vox_n[g.rec_off + id] = n_out;
 }
 
@@ -636,7 +678,9 @@ k_update(PairState* st, const double* __restrict__ partials, int chunks_per_pair
   for (int guard = 0; guard < 4; guard++) {
     double neg[6], d[6];
     for (int a = 0; a < 6; a++) neg[a] = -S.g[a];
-    ndtm::svd_solve6(S.H, neg, d);                                               // impl2:138-140
+    // impl2:138-140: JacobiSVD(H).solve(-g).  Well-conditioned H: exact LU solve (same answer to rounding);
+    // anything else (rank-deficient, H = 0, ill-conditioned): the thresholded pseudo-inverse itself.
+    if (!ndtm::lu_solve6(S.H, neg, d)) ndtm::svd_solve6(S.H, neg, d);
     double nrm = 0;
     for (int a = 0; a < 6; a++) nrm += d[a] * d[a];
     nrm = sqrt(nrm);
@@ -714,6 +758,7 @@ struct mi355ndt_handle {
   size_t keys_cap = 0;
   BitWord* d_words = nullptr; size_t words_cap = 0;
   VoxelRec* d_recs = nullptr; int *d_vox_idx = nullptr, *d_vox_n = nullptr;
+  unsigned* d_seg_start = nullptr; double* d_sums = nullptr;
   size_t recs_per_pair = 0, recs_cap = 0;
   unsigned* h_pin_u = nullptr;                  // pinned scratch (2 unsigned)
 
@@ -856,7 +901,7 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
   hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->d_tgt_own, h->d_src_own, h->d_tgt_cnt, h->d_src_cnt, h->d_minmax, h->d_grid, h->d_nwords, h->d_word_off,
                   h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, h->d_tmp, h->d_words, h->d_recs, h->d_vox_idx, h->d_vox_n,
-                  h->d_state, h->d_partials, h->d_guess, h->d_results, h->d_active, h->d_hook, h->d_aligned, h->d_hits};
+                  h->d_state, h->d_partials, h->d_guess, h->d_results, h->d_active, h->d_hook, h->d_aligned, h->d_hits, h->d_seg_start, h->d_sums};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_pin_u) hipHostFree(h->h_pin_u);
   if (h->h_pin_active) hipHostFree(h->h_pin_active);
@@ -1088,11 +1133,14 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
   const int minpts = h->prm.min_points_per_voxel;
   const size_t rpp = pitch / (size_t)minpts + 1;
   if ((size_t)B * rpp > h->recs_cap || rpp != h->recs_per_pair) {
-    size_t need = (size_t)B * rpp, c1 = 0, c2 = 0, c3 = 0;
+    size_t need = (size_t)B * rpp, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
     if (h->d_recs) { HIPCHK(h, hipFree(h->d_recs)); h->d_recs = nullptr; }
     if (h->d_vox_idx) { HIPCHK(h, hipFree(h->d_vox_idx)); h->d_vox_idx = nullptr; }
     if (h->d_vox_n) { HIPCHK(h, hipFree(h->d_vox_n)); h->d_vox_n = nullptr; }
+    if (h->d_seg_start) { HIPCHK(h, hipFree(h->d_seg_start)); h->d_seg_start = nullptr; }
+    if (h->d_sums) { HIPCHK(h, hipFree(h->d_sums)); h->d_sums = nullptr; }
     HIPCHK(h, grow(h->d_recs, c1, need)); HIPCHK(h, grow(h->d_vox_idx, c2, need)); HIPCHK(h, grow(h->d_vox_n, c3, need));
+    HIPCHK(h, grow(h->d_seg_start, c4, need)); HIPCHK(h, grow(h->d_sums, c5, need * 9));
     h->recs_cap = need; h->recs_per_pair = rpp;
   }
   const int end_bit = IDX_BITS + ceil_log2((unsigned)B);
@@ -1130,9 +1178,15 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
   if (total_words) HIPCHK(h, hipMemsetAsync(h->d_words, 0, total_words * sizeof(BitWord), s));
   k_mark<<<dim3(gx, B), 256, 0, s>>>(h->d_keys_b, pitch, h->d_grid, h->d_words, minpts);
   k_rank<<<B, 256, 0, s>>>(h->d_grid, h->d_words);
-  k_voxels<<<dim3(gx, B), 256, 0, s>>>(h->d_tgt, pitch, h->d_keys_b, h->d_vals_b, h->d_grid, h->d_words,
-                                       h->d_recs, h->d_vox_idx, h->d_vox_n, minpts, h->prm.min_covar_eigvalue_mult,
-                                       h->prm.variant == MI355NDT_VARIANT_PCA);
+  k_segstart<<<dim3(gx, B), 256, 0, s>>>(h->d_keys_b, pitch, h->d_grid, h->d_words, h->d_seg_start, minpts);
+  {
+    // enough waves per target to cover its leaves a few at a time; ~8 waves per SIMD overall
+    int lb = std::max(1, std::min((int)((rpp + LS_WAVES - 1) / LS_WAVES), std::max(8, 8192 / B)));
+    k_leafsum<<<dim3(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, h->d_keys_b, h->d_vals_b, h->d_grid, h->d_seg_start,
+                                                   h->d_sums, h->d_vox_idx, h->d_vox_n);
+  }
+  k_voxels<<<dim3((unsigned)((rpp + 255) / 256), B), 256, 0, s>>>(h->d_grid, h->d_sums, h->d_recs, h->d_vox_n,
+                                                                  h->prm.min_covar_eigvalue_mult, h->prm.variant == MI355NDT_VARIANT_PCA);
   HIPCHK(h, hipGetLastError());
   if (h->prof) {
     HIPCHK(h, ev_end(h, h->ev_build));

@@ -260,12 +260,20 @@ __device__ inline void eigen_sym3(const double Ain[9], double evals[3], double V
 // rank = #{sigma_i >= max(sigma_max * 6 eps, DBL_MIN)}.  One-sided (Hestenes) Jacobi.
 __device__ inline void svd_solve6(const double* H, const double b[6], double x[6]) {
   double A[6][6], V[6][6];
-  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { A[i][j] = H[i * 6 + j]; V[i][j] = (i == j) ? 1.0 : 0.0; }
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j < 6; j++) { A[i][j] = H[i * 6 + j]; V[i][j] = (i == j) ? 1.0 : 0.0; }
+#pragma unroll 1
   for (int sweep = 0; sweep < 60; sweep++) {
     int rotated = 0;
+    // p, q fully unrolled: every A/V index is a compile-time constant, so both matrices live in registers
+#pragma unroll
     for (int p = 0; p < 5; p++) {
+#pragma unroll
       for (int q = p + 1; q < 6; q++) {
         double alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
         for (int i = 0; i < 6; i++) { alpha += A[i][p] * A[i][p]; beta += A[i][q] * A[i][q]; gamma += A[i][p] * A[i][q]; }
         if (gamma == 0.0 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
         rotated = 1;
@@ -273,6 +281,7 @@ __device__ inline void svd_solve6(const double* H, const double b[6], double x[6
         double t = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
         if (zeta < 0) t = -t;
         double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
         for (int i = 0; i < 6; i++) {
           double aip = A[i][p], aiq = A[i][q];
           A[i][p] = c * aip - s * aiq;
@@ -286,8 +295,10 @@ __device__ inline void svd_solve6(const double* H, const double b[6], double x[6
     if (!rotated) break;
   }
   double sig[6], smax = 0;
+#pragma unroll
   for (int j = 0; j < 6; j++) {
     double s2 = 0;
+#pragma unroll
     for (int i = 0; i < 6; i++) s2 += A[i][j] * A[i][j];
     sig[j] = sqrt(s2);
     if (sig[j] > smax) smax = sig[j];
@@ -295,13 +306,64 @@ __device__ inline void svd_solve6(const double* H, const double b[6], double x[6
   double thr = smax * (6.0 * DBL_EPSILON);
   if (thr < DBL_MIN) thr = DBL_MIN;
   for (int i = 0; i < 6; i++) x[i] = 0;
+#pragma unroll
   for (int j = 0; j < 6; j++) {
     if (!(sig[j] >= thr) || sig[j] == 0.0) continue;
     double ub = 0;
+#pragma unroll
     for (int i = 0; i < 6; i++) ub += (A[i][j] / sig[j]) * b[i];
     double w = ub / sig[j];
+#pragma unroll
     for (int i = 0; i < 6; i++) x[i] += V[i][j] * w;
   }
+}
+
+// Fast path of the Newton solve: LU with partial pivoting.  Returns false (caller falls back to svd_solve6)
+// unless H is clearly well-conditioned (pivot ratio > 1e-6), where an exact solve and the reference's
+// JacobiSVD solve agree to ~cond * 1e-16 relative.  ~100x cheaper than the Jacobi SVD on one lane.
+__device__ inline bool lu_solve6(const double* H, const double b[6], double x[6]) {
+  double A[6][7];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) A[i][j] = H[i * 6 + j];
+    A[i][6] = b[i];
+  }
+  double pmin = DBL_MAX, pmax = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    // partial pivoting: bring the largest |A[i][k]|, i >= k, to row k (branch-free row swaps keep A in registers)
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) {
+      const bool sw = fabs(A[i][k]) > fabs(A[k][k]);
+#pragma unroll
+      for (int j = k; j < 7; j++) {
+        const double a = A[k][j], c = A[i][j];
+        A[k][j] = sw ? c : a;
+        A[i][j] = sw ? a : c;
+      }
+    }
+    const double piv = A[k][k];
+    const double ap = fabs(piv);
+    pmin = ap < pmin ? ap : pmin;
+    pmax = ap > pmax ? ap : pmax;
+    if (!(ap > 0.0)) return false;
+#pragma unroll
+    for (int i = k + 1; i < 6; i++) {
+      const double f = A[i][k] / piv;
+#pragma unroll
+      for (int j = k + 1; j < 7; j++) A[i][j] -= f * A[k][j];
+    }
+  }
+  if (!(pmin > 1e-6 * pmax) || !(pmax < DBL_MAX)) return false;
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    double s = A[i][6];
+#pragma unroll
+    for (int j = i + 1; j < 6; j++) s -= A[i][j] * x[j];
+    x[i] = s / A[i][i];
+  }
+  return true;
 }
 
 }  // namespace ndtm
