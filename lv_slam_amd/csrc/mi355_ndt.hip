@@ -26,7 +26,7 @@
 #define CHUNK_PTS      2048          // source points per reduction chunk (fixed => results independent of launch geometry)
 #define SWEEP_THREADS  256
 #ifndef SWEEP_WPE
-#define SWEEP_WPE       3             // waves per SIMD the sweep is register-allocated for (3: 168 VGPRs, measured faster than 2)
+#define SWEEP_WPE       2             // waves per SIMD the sweep is register-allocated for (2: no spills; measured faster than 3 with spills)
 #endif
 #define NACC           44            // score, g[6], H[36], hits
 #define IDX_BITS       26            // sort key = pair << 26 | cell ; cell < 2^25 ; bit 25 = "not binned"
@@ -78,7 +78,16 @@ struct SweepConst {
   float  d2f;
   int    K;                    // neighbour probes
   int    pca;
-  int    off[26][3];
+  int    table;                // row of c_off: 0 = DIRECT1, 1 = DIRECT7, 2 = DIRECT26
+};
+
+// Neighbour offsets in the reference's probe order.  DIRECT1: voxel_grid_covariance_omp_impl.hpp:441;
+// DIRECT7: impl:423-430; DIRECT26: pcl::getAllNeighborCellIndices() (PCL 1.8 voxel_grid.h) = 13 "half"
+// offsets followed by their negation.  __constant__: the wave-uniform probe index reads them with scalar loads.
+__constant__ int c_off[3][26][3] = {
+  {{0,0,0}},
+  {{0,0,0},{1,0,0},{-1,0,0},{0,1,0},{0,-1,0},{0,0,1},{0,0,-1}},
+  {{-1,-1,-1}, {-1,0,-1}, {-1,1,-1}, {0,-1,-1}, {0,0,-1}, {0,1,-1}, {1,-1,-1}, {1,0,-1}, {1,1,-1}, {-1,-1,0}, {0,-1,0}, {1,-1,0}, {-1,0,0}, {1,1,1}, {1,0,1}, {1,-1,1}, {0,1,1}, {0,0,1}, {0,-1,1}, {-1,1,1}, {-1,0,1}, {-1,-1,1}, {1,1,0}, {0,1,0}, {-1,1,0}, {1,0,0}}
 };
 
 // ------------------------------------------------------------------------------------ helpers
@@ -532,34 +541,52 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
         // probes run last-to-first so the ndt_pca weight of a hit (product of its own and all LATER hits' weights,
         // ndt_pca_impl2.hpp:295-296) is a running product; the order of the f64 additions is free anyway.
         double suf = 1.0;
+        // Probes are issued Q_GROUP at a time with all bitmap loads of the group in flight together, then all
+        // weight loads, then the ballots: one L2 round trip per stage instead of one per probe.
 #pragma unroll 1
-        for (int q = sc.K - 1; q >= 0; q--) {
-          const int a0 = c0 + sc.off[q][0], a1 = c1 + sc.off[q][1], a2 = c2 + sc.off[q][2];
-          bool hit = valid && a0 >= mb0 && a0 <= xb0 && a1 >= mb1 && a1 <= xb1 && a2 >= mb2 && a2 <= xb2;
-          unsigned id = 0;
-          if (hit) {
-            const unsigned cell = (unsigned)((a0 - mb0) + (a1 - mb1) * mul1 + (a2 - mb2) * mul2);
-            const BitWord bw = W[cell >> 6];
-            const unsigned long long bit = 1ull << (cell & 63);
-            hit = (bw.bits & bit) != 0ull;
-            id = bw.prefix + (unsigned)__popcll(bw.bits & (bit - 1ull));
+        for (int q1 = sc.K; q1 > 0; q1 -= Q_GROUP) {
+          unsigned cellv[Q_GROUP];
+          bool hitv[Q_GROUP];
+          BitWord bwv[Q_GROUP];
+#pragma unroll
+          for (int j = 0; j < Q_GROUP; j++) {
+            const int q = q1 - 1 - j;                 // wave-uniform
+            hitv[j] = false;
+            cellv[j] = 0;
+            if (q >= 0) {
+              const int a0 = c0 + c_off[sc.table][q][0], a1 = c1 + c_off[sc.table][q][1], a2 = c2 + c_off[sc.table][q][2];
+              hitv[j] = valid && a0 >= mb0 && a0 <= xb0 && a1 >= mb1 && a1 <= xb1 && a2 >= mb2 && a2 <= xb2;
+              cellv[j] = (unsigned)((a0 - mb0) + (a1 - mb1) * mul1 + (a2 - mb2) * mul2);
+              if (hitv[j]) bwv[j] = W[cellv[j] >> 6];
+            }
           }
-          if (hit) {
-            const int wi = R[id].weight;             // also pulls the record's line towards this CU for phase B
-            hit = wi != VOX_DEAD;                    // nr_points == -1: not a neighbour (impl:395)
-            if (PCA && hit) suf *= (double)wi;
+          unsigned idv[Q_GROUP];
+          int wiv[Q_GROUP];
+#pragma unroll
+          for (int j = 0; j < Q_GROUP; j++) {
+            idv[j] = 0;
+            wiv[j] = VOX_DEAD;
+            if (hitv[j]) {
+              const unsigned long long bit = 1ull << (cellv[j] & 63);
+              hitv[j] = (bwv[j].bits & bit) != 0ull;
+              idv[j] = bwv[j].prefix + (unsigned)__popcll(bwv[j].bits & (bit - 1ull));
+              if (hitv[j]) wiv[j] = R[idv[j]].weight;   // also pulls the record's line towards this CU for phase B
+            }
           }
-          const unsigned long long mask = __ballot(hit);
-          if (hit) {
-            const int pos = (qhead + qcount + (int)__popcll(mask & lt_mask)) & (Q_CAP - 1);
-            q_ent[wv][pos] = ((unsigned)slot << ID_BITS) | id;
-            if (PCA) q_w[wv][pos] = suf;
+#pragma unroll
+          for (int j = 0; j < Q_GROUP; j++) {
+            const bool hit = hitv[j] && wiv[j] != VOX_DEAD;   // nr_points == -1: not a neighbour (impl:395)
+            if (PCA && hit) suf *= (double)wiv[j];
+            const unsigned long long mask = __ballot(hit);
+            if (hit) {
+              const int pos = (qhead + qcount + (int)__popcll(mask & lt_mask)) & (Q_CAP - 1);
+              q_ent[wv][pos] = ((unsigned)slot << ID_BITS) | idv[j];
+              if (PCA) q_w[wv][pos] = suf;
+            }
+            qcount += (int)__popcll(mask);
           }
-          qcount += (int)__popcll(mask);
-          if (((sc.K - 1 - q) % Q_GROUP) == Q_GROUP - 1 || q == 0) {
-            __builtin_amdgcn_wave_barrier();
-            while (qcount >= 64) drain(64);
-          }
+          __builtin_amdgcn_wave_barrier();
+          while (qcount >= 64) drain(64);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -805,22 +832,9 @@ static hipError_t grow(T*& p, size_t& cap, size_t need) {
 }
 
 static void build_offsets(int mode, SweepConst& sc) {
-  // DIRECT7: voxel_grid_covariance_omp_impl.hpp:423-430; DIRECT1: impl:441;
-  // DIRECT26: pcl::getAllNeighborCellIndices() (PCL 1.8 voxel_grid.h): 13 half offsets, then their negation
-  memset(sc.off, 0, sizeof sc.off);
-  if (mode == MI355NDT_DIRECT1) { sc.K = 1; return; }
-  if (mode == MI355NDT_DIRECT7) {
-    static const int o7[7][3] = {{0,0,0},{1,0,0},{-1,0,0},{0,1,0},{0,-1,0},{0,0,1},{0,0,-1}};
-    memcpy(sc.off, o7, sizeof o7);
-    sc.K = 7;
-    return;
-  }
-  int k = 0;
-  for (int i = -1; i < 2; i++) for (int j = -1; j < 2; j++) { sc.off[k][0] = i; sc.off[k][1] = j; sc.off[k][2] = -1; k++; }
-  for (int i = -1; i < 2; i++) { sc.off[k][0] = i; sc.off[k][1] = -1; sc.off[k][2] = 0; k++; }
-  sc.off[k][0] = -1; sc.off[k][1] = 0; sc.off[k][2] = 0; k++;
-  for (int i = 0; i < 13; i++) for (int a = 0; a < 3; a++) sc.off[13 + i][a] = -sc.off[i][a];
-  sc.K = 26;
+  if (mode == MI355NDT_DIRECT1) { sc.K = 1; sc.table = 0; }
+  else if (mode == MI355NDT_DIRECT7) { sc.K = 7; sc.table = 1; }
+  else { sc.K = 26; sc.table = 2; }
 }
 
 static void gauss_constants(const mi355ndt_params& p, double& d1, double& d2) {
