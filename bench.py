@@ -72,12 +72,13 @@ def main():
     if dist is not None:
         dist.barrier()
     from lv_slam_amd import ndt, synth
+    from lv_slam_amd import dist as shard
 
     B, N = a.pairs, a.azimuth * 64
     # ---- synthetic inputs, generated on the GPU and left resident in HBM: [pair][3][N] SoA
     T = torch.empty(B, 3, N, device=dev, dtype=torch.float32)
     S = torch.empty(B, 3, N, device=dev, dtype=torch.float32)
-    pair_ids = [rank + i * world for i in range(B)]            # round-robin shard of the global pair index space
+    pair_ids = shard.shard_pairs(B * world, rank, world)       # round-robin shard of the global pair index space
     truth = []
     for k, pid in enumerate(pair_ids):
         t, s, dT = synth.make_pair(pid, a.azimuth, device=dev)
@@ -98,20 +99,14 @@ def main():
     gathered = torch.empty(world * B, 24, device=dev, dtype=torch.float32) if world > 1 else None
     res_np = np.frombuffer(res, dtype=np.dtype([("final", "<f4", 16), ("tp", "<f8"), ("score", "<f8"), ("it", "<i4"), ("conv", "<i4"),
                                                  ("sweeps", "<i4"), ("status", "<i4"), ("hits", "<i8")]))
-    pid_f = np.array(pair_ids, np.float32)
 
     def step():
         eng.batch_build_targets()                 # setInputTarget for every pair: voxelise
         eng.batch_align_raw(guesses, res)         # align every pair (synchronous: results on the host)
         if world > 1:                             # pose gather: {final[16], score, iters, converged, pair_id, pad} = 96 B per pair
-            r = rec_host.numpy()
-            r[:, :16] = res_np["final"]
-            r[:, 16] = res_np["score"]
-            r[:, 17] = res_np["it"]
-            r[:, 18] = res_np["conv"]
-            r[:, 19] = pid_f
+            rec_host.copy_(shard.pack_records(res_np["final"], res_np["score"], res_np["it"], res_np["conv"], pair_ids))
             rec_dev.copy_(rec_host, non_blocking=True)
-            dist.all_gather_into_tensor(gathered, rec_dev)
+            shard.gather_records(rec_dev, gathered)
 
     for _ in range(a.warmup):
         step()
@@ -134,8 +129,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         # gather check: pair ids form a permutation of the global index space
-        ids = sorted(int(x) for x in gathered[:, 19].cpu().numpy())
-        assert ids == list(range(world * B)), "pose gather lost or duplicated pairs"
+        got = shard.unpack_records(gathered)
+        assert sorted(got) == list(range(world * B)), "pose gather lost or duplicated pairs"
+        for k, pid in enumerate(pair_ids):        # my own records came back bit-identical
+            assert np.array_equal(got[pid]["final"], res_np["final"][k].reshape(4, 4).T)
 
     if rank != 0:
         eng.close()

@@ -1,0 +1,86 @@
+// mi355_ndt_pcl.hpp -- header-only pcl::Registration adaptor over the C-ABI of mi355_ndt.h.
+//
+// Compiled ONLY on the ROS/PCL host (it needs PCL + Eigen, which do not exist on the GPU build box); it is
+// the reference-side binding a maintainer adds to lv_slam: replace
+//     pclpca::NormalDistributionsTransform<PointT, PointT> reg_s2k;      // scan_matching_odom_nodelet.cpp:328
+//     pclomp::NormalDistributionsTransform<PointT, PointT>               // src/global_graph/registrations.cpp:78
+// by
+//     mi355ndt::NormalDistributionsTransform<PointT, PointT> reg_s2k(MI355NDT_VARIANT_PCA);
+// and link -lmi355ndt.  Every call site (setInputTarget / setInputSource / align / getFinalTransformation /
+// hasConverged and the ndt_omp.h:109-203 setters) compiles unchanged.
+#pragma once
+#include <pcl/registration/registration.h>
+#include <stdexcept>
+#include "mi355_ndt.h"
+
+namespace mi355ndt {
+
+enum NeighborSearchMethod { KDTREE = MI355NDT_KDTREE, DIRECT26 = MI355NDT_DIRECT26, DIRECT7 = MI355NDT_DIRECT7, DIRECT1 = MI355NDT_DIRECT1 };
+
+template <typename PointSource, typename PointTarget>
+class NormalDistributionsTransform : public pcl::Registration<PointSource, PointTarget> {
+ protected:
+  typedef pcl::Registration<PointSource, PointTarget> Base;
+  typedef typename Base::PointCloudSource PointCloudSource;
+  typedef typename Base::PointCloudTarget PointCloudTarget;
+  typedef typename PointCloudTarget::ConstPtr PointCloudTargetConstPtr;
+  using Base::reg_name_; using Base::input_; using Base::target_; using Base::nr_iterations_; using Base::max_iterations_;
+  using Base::final_transformation_; using Base::transformation_; using Base::previous_transformation_;
+  using Base::transformation_epsilon_; using Base::converged_;
+
+ public:
+  explicit NormalDistributionsTransform(int variant = MI355NDT_VARIANT_OMP, int device = 0) : h_(nullptr), trans_probability_(0) {
+    reg_name_ = "NormalDistributionsTransform";
+    mi355ndt_default_params(&prm_);            // ctor defaults of ndt_omp_impl2.hpp:53-83
+    prm_.variant = variant;
+    transformation_epsilon_ = prm_.trans_epsilon;
+    max_iterations_ = prm_.max_iterations;
+    if (mi355ndt_create(&prm_, device, &h_) != MI355NDT_OK) throw std::runtime_error("mi355ndt_create failed (no MI355X?)");
+  }
+  virtual ~NormalDistributionsTransform() { if (h_) mi355ndt_destroy(h_); }
+
+  void setNumThreads(int) {}                                   // ndt_omp.h:109 (OpenMP only)
+  inline void setInputTarget(const PointCloudTargetConstPtr& cloud) {   // ndt_omp.h:116-121
+    Base::setInputTarget(cloud);
+    push();
+    mi355ndt_set_target(h_, cloud->points.data(), cloud->points.size(), sizeof(PointTarget));
+  }
+  inline void setResolution(float r) { if (prm_.resolution != r) { prm_.resolution = r; push(); } }   // ndt_omp.h:126-136
+  inline float getResolution() const { return prm_.resolution; }
+  inline double getStepSize() const { return prm_.step_size; }
+  inline void setStepSize(double s) { prm_.step_size = s; }
+  inline double getOulierRatio() const { return prm_.outlier_ratio; }
+  inline void setOulierRatio(double o) { prm_.outlier_ratio = o; }
+  inline void setNeighborhoodSearchMethod(NeighborSearchMethod m) { prm_.neighbor_mode = m; }
+  inline double getTransformationProbability() const { return trans_probability_; }
+  inline int getFinalNumIteration() const { return nr_iterations_; }
+
+ protected:
+  void push() {
+    prm_.trans_epsilon = transformation_epsilon_;               // pcl::Registration::setTransformationEpsilon
+    prm_.max_iterations = max_iterations_;                      // pcl::Registration::setMaximumIterations
+    mi355ndt_set_params(h_, &prm_);
+  }
+  virtual void computeTransformation(PointCloudSource& output) { computeTransformation(output, Eigen::Matrix4f::Identity()); }
+  // ndt_omp.h:256-267 / ndt_omp_impl2.hpp:87-188.  PCL's align() has already copied the source into `output`.
+  virtual void computeTransformation(PointCloudSource& output, const Eigen::Matrix4f& guess) {
+    push();
+    mi355ndt_set_source(h_, input_->points.data(), input_->points.size(), sizeof(PointSource));
+    mi355ndt_result r;
+    nr_iterations_ = 0;
+    converged_ = false;
+    if (mi355ndt_align(h_, guess.data() /* Eigen::Matrix4f is column-major */, &r) != MI355NDT_OK) return;
+    final_transformation_ = Eigen::Map<const Eigen::Matrix4f>(r.final_colmajor);
+    nr_iterations_ = r.iterations;
+    converged_ = r.converged != 0;
+    trans_probability_ = r.trans_probability;
+    output.points.resize(input_->points.size());
+    mi355ndt_get_aligned(h_, output.points.data(), sizeof(PointSource));   // x,y,z of the moved source; other fields kept
+  }
+
+  mi355ndt_handle* h_;
+  mi355ndt_params prm_;
+  double trans_probability_;
+};
+
+}  // namespace mi355ndt

@@ -1,0 +1,75 @@
+"""CPU, world_size 2, gloo: the N>1 path of the benchmark -- round-robin pair sharding + the pose all-gather --
+is correct by construction (the GPU tier only ever runs N=1 here; the driver runs N=2/4/8)."""
+import os
+import socket
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from lv_slam_amd import dist as D
+
+
+def test_shard_is_a_partition():
+    for n in (1, 7, 271, 4541):
+        for w in (1, 2, 4, 8):
+            owned = [D.shard_pairs(n, r, w) for r in range(w)]
+            flat = sorted(i for o in owned for i in o)
+            assert flat == list(range(n))
+            assert all(i % w == r for r, o in enumerate(owned) for i in o)
+            assert max(len(o) for o in owned) - min(len(o) for o in owned) <= 1
+
+
+def _fake_result(pid):
+    rng = np.random.default_rng(pid)
+    F = np.eye(4, dtype=np.float32)
+    F[:3, 3] = rng.normal(size=3)
+    return F, float(rng.normal()), int(rng.integers(2, 9)), True
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = D.shard_pairs(n_total, rank, world)
+        cap = (n_total + world - 1) // world
+        res = [_fake_result(p) for p in mine]
+        rec = D.pack_records(np.stack([r[0] for r in res]) if res else np.zeros((0, 4, 4), np.float32),
+                             [r[1] for r in res], [r[2] for r in res], [r[3] for r in res], mine, capacity=cap)
+        g = D.gather_records(rec)
+        got = D.unpack_records(g)
+        ok = sorted(got) == list(range(n_total))
+        for pid, r in got.items():
+            F, s, it, c = _fake_result(pid)
+            ok = ok and np.array_equal(r["final"], F) and abs(r["score"] - np.float32(s)) < 1e-6 and r["iterations"] == it and r["converged"] == c
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [6, 7])
+def test_gather_world2_gloo(n_total):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(out) == [(0, True), (1, True)]
+
+
+def test_records_roundtrip_single_process():
+    F = np.stack([_fake_result(p)[0] for p in range(3)])
+    rec = D.pack_records(F, [1.0, 2.0, 3.0], [3, 4, 5], [1, 0, 1], [10, 11, 12], capacity=5)
+    assert rec.shape == (5, D.REC_FLOATS) and rec.element_size() * D.REC_FLOATS == 96
+    got = D.unpack_records(D.gather_records(rec))
+    assert sorted(got) == [10, 11, 12] and got[11]["converged"] is False and np.array_equal(got[12]["final"], F[2])
