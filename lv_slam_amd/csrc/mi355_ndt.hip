@@ -505,15 +505,20 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
       for (int a = 0; a < 9; a++) Cf[a] = vr.icov[a];
       double w = 1.0;
       if (PCA) w = q_w[wv][(qhead + k) & (Q_CAP - 1)];
+      // ndt_omp: leaves with nr_points = -1 (eigen / inverse failure) are not neighbours (impl:395): filtered here
+      const bool live = lane < m && (PCA || vr.weight != VOX_DEAD);
       float u[3] = {(float)((double)xt0 - m0), (float)((double)xt1 - m1), (float)((double)xt2 - m2)};   // impl2:276-279, 574
-      eval_hit<PCA>(u, r, Cf, sc.d1, sc.d2f, w, lane < m, acc);
-      nhits += (unsigned)m;
+      eval_hit<PCA>(u, r, Cf, sc.d1, sc.d2f, w, live, acc);
+      nhits += PCA ? (unsigned)m : (unsigned)__popcll(__ballot(live));
       qhead = (qhead + m) & (Q_CAP - 1);
       qcount -= m;
       q_old = q_old > m ? q_old - m : 0;
     };
 
     if (wbase < n && grid_ok) {
+      // points of the next tile are fetched one tile ahead (HBM latency ~2 us would otherwise be exposed per tile)
+      float nx = 0.f, ny = 0.f, nz = 0.f;
+      if (wbase + lane < n) { nx = X[wbase + lane]; ny = X[pitch + wbase + lane]; nz = X[2 * pitch + wbase + lane]; }
 #pragma unroll 1
       for (int t = 0; t < CHUNK_PTS / WAVES / 64; t++) {
         const int i = wbase + t * 64 + lane;
@@ -524,8 +529,8 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
         q_old = qcount;
         const int slot = (t & 1) * 64 + lane;
         bool valid = i < n;
-        float px = 0.f, py = 0.f, pz = 0.f;
-        if (valid) { px = X[i]; py = X[pitch + i]; pz = X[2 * pitch + i]; }
+        const float px = nx, py = ny, pz = nz;
+        if (t + 1 < CHUNK_PTS / WAVES / 64 && i + 64 < n) { nx = X[i + 64]; ny = X[pitch + i + 64]; nz = X[2 * pitch + i + 64]; }
         valid = valid && finite3(px, py, pz);
         // PCL 1.8 transformPointCloud scalar form; Jacobian point r = R x (impl2:507-508)
         float xt[3], r[3];
@@ -570,7 +575,9 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
               const unsigned long long bit = 1ull << (cellv[j] & 63);
               hitv[j] = (bwv[j].bits & bit) != 0ull;
               idv[j] = bwv[j].prefix + (unsigned)__popcll(bwv[j].bits & (bit - 1ull));
-              if (hitv[j]) wiv[j] = R[idv[j]].weight;   // also pulls the record's line towards this CU for phase B
+              // ndt_pca needs the weights now (suffix product); ndt_omp filters dead leaves in phase B instead and
+              // saves this dependent L2 round trip
+              if (PCA) { if (hitv[j]) wiv[j] = R[idv[j]].weight; } else wiv[j] = 1;
             }
           }
 #pragma unroll
