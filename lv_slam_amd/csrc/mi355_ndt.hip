@@ -438,39 +438,55 @@ __device__ __forceinline__ void eval_hit(const float u[3], const float r[3], con
 //   chunk end: flush the queue tail, wave butterfly + fixed-order wave sum -> one 44-double partial row per chunk.
 // The partial rows depend only on (CHUNK_PTS, input order), never on the launch geometry, so single and batched
 // runs of one pair are bit-identical.
+struct SweepCtl {               // zeroed by the host before every k_update / k_init_state
+  int n_active;                 // pairs whose next sweep is pending (entries of active_list)
+  int next_item[8];             // per-XCD work-item cursors of the sweep
+};
+#define QUARTERS WAVES          // a chunk is reduced as 4 wave-quarters of CHUNK_PTS/4 points
+
 template <bool PCA>
 __global__ void __launch_bounds__(SWEEP_THREADS, SWEEP_WPE)
 k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict__ st,
         const GridDesc* __restrict__ gd, const BitWord* __restrict__ words, const VoxelRec* __restrict__ recs,
-        double* partials, int chunks_per_pair, int n_pairs, int bx, int xcd_map, SweepConst sc) {
-  // XCD-aware mapping: workgroup L runs on XCD L % 8 (observed dispatch order, MI355X_MICROARCH.md); keep all
-  // blocks of one pair on one XCD so its voxel records / bitmap / points stay in that XCD's L2.
-  int b, bxi;
-  if (xcd_map) {
-    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
-    b = (j / bx) * 8 + xcd;
-    bxi = j % bx;
-    if (b >= n_pairs) return;
-  } else {
-    b = blockIdx.x / bx;
-    bxi = blockIdx.x % bx;
-  }
+        double* partials, int chunks_per_pair, const int* __restrict__ active_list, SweepCtl* ctl, SweepConst sc) {
+  // Persistent waves pulling work items.  One item = one wave-quarter (CHUNK_PTS/4 consecutive points) of one chunk
+  // of one active pair; every wave is independent (own LDS queue, own partial row, no block barrier), so a wave
+  // whose points have few hits simply takes the next item instead of idling at a barrier.
+  // Items are queued per XCD: pair slot a of the active list belongs to XCD a % 8 (workgroup L is observed to run on
+  // XCD L % 8, MI355X_MICROARCH.md), so one pair's records / bitmap / points stay in one L2; a wave whose XCD
+  // queue is empty steals from the others.  Which wave runs an item never changes the item's result.
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const int n_active = ctl->n_active;
+  const int items_per_pair = chunks_per_pair * QUARTERS;
+
+  __shared__ unsigned q_ent[WAVES][Q_CAP];
+  __shared__ double q_w[PCA ? WAVES : 1][PCA ? Q_CAP : 1];
+  __shared__ float stage[WAVES][128][6];           // two tiles of staged points: x'(3), R x (3)
+
+  const int my_xcd = blockIdx.x & 7;
+#pragma unroll 1
+  for (int probe = 0; probe < 8; probe++) {        // own XCD first, then steal
+    const int xcd = (my_xcd + probe) & 7;
+    const int pairs_here = n_active > xcd ? (n_active - xcd + 7) / 8 : 0;
+    const int items_here = pairs_here * items_per_pair;
+#pragma unroll 1
+    for (;;) {
+      int item = 0;
+      if (lane == 0) item = atomicAdd(&ctl->next_item[xcd], 1);
+      item = __builtin_amdgcn_readfirstlane(item);
+      if (item >= items_here) break;
+      const int b = active_list[xcd + 8 * (item / items_per_pair)];
+      const int rem = item % items_per_pair;
+      const int chunk = rem / QUARTERS, quarter = rem % QUARTERS;
+
   const PairState& S = st[b];
-  if (S.phase == PH_DONE) return;
   const int n = S.n_src;
   const GridDesc& g = gd[b];
   const float* X = src + (size_t)b * 3 * pitch;
   const BitWord* W = words + g.word_off;
   const VoxelRec* R = recs + g.rec_off;
   const bool grid_ok = (g.status == GRID_OK);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-
-  __shared__ unsigned q_ent[WAVES][Q_CAP];
-  __shared__ double q_w[PCA ? WAVES : 1][PCA ? Q_CAP : 1];
-  __shared__ float stage[WAVES][128][6];           // two tiles of staged points: x'(3), R x (3)
-  __shared__ double red[WAVES][NACC];
-
   float T[12], Rj[9];
 #pragma unroll
   for (int a = 0; a < 12; a++) T[a] = S.T[a];
@@ -480,15 +496,14 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
   const int mb0 = g.min_b[0], mb1 = g.min_b[1], mb2 = g.min_b[2];
   const int xb0 = g.max_b[0], xb1 = g.max_b[1], xb2 = g.max_b[2];
   const int mul1 = g.mul1, mul2 = g.mul2;
-
-  for (int chunk = bxi; chunk < chunks_per_pair; chunk += bx) {
+  {
     double acc[43];
 #pragma unroll
     for (int a = 0; a < 43; a++) acc[a] = 0.0;
     unsigned nhits = 0;                              // wave-uniform
     int qhead = 0, qcount = 0;                       // wave-uniform
     int q_old = 0;                                   // queued entries that reference the OTHER staging half (older tile)
-    const int wbase = chunk * CHUNK_PTS + wv * (CHUNK_PTS / WAVES);
+    const int wbase = chunk * CHUNK_PTS + quarter * (CHUNK_PTS / QUARTERS);
 
     // evaluate `m` queued hits (m <= 64), one per lane; lanes >= m re-read the last entry and contribute +0
     auto drain = [&](int m) {
@@ -599,7 +614,7 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
       __builtin_amdgcn_wave_barrier();
       if (qcount > 0) drain(qcount);
     }
-    // fixed-order block reduction: wave butterfly, then waves 0..3
+    // fixed-order reduction of the wave: 64-lane butterfly -> one 44-double row per (chunk, quarter)
 #pragma unroll
     for (int a = 0; a < 43; a++) {
       double v = acc[a];
@@ -607,17 +622,13 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
       for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
       acc[a] = v;
     }
-    __syncthreads();
     if (lane == 0) {
+      double* P = partials + (((size_t)b * chunks_per_pair + chunk) * QUARTERS + quarter) * NACC;
 #pragma unroll
-      for (int a = 0; a < 43; a++) red[wv][a] = acc[a];
-      red[wv][43] = (double)nhits;
+      for (int a = 0; a < 43; a++) P[a] = acc[a];
+      P[43] = (double)nhits;
     }
-    __syncthreads();
-    if (threadIdx.x < NACC) {
-      double v = red[0][threadIdx.x];
-      for (int k = 1; k < WAVES; k++) v += red[k][threadIdx.x];
-      partials[((size_t)b * chunks_per_pair + chunk) * NACC + threadIdx.x] = v;
+  }
     }
   }
 }
@@ -641,9 +652,11 @@ __device__ void finalize_pair(PairState& S, mi355ndt_result* res, int converged)
 
 // p = SE3(R,t).log(); first sweep moves the cloud by the caller's f32 guess itself (impl2:102-129)
 __global__ void k_init_state(PairState* st, const float* __restrict__ guess_cm, const int* __restrict__ src_cnt,
-                             const GridDesc* __restrict__ gd, int n_pairs) {
+                             const GridDesc* __restrict__ gd, int n_pairs, int* active_list, SweepCtl* ctl) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n_pairs) return;
+  active_list[b] = b;                            // the first sweep covers every pair
+  if (b == 0) ctl->n_active = n_pairs;
   PairState& S = st[b];
   const float* G = guess_cm + (size_t)b * 16;
   double R[9], t[3];
@@ -663,14 +676,17 @@ __global__ void k_init_state(PairState* st, const float* __restrict__ guess_cm, 
 
 // explicit sweep pose (parity hooks)
 __global__ void k_set_pose(PairState* st, int b, const float* __restrict__ T_cm, const float* __restrict__ Rj, const int* __restrict__ src_cnt,
-                           const GridDesc* __restrict__ gd) {
+                           const GridDesc* __restrict__ gd, int* active_list, SweepCtl* ctl) {
   PairState& S = st[b];
+  active_list[0] = b; ctl->n_active = 1;
   for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) S.T[r * 4 + c] = T_cm[c * 4 + r];
   for (int a = 0; a < 9; a++) S.Rj[a] = Rj[a];
   S.phase = PH_SWEEP0; S.n_src = src_cnt[b]; S.grid_status = gd[b].status; S.it = 0; S.sweeps = 1;
 }
-__global__ void k_set_pose_p(PairState* st, int b, const double* __restrict__ p, const int* __restrict__ src_cnt, const GridDesc* __restrict__ gd) {
+__global__ void k_set_pose_p(PairState* st, int b, const double* __restrict__ p, const int* __restrict__ src_cnt, const GridDesc* __restrict__ gd,
+                             int* active_list, SweepCtl* ctl) {
   PairState& S = st[b];
+  active_list[0] = b; ctl->n_active = 1;
   double pp[6];
   for (int a = 0; a < 6; a++) pp[a] = p[a];
   ndtm::pose_to_f32(pp, S.T, S.Rj);
@@ -681,7 +697,8 @@ __global__ void k_set_pose_p(PairState* st, int b, const double* __restrict__ p,
 // computeTransformation (impl2:131-183) with computeStepLengthMT's live prefix (impl2:846-907).
 __global__ void __launch_bounds__(64)
 k_update(PairState* st, const double* __restrict__ partials, int chunks_per_pair, mi355ndt_result* results,
-         int* active_counter, unsigned long long* hits_total, double step_max, double eps, int max_iterations, int reduce_only) {
+         int* active_counter, int* active_list, SweepCtl* ctl, unsigned long long* hits_total,
+         double step_max, double eps, int max_iterations, int reduce_only) {
   const int b = blockIdx.x;
   PairState& S = st[b];
   if (S.phase == PH_DONE) return;
@@ -689,8 +706,11 @@ k_update(PairState* st, const double* __restrict__ partials, int chunks_per_pair
   const int nchunks = (S.n_src + CHUNK_PTS - 1) / CHUNK_PTS;
   if (lane < NACC) {
     double v = 0.0;
-    const double* P = partials + (size_t)b * chunks_per_pair * NACC + lane;
-    for (int c = 0; c < nchunks; c++) v += P[(size_t)c * NACC];                  // impl2:298-302 (fixed order)
+    const double* P = partials + (size_t)b * chunks_per_pair * QUARTERS * NACC + lane;
+    for (int c = 0; c < nchunks; c++) {                                          // impl2:298-302 (fixed order)
+      const double* Q = P + (size_t)c * QUARTERS * NACC;
+      v += ((Q[0] + Q[NACC]) + Q[2 * NACC]) + Q[3 * NACC];                       // the chunk's four wave-quarters, in order
+    }
     if (lane == 0) S.score = v;
     else if (lane < 7) S.g[lane - 1] = v;
     else if (lane < 43) S.H[lane - 7] = v;
@@ -749,6 +769,7 @@ k_update(PairState* st, const double* __restrict__ partials, int chunks_per_pair
     S.phase = PH_STEP;
     S.sweeps++;
     atomicAdd(active_counter, 1);
+    active_list[atomicAdd(&ctl->n_active, 1)] = b;                               // this pair takes part in the next sweep
     return;
   }
   finalize_pair(S, &results[b], 1);
@@ -803,6 +824,9 @@ struct mi355ndt_handle {
   float* d_guess = nullptr;
   mi355ndt_result* d_results = nullptr;
   int* d_active = nullptr;                      // per-round active counters
+  int* d_active_list = nullptr;                 // pairs taking part in the next sweep (compacted by k_update)
+  SweepCtl* d_ctl = nullptr;
+  int n_cu = 256;
   int* h_pin_active = nullptr;
   unsigned long long* d_hits = nullptr;         // (point,voxel) evaluations, all sweeps
   float* d_hook = nullptr;                      // 16 + 9 floats, 6 doubles
@@ -900,6 +924,7 @@ int mi355ndt_create(const mi355ndt_params* params, int device, mi355ndt_handle**
   mi355ndt_handle* h = new mi355ndt_handle();
   h->device = device;
   h->prm = p;
+  { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
     return MI355NDT_ERR_HIP;
@@ -907,6 +932,7 @@ int mi355ndt_create(const mi355ndt_params* params, int device, mi355ndt_handle**
   if (hipHostMalloc((void**)&h->h_pin_u, 4 * sizeof(unsigned)) != hipSuccess ||
       hipHostMalloc((void**)&h->h_pin_active, 128 * sizeof(int)) != hipSuccess ||
       hipMalloc((void**)&h->d_active, 128 * sizeof(int)) != hipSuccess ||
+      hipMalloc((void**)&h->d_ctl, sizeof(SweepCtl)) != hipSuccess ||
       hipMalloc((void**)&h->d_hits, sizeof(unsigned long long)) != hipSuccess ||
       hipMalloc((void**)&h->d_hook, 64 * sizeof(double)) != hipSuccess) {
     delete h;
@@ -922,7 +948,8 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
   hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->d_tgt_own, h->d_src_own, h->d_tgt_cnt, h->d_src_cnt, h->d_minmax, h->d_grid, h->d_nwords, h->d_word_off,
                   h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, h->d_tmp, h->d_words, h->d_recs, h->d_vox_idx, h->d_vox_n,
-                  h->d_state, h->d_partials, h->d_guess, h->d_results, h->d_active, h->d_hook, h->d_aligned, h->d_hits, h->d_seg_start, h->d_sums};
+                  h->d_state, h->d_partials, h->d_guess, h->d_results, h->d_active, h->d_hook, h->d_aligned, h->d_hits, h->d_seg_start, h->d_sums,
+                  h->d_active_list, h->d_ctl};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_pin_u) hipHostFree(h->h_pin_u);
   if (h->h_pin_active) hipHostFree(h->h_pin_active);
@@ -984,6 +1011,7 @@ static int ensure_pair_arrays(mi355ndt_handle* h, int n_pairs) {
   HIPCHK(h, re((void**)&h->d_state, n_pairs * sizeof(PairState)));
   HIPCHK(h, re((void**)&h->d_guess, n_pairs * 16 * sizeof(float)));
   HIPCHK(h, re((void**)&h->d_results, n_pairs * sizeof(mi355ndt_result)));
+  HIPCHK(h, re((void**)&h->d_active_list, n_pairs * sizeof(int)));
   HIPCHK(h, hipMemsetAsync(h->d_grid, 0, n_pairs * sizeof(GridDesc), h->stream));
   HIPCHK(h, hipMemsetAsync(h->d_state, 0, n_pairs * sizeof(PairState), h->stream));
   h->cap_pairs = n_pairs;
@@ -1226,7 +1254,7 @@ static int prep_align_ws(mi355ndt_handle* h) {
   int maxn = 0;
   for (int b = 0; b < B; b++) maxn = std::max(maxn, h->h_src_cnt[b]);
   h->chunks_per_pair = std::max(1, (maxn + CHUNK_PTS - 1) / CHUNK_PTS);
-  size_t need = (size_t)B * h->chunks_per_pair * NACC;
+  size_t need = (size_t)B * h->chunks_per_pair * QUARTERS * NACC;
   HIPCHK(h, grow(h->d_partials, h->partials_cap, need));
   HIPCHK(h, hipMemcpyAsync(h->d_src_cnt, h->h_src_cnt.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1242,23 +1270,16 @@ static void make_sweep_const(const mi355ndt_handle* h, SweepConst& sc) {
   build_offsets(h->prm.neighbor_mode, sc);
 }
 
-static int launch_sweep(mi355ndt_handle* h, const SweepConst& sc, int first_pair, int n_pairs_launch) {
-  // bx blocks walk the chunks of one pair round-robin; enough blocks overall to fill 256 CUs several times
-  int bx = h->chunks_per_pair;
-  const int want = 8192;
-  if ((long long)bx * n_pairs_launch > want) bx = std::max(1, std::min(bx, want / n_pairs_launch));
-  const int xcd_map = n_pairs_launch >= 8;
-  const int groups = xcd_map ? ((n_pairs_launch + 7) / 8) * 8 : n_pairs_launch;
-  const dim3 grid((unsigned)(groups * bx));
+static int launch_sweep(mi355ndt_handle* h, const SweepConst& sc) {
+  // persistent waves: SWEEP_WPE workgroups per CU pull (pair, chunk, quarter) items until the per-XCD queues are dry
+  const dim3 grid((unsigned)(h->n_cu * SWEEP_WPE));
   if (h->prof) HIPCHK(h, ev_begin(h, h->ev_sweep));
-  const float* src = h->d_src + (size_t)first_pair * 3 * h->src_pitch;
-  double* part = h->d_partials + (size_t)first_pair * h->chunks_per_pair * NACC;
   if (sc.pca)
-    k_sweep<true><<<grid, SWEEP_THREADS, 0, h->stream>>>(src, h->src_pitch, h->d_state + first_pair, h->d_grid + first_pair,
-        h->d_words, h->d_recs, part, h->chunks_per_pair, n_pairs_launch, bx, xcd_map, sc);
+    k_sweep<true><<<grid, SWEEP_THREADS, 0, h->stream>>>(h->d_src, h->src_pitch, h->d_state, h->d_grid, h->d_words, h->d_recs,
+        h->d_partials, h->chunks_per_pair, h->d_active_list, h->d_ctl, sc);
   else
-    k_sweep<false><<<grid, SWEEP_THREADS, 0, h->stream>>>(src, h->src_pitch, h->d_state + first_pair, h->d_grid + first_pair,
-        h->d_words, h->d_recs, part, h->chunks_per_pair, n_pairs_launch, bx, xcd_map, sc);
+    k_sweep<false><<<grid, SWEEP_THREADS, 0, h->stream>>>(h->d_src, h->src_pitch, h->d_state, h->d_grid, h->d_words, h->d_recs,
+        h->d_partials, h->chunks_per_pair, h->d_active_list, h->d_ctl, sc);
   if (h->prof) HIPCHK(h, ev_end(h, h->ev_sweep));
   return MI355NDT_OK;
 }
@@ -1279,8 +1300,9 @@ int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_resu
   make_sweep_const(h, sc);
   HIPCHK(h, hipMemcpyAsync(h->d_guess, guesses, (size_t)B * 16 * sizeof(float), hipMemcpyHostToDevice, s));
   HIPCHK(h, hipStreamSynchronize(s));           // guesses may be pageable caller memory
-  k_init_state<<<(B + 63) / 64, 64, 0, s>>>(h->d_state, h->d_guess, h->d_src_cnt, h->d_grid, B);
-  rc = launch_sweep(h, sc, 0, B);
+  HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, sizeof(SweepCtl), s));
+  k_init_state<<<(B + 63) / 64, 64, 0, s>>>(h->d_state, h->d_guess, h->d_src_cnt, h->d_grid, B, h->d_active_list, h->d_ctl);
+  rc = launch_sweep(h, sc);
   if (rc) return rc;
   const int max_rounds = h->prm.max_iterations + 4;   // loop body runs for it = 0 .. max_iterations+1
   double pts_total = 0;
@@ -1298,10 +1320,12 @@ int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_resu
     const int r0 = round;
     for (int k = 0; k < burst && round < max_rounds; k++, round++) {
       if (h->prof) HIPCHK(h, ev_begin(h, h->ev_update));
+      HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, sizeof(SweepCtl), s));
       k_update<<<B, 64, 0, s>>>(h->d_state, h->d_partials, h->chunks_per_pair, h->d_results, h->d_active + (round - r0),
-                                h->prof ? h->d_hits : nullptr, h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations, 0);
+                                h->d_active_list, h->d_ctl, h->prof ? h->d_hits : nullptr,
+                                h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations, 0);
       if (h->prof) HIPCHK(h, ev_end(h, h->ev_update));
-      rc = launch_sweep(h, sc, 0, B);
+      rc = launch_sweep(h, sc);
       if (rc) return rc;
     }
     HIPCHK(h, hipMemcpyAsync(h->h_pin_active, h->d_active, burst * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1421,9 +1445,10 @@ int mi355ndt_get_aligned(mi355ndt_handle* h, void* out_pts, size_t stride) {
 static int run_hook_sweep(mi355ndt_handle* h, double* score, double g[6], double H[36], long long* hits) {
   SweepConst sc;
   make_sweep_const(h, sc);
-  int rc = launch_sweep(h, sc, 0, 1);
+  int rc = launch_sweep(h, sc);
   if (rc) return rc;
-  k_update<<<1, 64, 0, h->stream>>>(h->d_state, h->d_partials, h->chunks_per_pair, h->d_results, h->d_active, nullptr, 0, 0, 0, 1);
+  k_update<<<1, 64, 0, h->stream>>>(h->d_state, h->d_partials, h->chunks_per_pair, h->d_results, h->d_active, h->d_active_list, h->d_ctl,
+                                    nullptr, 0, 0, 0, 1);
   PairState S;
   HIPCHK(h, hipMemcpyAsync(&S, h->d_state, sizeof(PairState), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1451,7 +1476,8 @@ int mi355ndt_derivatives(mi355ndt_handle* h, const double p[6], double* score, d
   double* dp = (double*)h->d_hook;
   HIPCHK(h, hipMemcpyAsync(dp, p, 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  k_set_pose_p<<<1, 1, 0, h->stream>>>(h->d_state, 0, dp, h->d_src_cnt, h->d_grid);
+  HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, sizeof(SweepCtl), h->stream));
+  k_set_pose_p<<<1, 1, 0, h->stream>>>(h->d_state, 0, dp, h->d_src_cnt, h->d_grid, h->d_active_list, h->d_ctl);
   return run_hook_sweep(h, score, g, H, hits);
 }
 
@@ -1465,7 +1491,8 @@ int mi355ndt_derivatives_T(mi355ndt_handle* h, const float T[16], const float Rj
   memcpy(buf + 16, Rj, 9 * sizeof(float));
   HIPCHK(h, hipMemcpyAsync(h->d_hook, buf, sizeof buf, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  k_set_pose<<<1, 1, 0, h->stream>>>(h->d_state, 0, h->d_hook, h->d_hook + 16, h->d_src_cnt, h->d_grid);
+  HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, sizeof(SweepCtl), h->stream));
+  k_set_pose<<<1, 1, 0, h->stream>>>(h->d_state, 0, h->d_hook, h->d_hook + 16, h->d_src_cnt, h->d_grid, h->d_active_list, h->d_ctl);
   return run_hook_sweep(h, score, g, H, hits);
 }
 
