@@ -79,6 +79,8 @@ struct SweepConst {
   int    K;                    // neighbour probes
   int    pca;
   int    table;                // row of c_off: 0 = DIRECT1, 1 = DIRECT7, 2 = DIRECT26
+  int    leaf_pow2;            // resolution is a power of two: x / leaf == x * inv_leaf bit for bit
+  float  inv_leaf;
 };
 
 // Neighbour offsets in the reference's probe order.  DIRECT1: voxel_grid_covariance_omp_impl.hpp:441;
@@ -161,7 +163,7 @@ __global__ void k_griddesc(const int* __restrict__ mm, GridDesc* gd, unsigned* n
         g.mul1 = g.div_b[0];
         g.mul2 = g.div_b[0] * g.div_b[1];
         g.ncells = (int)nc;
-        g.nwords = (int)((nc + 63) >> 6);
+        g.nwords = (int)((nc + 63) >> 6) + 1;     // + one all-zero word: the landing cell of out-of-grid probes
       }
     }
   }
@@ -423,6 +425,14 @@ __device__ __forceinline__ void eval_hit(const float u[3], const float r[3], con
 #undef NDT_ACC
 }
 
+// Neighbour offset `a` (0..2) of probe q for a K-probe search, resolved at compile time in the sweep
+// (same tables and order as c_off above).
+__host__ __device__ constexpr int probe_off(int K, int q, int a) {
+  const int o7[7][3] = {{0,0,0},{1,0,0},{-1,0,0},{0,1,0},{0,-1,0},{0,0,1},{0,0,-1}};
+  const int o26[26][3] = {{-1,-1,-1}, {-1,0,-1}, {-1,1,-1}, {0,-1,-1}, {0,0,-1}, {0,1,-1}, {1,-1,-1}, {1,0,-1}, {1,1,-1}, {-1,-1,0}, {0,-1,0}, {1,-1,0}, {-1,0,0}, {1,1,1}, {1,0,1}, {1,-1,1}, {0,1,1}, {0,0,1}, {0,-1,1}, {-1,1,1}, {-1,0,1}, {-1,-1,1}, {1,1,0}, {0,1,0}, {-1,1,0}, {1,0,0}};
+  return K == 1 ? 0 : (K == 7 ? o7[q][a] : o26[q][a]);
+}
+
 #define Q_CAP   512                       // per-wave hit queue (entries); >= 63 + 7*64
 #define Q_GROUP 7                         // probes between queue drains
 #define ID_BITS 25                        // queue entry = slot << 25 | voxel id
@@ -444,7 +454,7 @@ struct SweepCtl {               // zeroed by the host before every k_update / k_
 };
 #define QUARTERS WAVES          // a chunk is reduced as 4 wave-quarters of CHUNK_PTS/4 points
 
-template <bool PCA>
+template <bool PCA, int K>
 __global__ void __launch_bounds__(SWEEP_THREADS, SWEEP_WPE)
 k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict__ st,
         const GridDesc* __restrict__ gd, const BitWord* __restrict__ words, const VoxelRec* __restrict__ recs,
@@ -495,7 +505,7 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
   const float leaf = g.leaf;
   const int mb0 = g.min_b[0], mb1 = g.min_b[1], mb2 = g.min_b[2];
   const int xb0 = g.max_b[0], xb1 = g.max_b[1], xb2 = g.max_b[2];
-  const int mul1 = g.mul1, mul2 = g.mul2;
+  const int mul1 = g.mul1, mul2 = g.mul2, nwords = g.nwords;
   {
     double acc[43];
 #pragma unroll
@@ -556,48 +566,54 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
         }
         float* sp = stage[wv][slot];
         sp[0] = xt[0]; sp[1] = xt[1]; sp[2] = xt[2]; sp[3] = r[0]; sp[4] = r[1]; sp[5] = r[2];
-        // getNeighborhoodAtPoint (voxel_grid_covariance_omp_impl.hpp:379-399)
-        const int c0 = (int)floorf(xt[0] / leaf), c1 = (int)floorf(xt[1] / leaf), c2 = (int)floorf(xt[2] / leaf);
+        // getNeighborhoodAtPoint (voxel_grid_covariance_omp_impl.hpp:379-399): cell of the point, f32 divide
+        // (x / 2^k is the same bits as x * 2^-k, so a power-of-two leaf takes the one-instruction path)
+        const int c0 = (int)floorf(sc.leaf_pow2 ? xt[0] * sc.inv_leaf : xt[0] / leaf);
+        const int c1 = (int)floorf(sc.leaf_pow2 ? xt[1] * sc.inv_leaf : xt[1] / leaf);
+        const int c2 = (int)floorf(sc.leaf_pow2 ? xt[2] * sc.inv_leaf : xt[2] / leaf);
+        // Branch-free probe stage.  Relative cell r = c - min_b; "inside the grid" (impl:382-392) is one unsigned
+        // compare per axis; a probe that falls outside (or belongs to an invalid lane) is redirected to the grid's
+        // spare all-zero bitmap word, so it misses without any flag having to be kept.
+        const int r0 = c0 - mb0, r1 = c1 - mb1, r2 = c2 - mb2;
+        const unsigned e0 = (unsigned)(xb0 - mb0), e1 = (unsigned)(xb1 - mb1), e2 = (unsigned)(xb2 - mb2);
+        const int cc = r0 + r1 * mul1 + r2 * mul2;
+        const unsigned empty_cell = (unsigned)(nwords - 1) << 6;
         // probes run last-to-first so the ndt_pca weight of a hit (product of its own and all LATER hits' weights,
         // ndt_pca_impl2.hpp:295-296) is a running product; the order of the f64 additions is free anyway.
         double suf = 1.0;
-        // Probes are issued Q_GROUP at a time with all bitmap loads of the group in flight together, then all
-        // weight loads, then the ballots: one L2 round trip per stage instead of one per probe.
-#pragma unroll 1
-        for (int q1 = sc.K; q1 > 0; q1 -= Q_GROUP) {
+        // Q_GROUP probes at a time: all bitmap loads of the group in flight together (then all ndt_pca weight loads),
+        // then the ballots -- one L2 round trip per stage instead of one per probe.
+#pragma unroll
+        for (int q1 = K; q1 > 0; q1 -= Q_GROUP) {      // compile-time groups: 1 for DIRECT1 / DIRECT7, 4 for DIRECT26
           unsigned cellv[Q_GROUP];
-          bool hitv[Q_GROUP];
-          BitWord bwv[Q_GROUP];
+          uint4 bwv[Q_GROUP];                          // BitWord: bits lo, bits hi, prefix, pad
 #pragma unroll
           for (int j = 0; j < Q_GROUP; j++) {
-            const int q = q1 - 1 - j;                 // wave-uniform
-            hitv[j] = false;
-            cellv[j] = 0;
+            const int q = q1 - 1 - j;                 // compile-time
+            cellv[j] = empty_cell;
             if (q >= 0) {
-              const int a0 = c0 + c_off[sc.table][q][0], a1 = c1 + c_off[sc.table][q][1], a2 = c2 + c_off[sc.table][q][2];
-              hitv[j] = valid && a0 >= mb0 && a0 <= xb0 && a1 >= mb1 && a1 <= xb1 && a2 >= mb2 && a2 <= xb2;
-              cellv[j] = (unsigned)((a0 - mb0) + (a1 - mb1) * mul1 + (a2 - mb2) * mul2);
-              if (hitv[j]) bwv[j] = W[cellv[j] >> 6];
+              const int o0 = probe_off(K, q, 0), o1 = probe_off(K, q, 1), o2 = probe_off(K, q, 2);
+              const bool inside = valid && (unsigned)(r0 + o0) <= e0 && (unsigned)(r1 + o1) <= e1 && (unsigned)(r2 + o2) <= e2;
+              if (inside) cellv[j] = (unsigned)(cc + o0 + o1 * mul1 + o2 * mul2);
             }
+            bwv[j] = *reinterpret_cast<const uint4*>(W + (cellv[j] >> 6));
           }
           unsigned idv[Q_GROUP];
           int wiv[Q_GROUP];
 #pragma unroll
           for (int j = 0; j < Q_GROUP; j++) {
-            idv[j] = 0;
-            wiv[j] = VOX_DEAD;
-            if (hitv[j]) {
-              const unsigned long long bit = 1ull << (cellv[j] & 63);
-              hitv[j] = (bwv[j].bits & bit) != 0ull;
-              idv[j] = bwv[j].prefix + (unsigned)__popcll(bwv[j].bits & (bit - 1ull));
-              // ndt_pca needs the weights now (suffix product); ndt_omp filters dead leaves in phase B instead and
-              // saves this dependent L2 round trip
-              if (PCA) { if (hitv[j]) wiv[j] = R[idv[j]].weight; } else wiv[j] = 1;
-            }
+            // shift the cell's bit to the top: sign = occupied, popcount = bits at or below it
+            const unsigned long long bits = ((unsigned long long)bwv[j].y << 32) | bwv[j].x;
+            const unsigned long long t = bits << (63u - (cellv[j] & 63u));
+            idv[j] = bwv[j].z + (unsigned)__popcll(t) - 1u;        // rank among the searchable leaves = voxel id
+            // occupied <=> the cell's bit (now the sign bit) is set; ndt_pca needs the weights now (suffix product),
+            // ndt_omp filters dead leaves in phase B instead and saves this dependent L2 round trip
+            wiv[j] = ((long long)t < 0) ? 1 : VOX_DEAD;
+            if (PCA) { if ((long long)t < 0) wiv[j] = R[idv[j]].weight; }
           }
 #pragma unroll
           for (int j = 0; j < Q_GROUP; j++) {
-            const bool hit = hitv[j] && wiv[j] != VOX_DEAD;   // nr_points == -1: not a neighbour (impl:395)
+            const bool hit = wiv[j] != VOX_DEAD;     // empty cell, or nr_points == -1: not a neighbour (impl:395)
             if (PCA && hit) suf *= (double)wiv[j];
             const unsigned long long mask = __ballot(hit);
             if (hit) {
@@ -1267,6 +1283,7 @@ static void make_sweep_const(const mi355ndt_handle* h, SweepConst& sc) {
   sc.d1 = d1;
   sc.d2f = (float)d2;                        // impl2:578
   sc.pca = h->prm.variant == MI355NDT_VARIANT_PCA;
+  { int ex; float mant = std::frexp(h->prm.resolution, &ex); sc.leaf_pow2 = (mant == 0.5f) && ex > -100 && ex < 100; sc.inv_leaf = 1.0f / h->prm.resolution; }
   build_offsets(h->prm.neighbor_mode, sc);
 }
 
@@ -1274,12 +1291,11 @@ static int launch_sweep(mi355ndt_handle* h, const SweepConst& sc) {
   // persistent waves: SWEEP_WPE workgroups per CU pull (pair, chunk, quarter) items until the per-XCD queues are dry
   const dim3 grid((unsigned)(h->n_cu * SWEEP_WPE));
   if (h->prof) HIPCHK(h, ev_begin(h, h->ev_sweep));
-  if (sc.pca)
-    k_sweep<true><<<grid, SWEEP_THREADS, 0, h->stream>>>(h->d_src, h->src_pitch, h->d_state, h->d_grid, h->d_words, h->d_recs,
-        h->d_partials, h->chunks_per_pair, h->d_active_list, h->d_ctl, sc);
-  else
-    k_sweep<false><<<grid, SWEEP_THREADS, 0, h->stream>>>(h->d_src, h->src_pitch, h->d_state, h->d_grid, h->d_words, h->d_recs,
-        h->d_partials, h->chunks_per_pair, h->d_active_list, h->d_ctl, sc);
+#define NDT_LAUNCH_SWEEP(P, KK) k_sweep<P, KK><<<grid, SWEEP_THREADS, 0, h->stream>>>(h->d_src, h->src_pitch, h->d_state, h->d_grid, \
+      h->d_words, h->d_recs, h->d_partials, h->chunks_per_pair, h->d_active_list, h->d_ctl, sc)
+  if (sc.pca) { if (sc.K == 1) NDT_LAUNCH_SWEEP(true, 1); else if (sc.K == 7) NDT_LAUNCH_SWEEP(true, 7); else NDT_LAUNCH_SWEEP(true, 26); }
+  else        { if (sc.K == 1) NDT_LAUNCH_SWEEP(false, 1); else if (sc.K == 7) NDT_LAUNCH_SWEEP(false, 7); else NDT_LAUNCH_SWEEP(false, 26); }
+#undef NDT_LAUNCH_SWEEP
   if (h->prof) HIPCHK(h, ev_end(h, h->ev_sweep));
   return MI355NDT_OK;
 }
