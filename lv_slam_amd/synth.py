@@ -169,3 +169,21 @@ def default_guess() -> np.ndarray:
     G = np.eye(4, dtype=np.float32)
     G[0, 3] = 1.0
     return G
+
+
+def make_sequence(n_frames: int, n_azimuth: int = 1024, device="cpu", seed: int = BASE_SEED, n_beams: int = 64,
+                  noise_sigma: float = 0.02):
+    """A drive along the street: frame k is scanned at pose P_k = P_{k-1} * dT_{k-1} (dT from pair_motion).
+    Returns (list of [N,3] f32 scans in their own sensor frames, list of 4x4 f64 ground-truth poses P_k)."""
+    n = n_azimuth * n_beams
+    P = np.eye(4)
+    scans, poses = [], []
+    for k in range(n_frames):
+        g = torch.Generator(device="cpu")
+        g.manual_seed((seed + 7919 * (k + 1)) & 0x7FFFFFFFFFFFFFFF)
+        noise = torch.randn(n, generator=g, dtype=torch.float64) * noise_sigma
+        ring = torch.rand(n, generator=g, dtype=torch.float64)
+        scans.append(cast_scan(P, n_azimuth, noise, ring, device, seed, n_beams))
+        poses.append(P.copy())
+        P = P @ pair_motion(k, seed)
+    return scans, poses
