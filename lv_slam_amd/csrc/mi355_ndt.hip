@@ -29,9 +29,9 @@
 #define SWEEP_WPE       2             // waves per SIMD the sweep is register-allocated for (2: no spills; measured faster than 3 with spills)
 #endif
 #define NACC           44            // score, g[6], H[36], hits
-#define IDX_BITS       26            // sort key = pair << 26 | cell ; cell < 2^25 ; bit 25 = "not binned"
+// sort key = pair << cb | cell, cb = bits needed for the largest grid of the batch + the all-ones "not binned" cell;
+// 32-bit keys whenever pair and cell fields fit (the usual case), else 64-bit
 #define MAX_CELLS      (1 << 25)
-#define INVALID_CELL   (1u << 25)
 
 enum { GRID_OK = 0, GRID_EMPTY = 1, GRID_OVERFLOW = 2, GRID_CAP = 3 };
 enum { PH_SWEEP0 = 0, PH_STEP = 1, PH_DONE = 2 };
@@ -117,17 +117,21 @@ __global__ void __launch_bounds__(256) k_minmax(const float* __restrict__ tgt, s
     mn[1] = min(mn[1], oy); mx[1] = max(mx[1], oy);
     mn[2] = min(mn[2], oz); mx[2] = max(mx[2], oz);
   }
+  __shared__ int red[4][6];
   for (int a = 0; a < 3; a++) {
     for (int o = 32; o > 0; o >>= 1) {
       mn[a] = min(mn[a], __shfl_xor(mn[a], o));
       mx[a] = max(mx[a], __shfl_xor(mx[a], o));
     }
   }
-  if ((threadIdx.x & 63) == 0) {
-    for (int a = 0; a < 3; a++) {
-      if (mn[a] != INT_MAX) atomicMin(&mm[b * 6 + a], mn[a]);
-      if (mx[a] != INT_MIN) atomicMax(&mm[b * 6 + 3 + a], mx[a]);
-    }
+  if ((threadIdx.x & 63) == 0) for (int a = 0; a < 3; a++) { red[threadIdx.x >> 6][a] = mn[a]; red[threadIdx.x >> 6][3 + a] = mx[a]; }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const bool is_min = threadIdx.x < 3;
+    int v = red[0][threadIdx.x];
+    for (int w = 1; w < 4; w++) v = is_min ? min(v, red[w][threadIdx.x]) : max(v, red[w][threadIdx.x]);
+    if (is_min) { if (v != INT_MAX) atomicMin(&mm[b * 6 + threadIdx.x], v); }
+    else if (v != INT_MIN) atomicMax(&mm[b * 6 + threadIdx.x], v);
   }
 }
 
@@ -171,19 +175,20 @@ __global__ void k_griddesc(const int* __restrict__ mm, GridDesc* gd, unsigned* n
   nwords[b] = (unsigned)g.nwords;
 }
 
-__global__ void k_set_word_off(GridDesc* gd, const unsigned* __restrict__ off, int n_pairs) {
+__global__ void k_set_word_off(GridDesc* gd, const unsigned* __restrict__ off, int n_pairs, unsigned* max_ncells) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < n_pairs) gd[b].word_off = off[b];
+  if (b < n_pairs) { gd[b].word_off = off[b]; atomicMax(max_ncells, (unsigned)gd[b].ncells); }
 }
 
 // first pass of applyFilter: cell index per point (impl:218-223)
+template <typename KeyT>
 __global__ void __launch_bounds__(256) k_keys(const float* __restrict__ tgt, size_t pitch, const int* __restrict__ cnt,
-                                               const GridDesc* __restrict__ gd, unsigned long long* keys, unsigned* vals) {
+                                               const GridDesc* __restrict__ gd, KeyT* keys, unsigned* vals, int cb) {
   const int b = blockIdx.y;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= pitch) return;
   const GridDesc& g = gd[b];
-  unsigned cell = INVALID_CELL;
+  unsigned cell = (1u << cb) - 1u;               // "not binned": padding, non-finite point or unusable grid
   if ((int)i < cnt[b] && g.status == GRID_OK) {
     const float* X = tgt + (size_t)b * 3 * pitch;
     float x = X[i], y = X[pitch + i], z = X[2 * pitch + i];
@@ -194,20 +199,22 @@ __global__ void __launch_bounds__(256) k_keys(const float* __restrict__ tgt, siz
       cell = (unsigned)(i0 + i1 * g.mul1 + i2 * g.mul2);
     }
   }
-  keys[(size_t)b * pitch + i] = ((unsigned long long)b << IDX_BITS) | cell;
+  keys[(size_t)b * pitch + i] = ((KeyT)b << cb) | (KeyT)cell;
   vals[(size_t)b * pitch + i] = (unsigned)i;
 }
 
 // mark cells that hold >= min_points points (impl:297) in the occupancy bitmap
-__global__ void __launch_bounds__(256) k_mark(const unsigned long long* __restrict__ keys, size_t pitch, const GridDesc* __restrict__ gd,
-                                               BitWord* words, int min_points) {
+template <typename KeyT>
+__global__ void __launch_bounds__(256) k_mark(const KeyT* __restrict__ keys, size_t pitch, const GridDesc* __restrict__ gd,
+                                               BitWord* words, int min_points, int cb) {
   const int b = blockIdx.y;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= pitch) return;
-  const unsigned long long* K = keys + (size_t)b * pitch;
-  const unsigned long long key = K[i];
-  const unsigned cell = (unsigned)(key & ((1u << IDX_BITS) - 1));
-  if (cell & INVALID_CELL) return;
+  const KeyT* K = keys + (size_t)b * pitch;
+  const KeyT key = K[i];
+  const unsigned cmask = (1u << cb) - 1u;
+  const unsigned cell = (unsigned)key & cmask;
+  if (cell == cmask) return;
   if (i != 0 && K[i - 1] == key) return;                       // not the head of its segment
   const size_t last = i + (size_t)(min_points > 0 ? min_points - 1 : 0);
   if (last >= pitch || K[last] != key) return;                 // fewer than min_points points
@@ -234,15 +241,17 @@ __global__ void __launch_bounds__(256) k_rank(GridDesc* gd, BitWord* words) {
 }
 
 // where does the point run of searchable leaf `id` start in the sorted order?
-__global__ void __launch_bounds__(256) k_segstart(const unsigned long long* __restrict__ keys, size_t pitch, const GridDesc* __restrict__ gd,
-                                                   const BitWord* __restrict__ words, unsigned* seg_start, int min_points) {
+template <typename KeyT>
+__global__ void __launch_bounds__(256) k_segstart(const KeyT* __restrict__ keys, size_t pitch, const GridDesc* __restrict__ gd,
+                                                   const BitWord* __restrict__ words, unsigned* seg_start, int min_points, int cb) {
   const int b = blockIdx.y;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= pitch) return;
-  const unsigned long long* K = keys + (size_t)b * pitch;
-  const unsigned long long key = K[i];
-  const unsigned cell = (unsigned)(key & ((1u << IDX_BITS) - 1));
-  if (cell & INVALID_CELL) return;
+  const KeyT* K = keys + (size_t)b * pitch;
+  const KeyT key = K[i];
+  const unsigned cmask = (1u << cb) - 1u;
+  const unsigned cell = (unsigned)key & cmask;
+  if (cell == cmask) return;
   if (i != 0 && K[i - 1] == key) return;
   const size_t last = i + (size_t)(min_points > 0 ? min_points - 1 : 0);
   if (last >= pitch || K[last] != key) return;
@@ -257,20 +266,21 @@ __global__ void __launch_bounds__(256) k_segstart(const unsigned long long* __re
 // order), parks the nine f64 terms of each point in LDS, and lanes 0..8 -- one per accumulator -- add them
 // strictly in input order, which keeps the sums bit-identical to the reference's sequential accumulation.
 #define LS_WAVES 4
+template <typename KeyT>
 __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restrict__ tgt, size_t pitch,
-                                                           const unsigned long long* __restrict__ keys, const unsigned* __restrict__ vals,
+                                                           const KeyT* __restrict__ keys, const unsigned* __restrict__ vals,
                                                            const GridDesc* __restrict__ gd, const unsigned* __restrict__ seg_start,
-                                                           double* sums, int* vox_idx, int* vox_n) {
+                                                           double* sums, int* vox_idx, int* vox_n, int cb) {
   __shared__ double term[LS_WAVES][64][9];
   const int b = blockIdx.y;
   const GridDesc& g = gd[b];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const unsigned long long* K = keys + (size_t)b * pitch;
+  const KeyT* K = keys + (size_t)b * pitch;
   const unsigned* V = vals + (size_t)b * pitch;
   const float* X = tgt + (size_t)b * 3 * pitch;
   for (int id = blockIdx.x * LS_WAVES + wv; id < g.n_voxels; id += gridDim.x * LS_WAVES) {
     const size_t start = seg_start[g.rec_off + id];
-    const unsigned long long key = K[start];
+    const KeyT key = K[start];
     // accumulator order: S0 S1 S2 C00 C01 C02 C11 C12 C22 ; cov_ is seeded with Identity (voxel_grid_covariance_omp.h:101)
     double acc = (lane == 3 || lane == 6 || lane == 8) ? 1.0 : 0.0;
     int cnt = 0;
@@ -293,7 +303,7 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restri
     }
     if (lane < 9) sums[(size_t)(g.rec_off + id) * 9 + lane] = acc;
     if (lane == 0) {
-      vox_idx[g.rec_off + id] = (int)(key & ((1u << IDX_BITS) - 1));
+      vox_idx[g.rec_off + id] = (int)((unsigned)key & ((1u << cb) - 1u));
       vox_n[g.rec_off + id] = cnt;
     }
   }
@@ -1022,7 +1032,7 @@ static int ensure_pair_arrays(mi355ndt_handle* h, int n_pairs) {
   HIPCHK(h, re((void**)&h->d_src_cnt, n_pairs * sizeof(int)));
   HIPCHK(h, re((void**)&h->d_minmax, n_pairs * 6 * sizeof(int)));
   HIPCHK(h, re((void**)&h->d_grid, n_pairs * sizeof(GridDesc)));
-  HIPCHK(h, re((void**)&h->d_nwords, (n_pairs + 1) * sizeof(unsigned)));
+  HIPCHK(h, re((void**)&h->d_nwords, (n_pairs + 2) * sizeof(unsigned)));
   HIPCHK(h, re((void**)&h->d_word_off, (n_pairs + 1) * sizeof(unsigned)));
   HIPCHK(h, re((void**)&h->d_state, n_pairs * sizeof(PairState)));
   HIPCHK(h, re((void**)&h->d_guess, n_pairs * 16 * sizeof(float)));
@@ -1208,11 +1218,12 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
     HIPCHK(h, grow(h->d_seg_start, c4, need)); HIPCHK(h, grow(h->d_sums, c5, need * 9));
     h->recs_cap = need; h->recs_per_pair = rpp;
   }
-  const int end_bit = IDX_BITS + ceil_log2((unsigned)B);
-  size_t need_tmp = 0, need_scan = 0;
-  HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(nullptr, need_tmp, h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, (int)total, 0, end_bit, s));
+  const int pb = ceil_log2((unsigned)B);
+  size_t need_tmp = 0, need_tmp32 = 0, need_scan = 0;
+  HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(nullptr, need_tmp, h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, (int)total, 0, 64, s));
+  HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(nullptr, need_tmp32, (unsigned*)h->d_keys_a, (unsigned*)h->d_keys_b, h->d_vals_a, h->d_vals_b, (int)total, 0, 32, s));
   HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(nullptr, need_scan, h->d_nwords, h->d_word_off, B + 1, s));
-  need_tmp = std::max(need_tmp, need_scan);
+  need_tmp = std::max(std::max(need_tmp, need_tmp32), need_scan);
   if (need_tmp > h->tmp_bytes) {
     if (h->d_tmp) { HIPCHK(h, hipFree(h->d_tmp)); h->d_tmp = nullptr; }
     HIPCHK(h, hipMalloc(&h->d_tmp, need_tmp));
@@ -1223,32 +1234,44 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
   if (h->prof) HIPCHK(h, ev_begin(h, h->ev_build));
   const int gx = (int)((pitch + 255) / 256);
   k_minmax_init<<<(B * 6 + 255) / 256, 256, 0, s>>>(h->d_minmax, B);
-  k_minmax<<<dim3(std::min(gx, 64), B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_minmax);
-  HIPCHK(h, hipMemsetAsync(h->d_nwords, 0, (B + 1) * sizeof(unsigned), s));
+  k_minmax<<<dim3(std::min(gx, 16), B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_minmax);
+  HIPCHK(h, hipMemsetAsync(h->d_nwords, 0, (B + 2) * sizeof(unsigned), s));
   k_griddesc<<<(B + 63) / 64, 64, 0, s>>>(h->d_minmax, h->d_grid, h->d_nwords, h->prm.resolution, B, (unsigned)rpp);
   size_t tb = h->tmp_bytes;
   HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(h->d_tmp, tb, h->d_nwords, h->d_word_off, B + 1, s));
-  k_set_word_off<<<(B + 63) / 64, 64, 0, s>>>(h->d_grid, h->d_word_off, B);
+  k_set_word_off<<<(B + 63) / 64, 64, 0, s>>>(h->d_grid, h->d_word_off, B, h->d_nwords + B + 1);
   HIPCHK(h, hipMemcpyAsync(h->h_pin_u, h->d_word_off + B, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-  k_keys<<<dim3(gx, B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_grid, h->d_keys_a, h->d_vals_a);
-  tb = h->tmp_bytes;
-  HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(h->d_tmp, tb, h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, (int)total, 0, end_bit, s));
-  HIPCHK(h, hipStreamSynchronize(s));           // total bitmap words -> size the pool
+  HIPCHK(h, hipMemcpyAsync(h->h_pin_u + 1, h->d_nwords + B + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));           // total bitmap words -> size the pool; largest grid -> key width
   const size_t total_words = h->h_pin_u[0];
+  const int cb = std::max(1, ceil_log2(h->h_pin_u[1] + 1u));   // cell field: every cell index + the all-ones "not binned" value
+  const bool k32 = cb + pb <= 32;
   if (total_words > h->words_cap) {
     size_t c = h->words_cap;
     HIPCHK(h, grow(h->d_words, c, std::max(total_words, (size_t)1024)));
     h->words_cap = c;
   }
   if (total_words) HIPCHK(h, hipMemsetAsync(h->d_words, 0, total_words * sizeof(BitWord), s));
-  k_mark<<<dim3(gx, B), 256, 0, s>>>(h->d_keys_b, pitch, h->d_grid, h->d_words, minpts);
-  k_rank<<<B, 256, 0, s>>>(h->d_grid, h->d_words);
-  k_segstart<<<dim3(gx, B), 256, 0, s>>>(h->d_keys_b, pitch, h->d_grid, h->d_words, h->d_seg_start, minpts);
-  {
-    // enough waves per target to cover its leaves a few at a time; ~8 waves per SIMD overall
-    int lb = std::max(1, std::min((int)((rpp + LS_WAVES - 1) / LS_WAVES), std::max(8, 8192 / B)));
-    k_leafsum<<<dim3(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, h->d_keys_b, h->d_vals_b, h->d_grid, h->d_seg_start,
-                                                   h->d_sums, h->d_vox_idx, h->d_vox_n);
+  const int lb = std::max(1, std::min((int)((rpp + LS_WAVES - 1) / LS_WAVES), std::max(8, 8192 / B)));
+  tb = h->tmp_bytes;
+  if (k32) {
+    unsigned *ka = (unsigned*)h->d_keys_a, *kb = (unsigned*)h->d_keys_b;
+    k_keys<unsigned><<<dim3(gx, B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_grid, ka, h->d_vals_a, cb);
+    HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(h->d_tmp, tb, ka, kb, h->d_vals_a, h->d_vals_b, (int)total, 0, cb + pb, s));
+    k_mark<unsigned><<<dim3(gx, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, minpts, cb);
+    k_rank<<<B, 256, 0, s>>>(h->d_grid, h->d_words);
+    k_segstart<unsigned><<<dim3(gx, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, h->d_seg_start, minpts, cb);
+    k_leafsum<unsigned><<<dim3(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start,
+                                                             h->d_sums, h->d_vox_idx, h->d_vox_n, cb);
+  } else {
+    typedef unsigned long long u64;
+    k_keys<u64><<<dim3(gx, B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_grid, h->d_keys_a, h->d_vals_a, cb);
+    HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(h->d_tmp, tb, h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, (int)total, 0, cb + pb, s));
+    k_mark<u64><<<dim3(gx, B), 256, 0, s>>>(h->d_keys_b, pitch, h->d_grid, h->d_words, minpts, cb);
+    k_rank<<<B, 256, 0, s>>>(h->d_grid, h->d_words);
+    k_segstart<u64><<<dim3(gx, B), 256, 0, s>>>(h->d_keys_b, pitch, h->d_grid, h->d_words, h->d_seg_start, minpts, cb);
+    k_leafsum<u64><<<dim3(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, h->d_keys_b, h->d_vals_b, h->d_grid, h->d_seg_start,
+                                                        h->d_sums, h->d_vox_idx, h->d_vox_n, cb);
   }
   k_voxels<<<dim3((unsigned)((rpp + 255) / 256), B), 256, 0, s>>>(h->d_grid, h->d_sums, h->d_recs, h->d_vox_n,
                                                                   h->prm.min_covar_eigvalue_mult, h->prm.variant == MI355NDT_VARIANT_PCA);
