@@ -278,3 +278,56 @@ def test_device_resident_batch_zero_copy():
         assert res[k]["iterations"] == ro["iterations"]
         dt, dr = se3_err(ro["final"], res[k]["final"])
         assert dt < 1e-4 and dr < 1e-5
+
+
+def test_sparse_hits_and_many_chunks():
+    """Regimes that stress the sweep's queue/staging logic: (a) a big source whose points mostly miss the target
+    (queue fills slowly, entries outlive a tile), (b) sources spanning many 2048-point chunks and several
+    per-XCD item queues, (c) DIRECT26 (four probe groups per tile) at a non-trivial size."""
+    rng = np.random.default_rng(11)
+    tgt = (rng.normal(0, 1.0, (20000, 3)) * np.array([6, 6, 1.5])).astype(np.float32)
+    # (a) sparse: source spread over a 10x larger volume
+    src = (rng.uniform(-1, 1, (30011, 3)) * np.array([60, 60, 15])).astype(np.float32)
+    for mode in (ndt.DIRECT7, ndt.DIRECT1, ndt.DIRECT26):
+        gp, op = both_params(trans_epsilon=0.01, max_iterations=64, neighbor_mode=mode)
+        eng = ndt.Engine(gp)
+        grid = O.Grid(tgt, op)
+        eng.set_target(tgt)
+        check_voxels(eng, grid)
+        eng.set_source(src)
+        for p in (np.zeros(6), np.array([0.3, -0.2, 0.1, 0.02, -0.01, 0.03])):
+            check_sweep(eng.derivatives(p), O.derivatives_at(grid, src, p))
+    # (b)+(c) dense, 17 chunks, DIRECT26, ndt_pca weights
+    src2 = (tgt[rng.integers(0, len(tgt), 33333)] + rng.normal(0, 0.05, (33333, 3))).astype(np.float32)
+    gp, op = both_params(trans_epsilon=0.01, max_iterations=64, neighbor_mode=ndt.DIRECT26, variant=1)
+    eng = ndt.Engine(gp)
+    grid = O.Grid(tgt, op)
+    eng.set_target(tgt)
+    eng.set_source(src2)
+    p = np.array([0.05, 0.02, -0.03, 0.004, 0.002, -0.006])
+    check_sweep(eng.derivatives(p), O.derivatives_at(grid, src2, p), rtol=1e-10)
+    G = np.eye(4, dtype=np.float32)
+    G[0, 3] = 0.2
+    r, ro = eng.align(G), O.align(grid, src2, G)
+    assert r["iterations"] == ro["iterations"] and r["converged"] == ro["converged"]
+    dt, dr = se3_err(ro["final"], r["final"])
+    assert dt < 1e-4 and dr < 1e-5, (dt, dr)
+
+
+def test_non_power_of_two_leaf():
+    """resolution 0.7 m: the sweep must take the true f32 division path for the cell index (impl:379-381)."""
+    tgt, src, _ = synth.make_pair(6, 256)
+    tgt, src = tgt.numpy(), src.numpy()
+    gp, op = both_params(resolution=0.7, trans_epsilon=0.01, max_iterations=64)
+    eng = ndt.Engine(gp)
+    grid = O.Grid(tgt, op)
+    eng.set_target(tgt)
+    check_voxels(eng, grid)
+    eng.set_source(src)
+    G = synth.default_guess()
+    p0 = O.se3_log(G.astype(np.float64))
+    check_sweep(eng.derivatives(p0), O.derivatives_at(grid, src, p0))
+    r, ro = eng.align(G), O.align(grid, src, G)
+    assert r["iterations"] == ro["iterations"]
+    dt, dr = se3_err(ro["final"], r["final"])
+    assert dt < 1e-4 and dr < 1e-5
