@@ -484,18 +484,24 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
   __shared__ double q_w[PCA ? WAVES : 1][PCA ? Q_CAP : 1];
   __shared__ float stage[WAVES][128][6];           // two tiles of staged points: x'(3), R x (3)
 
+  if (n_active == 0) return;                       // nothing left to sweep (the loop's last, empty round)
   const int my_xcd = blockIdx.x & 7;
 #pragma unroll 1
   for (int probe = 0; probe < 8; probe++) {        // own XCD first, then steal
     const int xcd = (my_xcd + probe) & 7;
     const int pairs_here = n_active > xcd ? (n_active - xcd + 7) / 8 : 0;
     const int items_here = pairs_here * items_per_pair;
+    if (items_here == 0) continue;
+    // a drained queue is recognised with a plain (L2) load; only a queue that still has items costs an atomic
+    if (__hip_atomic_load(&ctl->next_item[xcd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= items_here) continue;
+    int item = 0;
+    if (lane == 0) item = atomicAdd(&ctl->next_item[xcd], 1);
+    item = __builtin_amdgcn_readfirstlane(item);
 #pragma unroll 1
-    for (;;) {
-      int item = 0;
-      if (lane == 0) item = atomicAdd(&ctl->next_item[xcd], 1);
-      item = __builtin_amdgcn_readfirstlane(item);
-      if (item >= items_here) break;
+    while (item < items_here) {
+      // claim the NEXT item now; the atomic's round trip is hidden behind this item's work
+      int next_item = 0;
+      if (lane == 0) next_item = atomicAdd(&ctl->next_item[xcd], 1);
       const int b = active_list[xcd + 8 * (item / items_per_pair)];
       const int rem = item % items_per_pair;
       const int chunk = rem / QUARTERS, quarter = rem % QUARTERS;
@@ -655,6 +661,7 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
       P[43] = (double)nhits;
     }
   }
+      item = __builtin_amdgcn_readfirstlane(next_item);
     }
   }
 }
