@@ -60,13 +60,20 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # one process per GPU; LV_SLAM_BENCH_BACKEND=gloo lets several ranks share one GPU for a functional check of
+    # the N>1 path on a single-GPU box (the driver's scaling runs use the default: nccl = RCCL over xGMI)
+    backend = os.environ.get("LV_SLAM_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -97,8 +104,9 @@ def main():
     guesses = np.ascontiguousarray(np.broadcast_to(G.T.reshape(1, 16), (B, 16)), dtype=np.float32)
     res = (ndt.Result * B)()
     rec_host = torch.empty(B, 24, dtype=torch.float32).pin_memory()
-    rec_dev = torch.empty(B, 24, device=dev, dtype=torch.float32)
-    gathered = torch.empty(world * B, 24, device=dev, dtype=torch.float32) if world > 1 else None
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
+    rec_dev = torch.empty(B, 24, device=coll_dev, dtype=torch.float32)
+    gathered = torch.empty(world * B, 24, device=coll_dev, dtype=torch.float32) if world > 1 else None
     res_np = np.frombuffer(res, dtype=np.dtype([("final", "<f4", 16), ("tp", "<f8"), ("score", "<f8"), ("it", "<i4"), ("conv", "<i4"),
                                                  ("sweeps", "<i4"), ("status", "<i4"), ("hits", "<i8")]))
 
@@ -127,7 +135,7 @@ def main():
     prof = eng.profile_get()
     eng.profile_enable(False)
     if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         # gather check: pair ids form a permutation of the global index space

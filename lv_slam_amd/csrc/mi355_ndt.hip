@@ -1094,7 +1094,7 @@ int mi355ndt_batch_reserve(mi355ndt_handle* h, int n_pairs, size_t max_tgt, size
 
 static int upload_cloud(mi355ndt_handle* h, float* d_base, size_t pitch, int pair, const void* pts, size_t n, size_t stride) {
   if (!pts && n) return MI355NDT_ERR_BAD_ARG;
-  if (stride < 12 || n > pitch) return MI355NDT_ERR_BAD_ARG;
+  if ((n && stride < 12) || n > pitch) return MI355NDT_ERR_BAD_ARG;
   h->h_stage.resize(3 * pitch);
   const unsigned char* p = (const unsigned char*)pts;
   float* sx = h->h_stage.data(); float* sy = sx + pitch; float* sz = sy + pitch;
@@ -1421,7 +1421,7 @@ static int ensure_single(mi355ndt_handle* h, bool tgt, size_t n) {
 
 int mi355ndt_set_target(mi355ndt_handle* h, const void* pts, size_t n, size_t stride) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
-  if ((!pts && n) || stride < 12 || n >= (1u << 31)) return MI355NDT_ERR_BAD_ARG;
+  if ((!pts && n) || (n && stride < 12) || n >= (1u << 31)) return MI355NDT_ERR_BAD_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   int rc = ensure_single(h, true, n);
   if (rc) return rc;
@@ -1433,7 +1433,7 @@ int mi355ndt_set_target(mi355ndt_handle* h, const void* pts, size_t n, size_t st
 
 int mi355ndt_set_source(mi355ndt_handle* h, const void* pts, size_t n, size_t stride) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
-  if ((!pts && n) || stride < 12 || n >= (1u << 31)) return MI355NDT_ERR_BAD_ARG;
+  if ((!pts && n) || (n && stride < 12) || n >= (1u << 31)) return MI355NDT_ERR_BAD_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   int rc = ensure_single(h, false, n);
   if (rc) return rc;
@@ -1464,8 +1464,10 @@ int mi355ndt_align(mi355ndt_handle* h, const float guess[16], mi355ndt_result* o
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   if (!guess || !out) return MI355NDT_ERR_BAD_ARG;
   if (h->n_pairs < 1 || !h->have_target || !h->have_source) return MI355NDT_ERR_STATE;
-  if (h->n_pairs == 1) return mi355ndt_batch_align(h, guess, out);
-  return MI355NDT_ERR_STATE;                   // a batch is bound: use mi355ndt_batch_align
+  if (h->n_pairs != 1) return MI355NDT_ERR_STATE;                   // a batch is bound: use mi355ndt_batch_align
+  // pcl::Registration::initCompute() refuses empty clouds; align() then returns without touching converged_
+  if (h->h_tgt_cnt[0] <= 0 || h->h_src_cnt[0] <= 0) return MI355NDT_ERR_STATE;
+  return mi355ndt_batch_align(h, guess, out);
 }
 
 int mi355ndt_get_aligned(mi355ndt_handle* h, void* out_pts, size_t stride) {

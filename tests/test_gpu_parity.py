@@ -331,3 +331,46 @@ def test_non_power_of_two_leaf():
     assert r["iterations"] == ro["iterations"]
     dt, dr = se3_err(ro["final"], r["final"])
     assert dt < 1e-4 and dr < 1e-5
+
+
+def test_size_independent_properties_full_size():
+    """BASELINE sizes (65,536 and 131,072 points): properties that need no oracle run.
+    (1) additivity: the sweep over a cloud equals the sum of the sweeps over its two halves (per-point terms);
+    (2) permutation invariance of the source order (only the f64 summation order changes);
+    (3) the hit count is the integer sum of the halves; (4) run-to-run determinism, bit for bit."""
+    for naz, variant, mode in ((1024, 0, ndt.DIRECT7), (2048, 1, ndt.DIRECT7)):
+        tgt, src, _ = synth.make_pair(31, naz)
+        tgt, src = tgt.numpy(), src.numpy()
+        eng = ndt.Engine(ndt.default_params(trans_epsilon=0.01, max_iterations=64, neighbor_mode=mode, variant=variant,
+                                            resolution=1.0 if variant == 0 else 0.5))
+        eng.set_target(tgt)
+        p = O.se3_log(synth.default_guess().astype(np.float64))
+        eng.set_source(src)
+        whole = eng.derivatives(p)
+        again = eng.derivatives(p)
+        assert whole[0] == again[0] and np.array_equal(whole[2], again[2])            # (4)
+        half = len(src) // 2 + 333
+        eng.set_source(src[:half])
+        a = eng.derivatives(p)
+        eng.set_source(src[half:])
+        b = eng.derivatives(p)
+        assert a[3] + b[3] == whole[3]                                                  # (3)
+        scale = np.abs(whole[2]).max()
+        assert abs((a[0] + b[0]) - whole[0]) <= 1e-11 * max(1.0, abs(whole[0]))         # (1)
+        assert np.abs((a[1] + b[1]) - whole[1]).max() <= 1e-11 * scale
+        assert np.abs((a[2] + b[2]) - whole[2]).max() <= 1e-11 * scale
+        perm = np.random.default_rng(5).permutation(len(src))
+        eng.set_source(src[perm])
+        c = eng.derivatives(p)
+        assert c[3] == whole[3] and np.abs(c[2] - whole[2]).max() <= 1e-11 * scale      # (2)
+
+
+def test_empty_clouds_are_refused():
+    eng = ndt.Engine(ndt.default_params())
+    eng.set_target(np.zeros((0, 3), np.float32))
+    eng.set_source(np.zeros((10, 3), np.float32))
+    with pytest.raises(ndt.NDTError) as e:
+        eng.align(np.eye(4, dtype=np.float32))
+    assert e.value.code == -7
+    reg = ndt.NormalDistributionsTransform()
+    assert reg.align().shape == (0, 3) and not reg.hasConverged()      # no target/source yet: PCL prints an error and returns
