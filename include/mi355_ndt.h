@@ -129,6 +129,15 @@ int mi355ndt_align(mi355ndt_handle* h, const float guess_colmajor[16], mi355ndt_
  * Writes x,y,z into records `stride_bytes` apart. */
 int mi355ndt_get_aligned(mi355ndt_handle* h, void* out_pts, size_t stride_bytes);
 
+/* replaces pcl::Registration::getFitnessScore(max_range) as called by the loop-closure path
+ * (include/global_graph/loop_detector.hpp:249-262; identical recipe in-tree:
+ * src/global_graph/information_matrix_calculator.cpp:53-87): source moved by the final pose of the last align()
+ * (identity before any align), exact nearest target point per source point, mean of the SQUARED distances that are
+ * <= max_range (squared distance vs max_range, as the reference compares them); DBL_MAX when nothing is in range. */
+int mi355ndt_get_fitness_score(mi355ndt_handle* h, double max_range, double* score, long long* n_inliers);
+/* same with an explicit transform (column-major 4x4) */
+int mi355ndt_fitness_score_T(mi355ndt_handle* h, const float T_colmajor[16], double max_range, double* score, long long* n_inliers);
+
 /* parity hooks ------------------------------------------------------------------------------------ */
 /* one computeDerivatives sweep (ndt_omp_impl2.hpp:196-305) at tangent p = [upsilon; omega]:
  * points transformed by float(exp(p)), Jacobian from the same matrix (impl2:900-907).

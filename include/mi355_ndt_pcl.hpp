@@ -11,6 +11,7 @@
 #pragma once
 #include <pcl/registration/registration.h>
 #include <stdexcept>
+#include <limits>
 #include "mi355_ndt.h"
 
 namespace mi355ndt {
@@ -54,6 +55,14 @@ class NormalDistributionsTransform : public pcl::Registration<PointSource, Point
   inline void setNeighborhoodSearchMethod(NeighborSearchMethod m) { prm_.neighbor_mode = m; }
   inline double getTransformationProbability() const { return trans_probability_; }
   inline int getFinalNumIteration() const { return nr_iterations_; }
+  // GPU version of pcl::Registration::getFitnessScore (non-virtual in PCL: reached when the caller holds the derived type,
+  // e.g. boost::dynamic_pointer_cast<mi355ndt::NormalDistributionsTransform<PointT,PointT>>(registration) in
+  // loop_detector.hpp:256; through a base pointer PCL's own CPU kd-tree version runs and gives the same number)
+  inline double getFitnessScore(double max_range = std::numeric_limits<double>::max()) {
+    double s = std::numeric_limits<double>::max();
+    mi355ndt_get_fitness_score(h_, max_range, &s, nullptr);
+    return s;
+  }
 
  protected:
   void push() {

@@ -818,6 +818,90 @@ __global__ void k_transform(const float* __restrict__ src, size_t pitch, const P
   for (int a = 0; a < 3; a++) out[(size_t)a * n + i] = ((F[0 * 4 + a] * px + F[1 * 4 + a] * py) + F[2 * 4 + a] * pz) + F[3 * 4 + a];
 }
 
+// ------------------------------------------------------------------------------------ fitness score (loop-closure caller)
+// pcl::Registration::getFitnessScore(max_range) as used by include/global_graph/loop_detector.hpp:249-262, same recipe as
+// the in-tree InformationMatrixCalculator::calc_fitness_score (src/global_graph/information_matrix_calculator.cpp:53-87):
+// move the source by the final pose (f32), exact nearest target point per source point, and average the SQUARED
+// distances that are <= max_range (the comparison really is squared distance vs max_range in the reference).
+// The exact 1-NN runs on the target's voxel binning that setInputTarget already sorted: cells are visited ring by ring
+// around the query's cell and the search stops once the best distance cannot be beaten by an unvisited ring.
+template <typename KeyT>
+__global__ void __launch_bounds__(256) k_cellrange(const KeyT* __restrict__ keys, size_t pitch, int cb, unsigned* cstart, unsigned* cend) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pitch) return;
+  const unsigned cmask = (1u << cb) - 1u;
+  const KeyT key = keys[i];
+  const unsigned cell = (unsigned)key & cmask;
+  if (cell == cmask) return;
+  if (i == 0 || keys[i - 1] != key) cstart[cell] = (unsigned)i;
+  if (i + 1 == pitch || keys[i + 1] != key) cend[cell] = (unsigned)i + 1u;
+}
+
+__global__ void __launch_bounds__(256) k_fitness(const float* __restrict__ src, size_t spitch, int n_src,
+                                                 const float* __restrict__ tgt, size_t tpitch, const unsigned* __restrict__ vals,
+                                                 const GridDesc* __restrict__ gd, const unsigned* __restrict__ cstart, const unsigned* __restrict__ cend,
+                                                 const float* __restrict__ Tcm, float max_range, int ring_max, double* partial) {
+  // ring_max: rings needed to cover sqrt(max_range); the kernel also never walks past the grid's far side
+  const GridDesc& g = gd[0];
+  double sum = 0.0;
+  unsigned long long cnt = 0;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_src && g.status == GRID_OK) {
+    const float px = src[i], py = src[spitch + i], pz = src[2 * spitch + i];
+    float q[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) q[a] = ((Tcm[0 * 4 + a] * px + Tcm[1 * 4 + a] * py) + Tcm[2 * 4 + a] * pz) + Tcm[3 * 4 + a];   // PCL 1.8 scalar form
+    if (finite3(q[0], q[1], q[2])) {
+      const int c0 = (int)floorf(q[0] * g.inv_leaf) - g.min_b[0], c1 = (int)floorf(q[1] * g.inv_leaf) - g.min_b[1],
+                c2 = (int)floorf(q[2] * g.inv_leaf) - g.min_b[2];
+      // distance from the query's cell to the grid box in cells (0 inside): rings closer than that are empty
+      const int o0 = c0 < 0 ? -c0 : (c0 >= g.div_b[0] ? c0 - g.div_b[0] + 1 : 0);
+      const int o1 = c1 < 0 ? -c1 : (c1 >= g.div_b[1] ? c1 - g.div_b[1] + 1 : 0);
+      const int o2 = c2 < 0 ? -c2 : (c2 >= g.div_b[2] ? c2 - g.div_b[2] + 1 : 0);
+      const int r_first = max(o0, max(o1, o2));
+      const int r_last = min(ring_max, r_first + max(g.div_b[0], max(g.div_b[1], g.div_b[2])) + 1);
+      float best = __int_as_float(0x7f800000);
+      for (int r = r_first; r <= r_last; r++) {
+        // every point in ring >= r lies more than (r-1)*leaf away; 0.1 % of a cell of slack for the binning's rounding
+        const float reach = ((float)(r - 1) - 1e-3f) * g.leaf;
+        if (r > 1 && (best <= reach * reach || reach * reach > max_range)) break;
+        const int z0 = max(c2 - r, 0), z1 = min(c2 + r, g.div_b[2] - 1);
+        const int y0 = max(c1 - r, 0), y1 = min(c1 + r, g.div_b[1] - 1);
+        const int x0 = max(c0 - r, 0), x1 = min(c0 + r, g.div_b[0] - 1);
+        for (int z = z0; z <= z1; z++) {
+          const bool zface = (z == c2 - r || z == c2 + r);
+          for (int y = y0; y <= y1; y++) {
+            const bool yface = (y == c1 - r || y == c1 + r);
+            const int step = (zface || yface) ? 1 : max(1, (c0 + r) - (c0 - r));   // interior rows: only the two x faces
+            for (int x = (zface || yface) ? x0 : c0 - r; x <= x1; x += step) {
+              if (x < x0) continue;
+              const unsigned cell = (unsigned)(x + y * g.mul1 + z * g.mul2);
+              const unsigned s = cstart[cell], e = cend[cell];
+              for (unsigned j = s; j < e; j++) {
+                const unsigned pi = vals[j];
+                const float dx = q[0] - tgt[pi], dy = q[1] - tgt[tpitch + pi], dz = q[2] - tgt[2 * tpitch + pi];
+                const float d2 = (dx * dx + dy * dy) + dz * dz;          // FLANN L2_Simple accumulation order
+                best = d2 < best ? d2 : best;
+              }
+            }
+          }
+        }
+      }
+      if (best <= max_range) { sum = (double)best; cnt = 1; }
+    }
+  }
+  // deterministic block reduction
+  for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); cnt += __shfl_xor(cnt, o); }
+  __shared__ double rs[4];
+  __shared__ unsigned long long rc[4];
+  if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = sum; rc[threadIdx.x >> 6] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = ((rs[0] + rs[1]) + rs[2]) + rs[3];
+    partial[2 * blockIdx.x + 1] = (double)(rc[0] + rc[1] + rc[2] + rc[3]);
+  }
+}
+
 // ------------------------------------------------------------------------------------ host side
 struct mi355ndt_handle {
   int device = 0;
@@ -847,6 +931,9 @@ struct mi355ndt_handle {
   BitWord* d_words = nullptr; size_t words_cap = 0;
   VoxelRec* d_recs = nullptr; int *d_vox_idx = nullptr, *d_vox_n = nullptr;
   unsigned* d_seg_start = nullptr; double* d_sums = nullptr;
+  unsigned *d_cstart = nullptr, *d_cend = nullptr; size_t cell_cap = 0; bool cells_ready = false; int last_cb = 0;
+  double* d_fit = nullptr; size_t fit_cap = 0;
+  float last_final[16] = {1,0,0,0, 0,1,0,0, 0,0,1,0, 0,0,0,1};
   size_t recs_per_pair = 0, recs_cap = 0;
   unsigned* h_pin_u = nullptr;                  // pinned scratch (2 unsigned)
 
@@ -982,7 +1069,7 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
   void* ptrs[] = {h->d_tgt_own, h->d_src_own, h->d_tgt_cnt, h->d_src_cnt, h->d_minmax, h->d_grid, h->d_nwords, h->d_word_off,
                   h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, h->d_tmp, h->d_words, h->d_recs, h->d_vox_idx, h->d_vox_n,
                   h->d_state, h->d_partials, h->d_guess, h->d_results, h->d_active, h->d_hook, h->d_aligned, h->d_hits, h->d_seg_start, h->d_sums,
-                  h->d_active_list, h->d_ctl};
+                  h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_pin_u) hipHostFree(h->h_pin_u);
   if (h->h_pin_active) hipHostFree(h->h_pin_active);
@@ -1291,6 +1378,8 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
     h->P.build_alg_bytes += pts * (12 + 12 + 4 + 16);
   }
   h->targets_built = true;
+  h->cells_ready = false;
+  h->last_cb = cb;
   return MI355NDT_OK;
 }
 
@@ -1467,7 +1556,9 @@ int mi355ndt_align(mi355ndt_handle* h, const float guess[16], mi355ndt_result* o
   if (h->n_pairs != 1) return MI355NDT_ERR_STATE;                   // a batch is bound: use mi355ndt_batch_align
   // pcl::Registration::initCompute() refuses empty clouds; align() then returns without touching converged_
   if (h->h_tgt_cnt[0] <= 0 || h->h_src_cnt[0] <= 0) return MI355NDT_ERR_STATE;
-  return mi355ndt_batch_align(h, guess, out);
+  int rc = mi355ndt_batch_align(h, guess, out);
+  if (rc == MI355NDT_OK) memcpy(h->last_final, out->final_colmajor, sizeof h->last_final);
+  return rc;
 }
 
 int mi355ndt_get_aligned(mi355ndt_handle* h, void* out_pts, size_t stride) {
@@ -1584,6 +1675,65 @@ int mi355ndt_get_voxels(mi355ndt_handle* h, int pair, mi355ndt_voxel* out, size_
     out[i].weight = (r[i].weight == VOX_DEAD) ? 0 : r[i].weight;
   }
   return MI355NDT_OK;
+}
+
+// replaces pcl::Registration::getFitnessScore(max_range) for the loop-closure caller (loop_detector.hpp:249-262)
+int mi355ndt_fitness_score_T(mi355ndt_handle* h, const float T_colmajor[16], double max_range, double* score, long long* n_inliers) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (!T_colmajor || !score) return MI355NDT_ERR_BAD_ARG;
+  if (h->n_pairs != 1 || !h->have_target || !h->have_source) return MI355NDT_ERR_STATE;
+  if (h->h_tgt_cnt[0] <= 0 || h->h_src_cnt[0] <= 0) return MI355NDT_ERR_STATE;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->targets_built) { int rc = mi355ndt_batch_build_targets(h); if (rc) return rc; }
+  hipStream_t s = h->stream;
+  GridDesc g;
+  HIPCHK(h, hipMemcpyAsync(&g, h->d_grid, sizeof g, hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  if (g.status != GRID_OK) { *score = 1.7976931348623157e308; if (n_inliers) *n_inliers = 0; return MI355NDT_OK; }
+  if (!h->cells_ready) {
+    const size_t nc = (size_t)g.ncells;
+    if (nc > h->cell_cap) {
+      size_t c1 = 0, c2 = 0;
+      if (h->d_cstart) { HIPCHK(h, hipFree(h->d_cstart)); h->d_cstart = nullptr; }
+      if (h->d_cend) { HIPCHK(h, hipFree(h->d_cend)); h->d_cend = nullptr; }
+      HIPCHK(h, grow(h->d_cstart, c1, nc)); HIPCHK(h, grow(h->d_cend, c2, nc));
+      h->cell_cap = nc;
+    }
+    HIPCHK(h, hipMemsetAsync(h->d_cstart, 0, nc * sizeof(unsigned), s));
+    HIPCHK(h, hipMemsetAsync(h->d_cend, 0, nc * sizeof(unsigned), s));
+    k_cellrange<unsigned><<<(unsigned)((h->tgt_pitch + 255) / 256), 256, 0, s>>>((const unsigned*)h->d_keys_b, h->tgt_pitch, h->last_cb,
+                                                                                h->d_cstart, h->d_cend);
+    h->cells_ready = true;
+  }
+  const int n = h->h_src_cnt[0];
+  const int blocks = (n + 255) / 256;
+  HIPCHK(h, grow(h->d_fit, h->fit_cap, (size_t)2 * blocks));
+  HIPCHK(h, hipMemcpyAsync(h->d_hook, T_colmajor, 16 * sizeof(float), hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  const float mr = max_range >= 3.0e38 ? 3.0e38f : (float)max_range;
+  // rings needed to cover sqrt(max_range) (+1 cell of slack), capped by the grid's extent
+  const int extent = std::max(g.div_b[0], std::max(g.div_b[1], g.div_b[2])) + 2;
+  double rr = std::sqrt(std::min(max_range, 1e30)) / (double)g.leaf + 2.0;
+  int ring_max = rr > (double)(1 << 28) ? (1 << 28) : (int)rr;
+  // a query outside the grid may sit further away than the grid is wide: allow its distance to the box on top
+  ring_max = std::min(ring_max, (1 << 20));
+  (void)extent;
+  k_fitness<<<blocks, 256, 0, s>>>(h->d_src, h->src_pitch, n, h->d_tgt, h->tgt_pitch, h->d_vals_b, h->d_grid, h->d_cstart, h->d_cend,
+                                   h->d_hook, mr, ring_max, h->d_fit);
+  std::vector<double> part((size_t)2 * blocks);
+  HIPCHK(h, hipMemcpyAsync(part.data(), h->d_fit, part.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  HIPCHK(h, hipGetLastError());
+  double sum = 0, cnt = 0;
+  for (int b = 0; b < blocks; b++) { sum += part[2 * b]; cnt += part[2 * b + 1]; }
+  *score = cnt > 0 ? sum / cnt : 1.7976931348623157e308;     // std::numeric_limits<double>::max()
+  if (n_inliers) *n_inliers = (long long)cnt;
+  return MI355NDT_OK;
+}
+
+int mi355ndt_get_fitness_score(mi355ndt_handle* h, double max_range, double* score, long long* n_inliers) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  return mi355ndt_fitness_score_T(h, h->last_final, max_range, score, n_inliers);
 }
 
 }  // extern "C"

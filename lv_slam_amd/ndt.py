@@ -61,7 +61,7 @@ SYMBOLS = [
     "mi355ndt_version", "mi355ndt_device_count", "mi355ndt_default_params", "mi355ndt_create", "mi355ndt_destroy",
     "mi355ndt_set_params", "mi355ndt_get_params", "mi355ndt_set_stream", "mi355ndt_last_error",
     "mi355ndt_set_target", "mi355ndt_set_source", "mi355ndt_align", "mi355ndt_get_aligned",
-    "mi355ndt_derivatives", "mi355ndt_derivatives_T", "mi355ndt_get_grid", "mi355ndt_get_voxels",
+    "mi355ndt_get_fitness_score", "mi355ndt_fitness_score_T", "mi355ndt_derivatives", "mi355ndt_derivatives_T", "mi355ndt_get_grid", "mi355ndt_get_voxels",
     "mi355ndt_batch_reserve", "mi355ndt_batch_set_target", "mi355ndt_batch_set_source", "mi355ndt_batch_bind_device",
     "mi355ndt_batch_build_targets", "mi355ndt_batch_align", "mi355ndt_batch_size",
     "mi355ndt_profile_enable", "mi355ndt_profile_reset", "mi355ndt_profile_get", "mi355ndt_synchronize",
@@ -93,6 +93,8 @@ def load_library(path: str = LIB_PATH):
     L.mi355ndt_set_source.argtypes = [vp, vp, sz, sz]
     L.mi355ndt_align.argtypes = [vp, vp, C.POINTER(Result)]
     L.mi355ndt_get_aligned.argtypes = [vp, vp, sz]
+    L.mi355ndt_get_fitness_score.argtypes = [vp, C.c_double, vp, vp]
+    L.mi355ndt_fitness_score_T.argtypes = [vp, vp, C.c_double, vp, vp]
     L.mi355ndt_derivatives.argtypes = [vp, vp, vp, vp, vp, vp]
     L.mi355ndt_derivatives_T.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.mi355ndt_get_grid.argtypes = [vp, i, vp, vp, vp, vp]
@@ -196,6 +198,17 @@ class Engine:
         out = np.zeros((self._n_src, 3), np.float32)
         self._chk(self.lib.mi355ndt_get_aligned(self.h, out.ctypes.data_as(C.c_void_p), 12), "get_aligned")
         return out
+
+    def fitness_score(self, max_range: float = float("inf"), T=None):
+        """getFitnessScore(max_range); T = explicit 4x4 transform (default: final pose of the last align)."""
+        s, n = C.c_double(), C.c_longlong()
+        mr = 1.7976931348623157e308 if max_range == float("inf") else float(max_range)
+        if T is None:
+            self._chk(self.lib.mi355ndt_get_fitness_score(self.h, mr, C.byref(s), C.byref(n)), "get_fitness_score")
+        else:
+            t = _colmajor(T)
+            self._chk(self.lib.mi355ndt_fitness_score_T(self.h, t.ctypes.data_as(C.c_void_p), mr, C.byref(s), C.byref(n)), "fitness_score_T")
+        return s.value, n.value
 
     # -- parity hooks
     def derivatives(self, p):
@@ -381,6 +394,12 @@ class NormalDistributionsTransform:
 
     def hasConverged(self) -> bool:
         return bool(self._converged)
+
+    def getFitnessScore(self, max_range: float = float("inf")) -> float:
+        """pcl::Registration::getFitnessScore (loop_detector.hpp:256): mean squared NN distance within max_range."""
+        if not (self._has_target and self._has_source):
+            return 1.7976931348623157e308
+        return self._eng.fitness_score(max_range)[0]
 
     @property
     def engine(self) -> Engine:

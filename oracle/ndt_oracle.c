@@ -746,3 +746,38 @@ int ora_align(const ora_grid* g, const ora_params* prm,
   out->converged = 1; out->iterations = it; out->score = score; out->hits_last = hits; out->sweeps = sweeps;
   return 0;
 }
+
+/* pcl::Registration::getFitnessScore(max_range) == InformationMatrixCalculator::calc_fitness_score
+ * (src/global_graph/information_matrix_calculator.cpp:53-87): source moved by T (f32, PCL scalar form), exact nearest
+ * target point (brute force here; FLANN's L2_Simple f32 accumulation order), squared distance compared with max_range
+ * and averaged.  Returns DBL_MAX when no point is in range.  *n_in = number of source points counted. */
+double ora_fitness_score(const float* tx, const float* ty, const float* tz, size_t nt,
+                         const float* sx, const float* sy, const float* sz, size_t ns,
+                         const float T[16], double max_range, long* n_in) {
+  size_t nchunks = (ns + CHUNK - 1) / CHUNK;
+  double* part = (double*)calloc(nchunks ? nchunks : 1, 2 * sizeof(double));
+#ifdef _OPENMP
+  int nthr = g_threads > 0 ? g_threads : omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthr)
+#endif
+  for (long c = 0; c < (long)nchunks; c++) {
+    size_t i0 = (size_t)c * CHUNK, i1 = i0 + CHUNK < ns ? i0 + CHUNK : ns;
+    for (size_t i = i0; i < i1; i++) {
+      float q[3];
+      for (int a = 0; a < 3; a++) q[a] = ((T[0 * 4 + a] * sx[i] + T[1 * 4 + a] * sy[i]) + T[2 * 4 + a] * sz[i]) + T[3 * 4 + a];
+      if (!finite3(q[0], q[1], q[2])) continue;
+      float best = INFINITY;
+      for (size_t j = 0; j < nt; j++) {
+        float dx = q[0] - tx[j], dy = q[1] - ty[j], dz = q[2] - tz[j];
+        float d2 = (dx * dx + dy * dy) + dz * dz;
+        if (d2 < best) best = d2;
+      }
+      if ((double)best <= max_range) { part[2 * c] += (double)best; part[2 * c + 1] += 1; }
+    }
+  }
+  double sum = 0, cnt = 0;
+  for (size_t c = 0; c < nchunks; c++) { sum += part[2 * c]; cnt += part[2 * c + 1]; }
+  free(part);
+  if (n_in) *n_in = (long)cnt;
+  return cnt > 0 ? sum / cnt : DBL_MAX;
+}

@@ -114,6 +114,11 @@ void ora_svd_solve6(const double H[36], const double b[6], double x[6]);
 /* symmetric 3x3 eigen (lower triangle read), ascending; evecs row-major with eigenvectors as columns */
 void ora_eigen_sym3(const double A[9], double evals[3], double evecs[9]);
 
+/* getFitnessScore(max_range) restatement (information_matrix_calculator.cpp:53-87); T column-major 4x4 f32 */
+double ora_fitness_score(const float* tx, const float* ty, const float* tz, size_t nt,
+                         const float* sx, const float* sy, const float* sz, size_t ns,
+                         const float T_colmajor[16], double max_range, long* n_in);
+
 void ora_set_threads(int n);
 
 #ifdef __cplusplus

@@ -73,6 +73,8 @@ def lib():
         L.ora_gauss_constants.argtypes = [C.c_double, C.c_float, C.c_void_p]
         L.ora_default_params.argtypes = [C.POINTER(Params)]
         L.ora_set_threads.argtypes = [C.c_int]
+        L.ora_fitness_score.restype = C.c_double
+        L.ora_fitness_score.argtypes = [C.c_void_p] * 3 + [C.c_size_t] + [C.c_void_p] * 3 + [C.c_size_t, C.c_void_p, C.c_double, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -216,3 +218,14 @@ def gauss_constants(outlier_ratio: float, resolution: float):
     o = np.zeros(3)
     lib().ora_gauss_constants(outlier_ratio, resolution, _p(o))
     return o
+
+
+def fitness_score(tgt: np.ndarray, src: np.ndarray, T: np.ndarray, max_range: float = float("inf")):
+    """getFitnessScore restatement: (score, inliers).  T = 4x4 f32."""
+    tx, ty, tz = _soa(tgt)
+    sx, sy, sz = _soa(src)
+    Tc = np.asarray(T, np.float32).ravel(order="F").copy()
+    n = C.c_long()
+    mr = 1.7976931348623157e308 if max_range == float("inf") else float(max_range)
+    s = lib().ora_fitness_score(_p(tx), _p(ty), _p(tz), len(tgt), _p(sx), _p(sy), _p(sz), len(src), _p(Tc), mr, C.byref(n))
+    return s, n.value

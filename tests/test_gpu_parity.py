@@ -374,3 +374,34 @@ def test_empty_clouds_are_refused():
     assert e.value.code == -7
     reg = ndt.NormalDistributionsTransform()
     assert reg.align().shape == (0, 3) and not reg.hasConverged()      # no target/source yet: PCL prints an error and returns
+
+
+def test_fitness_score_loop_closure_surface():
+    """getFitnessScore(max_range) of the loop-closure caller (loop_detector.hpp:249-262)."""
+    tgt, src, dT = synth.make_pair(40, 256)
+    tgt, src = tgt.numpy(), src.numpy()
+    reg = ndt.NormalDistributionsTransform()
+    reg.setTransformationEpsilon(0.01)
+    reg.setMaximumIterations(64)
+    assert reg.getFitnessScore() == 1.7976931348623157e308           # nothing set yet
+    reg.setInputTarget(tgt)
+    reg.setInputSource(src)
+    # before any align the final transformation is the identity
+    s0, n0 = reg.engine.fitness_score(25.0)
+    e0, m0 = O.fitness_score(tgt, src, np.eye(4, dtype=np.float32), 25.0)
+    assert n0 == m0 and abs(s0 - e0) <= 1e-12 * max(1.0, e0)
+    reg.align(synth.default_guess())
+    F = reg.getFinalTransformation()
+    for mr in (0.04, 1.0, 25.0, float("inf")):
+        got, n = reg.engine.fitness_score(mr)
+        exp, m = O.fitness_score(tgt, src, F, mr)
+        assert n == m, (mr, n, m)
+        assert abs(got - exp) <= 1e-12 * max(1.0, exp), (mr, got, exp)
+    assert reg.getFitnessScore(25.0) < s0                              # the registration improved the fit
+    # explicit transform, source far outside the target grid, nothing in range
+    far = np.eye(4, dtype=np.float32)
+    far[0, 3] = 5000.0
+    assert reg.engine.fitness_score(4.0, far) == (1.7976931348623157e308, 0)
+    got, n = reg.engine.fitness_score(float("inf"), far)
+    exp, m = O.fitness_score(tgt, src, far, float("inf"))
+    assert n == m == len(src) and abs(got - exp) <= 1e-12 * exp

@@ -138,3 +138,25 @@ def test_align_edge_cases():
     tgt2[::7] = np.nan
     g2 = O.Grid(tgt2, prm)
     assert g2.ok and g2.leaves()["n"][g2.leaves()["n"] > 0].sum() == np.isfinite(tgt2).all(1).sum()
+
+
+def test_fitness_score_vs_kdtree():
+    """pins ora_fitness_score (brute force, f32 distances) against scipy's exact kd-tree in f64."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(9)
+    tgt = rng.uniform(-20, 20, (5000, 3)).astype(np.float32)
+    src = rng.uniform(-25, 25, (1500, 3)).astype(np.float32)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, 3] = [0.3, -0.2, 0.1]
+    c, s = np.float32(np.cos(0.05)), np.float32(np.sin(0.05))
+    T[:2, :2] = [[c, -s], [s, c]]
+    q = (src.astype(np.float64) @ T[:3, :3].astype(np.float64).T) + T[:3, 3].astype(np.float64)
+    d, _ = cKDTree(tgt.astype(np.float64)).query(q)
+    for mr in (0.5, 4.0, 25.0, float("inf")):
+        sel = d * d <= mr
+        exp = (d[sel] ** 2).mean() if sel.any() else 1.7976931348623157e308
+        got, n = O.fitness_score(tgt, src, T, mr)
+        assert abs(n - int(sel.sum())) <= 2            # f32 vs f64 at the threshold
+        assert abs(got - exp) <= 2e-5 * max(1.0, exp)
+    got, n = O.fitness_score(tgt, src + 1000.0, T, 1.0)
+    assert n == 0 and got == 1.7976931348623157e308
