@@ -169,6 +169,17 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h);
 int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses_colmajor, mi355ndt_result* out);
 int mi355ndt_batch_size(const mi355ndt_handle* h);
 
+/* ---- prefilter: the step immediately upstream of the path ------------------------------------------- */
+/* replaces PrefilteringNodelet::distance_filter + downsample (src/lidar_odometry/prefiltering_nodelet.cpp:137-181,
+ * launch/dlo_kitti.launch:30-36): keep near < |p| < far, then pcl::VoxelGrid centroid down-sampling with leaf
+ * `downsample_resolution` (<= 0: none), output ordered by ascending voxel index.  The result stays on the GPU
+ * (mi355ndt_use_prefiltered) and is copied to out_pts (x,y,z records, may be NULL) when it fits out_capacity. */
+int mi355ndt_prefilter(mi355ndt_handle* h, const void* pts, size_t n, size_t stride_bytes,
+                       int use_distance_filter, double distance_near, double distance_far, float downsample_resolution,
+                       void* out_pts, size_t out_capacity, size_t out_stride_bytes, size_t* n_out);
+/* install the last prefilter result as the registration source (role 1) or target (role 2) without a host round trip */
+int mi355ndt_use_prefiltered(mi355ndt_handle* h, int role);
+
 /* profiling: HIP-event timing of the engine's own kernels on the engine's stream */
 int mi355ndt_profile_enable(mi355ndt_handle* h, int on);
 int mi355ndt_profile_reset(mi355ndt_handle* h);

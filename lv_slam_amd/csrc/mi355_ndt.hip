@@ -902,6 +902,108 @@ __global__ void __launch_bounds__(256) k_fitness(const float* __restrict__ src, 
   }
 }
 
+// ------------------------------------------------------------------------------------ prefilter (upstream of the path)
+// PrefilteringNodelet::distance_filter + downsample (src/lidar_odometry/prefiltering_nodelet.cpp:137-181, parameters of
+// launch/dlo_kitti.launch:30-36): keep points with near < |p| < far (f32 norm compared as double), then pcl::VoxelGrid
+// centroid downsample (PCL 1.8 voxel_grid.hpp applyFilter, CentroidPoint / AccumulatorXYZ: f32 sums, divided by the
+// count), output in ascending voxel index.  Same binning + stable sort machinery as the NDT target build.
+__global__ void __launch_bounds__(256) k_pf_flag(const float* __restrict__ X, size_t pitch, int n, int use_df, double dnear, double dfar,
+                                                 unsigned char* keep, int* mm) {
+  int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float x = X[i], y = X[pitch + i], z = X[2 * pitch + i];
+    bool ok = true;
+    if (use_df) {
+      const double d = (double)sqrtf((x * x + y * y) + z * z);       // p.getVector3fMap().norm() (:168)
+      ok = d > dnear && d < dfar;                                    // NaN fails both compares
+    }
+    ok = ok && finite3(x, y, z);                                     // VoxelGrid skips non-finite points (is_dense = false, :175)
+    keep[i] = ok ? 1 : 0;
+    if (!ok) continue;
+    int ox = f2ord(x), oy = f2ord(y), oz = f2ord(z);
+    mn[0] = min(mn[0], ox); mx[0] = max(mx[0], ox);
+    mn[1] = min(mn[1], oy); mx[1] = max(mx[1], oy);
+    mn[2] = min(mn[2], oz); mx[2] = max(mx[2], oz);
+  }
+  for (int a = 0; a < 3; a++) {
+    for (int o = 32; o > 0; o >>= 1) { mn[a] = min(mn[a], __shfl_xor(mn[a], o)); mx[a] = max(mx[a], __shfl_xor(mx[a], o)); }
+    if ((threadIdx.x & 63) == 0) {
+      if (mn[a] != INT_MAX) atomicMin(&mm[a], mn[a]);
+      if (mx[a] != INT_MIN) atomicMax(&mm[3 + a], mx[a]);
+    }
+  }
+}
+
+struct PfGrid { int min_b[3], mul1, mul2, status; float inv_leaf; };   // status: 0 ok, 1 empty, 2 index overflow
+
+__global__ void k_pf_grid(const int* __restrict__ mm, float leaf, PfGrid* out) {
+  PfGrid g;
+  memset(&g, 0, sizeof g);
+  g.inv_leaf = 1.0f / leaf;
+  if (mm[0] == INT_MAX) { g.status = 1; *out = g; return; }
+  float mn[3], mx[3];
+  for (int a = 0; a < 3; a++) { mn[a] = ord2f(mm[a]); mx[a] = ord2f(mm[3 + a]); }
+  const long long d0 = (long long)((mx[0] - mn[0]) * g.inv_leaf) + 1, d1 = (long long)((mx[1] - mn[1]) * g.inv_leaf) + 1,
+                  d2 = (long long)((mx[2] - mn[2]) * g.inv_leaf) + 1;
+  if (d0 * d1 * d2 > (long long)INT_MAX) { g.status = 2; *out = g; return; }      // "Leaf size is too small": output = input
+  int maxb[3];
+  for (int a = 0; a < 3; a++) { g.min_b[a] = (int)floorf(mn[a] * g.inv_leaf); maxb[a] = (int)floorf(mx[a] * g.inv_leaf); }
+  g.mul1 = maxb[0] - g.min_b[0] + 1;
+  g.mul2 = g.mul1 * (maxb[1] - g.min_b[1] + 1);
+  *out = g;
+}
+
+__global__ void __launch_bounds__(256) k_pf_keys(const float* __restrict__ X, size_t pitch, int n, const unsigned char* __restrict__ keep,
+                                                 const PfGrid* __restrict__ pg, unsigned* keys, unsigned* vals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int)pitch) return;
+  const PfGrid g = *pg;
+  unsigned cell = 0x7FFFFFFFu;
+  if (i < n && keep[i] && g.status == 0) {
+    const int i0 = (int)(floorf(X[i] * g.inv_leaf) - (float)g.min_b[0]);
+    const int i1 = (int)(floorf(X[pitch + i] * g.inv_leaf) - (float)g.min_b[1]);
+    const int i2 = (int)(floorf(X[2 * pitch + i] * g.inv_leaf) - (float)g.min_b[2]);
+    cell = (unsigned)(i0 + i1 * g.mul1 + i2 * g.mul2);
+  }
+  keys[i] = cell;
+  vals[i] = (unsigned)i;
+}
+
+// head of every occupied voxel's run (or, without down-sampling, every kept point)
+__global__ void __launch_bounds__(256) k_pf_heads(const unsigned* __restrict__ keys, const unsigned char* __restrict__ keep, int n, size_t pitch,
+                                                  int downsample, int* flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int)pitch) return;
+  int f;
+  if (downsample) f = keys[i] != 0x7FFFFFFFu && (i == 0 || keys[i - 1] != keys[i]);
+  else f = i < n && keep[i];
+  flag[i] = f;
+}
+
+__global__ void __launch_bounds__(256) k_pf_emit(const float* __restrict__ X, size_t pitch, const unsigned* __restrict__ keys,
+                                                 const unsigned* __restrict__ vals, const int* __restrict__ flag, const int* __restrict__ pos,
+                                                 int downsample, float* out, size_t out_pitch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int)pitch || !flag[i]) return;
+  float sx, sy, sz;
+  if (downsample) {
+    const unsigned key = keys[i];
+    sx = sy = sz = 0.f;
+    int cnt = 0;
+    for (size_t j = i; j < pitch && keys[j] == key; j++) {           // AccumulatorXYZ: xyz += p (f32), input order
+      const unsigned pi = vals[j];
+      sx += X[pi]; sy += X[pitch + pi]; sz += X[2 * pitch + pi];
+      cnt++;
+    }
+    const float fn = (float)cnt;
+    sx /= fn; sy /= fn; sz /= fn;                                    // xyz / n
+  } else {
+    sx = X[i]; sy = X[pitch + i]; sz = X[2 * pitch + i];
+  }
+  const int o = pos[i];
+  out[o] = sx; out[out_pitch + o] = sy; out[2 * out_pitch + o] = sz;
+}
+
 // ------------------------------------------------------------------------------------ host side
 struct mi355ndt_handle {
   int device = 0;
@@ -933,6 +1035,10 @@ struct mi355ndt_handle {
   unsigned* d_seg_start = nullptr; double* d_sums = nullptr;
   unsigned *d_cstart = nullptr, *d_cend = nullptr; size_t cell_cap = 0; bool cells_ready = false; int last_cb = 0;
   double* d_fit = nullptr; size_t fit_cap = 0;
+  // prefilter workspace
+  float *d_pf_in = nullptr, *d_pf_out = nullptr; unsigned char* d_pf_keep = nullptr; unsigned *d_pf_keys = nullptr, *d_pf_vals = nullptr;
+  int *d_pf_flag = nullptr, *d_pf_pos = nullptr, *d_pf_mm = nullptr; PfGrid* d_pf_grid = nullptr; void* d_pf_tmp = nullptr;
+  size_t pf_cap = 0, pf_tmp_bytes = 0; int pf_count = 0; size_t pf_pitch = 0;
   float last_final[16] = {1,0,0,0, 0,1,0,0, 0,0,1,0, 0,0,0,1};
   size_t recs_per_pair = 0, recs_cap = 0;
   unsigned* h_pin_u = nullptr;                  // pinned scratch (2 unsigned)
@@ -957,8 +1063,6 @@ struct mi355ndt_handle {
   bool prof = false;
   mi355ndt_profile P{};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_sweep, ev_update, ev_build;
-  std::vector<double> ev_sweep_bytes_static;    // N*(12+4K) part per launch (hits added at collection)
-  hipEvent_t ev_pool_unused = nullptr;
 };
 
 #define HIPCHK(h, call)                                                                          \
@@ -1069,7 +1173,8 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
   void* ptrs[] = {h->d_tgt_own, h->d_src_own, h->d_tgt_cnt, h->d_src_cnt, h->d_minmax, h->d_grid, h->d_nwords, h->d_word_off,
                   h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, h->d_tmp, h->d_words, h->d_recs, h->d_vox_idx, h->d_vox_n,
                   h->d_state, h->d_partials, h->d_guess, h->d_results, h->d_active, h->d_hook, h->d_aligned, h->d_hits, h->d_seg_start, h->d_sums,
-                  h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit};
+                  h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit, h->d_pf_in, h->d_pf_out, h->d_pf_keep, h->d_pf_keys,
+                  h->d_pf_vals, h->d_pf_flag, h->d_pf_pos, h->d_pf_mm, h->d_pf_grid, h->d_pf_tmp};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_pin_u) hipHostFree(h->h_pin_u);
   if (h->h_pin_active) hipHostFree(h->h_pin_active);
@@ -1734,6 +1839,110 @@ int mi355ndt_fitness_score_T(mi355ndt_handle* h, const float T_colmajor[16], dou
 int mi355ndt_get_fitness_score(mi355ndt_handle* h, double max_range, double* score, long long* n_inliers) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   return mi355ndt_fitness_score_T(h, h->last_final, max_range, score, n_inliers);
+}
+
+// replaces PrefilteringNodelet::distance_filter + downsample (prefiltering_nodelet.cpp:137-181)
+int mi355ndt_prefilter(mi355ndt_handle* h, const void* pts, size_t n, size_t stride,
+                       int use_distance_filter, double distance_near, double distance_far, float downsample_resolution,
+                       void* out_pts, size_t out_capacity, size_t out_stride, size_t* n_out) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if ((!pts && n) || (n && stride < 12) || n >= (1u << 30) || !n_out || (out_pts && out_stride < 12)) return MI355NDT_ERR_BAD_ARG;
+  if (std::isnan(downsample_resolution)) return MI355NDT_ERR_BAD_ARG;
+  *n_out = 0;
+  h->pf_count = 0;
+  if (n == 0) return MI355NDT_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const size_t pitch = (n + 63) & ~(size_t)63;
+  if (pitch > h->pf_cap) {
+    HIPCHK(h, hipStreamSynchronize(s));
+    void** ps[] = {(void**)&h->d_pf_in, (void**)&h->d_pf_out, (void**)&h->d_pf_keep, (void**)&h->d_pf_keys, (void**)&h->d_pf_vals,
+                   (void**)&h->d_pf_flag, (void**)&h->d_pf_pos};
+    const size_t bytes[] = {3 * pitch * 4, 3 * pitch * 4, pitch, 2 * pitch * 4, 2 * pitch * 4, pitch * 4, pitch * 4};
+    for (int i = 0; i < 7; i++) { if (*ps[i]) { HIPCHK(h, hipFree(*ps[i])); *ps[i] = nullptr; } HIPCHK(h, hipMalloc(ps[i], bytes[i])); }
+    if (!h->d_pf_mm) HIPCHK(h, hipMalloc((void**)&h->d_pf_mm, 6 * sizeof(int)));
+    if (!h->d_pf_grid) HIPCHK(h, hipMalloc((void**)&h->d_pf_grid, sizeof(PfGrid)));
+    h->pf_cap = pitch;
+  }
+  h->pf_pitch = pitch;
+  int rc = upload_cloud(h, h->d_pf_in, pitch, 0, pts, n, stride);
+  if (rc) return rc;
+  const int gx = (int)((pitch + 255) / 256);
+  unsigned *ka = h->d_pf_keys, *kb = h->d_pf_keys + pitch, *va = h->d_pf_vals, *vb = h->d_pf_vals + pitch;
+  size_t t1 = 0, t2 = 0;
+  HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(nullptr, t1, ka, kb, va, vb, (int)pitch, 0, 31, s));
+  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(nullptr, t2, h->d_pf_flag, h->d_pf_pos, (int)pitch, s));
+  t1 = std::max(t1, t2);
+  if (t1 > h->pf_tmp_bytes) {
+    if (h->d_pf_tmp) { HIPCHK(h, hipFree(h->d_pf_tmp)); h->d_pf_tmp = nullptr; }
+    HIPCHK(h, hipMalloc(&h->d_pf_tmp, t1));
+    h->pf_tmp_bytes = t1;
+  }
+  k_minmax_init<<<1, 64, 0, s>>>(h->d_pf_mm, 1);
+  k_pf_flag<<<std::min(gx, 256), 256, 0, s>>>(h->d_pf_in, pitch, (int)n, use_distance_filter, distance_near, distance_far, h->d_pf_keep, h->d_pf_mm);
+  int downsample = downsample_resolution > 0.f;
+  const unsigned* keys_sorted = ka;
+  const unsigned* vals_sorted = va;
+  if (downsample) {
+    k_pf_grid<<<1, 1, 0, s>>>(h->d_pf_mm, downsample_resolution, h->d_pf_grid);
+    PfGrid g;
+    HIPCHK(h, hipMemcpyAsync(&g, h->d_pf_grid, sizeof g, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    if (g.status == 2) {                         // PCL: "Leaf size is too small for the input dataset" -> output = input
+      h->err = "prefilter: leaf size too small for the cloud's extent, voxel indices would overflow; cloud not down-sampled";
+      downsample = 0;
+    } else {
+      k_pf_keys<<<gx, 256, 0, s>>>(h->d_pf_in, pitch, (int)n, h->d_pf_keep, h->d_pf_grid, ka, va);
+      size_t tb = h->pf_tmp_bytes;
+      HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(h->d_pf_tmp, tb, ka, kb, va, vb, (int)pitch, 0, 31, s));
+      keys_sorted = kb; vals_sorted = vb;
+    }
+  }
+  k_pf_heads<<<gx, 256, 0, s>>>(keys_sorted, h->d_pf_keep, (int)n, pitch, downsample, h->d_pf_flag);
+  size_t tb = h->pf_tmp_bytes;
+  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(h->d_pf_tmp, tb, h->d_pf_flag, h->d_pf_pos, (int)pitch, s));
+  k_pf_emit<<<gx, 256, 0, s>>>(h->d_pf_in, pitch, keys_sorted, vals_sorted, h->d_pf_flag, h->d_pf_pos, downsample, h->d_pf_out, pitch);
+  int last_pos = 0, last_flag = 0;
+  HIPCHK(h, hipMemcpyAsync(&last_pos, h->d_pf_pos + (pitch - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipMemcpyAsync(&last_flag, h->d_pf_flag + (pitch - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  HIPCHK(h, hipGetLastError());
+  const size_t m = (size_t)last_pos + (size_t)last_flag;
+  h->pf_count = (int)m;
+  *n_out = m;
+  if (out_pts) {
+    if (m > out_capacity) return MI355NDT_ERR_BAD_ARG;
+    std::vector<float> tmp(3 * pitch);
+    HIPCHK(h, hipMemcpy(tmp.data(), h->d_pf_out, 3 * pitch * sizeof(float), hipMemcpyDeviceToHost));
+    unsigned char* o = (unsigned char*)out_pts;
+    for (size_t i = 0; i < m; i++) {
+      float v[3] = {tmp[i], tmp[pitch + i], tmp[2 * pitch + i]};
+      memcpy(o + i * out_stride, v, 12);
+    }
+  }
+  return MI355NDT_OK;
+}
+
+// hand the last prefilter result to the registration without leaving the GPU: role 1 = setInputSource, 2 = setInputTarget
+int mi355ndt_use_prefiltered(mi355ndt_handle* h, int role) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (role != 1 && role != 2) return MI355NDT_ERR_BAD_ARG;
+  if (!h->d_pf_out) return MI355NDT_ERR_STATE;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t m = (size_t)h->pf_count;
+  int rc = ensure_single(h, role == 2, m);
+  if (rc) return rc;
+  float* dst = role == 2 ? h->d_tgt_own : h->d_src_own;
+  const size_t dp = role == 2 ? h->tgt_pitch : h->src_pitch;
+  HIPCHK(h, hipMemsetAsync(dst, 0, 3 * dp * sizeof(float), h->stream));
+  for (int a = 0; a < 3; a++)
+    if (m) HIPCHK(h, hipMemcpyAsync(dst + a * dp, h->d_pf_out + a * h->pf_pitch, m * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  if (role == 2) {
+    h->h_tgt_cnt[0] = (int)m; h->have_target = true; h->targets_built = false;
+    return mi355ndt_batch_build_targets(h);
+  }
+  h->h_src_cnt[0] = (int)m; h->have_source = true;
+  return MI355NDT_OK;
 }
 
 }  // extern "C"

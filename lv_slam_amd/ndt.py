@@ -61,7 +61,7 @@ SYMBOLS = [
     "mi355ndt_version", "mi355ndt_device_count", "mi355ndt_default_params", "mi355ndt_create", "mi355ndt_destroy",
     "mi355ndt_set_params", "mi355ndt_get_params", "mi355ndt_set_stream", "mi355ndt_last_error",
     "mi355ndt_set_target", "mi355ndt_set_source", "mi355ndt_align", "mi355ndt_get_aligned",
-    "mi355ndt_get_fitness_score", "mi355ndt_fitness_score_T", "mi355ndt_derivatives", "mi355ndt_derivatives_T", "mi355ndt_get_grid", "mi355ndt_get_voxels",
+    "mi355ndt_get_fitness_score", "mi355ndt_fitness_score_T", "mi355ndt_prefilter", "mi355ndt_use_prefiltered", "mi355ndt_derivatives", "mi355ndt_derivatives_T", "mi355ndt_get_grid", "mi355ndt_get_voxels",
     "mi355ndt_batch_reserve", "mi355ndt_batch_set_target", "mi355ndt_batch_set_source", "mi355ndt_batch_bind_device",
     "mi355ndt_batch_build_targets", "mi355ndt_batch_align", "mi355ndt_batch_size",
     "mi355ndt_profile_enable", "mi355ndt_profile_reset", "mi355ndt_profile_get", "mi355ndt_synchronize",
@@ -95,6 +95,8 @@ def load_library(path: str = LIB_PATH):
     L.mi355ndt_get_aligned.argtypes = [vp, vp, sz]
     L.mi355ndt_get_fitness_score.argtypes = [vp, C.c_double, vp, vp]
     L.mi355ndt_fitness_score_T.argtypes = [vp, vp, C.c_double, vp, vp]
+    L.mi355ndt_prefilter.argtypes = [vp, vp, sz, sz, i, C.c_double, C.c_double, C.c_float, vp, sz, sz, C.POINTER(sz)]
+    L.mi355ndt_use_prefiltered.argtypes = [vp, i]
     L.mi355ndt_derivatives.argtypes = [vp, vp, vp, vp, vp, vp]
     L.mi355ndt_derivatives_T.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.mi355ndt_get_grid.argtypes = [vp, i, vp, vp, vp, vp]
@@ -209,6 +211,26 @@ class Engine:
             t = _colmajor(T)
             self._chk(self.lib.mi355ndt_fitness_score_T(self.h, t.ctypes.data_as(C.c_void_p), mr, C.byref(s), C.byref(n)), "fitness_score_T")
         return s.value, n.value
+
+    def prefilter(self, cloud, distance_near=0.5, distance_far=100.0, downsample_resolution=0.1, use_distance_filter=True,
+                  fetch=True):
+        """PrefilteringNodelet distance_filter + VoxelGrid downsample (defaults of launch/dlo_kitti.launch:30-36).
+        Returns the filtered [M,3] cloud (or just M when fetch=False; the result stays on the GPU for use_prefiltered)."""
+        a = _as_points(cloud)
+        n_out = C.c_size_t()
+        out = np.zeros((a.shape[0], 3), np.float32) if fetch else None
+        self._chk(self.lib.mi355ndt_prefilter(self.h, a.ctypes.data_as(C.c_void_p), a.shape[0], a.strides[0] if a.shape[0] else 12,
+                                              int(use_distance_filter), float(distance_near), float(distance_far),
+                                              float(downsample_resolution), out.ctypes.data_as(C.c_void_p) if fetch else None,
+                                              a.shape[0], 12, C.byref(n_out)), "prefilter")
+        self._pf_count = n_out.value
+        return out[: n_out.value].copy() if fetch else n_out.value
+
+    def use_prefiltered(self, as_target: bool):
+        """setInputTarget / setInputSource with the last prefilter result, device to device."""
+        self._chk(self.lib.mi355ndt_use_prefiltered(self.h, 2 if as_target else 1), "use_prefiltered")
+        if not as_target:
+            self._n_src = self._pf_count
 
     # -- parity hooks
     def derivatives(self, p):

@@ -781,3 +781,68 @@ double ora_fitness_score(const float* tx, const float* ty, const float* tz, size
   if (n_in) *n_in = (long)cnt;
   return cnt > 0 ? sum / cnt : DBL_MAX;
 }
+
+/* PrefilteringNodelet::distance_filter + downsample (src/lidar_odometry/prefiltering_nodelet.cpp:137-181):
+ * keep near < |p| < far (f32 norm, double compare), then pcl::VoxelGrid (PCL 1.8 voxel_grid.hpp) centroid per voxel:
+ * f32 sums (AccumulatorXYZ) divided by the count, output in ascending voxel index.  The reference sorts the
+ * (voxel, point) pairs with an unstable std::sort, so its f32 summation order inside a voxel is unspecified; this
+ * restatement sums in input order.  leaf <= 0: no down-sampling.  Index overflow guard: output = filtered input.
+ * out_* must hold n entries; returns the number of output points. */
+size_t ora_prefilter(const float* x, const float* y, const float* z, size_t n, int use_df, double dnear, double dfar, float leaf,
+                     float* ox, float* oy, float* oz) {
+  unsigned char* keep = (unsigned char*)malloc(n ? n : 1);
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  size_t nk = 0;
+  for (size_t i = 0; i < n; i++) {
+    int ok = 1;
+    if (use_df) { double d = (double)sqrtf((x[i] * x[i] + y[i] * y[i]) + z[i] * z[i]); ok = d > dnear && d < dfar; }
+    ok = ok && finite3(x[i], y[i], z[i]);
+    keep[i] = (unsigned char)ok;
+    if (!ok) continue;
+    nk++;
+    if (x[i] < mn[0]) mn[0] = x[i]; if (x[i] > mx[0]) mx[0] = x[i];
+    if (y[i] < mn[1]) mn[1] = y[i]; if (y[i] > mx[1]) mx[1] = y[i];
+    if (z[i] < mn[2]) mn[2] = z[i]; if (z[i] > mx[2]) mx[2] = z[i];
+  }
+  int down = leaf > 0 && nk > 0;
+  float inv = down ? 1.0f / leaf : 0.f;
+  int min_b[3] = {0, 0, 0}, mul1 = 0, mul2 = 0;
+  if (down) {
+    int64_t d0 = (int64_t)((mx[0] - mn[0]) * inv) + 1, d1 = (int64_t)((mx[1] - mn[1]) * inv) + 1, d2 = (int64_t)((mx[2] - mn[2]) * inv) + 1;
+    if (d0 * d1 * d2 > (int64_t)INT32_MAX) down = 0;
+    else {
+      int maxb[3];
+      for (int a = 0; a < 3; a++) { min_b[a] = (int)floorf(mn[a] * inv); maxb[a] = (int)floorf(mx[a] * inv); }
+      mul1 = maxb[0] - min_b[0] + 1;
+      mul2 = mul1 * (maxb[1] - min_b[1] + 1);
+    }
+  }
+  size_t m = 0;
+  if (!down) {
+    for (size_t i = 0; i < n; i++) if (keep[i]) { ox[m] = x[i]; oy[m] = y[i]; oz[m] = z[i]; m++; }
+    free(keep);
+    return m;
+  }
+  keypos* kp = (keypos*)malloc(nk * sizeof(keypos));
+  size_t c = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (!keep[i]) continue;
+    int i0 = (int)(floorf(x[i] * inv) - (float)min_b[0]), i1 = (int)(floorf(y[i] * inv) - (float)min_b[1]),
+        i2 = (int)(floorf(z[i] * inv) - (float)min_b[2]);
+    kp[c].idx = i0 + i1 * mul1 + i2 * mul2;
+    kp[c].pos = (uint32_t)i;
+    c++;
+  }
+  qsort(kp, nk, sizeof(keypos), cmp_keypos);
+  for (size_t s = 0; s < nk;) {
+    size_t e = s;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    while (e < nk && kp[e].idx == kp[s].idx) { size_t i = kp[e].pos; sx += x[i]; sy += y[i]; sz += z[i]; e++; }
+    float fn = (float)(e - s);
+    ox[m] = sx / fn; oy[m] = sy / fn; oz[m] = sz / fn;
+    m++;
+    s = e;
+  }
+  free(kp); free(keep);
+  return m;
+}

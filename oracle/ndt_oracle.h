@@ -119,6 +119,10 @@ double ora_fitness_score(const float* tx, const float* ty, const float* tz, size
                          const float* sx, const float* sy, const float* sz, size_t ns,
                          const float T_colmajor[16], double max_range, long* n_in);
 
+/* distance filter + VoxelGrid centroid downsample (prefiltering_nodelet.cpp:137-181); outputs sized n */
+size_t ora_prefilter(const float* x, const float* y, const float* z, size_t n, int use_df, double dnear, double dfar, float leaf,
+                     float* ox, float* oy, float* oz);
+
 void ora_set_threads(int n);
 
 #ifdef __cplusplus

@@ -73,6 +73,8 @@ def lib():
         L.ora_gauss_constants.argtypes = [C.c_double, C.c_float, C.c_void_p]
         L.ora_default_params.argtypes = [C.POINTER(Params)]
         L.ora_set_threads.argtypes = [C.c_int]
+        L.ora_prefilter.restype = C.c_size_t
+        L.ora_prefilter.argtypes = [C.c_void_p] * 3 + [C.c_size_t, C.c_int, C.c_double, C.c_double, C.c_float] + [C.c_void_p] * 3
         L.ora_fitness_score.restype = C.c_double
         L.ora_fitness_score.argtypes = [C.c_void_p] * 3 + [C.c_size_t] + [C.c_void_p] * 3 + [C.c_size_t, C.c_void_p, C.c_double, C.c_void_p]
         _LIB = L
@@ -229,3 +231,13 @@ def fitness_score(tgt: np.ndarray, src: np.ndarray, T: np.ndarray, max_range: fl
     mr = 1.7976931348623157e308 if max_range == float("inf") else float(max_range)
     s = lib().ora_fitness_score(_p(tx), _p(ty), _p(tz), len(tgt), _p(sx), _p(sy), _p(sz), len(src), _p(Tc), mr, C.byref(n))
     return s, n.value
+
+
+def prefilter(pts: np.ndarray, distance_near=0.5, distance_far=100.0, leaf=0.1, use_distance_filter=True) -> np.ndarray:
+    """distance_filter + VoxelGrid downsample restatement; returns [M,3] f32."""
+    x, y, z = _soa(pts)
+    n = len(pts)
+    ox, oy, oz = (np.zeros(max(n, 1), np.float32) for _ in range(3))
+    m = lib().ora_prefilter(_p(x), _p(y), _p(z), n, int(use_distance_filter), float(distance_near), float(distance_far), float(leaf),
+                            _p(ox), _p(oy), _p(oz))
+    return np.stack([ox[:m], oy[:m], oz[:m]], axis=1)

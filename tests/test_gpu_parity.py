@@ -405,3 +405,40 @@ def test_fitness_score_loop_closure_surface():
     got, n = reg.engine.fitness_score(float("inf"), far)
     exp, m = O.fitness_score(tgt, src, far, float("inf"))
     assert n == m == len(src) and abs(got - exp) <= 1e-12 * exp
+
+
+def test_prefilter_next_row_n2():
+    """PrefilteringNodelet distance_filter + VoxelGrid 0.1 m downsample on the device, then straight
+    into setInputSource / setInputTarget without a host round trip."""
+    scan, _, _ = synth.make_pair(50, 1024)
+    raw = scan.numpy().copy()
+    raw[::501] = np.nan
+    raw[7] = [0.2, 0.1, 0.0]
+    eng = ndt.Engine(ndt.default_params(trans_epsilon=0.01, max_iterations=64))
+    for near, far, leaf in ((0.5, 100.0, 0.1), (0.5, 100.0, 0.0), (1.0, 40.0, 0.25), (0.5, 100.0, 1e-4)):
+        got = eng.prefilter(raw, near, far, leaf)
+        exp = O.prefilter(raw, near, far, leaf)
+        assert got.shape == exp.shape, (leaf, got.shape, exp.shape)
+        assert np.array_equal(got, exp), leaf                     # same f32 sums in the same (input) order
+    # 32-byte PointXYZI-style records in, no distance filter
+    rec = np.zeros((len(raw), 8), np.float32)
+    rec[:, :3] = raw
+    assert np.array_equal(eng.prefilter(rec, use_distance_filter=False, downsample_resolution=0.2),
+                          O.prefilter(raw, leaf=0.2, use_distance_filter=False))
+    assert eng.prefilter(np.zeros((0, 3), np.float32)).shape == (0, 3)
+    # device-to-device hand-off: prefiltered key frame as target, prefiltered next scan as source == the host route
+    tgt, src, _ = synth.make_pair(51, 1024)
+    tgt, src = tgt.numpy(), src.numpy()
+    ft, fs = O.prefilter(tgt), O.prefilter(src)
+    eng.prefilter(tgt, fetch=False)
+    eng.use_prefiltered(as_target=True)
+    eng.prefilter(src, fetch=False)
+    eng.use_prefiltered(as_target=False)
+    G = synth.default_guess()
+    r = eng.align(G)
+    e2 = ndt.Engine(ndt.default_params(trans_epsilon=0.01, max_iterations=64))
+    e2.set_target(ft)
+    e2.set_source(fs)
+    r2 = e2.align(G)
+    assert r["iterations"] == r2["iterations"] and np.array_equal(r["final"], r2["final"]) and r["score"] == r2["score"]
+    assert eng.get_aligned().shape == fs.shape

@@ -160,3 +160,35 @@ def test_fitness_score_vs_kdtree():
         assert abs(got - exp) <= 2e-5 * max(1.0, exp)
     got, n = O.fitness_score(tgt, src + 1000.0, T, 1.0)
     assert n == 0 and got == 1.7976931348623157e308
+
+
+def test_prefilter_vs_numpy():
+    """pins ora_prefilter against a dictionary-based NumPy restatement of pcl::VoxelGrid + the distance filter."""
+    rng = np.random.default_rng(21)
+    pts = (rng.normal(0, 1, (20000, 3)) * np.array([30, 30, 2])).astype(np.float32)
+    pts[::97] = np.nan
+    pts[5] = [0.1, 0.1, 0.1]                 # inside the near threshold
+    pts[6] = [150, 0, 0]                     # beyond the far threshold
+    near, far, leaf = 0.5, 100.0, np.float32(0.1)
+    d = np.sqrt((pts[:, 0] * pts[:, 0] + pts[:, 1] * pts[:, 1]) + pts[:, 2] * pts[:, 2]).astype(np.float64)
+    keep = (d > near) & (d < far) & np.isfinite(pts).all(1)
+    f = pts[keep]
+    inv = np.float32(1.0) / leaf
+    min_b = np.floor(f.min(0) * inv).astype(np.int64)
+    max_b = np.floor(f.max(0) * inv).astype(np.int64)
+    div = max_b - min_b + 1
+    ijk = (np.floor(f * inv) - min_b.astype(np.float32)).astype(np.int64)
+    idx = ijk[:, 0] + ijk[:, 1] * div[0] + ijk[:, 2] * div[0] * div[1]
+    cells = {}
+    for k, p in zip(idx, f):
+        s = cells.setdefault(int(k), [np.zeros(3, np.float32), 0])
+        s[0] = (s[0] + p).astype(np.float32)
+        s[1] += 1
+    exp = np.array([cells[k][0] / np.float32(cells[k][1]) for k in sorted(cells)], np.float32)
+    got = O.prefilter(pts, near, far, float(leaf))
+    assert got.shape == exp.shape and np.array_equal(got, exp)
+    # no down-sampling: the distance filter alone keeps the input order
+    assert np.array_equal(O.prefilter(pts, near, far, 0.0), f)
+    # leaf far too small for the extent: PCL warns and returns the (filtered) input
+    assert np.array_equal(O.prefilter(pts, near, far, 1e-4), f)
+    assert len(O.prefilter(np.zeros((0, 3), np.float32))) == 0

@@ -1,0 +1,36 @@
+"""Single-registration latency (BASELINE config 2 / the live nodelet's mode): one 65,536-pt pair through the
+drop-in entry points (host AoS clouds in, PCIe included) and through the device-resident batch path with B = 1."""
+import sys, time, numpy as np, torch
+sys.path.insert(0, '.')
+from lv_slam_amd import ndt, synth
+tgt, src, _ = synth.make_pair(0, 1024, device="cuda")
+T = tgt.T.contiguous()[None].contiguous(); S = src.T.contiguous()[None].contiguous()
+tgt_h, src_h = tgt.cpu().numpy(), src.cpu().numpy()
+G = synth.default_guess()
+for variant, mode, name in ((0, ndt.DIRECT7, "ndt_omp/DIRECT7"), (1, ndt.DIRECT1, "ndt_pca/DIRECT1")):
+    prm = ndt.default_params(trans_epsilon=0.01, max_iterations=64, neighbor_mode=mode, variant=variant)
+    e = ndt.Engine(prm)
+    def host():
+        e.set_target(tgt_h); e.set_source(src_h); return e.align(G)
+    for _ in range(3): r = host()
+    t = []
+    for _ in range(20):
+        t0 = time.perf_counter(); r = host(); t.append(time.perf_counter() - t0)
+    t = np.array(t) * 1e3
+    e2 = ndt.Engine(prm)
+    n = tgt.shape[0]
+    e2.batch_bind_device(T.data_ptr(), [n], n, S.data_ptr(), [n], n)
+    def dev():
+        e2.batch_build_targets(); return e2.batch_align(G)[0]
+    for _ in range(3): r2 = dev()
+    u = []
+    for _ in range(20):
+        t0 = time.perf_counter(); r2 = dev(); u.append(time.perf_counter() - t0)
+    u = np.array(u) * 1e3
+    a = []
+    for _ in range(20):
+        t0 = time.perf_counter(); r3 = e2.batch_align(G)[0]; a.append(time.perf_counter() - t0)
+    a = np.array(a) * 1e3
+    print(f"{name}: iterations {r['iterations']}; host clouds in (set_target+set_source+align): median {np.median(t):.3f} ms "
+          f"(p10 {np.percentile(t,10):.3f}, p90 {np.percentile(t,90):.3f}); device-resident build+align: {np.median(u):.3f} ms; "
+          f"align only: {np.median(a):.3f} ms", flush=True)
