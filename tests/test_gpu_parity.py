@@ -442,3 +442,31 @@ def test_prefilter_next_row_n2():
     r2 = e2.align(G)
     assert r["iterations"] == r2["iterations"] and np.array_equal(r["final"], r2["final"]) and r["score"] == r2["score"]
     assert eng.get_aligned().shape == fs.shape
+
+
+def test_caller_stream_and_engine_cell_cap():
+    import torch
+    tgt, src, _ = synth.make_pair(60, 256)
+    tgt, src = tgt.numpy(), src.numpy()
+    G = synth.default_guess()
+    e1 = ndt.Engine(ndt.default_params(trans_epsilon=0.01, max_iterations=64))
+    e1.set_target(tgt); e1.set_source(src)
+    r1 = e1.align(G)
+    # the same work on a caller-owned HIP stream (torch's), then back on the engine's own stream
+    st = torch.cuda.Stream()
+    e2 = ndt.Engine(ndt.default_params(trans_epsilon=0.01, max_iterations=64))
+    e2.set_stream(st.cuda_stream)
+    e2.set_target(tgt); e2.set_source(src)
+    r2 = e2.align(G)
+    e2.set_stream(None)
+    r3 = e2.align(G)
+    assert np.array_equal(r1["final"], r2["final"]) and np.array_equal(r1["final"], r3["final"]) and r1["score"] == r2["score"] == r3["score"]
+    # a grid beyond the engine's 2^25-cell cap is reported per pair (status -4) and behaves like an empty target
+    e3 = ndt.Engine(ndt.default_params(resolution=0.02, trans_epsilon=0.01, max_iterations=64))
+    e3.set_target(tgt)
+    with pytest.raises(ndt.NDTError) as ex:
+        e3.get_grid()
+    assert ex.value.code == -4
+    e3.set_source(src)
+    r = e3.align(G)
+    assert r["status"] == -4 and r["hits_last"] == 0 and r["iterations"] == 0 and np.array_equal(r["final"], G)
