@@ -1,0 +1,277 @@
+// ndt_build.hpp -- target build kernels: VoxelGridCovariance::applyFilter on the device
+// (include/ndt_omp/voxel_grid_covariance_omp_impl.hpp:48-370; ndt_pca: voxel_grid_covariance_pca_impl.hpp:364-397).
+#pragma once
+#include "ndt_types.hpp"
+#include "ndt_math.hpp"
+
+// ------------------------------------------------------------------------------------ target build
+__global__ void k_minmax_init(int* mm, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n * 6) mm[i] = (i % 6) < 3 ? INT_MAX : INT_MIN;
+}
+
+// getMinMax3D over finite points (voxel_grid_covariance_omp_impl.hpp:72, 211-216)
+__global__ void __launch_bounds__(256) k_minmax(const float* __restrict__ tgt, size_t pitch, const int* __restrict__ cnt, int* mm) {
+  const int b = blockIdx.y;
+  const int n = cnt[b];
+  const float* X = tgt + (size_t)b * 3 * pitch;
+  int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float x = X[i], y = X[pitch + i], z = X[2 * pitch + i];
+    if (!finite3(x, y, z)) continue;
+    int ox = f2ord(x), oy = f2ord(y), oz = f2ord(z);
+    mn[0] = min(mn[0], ox); mx[0] = max(mx[0], ox);
+    mn[1] = min(mn[1], oy); mx[1] = max(mx[1], oy);
+    mn[2] = min(mn[2], oz); mx[2] = max(mx[2], oz);
+  }
+  __shared__ int red[4][6];
+  for (int a = 0; a < 3; a++) {
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[a] = min(mn[a], __shfl_xor(mn[a], o));
+      mx[a] = max(mx[a], __shfl_xor(mx[a], o));
+    }
+  }
+  if ((threadIdx.x & 63) == 0) for (int a = 0; a < 3; a++) { red[threadIdx.x >> 6][a] = mn[a]; red[threadIdx.x >> 6][3 + a] = mx[a]; }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const bool is_min = threadIdx.x < 3;
+    int v = red[0][threadIdx.x];
+    for (int w = 1; w < 4; w++) v = is_min ? min(v, red[w][threadIdx.x]) : max(v, red[w][threadIdx.x]);
+    if (is_min) { if (v != INT_MAX) atomicMin(&mm[b * 6 + threadIdx.x], v); }
+    else if (v != INT_MIN) atomicMax(&mm[b * 6 + threadIdx.x], v);
+  }
+}
+
+// min_b_/max_b_/div_b_/divb_mul_ (voxel_grid_covariance_omp_impl.hpp:75-103)
+__global__ void k_griddesc(const int* __restrict__ mm, GridDesc* gd, unsigned* nwords, float leaf, int n_pairs, unsigned recs_per_pair) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_pairs) return;
+  GridDesc g;
+  memset(&g, 0, sizeof g);
+  g.leaf = leaf;
+  g.inv_leaf = 1.0f / leaf;                      // pcl::VoxelGrid::setLeafSize
+  g.rec_off = (unsigned)b * recs_per_pair;
+  if (mm[b * 6] == INT_MAX) {
+    g.status = GRID_EMPTY;
+  } else {
+    float mn[3], mx[3];
+    for (int a = 0; a < 3; a++) { mn[a] = ord2f(mm[b * 6 + a]); mx[a] = ord2f(mm[b * 6 + 3 + a]); }
+    long long d0 = (long long)((mx[0] - mn[0]) * g.inv_leaf) + 1;
+    long long d1 = (long long)((mx[1] - mn[1]) * g.inv_leaf) + 1;
+    long long d2 = (long long)((mx[2] - mn[2]) * g.inv_leaf) + 1;
+    if (d0 * d1 * d2 > (long long)INT_MAX) {
+      g.status = GRID_OVERFLOW;                  // impl:79-84: empty grid
+    } else {
+      for (int a = 0; a < 3; a++) {
+        g.min_b[a] = (int)floorf(mn[a] * g.inv_leaf);
+        g.max_b[a] = (int)floorf(mx[a] * g.inv_leaf);
+        g.div_b[a] = g.max_b[a] - g.min_b[a] + 1;
+      }
+      long long nc = (long long)g.div_b[0] * g.div_b[1] * g.div_b[2];
+      if (nc > MAX_CELLS) {
+        g.status = GRID_CAP;
+      } else {
+        g.mul1 = g.div_b[0];
+        g.mul2 = g.div_b[0] * g.div_b[1];
+        g.ncells = (int)nc;
+        g.nwords = (int)((nc + 63) >> 6) + 1;     // + one all-zero word: the landing cell of out-of-grid probes
+      }
+    }
+  }
+  gd[b] = g;
+  nwords[b] = (unsigned)g.nwords;
+}
+
+__global__ void k_set_word_off(GridDesc* gd, const unsigned* __restrict__ off, int n_pairs, unsigned* max_ncells) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < n_pairs) { gd[b].word_off = off[b]; atomicMax(max_ncells, (unsigned)gd[b].ncells); }
+}
+
+// first pass of applyFilter: cell index per point (impl:218-223)
+template <typename KeyT>
+__global__ void __launch_bounds__(256) k_keys(const float* __restrict__ tgt, size_t pitch, const int* __restrict__ cnt,
+                                               const GridDesc* __restrict__ gd, KeyT* keys, unsigned* vals, int cb) {
+  const int b = blockIdx.y;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pitch) return;
+  const GridDesc& g = gd[b];
+  unsigned cell = (1u << cb) - 1u;               // "not binned": padding, non-finite point or unusable grid
+  if ((int)i < cnt[b] && g.status == GRID_OK) {
+    const float* X = tgt + (size_t)b * 3 * pitch;
+    float x = X[i], y = X[pitch + i], z = X[2 * pitch + i];
+    if (finite3(x, y, z)) {
+      int i0 = (int)(floorf(x * g.inv_leaf) - (float)g.min_b[0]);
+      int i1 = (int)(floorf(y * g.inv_leaf) - (float)g.min_b[1]);
+      int i2 = (int)(floorf(z * g.inv_leaf) - (float)g.min_b[2]);
+      cell = (unsigned)(i0 + i1 * g.mul1 + i2 * g.mul2);
+    }
+  }
+  keys[(size_t)b * pitch + i] = ((KeyT)b << cb) | (KeyT)cell;
+  vals[(size_t)b * pitch + i] = (unsigned)i;
+}
+
+// mark cells that hold >= min_points points (impl:297) in the occupancy bitmap
+template <typename KeyT>
+__global__ void __launch_bounds__(256) k_mark(const KeyT* __restrict__ keys, size_t pitch, const GridDesc* __restrict__ gd,
+                                               BitWord* words, int min_points, int cb) {
+  const int b = blockIdx.y;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pitch) return;
+  const KeyT* K = keys + (size_t)b * pitch;
+  const KeyT key = K[i];
+  const unsigned cmask = (1u << cb) - 1u;
+  const unsigned cell = (unsigned)key & cmask;
+  if (cell == cmask) return;
+  if (i != 0 && K[i - 1] == key) return;                       // not the head of its segment
+  const size_t last = i + (size_t)(min_points > 0 ? min_points - 1 : 0);
+  if (last >= pitch || K[last] != key) return;                 // fewer than min_points points
+  atomicOr(&words[gd[b].word_off + (cell >> 6)].bits, 1ull << (cell & 63));
+}
+
+// exclusive popcount prefix over the bitmap words of each target: voxel id = rank in ascending cell order
+__global__ void __launch_bounds__(256) k_rank(GridDesc* gd, BitWord* words) {
+  typedef hipcub::BlockScan<unsigned, 256> Scan;
+  __shared__ typename Scan::TempStorage tmp;
+  const int b = blockIdx.x;
+  BitWord* W = words + gd[b].word_off;
+  const int nw = gd[b].nwords;
+  unsigned base = 0;
+  for (int w0 = 0; w0 < nw; w0 += 256) {
+    int w = w0 + threadIdx.x;
+    unsigned c = (w < nw) ? (unsigned)__popcll(W[w].bits) : 0u, ex, tot;
+    Scan(tmp).ExclusiveSum(c, ex, tot);
+    if (w < nw) W[w].prefix = base + ex;
+    base += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) gd[b].n_voxels = (int)base;
+}
+
+// where does the point run of searchable leaf `id` start in the sorted order?
+template <typename KeyT>
+__global__ void __launch_bounds__(256) k_segstart(const KeyT* __restrict__ keys, size_t pitch, const GridDesc* __restrict__ gd,
+                                                   const BitWord* __restrict__ words, unsigned* seg_start, int min_points, int cb) {
+  const int b = blockIdx.y;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pitch) return;
+  const KeyT* K = keys + (size_t)b * pitch;
+  const KeyT key = K[i];
+  const unsigned cmask = (1u << cb) - 1u;
+  const unsigned cell = (unsigned)key & cmask;
+  if (cell == cmask) return;
+  if (i != 0 && K[i - 1] == key) return;
+  const size_t last = i + (size_t)(min_points > 0 ? min_points - 1 : 0);
+  if (last >= pitch || K[last] != key) return;
+  const GridDesc& g = gd[b];
+  const BitWord bw = words[g.word_off + (cell >> 6)];
+  const unsigned id = bw.prefix + (unsigned)__popcll(bw.bits & ((1ull << (cell & 63)) - 1ull));
+  seg_start[g.rec_off + id] = (unsigned)i;
+}
+
+// leaf.mean_ += pt ; leaf.cov_ += pt pt^T (impl:233-237) for every searchable leaf: one WAVE per leaf.
+// The wave gathers 64 points of the leaf's run at a time (the radix sort is stable, so the run is in input
+// order), parks the nine f64 terms of each point in LDS, and lanes 0..8 -- one per accumulator -- add them
+// strictly in input order, which keeps the sums bit-identical to the reference's sequential accumulation.
+#define LS_WAVES 4
+template <typename KeyT>
+__global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restrict__ tgt, size_t pitch,
+                                                           const KeyT* __restrict__ keys, const unsigned* __restrict__ vals,
+                                                           const GridDesc* __restrict__ gd, const unsigned* __restrict__ seg_start,
+                                                           double* sums, int* vox_idx, int* vox_n, int cb) {
+  __shared__ double term[LS_WAVES][64][9];
+  const int b = blockIdx.y;
+  const GridDesc& g = gd[b];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const KeyT* K = keys + (size_t)b * pitch;
+  const unsigned* V = vals + (size_t)b * pitch;
+  const float* X = tgt + (size_t)b * 3 * pitch;
+  for (int id = blockIdx.x * LS_WAVES + wv; id < g.n_voxels; id += gridDim.x * LS_WAVES) {
+    const size_t start = seg_start[g.rec_off + id];
+    const KeyT key = K[start];
+    // accumulator order: S0 S1 S2 C00 C01 C02 C11 C12 C22 ; cov_ is seeded with Identity (voxel_grid_covariance_omp.h:101)
+    double acc = (lane == 3 || lane == 6 || lane == 8) ? 1.0 : 0.0;
+    int cnt = 0;
+    for (size_t j0 = start;; j0 += 64) {
+      const size_t j = j0 + lane;
+      const bool in = j < pitch && K[j] == key;
+      const int m = (int)__popcll(__ballot(in));
+      if (in) {
+        const unsigned pi = V[j];
+        const double x = (double)X[pi], y = (double)X[pitch + pi], z = (double)X[2 * pitch + pi];
+        double* t = term[wv][lane];
+        t[0] = x; t[1] = y; t[2] = z;
+        t[3] = x * x; t[4] = x * y; t[5] = x * z; t[6] = y * y; t[7] = y * z; t[8] = z * z;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 9) for (int l = 0; l < m; l++) acc += term[wv][l][lane];
+      __builtin_amdgcn_wave_barrier();
+      cnt += m;
+      if (m < 64) break;
+    }
+    if (lane < 9) sums[(size_t)(g.rec_off + id) * 9 + lane] = acc;
+    if (lane == 0) {
+      vox_idx[g.rec_off + id] = (int)((unsigned)key & ((1u << cb) - 1u));
+      vox_n[g.rec_off + id] = cnt;
+    }
+  }
+}
+
+// second pass of applyFilter (impl:282-367; pca impl:364-397): one thread per searchable leaf
+__global__ void __launch_bounds__(256) k_voxels(const GridDesc* __restrict__ gd, const double* __restrict__ sums,
+                                                 VoxelRec* recs, int* vox_n, double eig_mult, int pca) {
+  const int b = blockIdx.y;
+  const GridDesc& g = gd[b];
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= g.n_voxels) return;
+  const double* A = sums + (size_t)(g.rec_off + id) * 9;
+  const double S[3] = {A[0], A[1], A[2]};
+  const double C[9] = {A[3], A[4], A[5], A[4], A[6], A[7], A[5], A[7], A[8]};
+  const int cnt = vox_n[g.rec_off + id];
+  const double dn = (double)cnt;
+  double mu[3] = {S[0] / dn, S[1] / dn, S[2] / dn};                              // impl:293
+  double cov[9];
+  for (int a = 0; a < 3; a++)
+    for (int c = 0; c < 3; c++) cov[a * 3 + c] = (C[a * 3 + c] - 2 * (S[a] * mu[c])) / dn + mu[a] * mu[c];   // impl:329
+  const double f = (dn - 1.0) / dn;
+  for (int a = 0; a < 9; a++) cov[a] *= f;                                       // impl:330
+  double ev[3], Vm[9];
+  ndtm::eigen_sym3(cov, ev, Vm);                                                 // impl:333-335
+  VoxelRec r;
+  r.mean[0] = mu[0]; r.mean[1] = mu[1]; r.mean[2] = mu[2];
+  for (int a = 0; a < 9; a++) r.icov[a] = 0.f;
+  r.weight = 1;
+  int n_out = cnt;
+  if (ev[0] < 0 || ev[1] < 0 || ev[2] <= 0) {                                    // impl:337-341
+    n_out = -1;
+    r.weight = VOX_DEAD;
+  } else {
+    const double minev = eig_mult * ev[2];                                       // impl:345
+    if (ev[0] < minev) {
+      ev[0] = minev;
+      if (ev[1] < minev) ev[1] = minev;
+      double VD[9], Vi[9];
+      for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) VD[a * 3 + c] = Vm[a * 3 + c] * ev[c];
+      ndtm::mat3_inverse(Vm, Vi);
+      ndtm::mat3_mul(VD, Vi, cov);                                               // impl:355
+    }
+    if (pca) {                                                                   // pca impl:364-397
+      double s0 = sqrt(ev[0]), s1 = sqrt(ev[1]), s2 = sqrt(ev[2]);
+      double f0 = (s2 - s1) / s2, f1 = (s1 - s0) / s2, f2 = s0 / s2;
+      int label = 1;
+      double fm = f0;
+      if (f1 > fm) { fm = f1; label = 2; }
+      if (f2 > fm) { label = 3; }
+      double scale = (label == 2) ? 1.25 : ((label == 1) ? 0.75 : 1.0);
+      double d2d = scale * sqrt((mu[0] * mu[0] + mu[1] * mu[1]) + mu[2] * mu[2]);
+      r.weight = (int)d2d;                                                       // getDimension2d() returns int (pca.h:222-226)
+    }
+    double ic[9];
+    ndtm::mat3_inverse(cov, ic);                                                 // impl:359
+    bool bad = false;
+    for (int a = 0; a < 9; a++) { if (!isfinite(ic[a])) bad = true; r.icov[a] = (float)ic[a]; }
+    if (bad) { n_out = -1; r.weight = VOX_DEAD; }                                // impl:360-364
+  }
+  recs[g.rec_off + id] = r;
+  vox_n[g.rec_off + id] = n_out;
+}
+

@@ -1,0 +1,303 @@
+// ndt_sweep.hpp -- the derivative sweep (computeDerivatives + updateDerivatives + neighbour lookup,
+// include/ndt_omp/ndt_omp_impl2.hpp:196-305, 503-532, 566-619; voxel_grid_covariance_omp_impl.hpp:373-442).
+#pragma once
+#include "ndt_types.hpp"
+
+// ------------------------------------------------------------------------------------ derivative sweep
+// One (point, voxel) evaluation: updateDerivatives (ndt_omp_impl2.hpp:566-619) with the Jacobian /
+// Hessian patterns of computePointDerivatives_AngleAxisd (impl2:503-532) folded in (J and Hp are never
+// materialised).  f32 ops single, left to right; f64 accumulation.  `w` = weight multiplier of the hit
+// (ndt_pca compounding, applied as a suffix product; unused for ndt_omp).
+template <bool PCA>
+__device__ __forceinline__ void eval_hit(const float u[3], const float r[3], const float C[9],
+                                         const double d1, const float d2f, const double w, const bool ok_in, double acc[43]) {
+  float y[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) y[j] = (u[0] * C[j] + u[1] * C[3 + j]) + u[2] * C[6 + j];
+  const float qf = (u[0] * y[0] + u[1] * y[1]) + u[2] * y[2];
+  const float e0 = (float)exp((double)((-d2f * qf) * 0.5f));                     // impl2:581
+  float s_inc = (float)(-d1 * (double)e0);                                       // impl2:583
+  const float e1 = d2f * e0;                                                     // impl2:585
+  // impl2:588-589, branch-free: a rejected hit (or an idle lane, ok_in = false) multiplies every term by e = 0 and so
+  // adds +0 to all 43 sums (all operands are finite here: dead voxels never enter the queue).
+  const bool ok = ok_in && !(e1 > 1.f || e1 < 0.f || e1 != e1);
+  float e = (float)((double)e1 * d1);                                            // impl2:592
+  e = ok ? e : 0.f;
+  s_inc = ok ? s_inc : 0.f;
+  // CJ = c_inv4 * point_gradient4 (impl2:594): columns 0..2 are C itself
+  float CJ[3][6];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    CJ[a][0] = C[a * 3 + 0]; CJ[a][1] = C[a * 3 + 1]; CJ[a][2] = C[a * 3 + 2];
+    CJ[a][3] = C[a * 3 + 1] * (-r[2]) + C[a * 3 + 2] * r[1];
+    CJ[a][4] = C[a * 3 + 0] * r[2] + C[a * 3 + 2] * (-r[0]);
+    CJ[a][5] = C[a * 3 + 0] * (-r[1]) + C[a * 3 + 1] * r[0];
+  }
+  float v[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) v[k] = (u[0] * CJ[0][k] + u[1] * CJ[1][k]) + u[2] * CJ[2][k];   // impl2:595
+  // w * term: the product is a single rounding away from the reference's nested multiplies (both ~1e-16)
+#define NDT_ACC(slot, val) do { if (PCA) acc[slot] = fma(w, (double)(val), acc[slot]); else acc[slot] += (double)(val); } while (0)
+  NDT_ACC(0, s_inc);
+#pragma unroll
+  for (int k = 0; k < 6; k++) NDT_ACC(1 + k, e * v[k]);                                        // impl2:597
+  // z_i[j] = y * Hp_block_i (impl2:607) -- nine non-zero entries (impl2:522-530)
+  float Z[3][3];
+  Z[0][0] = y[1] * (-r[1]) + y[2] * (-r[2]);
+  Z[1][0] = y[0] * r[1];
+  Z[2][0] = y[0] * r[2];
+  Z[0][1] = y[1] * r[0];
+  Z[1][1] = y[0] * (-r[0]) + y[2] * (-r[2]);
+  Z[2][1] = y[1] * r[2];
+  Z[0][2] = y[2] * r[0];
+  Z[1][2] = y[2] * r[1];
+  Z[2][2] = y[0] * (-r[0]) + y[1] * (-r[1]);
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      // JCJ[j][i] = (J^T CJ)(j,i) (impl2:601)
+      float jcj;
+      if (j < 3) jcj = CJ[j][i];
+      else if (j == 3) jcj = (-r[2]) * CJ[1][i] + r[1] * CJ[2][i];
+      else if (j == 4) jcj = r[2] * CJ[0][i] + (-r[0]) * CJ[2][i];
+      else jcj = (-r[1]) * CJ[0][i] + r[0] * CJ[1][i];
+      const float z = (i >= 3 && j >= 3) ? Z[i - 3][j - 3] : 0.f;
+      const float h = e * ((((-d2f) * v[i]) * v[j] + z) + jcj);                                // impl2:611-613
+      NDT_ACC(7 + i * 6 + j, h);
+    }
+  }
+#undef NDT_ACC
+}
+
+// Neighbour offset `a` (0..2) of probe q for a K-probe search, resolved at compile time in the sweep
+// (same tables and order as c_off above).
+__host__ __device__ constexpr int probe_off(int K, int q, int a) {
+  const int o7[7][3] = {{0,0,0},{1,0,0},{-1,0,0},{0,1,0},{0,-1,0},{0,0,1},{0,0,-1}};
+  const int o26[26][3] = {{-1,-1,-1}, {-1,0,-1}, {-1,1,-1}, {0,-1,-1}, {0,0,-1}, {0,1,-1}, {1,-1,-1}, {1,0,-1}, {1,1,-1}, {-1,-1,0}, {0,-1,0}, {1,-1,0}, {-1,0,0}, {1,1,1}, {1,0,1}, {1,-1,1}, {0,1,1}, {0,0,1}, {0,-1,1}, {-1,1,1}, {-1,0,1}, {-1,-1,1}, {1,1,0}, {0,1,0}, {-1,1,0}, {1,0,0}};
+  return K == 1 ? 0 : (K == 7 ? o7[q][a] : o26[q][a]);
+}
+
+#define Q_CAP   512                       // per-wave hit queue (entries); >= 63 + 7*64
+#define Q_GROUP 7                         // probes between queue drains
+#define ID_BITS 25                        // queue entry = slot << 25 | voxel id
+#define WAVES   (SWEEP_THREADS / 64)
+
+// The sweep.  Work decomposition (MI355X-first):
+//   block = 4 waves = one CHUNK_PTS chunk of one pair at a time; each wave owns CHUNK_PTS/4 consecutive points.
+//   phase A (probe, lane = point): transform the point (f32), probe its K neighbour cells in the rank-bitmap,
+//     and push every hit as a 4-byte entry into the wave's LDS queue (ballot + popcount compaction).
+//   phase B (evaluate, lane = hit): lanes pull 64 queue entries at a time -- every lane busy no matter how the
+//     hits were distributed over points -- read the staged point (LDS) and the 64-B voxel record, and add the
+//     43 f64 terms into per-lane accumulators.
+//   chunk end: flush the queue tail, wave butterfly + fixed-order wave sum -> one 44-double partial row per chunk.
+// The partial rows depend only on (CHUNK_PTS, input order), never on the launch geometry, so single and batched
+// runs of one pair are bit-identical.
+struct SweepCtl {               // zeroed by the host before every k_update / k_init_state
+  int n_active;                 // pairs whose next sweep is pending (entries of active_list)
+  int next_item[8];             // per-XCD work-item cursors of the sweep
+};
+#define QUARTERS WAVES          // a chunk is reduced as 4 wave-quarters of CHUNK_PTS/4 points
+
+template <bool PCA, int K>
+__global__ void __launch_bounds__(SWEEP_THREADS, SWEEP_WPE)
+k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict__ st,
+        const GridDesc* __restrict__ gd, const BitWord* __restrict__ words, const VoxelRec* __restrict__ recs,
+        double* partials, int chunks_per_pair, const int* __restrict__ active_list, SweepCtl* ctl, SweepConst sc) {
+  // Persistent waves pulling work items.  One item = one wave-quarter (CHUNK_PTS/4 consecutive points) of one chunk
+  // of one active pair; every wave is independent (own LDS queue, own partial row, no block barrier), so a wave
+  // whose points have few hits simply takes the next item instead of idling at a barrier.
+  // Items are queued per XCD: pair slot a of the active list belongs to XCD a % 8 (workgroup L is observed to run on
+  // XCD L % 8, MI355X_MICROARCH.md), so one pair's records / bitmap / points stay in one L2; a wave whose XCD
+  // queue is empty steals from the others.  Which wave runs an item never changes the item's result.
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const int n_active = ctl->n_active;
+  const int items_per_pair = chunks_per_pair * QUARTERS;
+
+  __shared__ unsigned q_ent[WAVES][Q_CAP];
+  __shared__ double q_w[PCA ? WAVES : 1][PCA ? Q_CAP : 1];
+  __shared__ float stage[WAVES][128][6];           // two tiles of staged points: x'(3), R x (3)
+
+  if (n_active == 0) return;                       // nothing left to sweep (the loop's last, empty round)
+  const int my_xcd = blockIdx.x & 7;
+#pragma unroll 1
+  for (int probe = 0; probe < 8; probe++) {        // own XCD first, then steal
+    const int xcd = (my_xcd + probe) & 7;
+    const int pairs_here = n_active > xcd ? (n_active - xcd + 7) / 8 : 0;
+    const int items_here = pairs_here * items_per_pair;
+    if (items_here == 0) continue;
+    // a drained queue is recognised with a plain (L2) load; only a queue that still has items costs an atomic
+    if (__hip_atomic_load(&ctl->next_item[xcd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= items_here) continue;
+    int item = 0;
+    if (lane == 0) item = atomicAdd(&ctl->next_item[xcd], 1);
+    item = __builtin_amdgcn_readfirstlane(item);
+#pragma unroll 1
+    while (item < items_here) {
+      // claim the NEXT item now; the atomic's round trip is hidden behind this item's work
+      int next_item = 0;
+      if (lane == 0) next_item = atomicAdd(&ctl->next_item[xcd], 1);
+      const int b = active_list[xcd + 8 * (item / items_per_pair)];
+      const int rem = item % items_per_pair;
+      const int chunk = rem / QUARTERS, quarter = rem % QUARTERS;
+
+  const PairState& S = st[b];
+  const int n = S.n_src;
+  const GridDesc& g = gd[b];
+  const float* X = src + (size_t)b * 3 * pitch;
+  const BitWord* W = words + g.word_off;
+  const VoxelRec* R = recs + g.rec_off;
+  const bool grid_ok = (g.status == GRID_OK);
+  float T[12], Rj[9];
+#pragma unroll
+  for (int a = 0; a < 12; a++) T[a] = S.T[a];
+#pragma unroll
+  for (int a = 0; a < 9; a++) Rj[a] = S.Rj[a];
+  const float leaf = g.leaf;
+  const int mb0 = g.min_b[0], mb1 = g.min_b[1], mb2 = g.min_b[2];
+  const int xb0 = g.max_b[0], xb1 = g.max_b[1], xb2 = g.max_b[2];
+  const int mul1 = g.mul1, mul2 = g.mul2, nwords = g.nwords;
+  {
+    double acc[43];
+#pragma unroll
+    for (int a = 0; a < 43; a++) acc[a] = 0.0;
+    unsigned nhits = 0;                              // wave-uniform
+    int qhead = 0, qcount = 0;                       // wave-uniform
+    int q_old = 0;                                   // queued entries that reference the OTHER staging half (older tile)
+    const int wbase = chunk * CHUNK_PTS + quarter * (CHUNK_PTS / QUARTERS);
+
+    // evaluate `m` queued hits (m <= 64), one per lane; lanes >= m re-read the last entry and contribute +0
+    auto drain = [&](int m) {
+      const int k = lane < m ? lane : m - 1;
+      const unsigned ent = q_ent[wv][(qhead + k) & (Q_CAP - 1)];
+      const unsigned slot = ent >> ID_BITS, id = ent & ((1u << ID_BITS) - 1);
+      const float* sp = stage[wv][slot];
+      const float xt0 = sp[0], xt1 = sp[1], xt2 = sp[2];
+      float r[3] = {sp[3], sp[4], sp[5]};
+      const VoxelRec& vr = R[id];
+      const double m0 = vr.mean[0], m1 = vr.mean[1], m2 = vr.mean[2];
+      float Cf[9];
+#pragma unroll
+      for (int a = 0; a < 9; a++) Cf[a] = vr.icov[a];
+      double w = 1.0;
+      if (PCA) w = q_w[wv][(qhead + k) & (Q_CAP - 1)];
+      // ndt_omp: leaves with nr_points = -1 (eigen / inverse failure) are not neighbours (impl:395): filtered here
+      const bool live = lane < m && (PCA || vr.weight != VOX_DEAD);
+      float u[3] = {(float)((double)xt0 - m0), (float)((double)xt1 - m1), (float)((double)xt2 - m2)};   // impl2:276-279, 574
+      eval_hit<PCA>(u, r, Cf, sc.d1, sc.d2f, w, live, acc);
+      nhits += PCA ? (unsigned)m : (unsigned)__popcll(__ballot(live));
+      qhead = (qhead + m) & (Q_CAP - 1);
+      qcount -= m;
+      q_old = q_old > m ? q_old - m : 0;
+    };
+
+    if (wbase < n && grid_ok) {
+      // points of the next tile are fetched one tile ahead (HBM latency ~2 us would otherwise be exposed per tile)
+      float nx = 0.f, ny = 0.f, nz = 0.f;
+      if (wbase + lane < n) { nx = X[wbase + lane]; ny = X[pitch + wbase + lane]; nz = X[2 * pitch + wbase + lane]; }
+#pragma unroll 1
+      for (int t = 0; t < CHUNK_PTS / WAVES / 64; t++) {
+        const int i = wbase + t * 64 + lane;
+        if (wbase + t * 64 >= n) break;              // wave-uniform
+        // the staging area holds two tiles: entries of tile t-2 must be gone before tile t overwrites their half
+        // (only happens when hits are sparse; dense tiles are consumed by the regular 64-wide drains)
+        if (q_old > 0) { __builtin_amdgcn_wave_barrier(); drain(q_old); }
+        q_old = qcount;
+        const int slot = (t & 1) * 64 + lane;
+        bool valid = i < n;
+        const float px = nx, py = ny, pz = nz;
+        if (t + 1 < CHUNK_PTS / WAVES / 64 && i + 64 < n) { nx = X[i + 64]; ny = X[pitch + i + 64]; nz = X[2 * pitch + i + 64]; }
+        valid = valid && finite3(px, py, pz);
+        // PCL 1.8 transformPointCloud scalar form; Jacobian point r = R x (impl2:507-508)
+        float xt[3], r[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          xt[a] = ((T[a * 4 + 0] * px + T[a * 4 + 1] * py) + T[a * 4 + 2] * pz) + T[a * 4 + 3];
+          r[a] = (Rj[a * 3 + 0] * px + Rj[a * 3 + 1] * py) + Rj[a * 3 + 2] * pz;
+        }
+        float* sp = stage[wv][slot];
+        sp[0] = xt[0]; sp[1] = xt[1]; sp[2] = xt[2]; sp[3] = r[0]; sp[4] = r[1]; sp[5] = r[2];
+        // getNeighborhoodAtPoint (voxel_grid_covariance_omp_impl.hpp:379-399): cell of the point, f32 divide
+        // (x / 2^k is the same bits as x * 2^-k, so a power-of-two leaf takes the one-instruction path)
+        const int c0 = (int)floorf(sc.leaf_pow2 ? xt[0] * sc.inv_leaf : xt[0] / leaf);
+        const int c1 = (int)floorf(sc.leaf_pow2 ? xt[1] * sc.inv_leaf : xt[1] / leaf);
+        const int c2 = (int)floorf(sc.leaf_pow2 ? xt[2] * sc.inv_leaf : xt[2] / leaf);
+        // Branch-free probe stage.  Relative cell r = c - min_b; "inside the grid" (impl:382-392) is one unsigned
+        // compare per axis; a probe that falls outside (or belongs to an invalid lane) is redirected to the grid's
+        // spare all-zero bitmap word, so it misses without any flag having to be kept.
+        const int r0 = c0 - mb0, r1 = c1 - mb1, r2 = c2 - mb2;
+        const unsigned e0 = (unsigned)(xb0 - mb0), e1 = (unsigned)(xb1 - mb1), e2 = (unsigned)(xb2 - mb2);
+        const int cc = r0 + r1 * mul1 + r2 * mul2;
+        const unsigned empty_cell = (unsigned)(nwords - 1) << 6;
+        // probes run last-to-first so the ndt_pca weight of a hit (product of its own and all LATER hits' weights,
+        // ndt_pca_impl2.hpp:295-296) is a running product; the order of the f64 additions is free anyway.
+        double suf = 1.0;
+        // Q_GROUP probes at a time: all bitmap loads of the group in flight together (then all ndt_pca weight loads),
+        // then the ballots -- one L2 round trip per stage instead of one per probe.
+#pragma unroll
+        for (int q1 = K; q1 > 0; q1 -= Q_GROUP) {      // compile-time groups: 1 for DIRECT1 / DIRECT7, 4 for DIRECT26
+          unsigned cellv[Q_GROUP];
+          uint4 bwv[Q_GROUP];                          // BitWord: bits lo, bits hi, prefix, pad
+#pragma unroll
+          for (int j = 0; j < Q_GROUP; j++) {
+            const int q = q1 - 1 - j;                 // compile-time
+            cellv[j] = empty_cell;
+            if (q >= 0) {
+              const int o0 = probe_off(K, q, 0), o1 = probe_off(K, q, 1), o2 = probe_off(K, q, 2);
+              const bool inside = valid && (unsigned)(r0 + o0) <= e0 && (unsigned)(r1 + o1) <= e1 && (unsigned)(r2 + o2) <= e2;
+              if (inside) cellv[j] = (unsigned)(cc + o0 + o1 * mul1 + o2 * mul2);
+            }
+            bwv[j] = *reinterpret_cast<const uint4*>(W + (cellv[j] >> 6));
+          }
+          unsigned idv[Q_GROUP];
+          int wiv[Q_GROUP];
+#pragma unroll
+          for (int j = 0; j < Q_GROUP; j++) {
+            // shift the cell's bit to the top: sign = occupied, popcount = bits at or below it
+            const unsigned long long bits = ((unsigned long long)bwv[j].y << 32) | bwv[j].x;
+            const unsigned long long t = bits << (63u - (cellv[j] & 63u));
+            idv[j] = bwv[j].z + (unsigned)__popcll(t) - 1u;        // rank among the searchable leaves = voxel id
+            // occupied <=> the cell's bit (now the sign bit) is set; ndt_pca needs the weights now (suffix product),
+            // ndt_omp filters dead leaves in phase B instead and saves this dependent L2 round trip
+            wiv[j] = ((long long)t < 0) ? 1 : VOX_DEAD;
+            if (PCA) { if ((long long)t < 0) wiv[j] = R[idv[j]].weight; }
+          }
+#pragma unroll
+          for (int j = 0; j < Q_GROUP; j++) {
+            const bool hit = wiv[j] != VOX_DEAD;     // empty cell, or nr_points == -1: not a neighbour (impl:395)
+            if (PCA && hit) suf *= (double)wiv[j];
+            const unsigned long long mask = __ballot(hit);
+            if (hit) {
+              const int pos = (qhead + qcount + (int)__popcll(mask & lt_mask)) & (Q_CAP - 1);
+              q_ent[wv][pos] = ((unsigned)slot << ID_BITS) | idv[j];
+              if (PCA) q_w[wv][pos] = suf;
+            }
+            qcount += (int)__popcll(mask);
+          }
+          __builtin_amdgcn_wave_barrier();
+          while (qcount >= 64) drain(64);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (qcount > 0) drain(qcount);
+    }
+    // fixed-order reduction of the wave: 64-lane butterfly -> one 44-double row per (chunk, quarter)
+#pragma unroll
+    for (int a = 0; a < 43; a++) {
+      double v = acc[a];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      acc[a] = v;
+    }
+    if (lane == 0) {
+      double* P = partials + (((size_t)b * chunks_per_pair + chunk) * QUARTERS + quarter) * NACC;
+#pragma unroll
+      for (int a = 0; a < 43; a++) P[a] = acc[a];
+      P[43] = (double)nhits;
+    }
+  }
+      item = __builtin_amdgcn_readfirstlane(next_item);
+    }
+  }
+}
+

@@ -1,0 +1,83 @@
+// ndt_types.hpp -- constants, device-resident structures and small helpers shared by all kernels of the
+// MI355X NDT engine (included by mi355_ndt.hip; one translation unit).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <climits>
+#include <cstring>
+#include "mi355_ndt.h"
+
+// ------------------------------------------------------------------------------------ constants
+#define CHUNK_PTS      2048          // source points per reduction chunk (fixed => results independent of launch geometry)
+#define SWEEP_THREADS  256
+#ifndef SWEEP_WPE
+#define SWEEP_WPE       2             // waves per SIMD the sweep is register-allocated for (2: no spills; measured faster than 3 with spills)
+#endif
+#define NACC           44            // score, g[6], H[36], hits
+// sort key = pair << cb | cell, cb = bits needed for the largest grid of the batch + the all-ones "not binned" cell;
+// 32-bit keys whenever pair and cell fields fit (the usual case), else 64-bit
+#define MAX_CELLS      (1 << 25)
+
+enum { GRID_OK = 0, GRID_EMPTY = 1, GRID_OVERFLOW = 2, GRID_CAP = 3 };
+enum { PH_SWEEP0 = 0, PH_STEP = 1, PH_DONE = 2 };
+
+struct GridDesc {              // one per target
+  int   min_b[3], max_b[3], div_b[3];
+  int   mul1, mul2;            // divb_mul_ = (1, mul1, mul2)
+  float leaf, inv_leaf;
+  int   ncells, nwords;
+  int   status;
+  int   n_voxels;              // searchable leaves (n >= min_points), including eigen-failed ones
+  unsigned word_off;           // into the BitWord pool
+  unsigned rec_off;            // into the VoxelRec pool
+};
+
+struct BitWord {               // occupancy of 64 consecutive cells + rank of the first one
+  unsigned long long bits;
+  unsigned prefix;
+  unsigned pad;
+};
+
+struct VoxelRec {              // 64 B, what one (point, voxel) evaluation reads
+  double mean[3];
+  float  icov[9];
+  int    weight;               // ndt_pca integer weight; 1 for ndt_omp; INT_MIN = dead (eigen/inverse failure)
+};
+#define VOX_DEAD INT_MIN
+
+struct PairState {
+  float  T[12];                // 3x4 row-major point transform (f32)
+  float  Rj[9];                // rotation used for the point Jacobian (f32)
+  double p[6];                 // current tangent [upsilon; omega]
+  double dir[6];               // pending step direction
+  double a_t;                  // pending step length
+  double score, g[6], H[36];
+  double trans_probability;
+  long long hits;
+  float  final_cm[16];
+  int    it, phase, converged, sweeps, n_src, grid_status;
+};
+
+struct SweepConst {
+  double d1;
+  float  d2f;
+  int    K;                    // neighbour probes
+  int    pca;
+  int    table;                // row of c_off: 0 = DIRECT1, 1 = DIRECT7, 2 = DIRECT26
+  int    leaf_pow2;            // resolution is a power of two: x / leaf == x * inv_leaf bit for bit
+  float  inv_leaf;
+};
+
+// Neighbour offsets in the reference's probe order.  DIRECT1: voxel_grid_covariance_omp_impl.hpp:441;
+// DIRECT7: impl:423-430; DIRECT26: pcl::getAllNeighborCellIndices() (PCL 1.8 voxel_grid.h) = 13 "half"
+// offsets followed by their negation.  __constant__: the wave-uniform probe index reads them with scalar loads.
+__constant__ int c_off[3][26][3] = {
+  {{0,0,0}},
+  {{0,0,0},{1,0,0},{-1,0,0},{0,1,0},{0,-1,0},{0,0,1},{0,0,-1}},
+  {{-1,-1,-1}, {-1,0,-1}, {-1,1,-1}, {0,-1,-1}, {0,0,-1}, {0,1,-1}, {1,-1,-1}, {1,0,-1}, {1,1,-1}, {-1,-1,0}, {0,-1,0}, {1,-1,0}, {-1,0,0}, {1,1,1}, {1,0,1}, {1,-1,1}, {0,1,1}, {0,0,1}, {0,-1,1}, {-1,1,1}, {-1,0,1}, {-1,-1,1}, {1,1,0}, {0,1,0}, {-1,1,0}, {1,0,0}}
+};
+
+// ------------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
+__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+__device__ __forceinline__ bool finite3(float x, float y, float z) { return isfinite(x) && isfinite(y) && isfinite(z); }
+
