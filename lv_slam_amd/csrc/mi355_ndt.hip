@@ -58,7 +58,7 @@ struct mi355ndt_handle {
   size_t keys_cap = 0;
   BitWord* d_words = nullptr; size_t words_cap = 0;
   VoxelRec* d_recs = nullptr; int *d_vox_idx = nullptr, *d_vox_n = nullptr;
-  unsigned* d_seg_start = nullptr; double* d_sums = nullptr;
+  unsigned* d_seg_start = nullptr; double* d_sums = nullptr; float* d_cent = nullptr;
   unsigned *d_cstart = nullptr, *d_cend = nullptr; size_t cell_cap = 0; bool cells_ready = false; int last_cb = 0;
   double* d_fit = nullptr; size_t fit_cap = 0;
   // prefilter workspace
@@ -115,7 +115,8 @@ static hipError_t grow(T*& p, size_t& cap, size_t need) {
 static void build_offsets(int mode, SweepConst& sc) {
   if (mode == MI355NDT_DIRECT1) { sc.K = 1; sc.table = 0; }
   else if (mode == MI355NDT_DIRECT7) { sc.K = 7; sc.table = 1; }
-  else { sc.K = 26; sc.table = 2; }
+  else if (mode == MI355NDT_DIRECT26) { sc.K = 26; sc.table = 2; }
+  else { sc.K = 27; sc.table = 2; }            // KDTREE: 27-cell block + centroid radius test
 }
 
 static void gauss_constants(const mi355ndt_params& p, double& d1, double& d2) {
@@ -199,7 +200,7 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
   void* ptrs[] = {h->d_tgt_own, h->d_src_own, h->d_tgt_cnt, h->d_src_cnt, h->d_minmax, h->d_grid, h->d_nwords, h->d_word_off,
                   h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, h->d_tmp, h->d_words, h->d_recs, h->d_vox_idx, h->d_vox_n,
                   h->d_state, h->d_partials, h->d_guess, h->d_results, h->d_active, h->d_hook, h->d_aligned, h->d_hits, h->d_seg_start, h->d_sums,
-                  h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit, h->d_pf_in, h->d_pf_out, h->d_pf_keep, h->d_pf_keys,
+                  h->d_cent, h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit, h->d_pf_in, h->d_pf_out, h->d_pf_keep, h->d_pf_keys,
                   h->d_pf_vals, h->d_pf_flag, h->d_pf_pos, h->d_pf_mm, h->d_pf_grid, h->d_pf_tmp};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_pin_u) hipHostFree(h->h_pin_u);
@@ -414,7 +415,7 @@ int mi355ndt_profile_get(mi355ndt_handle* h, mi355ndt_profile* out) {
 int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   if (h->n_pairs <= 0 || !h->d_tgt) return MI355NDT_ERR_STATE;
-  if (h->prm.neighbor_mode == MI355NDT_KDTREE) return MI355NDT_ERR_UNSUPPORTED;
+  if (h->prm.neighbor_mode == MI355NDT_KDTREE && h->prm.variant == MI355NDT_VARIANT_PCA) return MI355NDT_ERR_UNSUPPORTED;
   HIPCHK(h, hipSetDevice(h->device));
   const int B = h->n_pairs;
   const size_t pitch = h->tgt_pitch;
@@ -440,8 +441,10 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
     if (h->d_vox_n) { HIPCHK(h, hipFree(h->d_vox_n)); h->d_vox_n = nullptr; }
     if (h->d_seg_start) { HIPCHK(h, hipFree(h->d_seg_start)); h->d_seg_start = nullptr; }
     if (h->d_sums) { HIPCHK(h, hipFree(h->d_sums)); h->d_sums = nullptr; }
+    if (h->d_cent) { HIPCHK(h, hipFree(h->d_cent)); h->d_cent = nullptr; }
     HIPCHK(h, grow(h->d_recs, c1, need)); HIPCHK(h, grow(h->d_vox_idx, c2, need)); HIPCHK(h, grow(h->d_vox_n, c3, need));
     HIPCHK(h, grow(h->d_seg_start, c4, need)); HIPCHK(h, grow(h->d_sums, c5, need * 9));
+    { size_t c6 = 0; HIPCHK(h, grow(h->d_cent, c6, need * 3)); }
     h->recs_cap = need; h->recs_per_pair = rpp;
   }
   const int pb = ceil_log2((unsigned)B);
@@ -488,7 +491,7 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
     k_rank<<<B, 256, 0, s>>>(h->d_grid, h->d_words);
     k_segstart<unsigned><<<dim3(gx, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, h->d_seg_start, minpts, cb);
     k_leafsum<unsigned><<<dim3(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start,
-                                                             h->d_sums, h->d_vox_idx, h->d_vox_n, cb);
+                                                             h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent);
   } else {
     typedef unsigned long long u64;
     k_keys<u64><<<dim3(gx, B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_grid, h->d_keys_a, h->d_vals_a, cb);
@@ -497,7 +500,7 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
     k_rank<<<B, 256, 0, s>>>(h->d_grid, h->d_words);
     k_segstart<u64><<<dim3(gx, B), 256, 0, s>>>(h->d_keys_b, pitch, h->d_grid, h->d_words, h->d_seg_start, minpts, cb);
     k_leafsum<u64><<<dim3(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, h->d_keys_b, h->d_vals_b, h->d_grid, h->d_seg_start,
-                                                        h->d_sums, h->d_vox_idx, h->d_vox_n, cb);
+                                                        h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent);
   }
   k_voxels<<<dim3((unsigned)((rpp + 255) / 256), B), 256, 0, s>>>(h->d_grid, h->d_sums, h->d_recs, h->d_vox_n,
                                                                   h->prm.min_covar_eigvalue_mult, h->prm.variant == MI355NDT_VARIANT_PCA);
@@ -535,6 +538,7 @@ static void make_sweep_const(const mi355ndt_handle* h, SweepConst& sc) {
   sc.d2f = (float)d2;                        // impl2:578
   sc.pca = h->prm.variant == MI355NDT_VARIANT_PCA;
   { int ex; float mant = std::frexp(h->prm.resolution, &ex); sc.leaf_pow2 = (mant == 0.5f) && ex > -100 && ex < 100; sc.inv_leaf = 1.0f / h->prm.resolution; }
+  sc.kd_r2 = (float)((double)h->prm.resolution * (double)h->prm.resolution);   // KdTreeFLANN::radiusSearch: float(radius * radius)
   build_offsets(h->prm.neighbor_mode, sc);
 }
 
@@ -543,9 +547,10 @@ static int launch_sweep(mi355ndt_handle* h, const SweepConst& sc) {
   const dim3 grid((unsigned)(h->n_cu * SWEEP_WPE));
   if (h->prof) HIPCHK(h, ev_begin(h, h->ev_sweep));
 #define NDT_LAUNCH_SWEEP(P, KK) k_sweep<P, KK><<<grid, SWEEP_THREADS, 0, h->stream>>>(h->d_src, h->src_pitch, h->d_state, h->d_grid, \
-      h->d_words, h->d_recs, h->d_partials, h->chunks_per_pair, h->d_active_list, h->d_ctl, sc)
+      h->d_words, h->d_recs, h->d_partials, h->chunks_per_pair, h->d_active_list, h->d_ctl, sc, h->d_cent)
   if (sc.pca) { if (sc.K == 1) NDT_LAUNCH_SWEEP(true, 1); else if (sc.K == 7) NDT_LAUNCH_SWEEP(true, 7); else NDT_LAUNCH_SWEEP(true, 26); }
-  else        { if (sc.K == 1) NDT_LAUNCH_SWEEP(false, 1); else if (sc.K == 7) NDT_LAUNCH_SWEEP(false, 7); else NDT_LAUNCH_SWEEP(false, 26); }
+  else        { if (sc.K == 1) NDT_LAUNCH_SWEEP(false, 1); else if (sc.K == 7) NDT_LAUNCH_SWEEP(false, 7); else if (sc.K == 26) NDT_LAUNCH_SWEEP(false, 26);
+                else NDT_LAUNCH_SWEEP(false, 27); }
 #undef NDT_LAUNCH_SWEEP
   if (h->prof) HIPCHK(h, ev_end(h, h->ev_sweep));
   return MI355NDT_OK;
@@ -555,7 +560,7 @@ int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_resu
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   if (!guesses || !out) return MI355NDT_ERR_BAD_ARG;
   if (h->n_pairs <= 0 || !h->d_tgt || !h->d_src) return MI355NDT_ERR_STATE;
-  if (h->prm.neighbor_mode == MI355NDT_KDTREE) return MI355NDT_ERR_UNSUPPORTED;
+  if (h->prm.neighbor_mode == MI355NDT_KDTREE && h->prm.variant == MI355NDT_VARIANT_PCA) return MI355NDT_ERR_UNSUPPORTED;
   if (!((h->prm.step_size - h->prm.trans_epsilon / 2) > 0)) return MI355NDT_ERR_UNSUPPORTED;   // impl2:888: live More-Thuente loop
   HIPCHK(h, hipSetDevice(h->device));
   if (!h->targets_built) { int rc = mi355ndt_batch_build_targets(h); if (rc) return rc; }
@@ -676,7 +681,7 @@ int mi355ndt_set_params(mi355ndt_handle* h, const mi355ndt_params* p) {
                       old.min_covar_eigvalue_mult != p->min_covar_eigvalue_mult;
   if (regrid && h->targets_built) {
     h->targets_built = false;
-    if (p->neighbor_mode != MI355NDT_KDTREE) return mi355ndt_batch_build_targets(h);   // setResolution -> init() (ndt_omp.h:126-136)
+    if (!(p->neighbor_mode == MI355NDT_KDTREE && p->variant == MI355NDT_VARIANT_PCA)) return mi355ndt_batch_build_targets(h);   // setResolution -> init() (ndt_omp.h:126-136)
   }
   return MI355NDT_OK;
 }
@@ -733,7 +738,7 @@ static int run_hook_sweep(mi355ndt_handle* h, double* score, double g[6], double
 
 static int hook_ready(mi355ndt_handle* h) {
   if (h->n_pairs < 1 || !h->have_target || !h->have_source) return MI355NDT_ERR_STATE;
-  if (h->prm.neighbor_mode == MI355NDT_KDTREE) return MI355NDT_ERR_UNSUPPORTED;
+  if (h->prm.neighbor_mode == MI355NDT_KDTREE && h->prm.variant == MI355NDT_VARIANT_PCA) return MI355NDT_ERR_UNSUPPORTED;
   HIPCHK(h, hipSetDevice(h->device));
   if (!h->targets_built) { int rc = mi355ndt_batch_build_targets(h); if (rc) return rc; }
   return prep_align_ws(h);

@@ -177,8 +177,9 @@ template <typename KeyT>
 __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restrict__ tgt, size_t pitch,
                                                            const KeyT* __restrict__ keys, const unsigned* __restrict__ vals,
                                                            const GridDesc* __restrict__ gd, const unsigned* __restrict__ seg_start,
-                                                           double* sums, int* vox_idx, int* vox_n, int cb) {
+                                                           double* sums, int* vox_idx, int* vox_n, int cb, float* cent) {
   __shared__ double term[LS_WAVES][64][9];
+  __shared__ float termf[LS_WAVES][64][3];
   const int b = blockIdx.y;
   const GridDesc& g = gd[b];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -190,6 +191,7 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restri
     const KeyT key = K[start];
     // accumulator order: S0 S1 S2 C00 C01 C02 C11 C12 C22 ; cov_ is seeded with Identity (voxel_grid_covariance_omp.h:101)
     double acc = (lane == 3 || lane == 6 || lane == 8) ? 1.0 : 0.0;
+    float accf = 0.f;                            // lanes 9..11: leaf.centroid += pt (f32, impl:242-243)
     int cnt = 0;
     for (size_t j0 = start;; j0 += 64) {
       const size_t j = j0 + lane;
@@ -201,14 +203,17 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restri
         double* t = term[wv][lane];
         t[0] = x; t[1] = y; t[2] = z;
         t[3] = x * x; t[4] = x * y; t[5] = x * z; t[6] = y * y; t[7] = y * z; t[8] = z * z;
+        termf[wv][lane][0] = X[pi]; termf[wv][lane][1] = X[pitch + pi]; termf[wv][lane][2] = X[2 * pitch + pi];
       }
       __builtin_amdgcn_wave_barrier();
       if (lane < 9) for (int l = 0; l < m; l++) acc += term[wv][l][lane];
+      else if (lane < 12) for (int l = 0; l < m; l++) accf += termf[wv][l][lane - 9];
       __builtin_amdgcn_wave_barrier();
       cnt += m;
       if (m < 64) break;
     }
     if (lane < 9) sums[(size_t)(g.rec_off + id) * 9 + lane] = acc;
+    else if (lane < 12) cent[(size_t)(g.rec_off + id) * 3 + (lane - 9)] = accf / (float)cnt;   // centroid /= nr_points (impl:289)
     if (lane == 0) {
       vox_idx[g.rec_off + id] = (int)((unsigned)key & ((1u << cb) - 1u));
       vox_n[g.rec_off + id] = cnt;

@@ -75,7 +75,8 @@ __device__ __forceinline__ void eval_hit(const float u[3], const float r[3], con
 __host__ __device__ constexpr int probe_off(int K, int q, int a) {
   const int o7[7][3] = {{0,0,0},{1,0,0},{-1,0,0},{0,1,0},{0,-1,0},{0,0,1},{0,0,-1}};
   const int o26[26][3] = {{-1,-1,-1}, {-1,0,-1}, {-1,1,-1}, {0,-1,-1}, {0,0,-1}, {0,1,-1}, {1,-1,-1}, {1,0,-1}, {1,1,-1}, {-1,-1,0}, {0,-1,0}, {1,-1,0}, {-1,0,0}, {1,1,1}, {1,0,1}, {1,-1,1}, {0,1,1}, {0,0,1}, {0,-1,1}, {-1,1,1}, {-1,0,1}, {-1,-1,1}, {1,1,0}, {0,1,0}, {-1,1,0}, {1,0,0}};
-  return K == 1 ? 0 : (K == 7 ? o7[q][a] : o26[q][a]);
+  // K == 27: the KDTREE emulation -- every cell of the 3x3x3 block around the point (centre included)
+  return K == 1 ? 0 : (K == 7 ? o7[q][a] : (K == 26 ? o26[q][a] : (a == 0 ? q % 3 - 1 : (a == 1 ? (q / 3) % 3 - 1 : q / 9 - 1))));
 }
 
 #define Q_CAP   512                       // per-wave hit queue (entries); >= 63 + 7*64
@@ -103,7 +104,13 @@ template <bool PCA, int K>
 __global__ void __launch_bounds__(SWEEP_THREADS, SWEEP_WPE)
 k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict__ st,
         const GridDesc* __restrict__ gd, const BitWord* __restrict__ words, const VoxelRec* __restrict__ recs,
-        double* partials, int chunks_per_pair, const int* __restrict__ active_list, SweepCtl* ctl, SweepConst sc) {
+        double* partials, int chunks_per_pair, const int* __restrict__ active_list, SweepCtl* ctl, SweepConst sc,
+        const float* __restrict__ cent) {
+  // K == 27 is the KDTREE mode (ndt_omp_impl2.hpp:251-253): radiusSearch(point, resolution) over the f32 centroids of the
+  // searchable leaves (voxel_grid_covariance_omp.h:505-534).  A centroid lies inside its own cell, so every centroid closer
+  // than one leaf sits in the 3x3x3 block around the point's cell: probe those 27 cells and keep d^2 < float(r*r).  The
+  // reference does not re-check nr_points there, so eigen/inverse-failed leaves DO take part (their icov is zero / non-finite).
+  constexpr bool KD = (K == 27);
   // Persistent waves pulling work items.  One item = one wave-quarter (CHUNK_PTS/4 consecutive points) of one chunk
   // of one active pair; every wave is independent (own LDS queue, own partial row, no block barrier), so a wave
   // whose points have few hits simply takes the next item instead of idling at a barrier.
@@ -182,7 +189,7 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
       double w = 1.0;
       if (PCA) w = q_w[wv][(qhead + k) & (Q_CAP - 1)];
       // ndt_omp: leaves with nr_points = -1 (eigen / inverse failure) are not neighbours (impl:395): filtered here
-      const bool live = lane < m && (PCA || vr.weight != VOX_DEAD);
+      const bool live = lane < m && (PCA || KD || vr.weight != VOX_DEAD);
       float u[3] = {(float)((double)xt0 - m0), (float)((double)xt1 - m1), (float)((double)xt2 - m2)};   // impl2:276-279, 574
       eval_hit<PCA>(u, r, Cf, sc.d1, sc.d2f, w, live, acc);
       nhits += PCA ? (unsigned)m : (unsigned)__popcll(__ballot(live));
@@ -261,6 +268,11 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
             // ndt_omp filters dead leaves in phase B instead and saves this dependent L2 round trip
             wiv[j] = ((long long)t < 0) ? 1 : VOX_DEAD;
             if (PCA) { if ((long long)t < 0) wiv[j] = R[idv[j]].weight; }
+            if (KD && (long long)t < 0) {                     // FLANN L2_Simple distance to the leaf's f32 centroid
+              const float* cp = cent + 3 * (size_t)(g.rec_off + idv[j]);
+              const float dx = xt[0] - cp[0], dy = xt[1] - cp[1], dz = xt[2] - cp[2];
+              if (!(((dx * dx + dy * dy) + dz * dz) < sc.kd_r2)) wiv[j] = VOX_DEAD;
+            }
           }
 #pragma unroll
           for (int j = 0; j < Q_GROUP; j++) {

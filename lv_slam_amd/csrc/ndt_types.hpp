@@ -63,6 +63,7 @@ struct SweepConst {
   int    K;                    // neighbour probes
   int    pca;
   int    table;                // row of c_off: 0 = DIRECT1, 1 = DIRECT7, 2 = DIRECT26
+  float  kd_r2;                // KDTREE: float(resolution * resolution), the squared search radius
   int    leaf_pow2;            // resolution is a power of two: x / leaf == x * inv_leaf bit for bit
   float  inv_leaf;
 };

@@ -433,15 +433,19 @@ ora_grid* ora_grid_build(const float* x, const float* y, const float* z, size_t 
     /* Leaf ctor: mean_ = 0, cov_ = Identity, icov_ = 0 (voxel_grid_covariance_omp.h:97-106) */
     double S[3] = {0, 0, 0};
     double C[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    float cen[3] = {0.f, 0.f, 0.f};                                  /* leaf.centroid (f32), impl:229-230 */
     int cnt = 0;
     for (size_t k = s; k < e; k++) {
       size_t i = kp[k].pos;
       double p3[3] = {(double)x[i], (double)y[i], (double)z[i]};
       for (int a = 0; a < 3; a++) S[a] += p3[a];                       /* impl:235 */
       for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) C[a * 3 + b] += p3[a] * p3[b]; /* impl:237 */
+      cen[0] += x[i]; cen[1] += y[i]; cen[2] += z[i];                  /* impl:242-243 */
       cnt++;
     }
     L->n = cnt;
+    L->n_pushed = cnt;                                               /* what voxel_centroids_ saw (impl:297-302) */
+    for (int a = 0; a < 3; a++) L->centroid[a] = cen[a] / (float)cnt;   /* impl:289 */
     double mu[3];
     for (int a = 0; a < 3; a++) mu[a] = S[a] / (double)cnt;            /* impl:293 */
     memcpy(L->mean, mu, sizeof mu);
@@ -537,7 +541,7 @@ static int build_offsets(int mode, int off[26][3]) {
     for (int i = 0; i < 13; i++) { off[13 + i][0] = -off[i][0]; off[13 + i][1] = -off[i][1]; off[13 + i][2] = -off[i][2]; }
     return 26;
   }
-  return 0; /* KDTREE: not restated (dead in shipped configs) */
+  return 0; /* KDTREE: handled by radius_search() */
 }
 
 /* -------------------------------------------------- one (point, voxel) evaluation */
@@ -595,6 +599,30 @@ static double eval_hit(const float u[3], const float r[3], const float C[9], dou
 
 #define CHUNK 256
 
+/* VoxelGridCovariance::radiusSearch (voxel_grid_covariance_omp.h:505-534): FLANN radius query over the f32 centroids of
+ * the leaves that had >= min_points points when applyFilter pushed them (impl:297-302), squared radius float(r*r), strict
+ * '<', results sorted by distance; NO nr_points re-check, so eigen/inverse-failed leaves are returned too.
+ * Brute force here.  Returns the number of neighbours (<= cap). */
+typedef struct { float d2; int li; } kd_hit;
+static int cmp_kd(const void* a, const void* b) {
+  const kd_hit* A = (const kd_hit*)a; const kd_hit* B = (const kd_hit*)b;
+  if (A->d2 != B->d2) return A->d2 < B->d2 ? -1 : 1;
+  return A->li < B->li ? -1 : (A->li > B->li);
+}
+static int radius_search(const ora_grid* g, const float q[3], double radius, kd_hit* out, int cap) {
+  const float r2 = (float)(radius * radius);
+  int k = 0;
+  for (size_t i = 0; i < g->n_leaves; i++) {
+    const ora_leaf* L = &g->leaves[i];
+    if (L->n_pushed < g->min_points) continue;
+    float dx = q[0] - L->centroid[0], dy = q[1] - L->centroid[1], dz = q[2] - L->centroid[2];
+    float d2 = (dx * dx + dy * dy) + dz * dz;
+    if (d2 < r2 && k < cap) { out[k].d2 = d2; out[k].li = (int)i; k++; }
+  }
+  qsort(out, k, sizeof(kd_hit), cmp_kd);
+  return k;
+}
+
 long ora_derivatives(const ora_grid* g, const ora_params* prm,
                      const float* x, const float* y, const float* z, size_t n,
                      const float T[16], const float Rj[9],
@@ -627,13 +655,25 @@ long ora_derivatives(const ora_grid* g, const ora_params* prm,
       /* getNeighborhoodAtPoint, voxel_grid_covariance_omp_impl.hpp:379-399 */
       int ijk[3] = {(int)floorf(xt[0] / g->leaf[0]), (int)floorf(xt[1] / g->leaf[1]), (int)floorf(xt[2] / g->leaf[2])};
       double s_pt = 0, g_pt[6] = {0}, H_pt[36] = {0};
-      for (int k = 0; k < K; k++) {
-        int c3[3] = {ijk[0] + off[k][0], ijk[1] + off[k][1], ijk[2] + off[k][2]};
-        if (c3[0] < g->min_b[0] || c3[0] > g->max_b[0] || c3[1] < g->min_b[1] || c3[1] > g->max_b[1] ||
-            c3[2] < g->min_b[2] || c3[2] > g->max_b[2]) continue;
-        int32_t idx = (c3[0] - g->min_b[0]) * g->mul[0] + (c3[1] - g->min_b[1]) * g->mul[1] + (c3[2] - g->min_b[2]) * g->mul[2];
-        const ora_leaf* L = grid_find(g, idx);
-        if (!L || L->n < g->min_points) continue;
+      const ora_leaf* nb[64];
+      int nnb = 0;
+      if (prm->neighbor_mode == ORA_KDTREE) {                      /* impl2:251-253 */
+        kd_hit hits[64];
+        int kh = radius_search(g, xt, (double)prm->resolution, hits, 64);
+        for (int k = 0; k < kh; k++) nb[nnb++] = &g->leaves[hits[k].li];
+      } else {
+        for (int k = 0; k < K; k++) {
+          int c3[3] = {ijk[0] + off[k][0], ijk[1] + off[k][1], ijk[2] + off[k][2]};
+          if (c3[0] < g->min_b[0] || c3[0] > g->max_b[0] || c3[1] < g->min_b[1] || c3[1] > g->max_b[1] ||
+              c3[2] < g->min_b[2] || c3[2] > g->max_b[2]) continue;
+          int32_t idx = (c3[0] - g->min_b[0]) * g->mul[0] + (c3[1] - g->min_b[1]) * g->mul[1] + (c3[2] - g->min_b[2]) * g->mul[2];
+          const ora_leaf* L = grid_find(g, idx);
+          if (!L || L->n < g->min_points) continue;
+          nb[nnb++] = L;
+        }
+      }
+      for (int k = 0; k < nnb; k++) {
+        const ora_leaf* L = nb[k];
         /* impl2:276-281, 574-576 */
         float u[3], Cf[9];
         for (int a = 0; a < 3; a++) u[a] = (float)((double)xt[a] - L->mean[a]);

@@ -52,6 +52,8 @@ typedef struct {
   int32_t label;      /* ndt_pca dimension_label_ (1/2/3), 0 if not computed */
   int32_t weight;     /* ndt_pca (int)dimension_2d_  */
   double  dim2d;      /* ndt_pca dimension_2d_ */
+  float   centroid[3];/* f32 centroid (impl:242-243, 289), the point voxel_centroids_ / the kd-tree holds */
+  int32_t n_pushed;   /* nr_points when applyFilter decided to push the centroid (before any -1 flag) */
 } ora_leaf;
 
 typedef struct ora_grid ora_grid;

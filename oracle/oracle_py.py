@@ -26,7 +26,8 @@ class Params(C.Structure):
 class Leaf(C.Structure):
     _fields_ = [("idx", C.c_int32), ("n", C.c_int32), ("mean", C.c_double * 3), ("cov", C.c_double * 9),
                 ("icov", C.c_double * 9), ("evals", C.c_double * 3), ("evecs", C.c_double * 9),
-                ("label", C.c_int32), ("weight", C.c_int32), ("dim2d", C.c_double)]
+                ("label", C.c_int32), ("weight", C.c_int32), ("dim2d", C.c_double), ("centroid", C.c_float * 3),
+                ("n_pushed", C.c_int32)]
 
 
 class Result(C.Structure):
@@ -132,7 +133,8 @@ class Grid:
         arr = lib().ora_grid_leaves(self.h)
         buf = np.ctypeslib.as_array(C.cast(arr, C.POINTER(C.c_uint8)), shape=(n * C.sizeof(Leaf),))
         dt = np.dtype([("idx", "<i4"), ("n", "<i4"), ("mean", "<f8", 3), ("cov", "<f8", 9), ("icov", "<f8", 9),
-                       ("evals", "<f8", 3), ("evecs", "<f8", 9), ("label", "<i4"), ("weight", "<i4"), ("dim2d", "<f8")])
+                       ("evals", "<f8", 3), ("evecs", "<f8", 9), ("label", "<i4"), ("weight", "<i4"), ("dim2d", "<f8"),
+                       ("centroid", "<f4", 3), ("n_pushed", "<i4")])
         assert dt.itemsize == C.sizeof(Leaf)
         return np.frombuffer(buf.tobytes(), dtype=dt)
 

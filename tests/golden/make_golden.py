@@ -83,7 +83,7 @@ def se3_log(M):
 
 # ----------------------------------------------------------------------------- voxel grid
 class Leaf:
-    __slots__ = ("n", "S", "C", "mean", "cov", "icov", "evals", "label", "weight", "dim2d")
+    __slots__ = ("n", "S", "C", "mean", "cov", "icov", "evals", "label", "weight", "dim2d", "cen", "n_pushed")
 
     def __init__(self):
         self.n = 0
@@ -93,6 +93,8 @@ class Leaf:
         self.label = 0
         self.weight = 0
         self.dim2d = 0.0
+        self.cen = np.zeros(3, f32)   # leaf.centroid, f32 running sum (vgc:229-230, 242-243)
+        self.n_pushed = 0
 
 
 def build_grid(pts, resolution, min_points=6, eig_mult=0.01, pca=False):
@@ -118,10 +120,13 @@ def build_grid(pts, resolution, min_points=6, eig_mult=0.01, pca=False):
         p3 = p.astype(f64)
         L.S = L.S + p3                                     # vgc:235
         L.C = L.C + np.outer(p3, p3)                       # vgc:237
+        L.cen = (L.cen + p).astype(f32)                    # vgc:242-243
         L.n += 1
     for idx in sorted(leaves):                             # std::map order, vgc:282
         L = leaves[idx]
         L.mean = L.S / L.n                                 # vgc:293
+        L.cen = (L.cen / f32(L.n)).astype(f32)             # vgc:289
+        L.n_pushed = L.n                                   # what voxel_centroids_ sees (vgc:297-302)
         if L.n >= min_points:
             cov = (L.C - 2 * np.outer(L.S, L.mean)) / L.n + np.outer(L.mean, L.mean)    # vgc:329
             cov = cov * ((L.n - 1.0) / L.n)                                             # vgc:330
@@ -163,8 +168,26 @@ def neighbour_offsets(mode):
     raise ValueError(mode)
 
 
+def radius_search(grid, xt, radius):
+    """VoxelGridCovariance::radiusSearch (voxel_grid_covariance_omp.h:505-534): FLANN radius query over the f32
+    centroids of the leaves pushed by applyFilter (>= min_points at that time), squared radius float(r*r), strict '<',
+    sorted by distance; no nr_points re-check (eigen-failed leaves are returned)."""
+    cand = [L for k, L in sorted(grid["leaves"].items()) if L.n_pushed >= grid["min_points"]]
+    if not cand:
+        return []
+    cen = np.array([L.cen for L in cand], f32)
+    d = (xt[None, :].astype(f32) - cen).astype(f32)
+    d2 = ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(f32) + d[:, 2] * d[:, 2]).astype(f32)
+    r2 = f32(float(radius) * float(radius))
+    sel = np.nonzero(d2 < r2)[0]
+    sel = sel[np.argsort(d2[sel], kind="stable")]
+    return [cand[i] for i in sel]
+
+
 def neighbourhood(grid, xt, mode):
-    """vgc:373-404"""
+    """vgc:373-404 (DIRECT modes); omp:251-253 (KDTREE)"""
+    if mode == KDTREE:
+        return radius_search(grid, xt, float(grid["leaf"]))
     leaf = grid["leaf"]
     ijk = [int(np.floor(f32(xt[a] / leaf))) for a in range(3)]     # f32 divide, vgc:379-381
     out = []
@@ -360,9 +383,13 @@ def se3_vectors():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "kdtree":      # only the case added after the first fixtures were frozen
+        make_case("omp_kdtree_r1", pair=13, n_az=128, n_beams=32, resolution=1.0, mode=KDTREE, variant=0)
+        sys.exit(0)
     se3_vectors()
     make_case("omp_direct7_r1", pair=3, n_az=128, n_beams=32, resolution=1.0, mode=DIRECT7, variant=0)
     make_case("omp_direct1_r1", pair=5, n_az=128, n_beams=32, resolution=1.0, mode=DIRECT1, variant=0)
     make_case("omp_direct26_r2", pair=7, n_az=128, n_beams=32, resolution=2.0, mode=DIRECT26, variant=0, n_src_sweep=120, n_src_align=250)
     make_case("pca_direct7_r1", pair=9, n_az=128, n_beams=32, resolution=1.0, mode=DIRECT7, variant=1)
     make_case("pca_direct1_r05", pair=11, n_az=256, n_beams=32, resolution=0.5, mode=DIRECT1, variant=1)
+    make_case("omp_kdtree_r1", pair=13, n_az=128, n_beams=32, resolution=1.0, mode=KDTREE, variant=0)

@@ -14,7 +14,7 @@ from oracle import oracle_py as O
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["omp_direct7_r1", "omp_direct1_r1", "omp_direct26_r2", "pca_direct7_r1", "pca_direct1_r05"]
+CASES = ["omp_direct7_r1", "omp_direct1_r1", "omp_direct26_r2", "pca_direct7_r1", "pca_direct1_r05", "omp_kdtree_r1"]
 FIELDS = ["resolution", "step_size", "outlier_ratio", "trans_epsilon", "max_iterations", "neighbor_mode", "variant",
           "min_points_per_voxel", "min_covar_eigvalue_mult"]
 
@@ -102,7 +102,7 @@ def test_golden_voxels_sweep_align(golden_dir, name):
     assert np.array_equal(out, exp.astype(np.float32))
 
 
-@pytest.mark.parametrize("mode,variant,res", [(ndt.DIRECT7, 0, 1.0), (ndt.DIRECT1, 1, 1.0), (ndt.DIRECT7, 1, 0.5)])
+@pytest.mark.parametrize("mode,variant,res", [(ndt.DIRECT7, 0, 1.0), (ndt.DIRECT1, 1, 1.0), (ndt.DIRECT7, 1, 0.5), (ndt.KDTREE, 0, 1.0)])
 def test_full_size_pair_vs_oracle(mode, variant, res):
     """BASELINE config 2 (65,536-pt pair, HIP path, SE(3) checked against the CPU restatement) + the nodelet's
     pca/DIRECT1 setting + config 5's 0.5 m pca grid."""
@@ -181,8 +181,8 @@ def test_edge_cases():
         ndt.Engine(ndt.default_params(trans_epsilon=0.5, step_size=0.1)).align(G) if False else \
             _align_with(ndt.default_params(trans_epsilon=0.5, step_size=0.1), tgt, src, G)
     assert e.value.code == -6
-    with pytest.raises(ndt.NDTError) as e:
-        _align_with(ndt.default_params(neighbor_mode=ndt.KDTREE), tgt, src, G)
+    with pytest.raises(ndt.NDTError) as e:      # KDTREE is emulated for ndt_omp only (ndt_pca needs FLANN's result order)
+        _align_with(ndt.default_params(neighbor_mode=ndt.KDTREE, variant=ndt.VARIANT_PCA), tgt, src, G)
     assert e.value.code == -6
     # stride: PointXYZI-style 32-byte records
     rec = np.zeros((len(tgt), 8), np.float32)
