@@ -47,6 +47,7 @@ struct mi355ndt_handle {
   int *d_tgt_cnt = nullptr, *d_src_cnt = nullptr;
   std::vector<int> h_tgt_cnt, h_src_cnt;
   bool targets_built = false, have_target = false, have_source = false;
+  bool cent_built = false;                        // last target build also produced the f32 leaf centroids (KDTREE mode)
 
   // build workspace
   int* d_minmax = nullptr;
@@ -482,6 +483,8 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
   }
   if (total_words) HIPCHK(h, hipMemsetAsync(h->d_words, 0, total_words * sizeof(BitWord), s));
   const int lb = std::max(1, std::min((int)((rpp + LS_WAVES - 1) / LS_WAVES), std::max(8, 8192 / B)));
+  const bool want_cent = h->prm.neighbor_mode == MI355NDT_KDTREE;      // f32 leaf centroids are only read by the KDTREE probe
+  h->cent_built = want_cent;
   tb = h->tmp_bytes;
   if (k32) {
     unsigned *ka = (unsigned*)h->d_keys_a, *kb = (unsigned*)h->d_keys_b;
@@ -490,8 +493,10 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
     k_mark<unsigned><<<dim3(gx, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, minpts, cb);
     k_rank<<<B, 256, 0, s>>>(h->d_grid, h->d_words);
     k_segstart<unsigned><<<dim3(gx, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, h->d_seg_start, minpts, cb);
-    k_leafsum<unsigned><<<dim3(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start,
-                                                             h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent);
+    if (want_cent) k_leafsum<unsigned, true><<<dim3(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start,
+                                                                                    h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent);
+    else k_leafsum<unsigned, false><<<dim3(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start,
+                                                                          h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent);
   } else {
     typedef unsigned long long u64;
     k_keys<u64><<<dim3(gx, B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_grid, h->d_keys_a, h->d_vals_a, cb);
@@ -499,8 +504,10 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
     k_mark<u64><<<dim3(gx, B), 256, 0, s>>>(h->d_keys_b, pitch, h->d_grid, h->d_words, minpts, cb);
     k_rank<<<B, 256, 0, s>>>(h->d_grid, h->d_words);
     k_segstart<u64><<<dim3(gx, B), 256, 0, s>>>(h->d_keys_b, pitch, h->d_grid, h->d_words, h->d_seg_start, minpts, cb);
-    k_leafsum<u64><<<dim3(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, h->d_keys_b, h->d_vals_b, h->d_grid, h->d_seg_start,
-                                                        h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent);
+    if (want_cent) k_leafsum<u64, true><<<dim3(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, h->d_keys_b, h->d_vals_b, h->d_grid, h->d_seg_start,
+                                                                               h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent);
+    else k_leafsum<u64, false><<<dim3(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, h->d_keys_b, h->d_vals_b, h->d_grid, h->d_seg_start,
+                                                                     h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent);
   }
   k_voxels<<<dim3((unsigned)((rpp + 255) / 256), B), 256, 0, s>>>(h->d_grid, h->d_sums, h->d_recs, h->d_vox_n,
                                                                   h->prm.min_covar_eigvalue_mult, h->prm.variant == MI355NDT_VARIANT_PCA);
@@ -678,7 +685,8 @@ int mi355ndt_set_params(mi355ndt_handle* h, const mi355ndt_params* p) {
   h->prm = *p;
   const bool regrid = old.resolution != p->resolution || old.variant != p->variant ||
                       old.min_points_per_voxel != p->min_points_per_voxel ||
-                      old.min_covar_eigvalue_mult != p->min_covar_eigvalue_mult;
+                      old.min_covar_eigvalue_mult != p->min_covar_eigvalue_mult ||
+                      (p->neighbor_mode == MI355NDT_KDTREE && !h->cent_built);      // KDTREE needs the centroids the build skipped
   if (regrid && h->targets_built) {
     h->targets_built = false;
     if (!(p->neighbor_mode == MI355NDT_KDTREE && p->variant == MI355NDT_VARIANT_PCA)) return mi355ndt_batch_build_targets(h);   // setResolution -> init() (ndt_omp.h:126-136)

@@ -173,13 +173,13 @@ __global__ void __launch_bounds__(256) k_segstart(const KeyT* __restrict__ keys,
 // order), parks the nine f64 terms of each point in LDS, and lanes 0..8 -- one per accumulator -- add them
 // strictly in input order, which keeps the sums bit-identical to the reference's sequential accumulation.
 #define LS_WAVES 4
-template <typename KeyT>
+template <typename KeyT, bool CENT>
 __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restrict__ tgt, size_t pitch,
                                                            const KeyT* __restrict__ keys, const unsigned* __restrict__ vals,
                                                            const GridDesc* __restrict__ gd, const unsigned* __restrict__ seg_start,
                                                            double* sums, int* vox_idx, int* vox_n, int cb, float* cent) {
   __shared__ double term[LS_WAVES][64][9];
-  __shared__ float termf[LS_WAVES][64][3];
+  __shared__ float termf[CENT ? LS_WAVES : 1][64][3];
   const int b = blockIdx.y;
   const GridDesc& g = gd[b];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -203,17 +203,28 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restri
         double* t = term[wv][lane];
         t[0] = x; t[1] = y; t[2] = z;
         t[3] = x * x; t[4] = x * y; t[5] = x * z; t[6] = y * y; t[7] = y * z; t[8] = z * z;
-        termf[wv][lane][0] = X[pi]; termf[wv][lane][1] = X[pitch + pi]; termf[wv][lane][2] = X[2 * pitch + pi];
+        if (CENT) { termf[wv][lane][0] = X[pi]; termf[wv][lane][1] = X[pitch + pi]; termf[wv][lane][2] = X[2 * pitch + pi]; }
       }
       __builtin_amdgcn_wave_barrier();
-      if (lane < 9) for (int l = 0; l < m; l++) acc += term[wv][l][lane];
-      else if (lane < 12) for (int l = 0; l < m; l++) accf += termf[wv][l][lane - 9];
+      if (lane < 9) {                            // strictly sequential adds (input order); the LDS reads are batched ahead of them
+        int l = 0;
+        for (; l + 8 <= m; l += 8) {
+          double t[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) t[u] = term[wv][l + u][lane];
+#pragma unroll
+          for (int u = 0; u < 8; u++) acc += t[u];
+        }
+        for (; l < m; l++) acc += term[wv][l][lane];
+      } else if (CENT && lane < 12) {
+        for (int l = 0; l < m; l++) accf += termf[wv][l][lane - 9];
+      }
       __builtin_amdgcn_wave_barrier();
       cnt += m;
       if (m < 64) break;
     }
     if (lane < 9) sums[(size_t)(g.rec_off + id) * 9 + lane] = acc;
-    else if (lane < 12) cent[(size_t)(g.rec_off + id) * 3 + (lane - 9)] = accf / (float)cnt;   // centroid /= nr_points (impl:289)
+    else if (CENT && lane < 12) cent[(size_t)(g.rec_off + id) * 3 + (lane - 9)] = accf / (float)cnt;   // centroid /= nr_points (impl:289)
     if (lane == 0) {
       vox_idx[g.rec_off + id] = (int)((unsigned)key & ((1u << cb) - 1u));
       vox_n[g.rec_off + id] = cnt;

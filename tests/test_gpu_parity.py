@@ -129,6 +129,40 @@ def test_full_size_pair_vs_oracle(mode, variant, res):
     assert dt < 0.1 and dr < 0.01, (dt, dr)
 
 
+def test_window_map_target_vs_oracle():
+    """`align` against a multi-scan "window map" (loop_detector.hpp:219, global_graph_nodelet.cpp:212-242):
+    target = 8 consecutive scans merged in the first scan's frame (524,288 pts, >> one scan), source = the next scan."""
+    scans, poses = synth.make_sequence(9, 1024)
+    P0i = np.linalg.inv(poses[0])
+    parts = []
+    for k in range(8):
+        M = (P0i @ poses[k]).astype(np.float32)
+        parts.append((scans[k].numpy() @ M[:3, :3].T + M[:3, 3]).astype(np.float32))
+    tgt = np.ascontiguousarray(np.concatenate(parts, axis=0))
+    src = scans[8].numpy()
+    true = P0i @ poses[8]
+    kw = dict(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=ndt.DIRECT7)
+    gp, op = both_params(**kw)
+    eng = ndt.Engine(gp)
+    grid = O.Grid(tgt, op)
+    eng.set_target(tgt)
+    assert check_voxels(eng, grid) > 2000
+    eng.set_source(src)
+    G = true.copy()
+    G[0, 3] += 0.4                                   # a loop-closure style guess: close, not exact
+    G = G.astype(np.float32)
+    p0 = O.se3_log(G.astype(np.float64))
+    check_sweep(eng.derivatives(p0), O.derivatives_at(grid, src, p0))
+    r, ro = eng.align(G), O.align(grid, src, G)
+    assert r["iterations"] == ro["iterations"] and r["converged"] == ro["converged"]
+    dt, dr = se3_err(ro["final"], r["final"])
+    assert dt < 1e-4 and dr < 1e-5, (dt, dr)
+    dt, dr = se3_err(true, r["final"])
+    assert dt < 0.1 and dr < 0.01, (dt, dr)
+    (fs, n_in), (fo, n_o) = eng.fitness_score(2.0), O.fitness_score(tgt, src, r["final"], 2.0)    # loop_detector.hpp:249-262
+    assert n_in == n_o and abs(fs - fo) <= 1e-12 * max(1.0, abs(fo))
+
+
 def test_identity_alignment_property():
     """identical clouds + identity guess => nothing to do: |delta| -> 0 within the 3-sweep minimum."""
     tgt, _, _ = synth.make_pair(2, 256)
@@ -219,6 +253,29 @@ def test_set_resolution_revoxelises():
     assert dt < 1e-4 and dr < 1e-5
     assert out.shape == src.shape
     assert abs(reg.getTransformationProbability() - ro["trans_probability"]) < 1e-9
+
+
+def test_switch_to_kdtree_after_target():
+    """setNeighborhoodSearchMethod(KDTREE) after setInputTarget (ndt_omp.h:162-164 just stores the enum; the reference's grid
+    always owns its kd-tree): the engine has to produce the leaf centroids it skipped for the DIRECT build."""
+    tgt, src, _ = synth.make_pair(6, 256, n_beams=32)
+    tgt, src = tgt.numpy(), src.numpy()
+    reg = ndt.NormalDistributionsTransform()
+    reg.setTransformationEpsilon(0.01)
+    reg.setMaximumIterations(64)
+    reg.setInputTarget(tgt)
+    reg.setInputSource(src)
+    reg.align(synth.default_guess())
+    it7 = reg.getFinalNumIteration()
+    reg.setNeighborhoodSearchMethod(ndt.KDTREE)
+    reg.align(synth.default_guess())
+    ro = O.align(O.Grid(tgt, O.default_params(trans_epsilon=0.01, max_iterations=64, neighbor_mode=O.KDTREE)), src, synth.default_guess())
+    assert reg.getFinalNumIteration() == ro["iterations"] and reg.hasConverged() == ro["converged"]
+    dt, dr = se3_err(ro["final"], reg.getFinalTransformation())
+    assert dt < 1e-4 and dr < 1e-5
+    reg.setNeighborhoodSearchMethod(ndt.DIRECT7)             # and back: same answer as before the detour
+    reg.align(synth.default_guess())
+    assert reg.getFinalNumIteration() == it7
 
 
 def test_batch_matches_single_and_oracle():
