@@ -31,8 +31,8 @@ MODES = {"direct1": 3, "direct7": 2, "direct26": 1}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=271, help="pairs per GPU per step (BASELINE config 3: 271)")
     ap.add_argument("--azimuth", type=int, default=1024, help="firings per revolution; x64 beams = points per cloud")
     ap.add_argument("--mode", default="direct7", choices=sorted(MODES))

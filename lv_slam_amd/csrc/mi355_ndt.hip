@@ -81,6 +81,7 @@ struct mi355ndt_handle {
   SweepCtl* d_ctl = nullptr;
   int n_cu = 256;
   int* h_pin_active = nullptr;
+  hipEvent_t ev_burst[2] = {nullptr, nullptr};   // one per in-flight burst of align rounds
   unsigned long long* d_hits = nullptr;         // (point,voxel) evaluations, all sweeps
   float* d_hook = nullptr;                      // 16 + 9 floats, 6 doubles
   float* d_aligned = nullptr; size_t aligned_cap = 0;
@@ -186,7 +187,9 @@ int mi355ndt_create(const mi355ndt_params* params, int device, mi355ndt_handle**
       hipMalloc((void**)&h->d_active, 128 * sizeof(int)) != hipSuccess ||
       hipMalloc((void**)&h->d_ctl, sizeof(SweepCtl)) != hipSuccess ||
       hipMalloc((void**)&h->d_hits, sizeof(unsigned long long)) != hipSuccess ||
-      hipMalloc((void**)&h->d_hook, 64 * sizeof(double)) != hipSuccess) {
+      hipMalloc((void**)&h->d_hook, 64 * sizeof(double)) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_burst[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_burst[1], hipEventDisableTiming) != hipSuccess) {
     delete h;
     return MI355NDT_ERR_HIP;
   }
@@ -206,6 +209,7 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_pin_u) hipHostFree(h->h_pin_u);
   if (h->h_pin_active) hipHostFree(h->h_pin_active);
+  for (hipEvent_t e : h->ev_burst) if (e) hipEventDestroy(e);
   for (auto& e : h->ev_sweep) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   for (auto& e : h->ev_update) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   for (auto& e : h->ev_build) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -592,32 +596,50 @@ int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_resu
     h->P.sweep_alg_bytes += alg_static;                          // the initial sweep covers all pairs
     h->P.sweep_points += (long long)pts_total;
   }
-  const int burst = 2;                                           // update+sweep rounds enqueued between host checks
-  int round = 0;
-  while (round < max_rounds) {
-    HIPCHK(h, hipMemsetAsync(h->d_active, 0, 128 * sizeof(int), s));
-    const int r0 = round;
-    for (int k = 0; k < burst && round < max_rounds; k++, round++) {
+  // update+sweep rounds are enqueued in bursts of two; the host always keeps ONE burst queued ahead of the one whose
+  // "pairs still active" counters it is waiting for, so the device never idles over a host round trip.  The price is
+  // at most one speculative burst after the last pair finished (k_update / k_sweep return at once with nothing active).
+  const int burst = 2;
+  int round = 0, n_enq = 0;
+  int cnt[2] = {0, 0};                                           // rounds in the burst held by ring slot 0 / 1
+  auto enqueue_burst = [&]() -> int {
+    const int slot = n_enq & 1;
+    int* dact = h->d_active + slot * burst;
+    hipError_t e = hipMemsetAsync(dact, 0, burst * sizeof(int), s);
+    if (e != hipSuccess) return MI355NDT_ERR_HIP;
+    int k = 0;
+    for (; k < burst && round < max_rounds; k++, round++) {
       if (h->prof) HIPCHK(h, ev_begin(h, h->ev_update));
       HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, sizeof(SweepCtl), s));
-      k_update<<<B, 64, 0, s>>>(h->d_state, h->d_partials, h->chunks_per_pair, h->d_results, h->d_active + (round - r0),
+      k_update<<<B, 64, 0, s>>>(h->d_state, h->d_partials, h->chunks_per_pair, h->d_results, dact + k,
                                 h->d_active_list, h->d_ctl, h->prof ? h->d_hits : nullptr,
                                 h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations, 0);
       if (h->prof) HIPCHK(h, ev_end(h, h->ev_update));
-      rc = launch_sweep(h, sc);
-      if (rc) return rc;
+      int r = launch_sweep(h, sc);
+      if (r) return r;
     }
-    HIPCHK(h, hipMemcpyAsync(h->h_pin_active, h->d_active, burst * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipStreamSynchronize(s));
+    cnt[slot] = k;
+    HIPCHK(h, hipMemcpyAsync(h->h_pin_active + slot * burst, dact, burst * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipEventRecord(h->ev_burst[slot], s));
+    n_enq++;
+    return MI355NDT_OK;
+  };
+  rc = enqueue_burst();
+  if (rc) return rc;
+  for (int done = 0; done < n_enq; done++) {
+    if (round < max_rounds) { rc = enqueue_burst(); if (rc) return rc; }     // speculative: one burst ahead
+    const int slot = done & 1;
+    HIPCHK(h, hipEventSynchronize(h->ev_burst[slot]));
+    const int* act = h->h_pin_active + slot * burst;
     if (h->prof) {
       // sweep k of this burst streamed the pairs that scheduled a step in update k (equal-size pairs assumed)
-      for (int k = 0; k < round - r0; k++) {
-        const double frac = (double)h->h_pin_active[k] / B;
+      for (int k = 0; k < cnt[slot]; k++) {
+        const double frac = (double)act[k] / B;
         h->P.sweep_alg_bytes += alg_static * frac;
         h->P.sweep_points += (long long)(pts_total * frac);
       }
     }
-    if (h->h_pin_active[round - r0 - 1] == 0) break;
+    if (act[cnt[slot] - 1] == 0) break;
   }
   if (h->prof) {
     // one more reduction so the hits of the very last sweeps are counted is not needed: every sweep is
