@@ -40,7 +40,7 @@ extern "C" {
 #define MI355NDT_ERR_GRID        (-4)  /* target grid unusable: reference int32 guard
                                           (voxel_grid_covariance_omp_impl.hpp:75-84) or engine cell cap */
 #define MI355NDT_ERR_NO_DEVICE   (-5)
-#define MI355NDT_ERR_UNSUPPORTED (-6)  /* KDTREE with ndt_pca, or step_size <= trans_epsilon/2 (live More-Thuente loop) */
+#define MI355NDT_ERR_UNSUPPORTED (-6)  /* KDTREE neighbour search with ndt_pca (depends on FLANN's result order) */
 #define MI355NDT_ERR_STATE       (-7)  /* align/derivatives before target+source were set */
 
 /* pclomp::NeighborSearchMethod, include/ndt_omp/ndt_omp.h:51-56 (same enum order) */
@@ -66,7 +66,8 @@ typedef struct mi355ndt_result {
   double    score;                /* score of the last derivative sweep */
   int       iterations;           /* getFinalNumIteration()            (nr_iterations_) */
   int       converged;            /* hasConverged()                    (converged_) */
-  int       sweeps;               /* number of computeDerivatives passes executed (1 + steps taken) */
+  int       sweeps;               /* computeDerivatives passes (1 + steps taken); live More-Thuente case: the count the
+                                     reference makes -- repeated evaluations of an unchanged pose are reused, not re-run */
   int       status;               /* per-pair status: MI355NDT_OK or MI355NDT_ERR_GRID */
   long long hits_last;            /* (point,voxel) evaluations in the last sweep */
 } mi355ndt_result;
@@ -143,6 +144,10 @@ int mi355ndt_fitness_score_T(mi355ndt_handle* h, const float T_colmajor[16], dou
  * points transformed by float(exp(p)), Jacobian from the same matrix (impl2:900-907).
  * H is 6x6 row-major and NOT symmetric. */
 int mi355ndt_derivatives(mi355ndt_handle* h, const double p[6], double* score, double g[6], double H[36], long long* hits);
+/* computeHessian + updateHessian (ndt_omp_impl2.hpp:622-714) at tangent p: the f64 Hessian-only pass over kd-tree
+ * neighbourhoods that computeStepLengthMT runs after its More-Thuente loop iterated (impl2:999-1000; live only when
+ * step_size <= transformation_epsilon/2).  Cloud moved by float(exp(p)).  H is 6x6 row-major. */
+int mi355ndt_compute_hessian(mi355ndt_handle* h, const double p[6], double H[36]);
 /* same sweep with an explicit point transform (column-major 4x4) and Jacobian rotation (row-major 3x3),
  * i.e. the first sweep of align() where the cloud is moved by the caller's guess (impl2:102-129) */
 int mi355ndt_derivatives_T(mi355ndt_handle* h, const float T_colmajor[16], const float Rj_rowmajor[9],

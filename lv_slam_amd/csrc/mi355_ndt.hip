@@ -5,9 +5,9 @@
 //                   -> k_rank -> k_segstart -> k_leafsum -> k_voxels          (VoxelGridCovariance::applyFilter,
 //                   include/ndt_omp/voxel_grid_covariance_omp_impl.hpp:48-370)
 //   align         : k_init_state -> k_sweep -> [k_update -> k_sweep]*      (computeTransformation +
-//                   computeDerivatives + the live prefix of computeStepLengthMT,
-//                   include/ndt_omp/ndt_omp_impl2.hpp:87-188, 196-305, 841-907)
-// Kernels live in ndt_build.hpp / ndt_sweep.hpp / ndt_update.hpp / ndt_fitness.hpp / ndt_prefilter.hpp; this file is
+//                   computeDerivatives + computeStepLengthMT, include/ndt_omp/ndt_omp_impl2.hpp:87-188, 196-305, 841-1003;
+//                   step_size <= eps/2 only: [k_update -> k_hessian -> k_update -> k_sweep]*, impl2:622-714, 920-1000)
+// Kernels live in ndt_build.hpp / ndt_sweep.hpp / ndt_update.hpp / ndt_hessian.hpp / ndt_fitness.hpp / ndt_prefilter.hpp; this file is
 // the host side of the C-ABI (one translation unit).  Data layout in HBM: DESIGN.md.  Built with -ffp-contract=off: every f32/f64 step of the
 // reference recipe is a separately rounded operation.
 #include <hip/hip_runtime.h>
@@ -26,6 +26,7 @@
 #include "ndt_build.hpp"
 #include "ndt_sweep.hpp"
 #include "ndt_update.hpp"
+#include "ndt_hessian.hpp"
 #include "ndt_fitness.hpp"
 #include "ndt_prefilter.hpp"
 
@@ -47,6 +48,7 @@ struct mi355ndt_handle {
   int *d_tgt_cnt = nullptr, *d_src_cnt = nullptr;
   std::vector<int> h_tgt_cnt, h_src_cnt;
   bool targets_built = false, have_target = false, have_source = false;
+  bool icov64_built = false;                      // ... and the f64 inverse covariances computeHessian reads (live More-Thuente)
   bool cent_built = false;                        // last target build also produced the f32 leaf centroids (KDTREE mode)
 
   // build workspace
@@ -59,7 +61,7 @@ struct mi355ndt_handle {
   size_t keys_cap = 0;
   BitWord* d_words = nullptr; size_t words_cap = 0;
   VoxelRec* d_recs = nullptr; int *d_vox_idx = nullptr, *d_vox_n = nullptr;
-  unsigned* d_seg_start = nullptr; double* d_sums = nullptr; float* d_cent = nullptr;
+  unsigned* d_seg_start = nullptr; double* d_sums = nullptr; float* d_cent = nullptr; double* d_icov64 = nullptr; size_t icov64_cap = 0;
   unsigned *d_cstart = nullptr, *d_cend = nullptr; size_t cell_cap = 0; bool cells_ready = false; int last_cb = 0;
   double* d_fit = nullptr; size_t fit_cap = 0;
   // prefilter workspace
@@ -139,6 +141,9 @@ static int check_params(const mi355ndt_params& p) {
   return MI355NDT_OK;
 }
 
+// impl2:888: the More-Thuente loop (and computeHessian after it) runs iff !(step_max - step_min > 0), step_min = eps/2
+static bool mt_is_live(const mi355ndt_params& p) { return !((p.step_size - p.trans_epsilon / 2) > 0); }
+
 extern "C" {
 
 const char* mi355ndt_version(void) { return "mi355ndt 0.1 (gfx950)"; }
@@ -204,7 +209,7 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
   void* ptrs[] = {h->d_tgt_own, h->d_src_own, h->d_tgt_cnt, h->d_src_cnt, h->d_minmax, h->d_grid, h->d_nwords, h->d_word_off,
                   h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, h->d_tmp, h->d_words, h->d_recs, h->d_vox_idx, h->d_vox_n,
                   h->d_state, h->d_partials, h->d_guess, h->d_results, h->d_active, h->d_hook, h->d_aligned, h->d_hits, h->d_seg_start, h->d_sums,
-                  h->d_cent, h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit, h->d_pf_in, h->d_pf_out, h->d_pf_keep, h->d_pf_keys,
+                  h->d_cent, h->d_icov64, h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit, h->d_pf_in, h->d_pf_out, h->d_pf_keep, h->d_pf_keys,
                   h->d_pf_vals, h->d_pf_flag, h->d_pf_pos, h->d_pf_mm, h->d_pf_grid, h->d_pf_tmp};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_pin_u) hipHostFree(h->h_pin_u);
@@ -487,8 +492,11 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
   }
   if (total_words) HIPCHK(h, hipMemsetAsync(h->d_words, 0, total_words * sizeof(BitWord), s));
   const int lb = std::max(1, std::min((int)((rpp + LS_WAVES - 1) / LS_WAVES), std::max(8, 8192 / B)));
-  const bool want_cent = h->prm.neighbor_mode == MI355NDT_KDTREE;      // f32 leaf centroids are only read by the KDTREE probe
+  const bool mt_live = mt_is_live(h->prm);
+  const bool want_cent = h->prm.neighbor_mode == MI355NDT_KDTREE || mt_live;   // f32 leaf centroids: KDTREE probe, computeHessian
   h->cent_built = want_cent;
+  h->icov64_built = mt_live;
+  if (mt_live) HIPCHK(h, grow(h->d_icov64, h->icov64_cap, h->recs_cap * 9));
   tb = h->tmp_bytes;
   if (k32) {
     unsigned *ka = (unsigned*)h->d_keys_a, *kb = (unsigned*)h->d_keys_b;
@@ -514,7 +522,8 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
                                                                      h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent);
   }
   k_voxels<<<dim3((unsigned)((rpp + 255) / 256), B), 256, 0, s>>>(h->d_grid, h->d_sums, h->d_recs, h->d_vox_n,
-                                                                  h->prm.min_covar_eigvalue_mult, h->prm.variant == MI355NDT_VARIANT_PCA);
+                                                                  h->prm.min_covar_eigvalue_mult, h->prm.variant == MI355NDT_VARIANT_PCA,
+                                                                  mt_live ? h->d_icov64 : nullptr);
   HIPCHK(h, hipGetLastError());
   if (h->prof) {
     HIPCHK(h, ev_end(h, h->ev_build));
@@ -567,14 +576,22 @@ static int launch_sweep(mi355ndt_handle* h, const SweepConst& sc) {
   return MI355NDT_OK;
 }
 
+static void launch_hessian(mi355ndt_handle* h, const SweepConst& sc) {
+  double gc[3] = {0, 0, 0};
+  gauss_constants(h->prm, gc[0], gc[1]);
+  k_hessian<<<dim3((unsigned)h->chunks_per_pair, (unsigned)h->n_pairs), HESS_THREADS, 0, h->stream>>>(
+      h->d_src, h->src_pitch, h->d_state, h->d_grid, h->d_words, h->d_recs, h->d_icov64, h->d_cent, h->d_partials, h->chunks_per_pair,
+      gc[0], gc[1], sc.kd_r2, sc.leaf_pow2, sc.inv_leaf);
+}
+
 int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_result* out) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   if (!guesses || !out) return MI355NDT_ERR_BAD_ARG;
   if (h->n_pairs <= 0 || !h->d_tgt || !h->d_src) return MI355NDT_ERR_STATE;
   if (h->prm.neighbor_mode == MI355NDT_KDTREE && h->prm.variant == MI355NDT_VARIANT_PCA) return MI355NDT_ERR_UNSUPPORTED;
-  if (!((h->prm.step_size - h->prm.trans_epsilon / 2) > 0)) return MI355NDT_ERR_UNSUPPORTED;   // impl2:888: live More-Thuente loop
   HIPCHK(h, hipSetDevice(h->device));
-  if (!h->targets_built) { int rc = mi355ndt_batch_build_targets(h); if (rc) return rc; }
+  const bool mt_live = mt_is_live(h->prm);                       // impl2:888: More-Thuente loop + computeHessian are live
+  if (!h->targets_built || (mt_live && !h->icov64_built)) { int rc = mi355ndt_batch_build_targets(h); if (rc) return rc; }
   int rc = prep_align_ws(h);
   if (rc) return rc;
   const int B = h->n_pairs;
@@ -613,7 +630,13 @@ int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_resu
       HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, sizeof(SweepCtl), s));
       k_update<<<B, 64, 0, s>>>(h->d_state, h->d_partials, h->chunks_per_pair, h->d_results, dact + k,
                                 h->d_active_list, h->d_ctl, h->prof ? h->d_hits : nullptr,
-                                h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations, 0);
+                                h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations, 0, mt_live ? 1 : 0);
+      if (mt_live) {      // pairs whose More-Thuente loop iterated get their Hessian from computeHessian (impl2:999-1000)
+        launch_hessian(h, sc);
+        k_update<<<B, 64, 0, s>>>(h->d_state, h->d_partials, h->chunks_per_pair, h->d_results, dact + k,
+                                  h->d_active_list, h->d_ctl, nullptr,
+                                  h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations, 0, 2);
+      }
       if (h->prof) HIPCHK(h, ev_end(h, h->ev_update));
       int r = launch_sweep(h, sc);
       if (r) return r;
@@ -708,7 +731,8 @@ int mi355ndt_set_params(mi355ndt_handle* h, const mi355ndt_params* p) {
   const bool regrid = old.resolution != p->resolution || old.variant != p->variant ||
                       old.min_points_per_voxel != p->min_points_per_voxel ||
                       old.min_covar_eigvalue_mult != p->min_covar_eigvalue_mult ||
-                      (p->neighbor_mode == MI355NDT_KDTREE && !h->cent_built);      // KDTREE needs the centroids the build skipped
+                      ((p->neighbor_mode == MI355NDT_KDTREE || mt_is_live(*p)) && !h->cent_built) ||   // centroids the build skipped
+                      (mt_is_live(*p) && !h->icov64_built);
   if (regrid && h->targets_built) {
     h->targets_built = false;
     if (!(p->neighbor_mode == MI355NDT_KDTREE && p->variant == MI355NDT_VARIANT_PCA)) return mi355ndt_batch_build_targets(h);   // setResolution -> init() (ndt_omp.h:126-136)
@@ -754,7 +778,7 @@ static int run_hook_sweep(mi355ndt_handle* h, double* score, double g[6], double
   int rc = launch_sweep(h, sc);
   if (rc) return rc;
   k_update<<<1, 64, 0, h->stream>>>(h->d_state, h->d_partials, h->chunks_per_pair, h->d_results, h->d_active, h->d_active_list, h->d_ctl,
-                                    nullptr, 0, 0, 0, 1);
+                                    nullptr, 0, 0, 0, 1, 0);
   PairState S;
   HIPCHK(h, hipMemcpyAsync(&S, h->d_state, sizeof(PairState), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -783,8 +807,38 @@ int mi355ndt_derivatives(mi355ndt_handle* h, const double p[6], double* score, d
   HIPCHK(h, hipMemcpyAsync(dp, p, 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, sizeof(SweepCtl), h->stream));
-  k_set_pose_p<<<1, 1, 0, h->stream>>>(h->d_state, 0, dp, h->d_src_cnt, h->d_grid, h->d_active_list, h->d_ctl);
+  k_set_pose_p<<<1, 1, 0, h->stream>>>(h->d_state, 0, dp, h->d_src_cnt, h->d_grid, h->d_active_list, h->d_ctl, 0);
   return run_hook_sweep(h, score, g, H, hits);
+}
+
+int mi355ndt_compute_hessian(mi355ndt_handle* h, const double p[6], double H[36]) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (!p || !H) return MI355NDT_ERR_BAD_ARG;
+  int rc = hook_ready(h);
+  if (rc) return rc;
+  if (!h->cent_built || !h->icov64_built) {                       // the grid was built for a configuration that never needs it
+    const mi355ndt_params keep = h->prm;
+    h->prm.step_size = 0; h->prm.trans_epsilon = 0;               // "live" build flavour: centroids + f64 inverse covariances
+    rc = mi355ndt_batch_build_targets(h);
+    h->prm = keep;
+    if (rc) return rc;
+  }
+  double* dp = (double*)h->d_hook;
+  HIPCHK(h, hipMemcpyAsync(dp, p, 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, sizeof(SweepCtl), h->stream));
+  k_set_pose_p<<<1, 1, 0, h->stream>>>(h->d_state, 0, dp, h->d_src_cnt, h->d_grid, h->d_active_list, h->d_ctl, 1);
+  SweepConst sc;
+  make_sweep_const(h, sc);
+  launch_hessian(h, sc);
+  k_update<<<1, 64, 0, h->stream>>>(h->d_state, h->d_partials, h->chunks_per_pair, h->d_results, h->d_active, h->d_active_list, h->d_ctl,
+                                    nullptr, 0, 0, 0, 1, 2);
+  PairState S;
+  HIPCHK(h, hipMemcpyAsync(&S, h->d_state, sizeof(PairState), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipGetLastError());
+  memcpy(H, S.H, sizeof S.H);
+  return MI355NDT_OK;
 }
 
 int mi355ndt_derivatives_T(mi355ndt_handle* h, const float T[16], const float Rj[9], double* score, double g[6], double H[36], long long* hits) {

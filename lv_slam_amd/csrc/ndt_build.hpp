@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restri
 
 // second pass of applyFilter (impl:282-367; pca impl:364-397): one thread per searchable leaf
 __global__ void __launch_bounds__(256) k_voxels(const GridDesc* __restrict__ gd, const double* __restrict__ sums,
-                                                 VoxelRec* recs, int* vox_n, double eig_mult, int pca) {
+                                                 VoxelRec* recs, int* vox_n, double eig_mult, int pca, double* icov64) {
   const int b = blockIdx.y;
   const GridDesc& g = gd[b];
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -260,6 +260,7 @@ __global__ void __launch_bounds__(256) k_voxels(const GridDesc* __restrict__ gd,
   if (ev[0] < 0 || ev[1] < 0 || ev[2] <= 0) {                                    // impl:337-341
     n_out = -1;
     r.weight = VOX_DEAD;
+    if (icov64) for (int a = 0; a < 9; a++) icov64[(size_t)(g.rec_off + id) * 9 + a] = 0.0;   // icov_ stays at its Zero seed (h:103)
   } else {
     const double minev = eig_mult * ev[2];                                       // impl:345
     if (ev[0] < minev) {
@@ -286,6 +287,7 @@ __global__ void __launch_bounds__(256) k_voxels(const GridDesc* __restrict__ gd,
     bool bad = false;
     for (int a = 0; a < 9; a++) { if (!isfinite(ic[a])) bad = true; r.icov[a] = (float)ic[a]; }
     if (bad) { n_out = -1; r.weight = VOX_DEAD; }                                // impl:360-364
+    if (icov64) for (int a = 0; a < 9; a++) icov64[(size_t)(g.rec_off + id) * 9 + a] = ic[a];   // computeHessian reads icov_ in double
   }
   recs[g.rec_off + id] = r;
   vox_n[g.rec_off + id] = n_out;

@@ -222,6 +222,9 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
           xt[a] = ((T[a * 4 + 0] * px + T[a * 4 + 1] * py) + T[a * 4 + 2] * pz) + T[a * 4 + 3];
           r[a] = (Rj[a * 3 + 0] * px + Rj[a * 3 + 1] * py) + Rj[a * 3 + 2] * pz;
         }
+        // a non-finite moved point (NaN pose: only reachable through a NaN More-Thuente trial value) has no neighbours;
+        // the reference's float->int cast is undefined there
+        valid = valid && finite3(xt[0], xt[1], xt[2]);
         float* sp = stage[wv][slot];
         sp[0] = xt[0]; sp[1] = xt[1]; sp[2] = xt[2]; sp[3] = r[0]; sp[4] = r[1]; sp[5] = r[2];
         // getNeighborhoodAtPoint (voxel_grid_covariance_omp_impl.hpp:379-399): cell of the point, f32 divide

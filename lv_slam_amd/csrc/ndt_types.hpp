@@ -18,7 +18,7 @@
 #define MAX_CELLS      (1 << 25)
 
 enum { GRID_OK = 0, GRID_EMPTY = 1, GRID_OVERFLOW = 2, GRID_CAP = 3 };
-enum { PH_SWEEP0 = 0, PH_STEP = 1, PH_DONE = 2 };
+enum { PH_SWEEP0 = 0, PH_STEP = 1, PH_DONE = 2, PH_HESS = 3 };   // PH_HESS: waiting for the computeHessian pass (live More-Thuente only)
 
 struct GridDesc {              // one per target
   int   min_b[3], max_b[3], div_b[3];
@@ -55,6 +55,9 @@ struct PairState {
   long long hits;
   float  final_cm[16];
   int    it, phase, converged, sweeps, n_src, grid_status;
+  // live More-Thuente case only (step_size <= eps/2, impl2:888): tangent of the pending trial, phi(0), phi'(0)
+  double xt[6], phi0, dphi0;
+  int    mt_loops, pad_;
 };
 
 struct SweepConst {

@@ -41,7 +41,7 @@ __global__ void k_init_state(PairState* st, const float* __restrict__ guess_cm, 
   ndtm::se3_log(ndtm::se3_from_Rt(R, t), S.p);
   float Tdummy[12];
   ndtm::pose_to_f32(S.p, Tdummy, S.Rj);
-  S.it = 0; S.phase = PH_SWEEP0; S.converged = 0; S.sweeps = 1; S.a_t = 0; S.hits = 0; S.score = 0;
+  S.it = 0; S.phase = PH_SWEEP0; S.converged = 0; S.sweeps = 1; S.a_t = 0; S.hits = 0; S.score = 0; S.mt_loops = 0;
   S.n_src = src_cnt[b];
   S.grid_status = gd[b].status;
 }
@@ -56,27 +56,110 @@ __global__ void k_set_pose(PairState* st, int b, const float* __restrict__ T_cm,
   S.phase = PH_SWEEP0; S.n_src = src_cnt[b]; S.grid_status = gd[b].status; S.it = 0; S.sweeps = 1;
 }
 __global__ void k_set_pose_p(PairState* st, int b, const double* __restrict__ p, const int* __restrict__ src_cnt, const GridDesc* __restrict__ gd,
-                             int* active_list, SweepCtl* ctl) {
+                             int* active_list, SweepCtl* ctl, int for_hessian) {
   PairState& S = st[b];
   active_list[0] = b; ctl->n_active = 1;
   double pp[6];
-  for (int a = 0; a < 6; a++) pp[a] = p[a];
+  for (int a = 0; a < 6; a++) { pp[a] = p[a]; S.xt[a] = p[a]; }
   ndtm::pose_to_f32(pp, S.T, S.Rj);
-  S.phase = PH_SWEEP0; S.n_src = src_cnt[b]; S.grid_status = gd[b].status; S.it = 0; S.sweeps = 1;
+  S.phase = for_hessian ? PH_HESS : PH_SWEEP0; S.n_src = src_cnt[b]; S.grid_status = gd[b].status; S.it = 0; S.sweeps = 1;
+}
+
+// ---- More-Thuente pieces (impl2:717-838), live only when step_size <= eps/2 (impl2:888) -------------------------------
+// std::min / std::max as libstdc++ evaluates them: a NaN first argument is returned unchanged
+__device__ inline double mt_cmin(double a, double b) { return b < a ? b : a; }
+__device__ inline double mt_cmax(double a, double b) { return a < b ? b : a; }
+
+// updateIntervalMT (impl2:717-755); I = {a_l, f_l, g_l, a_u, f_u, g_u}
+__device__ inline bool mt_update_interval(double I[6], double a_t, double f_t, double g_t) {
+  if (f_t > I[1]) { I[3] = a_t; I[4] = f_t; I[5] = g_t; return false; }
+  if (g_t * (I[0] - a_t) > 0) { I[0] = a_t; I[1] = f_t; I[2] = g_t; return false; }
+  if (g_t * (I[0] - a_t) < 0) { I[3] = I[0]; I[4] = I[1]; I[5] = I[2]; I[0] = a_t; I[1] = f_t; I[2] = g_t; return false; }
+  return true;
+}
+
+// trialValueSelectionMT (impl2:758-838)
+__device__ inline double mt_trial_value(const double I[6], double a_t, double f_t, double g_t) {
+  const double a_l = I[0], f_l = I[1], g_l = I[2], a_u = I[3], f_u = I[4], g_u = I[5];
+  if (f_t > f_l) {
+    const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+    const double w = sqrt(z * z - g_t * g_l);
+    const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    const double a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t));
+    return fabs(a_c - a_l) < fabs(a_q - a_l) ? a_c : 0.5 * (a_q + a_c);
+  }
+  if (g_t * g_l < 0) {
+    const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+    const double w = sqrt(z * z - g_t * g_l);
+    const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+    return fabs(a_c - a_t) >= fabs(a_s - a_t) ? a_c : a_s;
+  }
+  if (fabs(g_t) <= fabs(g_l)) {
+    const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+    const double w = sqrt(z * z - g_t * g_l);
+    const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+    const double a_n = fabs(a_c - a_t) < fabs(a_s - a_t) ? a_c : a_s;
+    return a_t > a_l ? mt_cmin(a_t + 0.66 * (a_u - a_t), a_n) : mt_cmax(a_t + 0.66 * (a_u - a_t), a_n);
+  }
+  const double z = 3 * (f_t - f_u) / (a_t - a_u) - g_t - g_u;
+  const double w = sqrt(z * z - g_t * g_u);
+  return a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w);
+}
+
+// The loop of computeStepLengthMT (impl2:920-994) after the first trial's sweep has been reduced into S.score / S.g.
+// With step_max <= step_min every clamped trial value is step_min again (or NaN, which std::min/max let through), so the
+// reference re-sweeps an unchanged pose: those evaluations are reused here, not re-run (identical by determinism); a NaN
+// trial value means a NaN cloud, which has no neighbours (score, gradient = 0).  Returns step_iterations.
+__device__ inline int mt_loop(PairState& S, double step_max, double step_min) {
+  const double mu = 1.e-4, nu = 0.9;
+  const double phi_0 = S.phi0, d_phi_0 = S.dphi0;
+  // auxilaryFunction_PsiMT / dPsiMT (ndt_omp.h:480-496) at a = 0
+  double I[6] = {0, phi_0 - phi_0 - mu * d_phi_0 * 0.0, d_phi_0 - mu * d_phi_0, 0, phi_0 - phi_0 - mu * d_phi_0 * 0.0, d_phi_0 - mu * d_phi_0};
+  bool interval_converged = (step_max - step_min) > 0, open_interval = true;      // impl2:888
+  double a_t = S.a_t;
+  const double score_c = S.score;
+  double g_c[6];
+  for (int a = 0; a < 6; a++) g_c[a] = S.g[a];
+  double score = score_c, gd = 0;
+  for (int a = 0; a < 6; a++) gd += g_c[a] * S.dir[a];
+  double phi_t = -score, d_phi_t = -gd;
+  double psi_t = phi_t - phi_0 - mu * d_phi_0 * a_t, d_psi_t = d_phi_t - mu * d_phi_0;
+  int its = 0;
+  while (!interval_converged && its < 10 && !(psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) {
+    a_t = open_interval ? mt_trial_value(I, a_t, psi_t, d_psi_t) : mt_trial_value(I, a_t, phi_t, d_phi_t);
+    a_t = mt_cmax(mt_cmin(a_t, step_max), step_min);                             // impl2:936-937
+    if (a_t != a_t) { score = 0; gd = 0; } else { score = score_c; gd = 0; for (int a = 0; a < 6; a++) gd += g_c[a] * S.dir[a]; }
+    phi_t = -score; d_phi_t = -gd;
+    psi_t = phi_t - phi_0 - mu * d_phi_0 * a_t; d_psi_t = d_phi_t - mu * d_phi_0;
+    if (open_interval && (psi_t <= 0 && d_psi_t >= 0)) {                         // impl2:963-974
+      open_interval = false;
+      I[1] = I[1] + phi_0 - mu * d_phi_0 * I[0]; I[2] = I[2] + mu * d_phi_0;
+      I[4] = I[4] + phi_0 - mu * d_phi_0 * I[3]; I[5] = I[5] + mu * d_phi_0;
+    }
+    interval_converged = open_interval ? mt_update_interval(I, a_t, psi_t, d_psi_t) : mt_update_interval(I, a_t, phi_t, d_phi_t);
+    its++;
+  }
+  S.a_t = a_t;
+  return its;
 }
 
 // One wave per pair: fixed-order reduction of the chunk partials, then the body of the while loop of
-// computeTransformation (impl2:131-183) with computeStepLengthMT's live prefix (impl2:846-907).
+// computeTransformation (impl2:131-183) with computeStepLengthMT (impl2:841-1003).
+// mt = 0: step_size > eps/2, the More-Thuente loop is dead (every shipped configuration);
+// mt = 1: live case, called after a derivative sweep;  mt = 2: live case, called after the computeHessian pass.
 __global__ void __launch_bounds__(64)
 k_update(PairState* st, const double* __restrict__ partials, int chunks_per_pair, mi355ndt_result* results,
          int* active_counter, int* active_list, SweepCtl* ctl, unsigned long long* hits_total,
-         double step_max, double eps, int max_iterations, int reduce_only) {
+         double step_max, double eps, int max_iterations, int reduce_only, int mt) {
   const int b = blockIdx.x;
   PairState& S = st[b];
   if (S.phase == PH_DONE) return;
+  if (mt == 2 && S.phase != PH_HESS) return;                                     // only pairs whose Hessian pass just ran
   const int lane = threadIdx.x;
   const int nchunks = (S.n_src + CHUNK_PTS - 1) / CHUNK_PTS;
-  if (lane < NACC) {
+  if (lane < NACC && (mt != 2 || (lane >= 7 && lane < 43))) {
     double v = 0.0;
     const double* P = partials + (size_t)b * chunks_per_pair * QUARTERS * NACC + lane;
     for (int c = 0; c < nchunks; c++) {                                          // impl2:298-302 (fixed order)
@@ -92,6 +175,30 @@ k_update(PairState* st, const double* __restrict__ partials, int chunks_per_pair
   if (lane != 0 || reduce_only) return;
 
   const double step_min = eps / 2;
+  if (mt == 1 && S.phase == PH_STEP) {                                           // impl2:920-1000
+    const int its = mt_loop(S, step_max, step_min);
+    S.mt_loops += its;
+    S.sweeps += its;                                                             // computeDerivatives calls the reference makes
+    if (its) {
+      bool fin = S.a_t == S.a_t;
+      if (!fin) {                                                                // NaN trial value: NaN pose, nothing is hit
+        for (int a = 0; a < 6; a++) S.xt[a] = S.p[a] + S.dir[a] * S.a_t;
+        ndtm::pose_to_f32(S.xt, S.T, S.Rj);
+        for (int r = 0; r < 3; r++) {
+          for (int c = 0; c < 4; c++) S.final_cm[c * 4 + r] = S.T[r * 4 + c];
+          S.final_cm[r * 4 + 3] = 0.f;
+        }
+        S.final_cm[15] = 1.f;
+        S.score = 0; S.hits = 0;
+        for (int a = 0; a < 6; a++) S.g[a] = 0;
+        for (int a = 0; a < 36; a++) S.H[a] = 0;                                 // computeHessian over a NaN cloud
+      } else {
+        S.phase = PH_HESS;                                                       // impl2:999-1000: H comes from computeHessian
+        return;
+      }
+    }
+  }
+  if (S.phase == PH_HESS) S.phase = PH_STEP;
   if (S.phase == PH_STEP) {
     double dp[6], pn[6];
     for (int a = 0; a < 6; a++) dp[a] = S.dir[a] * S.a_t;                        // impl2:156
@@ -130,8 +237,10 @@ k_update(PairState* st, const double* __restrict__ partials, int chunks_per_pair
     a_t = a_t < step_max ? a_t : step_max;                                       // impl2:890-892
     a_t = a_t > step_min ? a_t : step_min;
     double xt[6];
-    for (int a = 0; a < 6; a++) { S.dir[a] = d[a]; xt[a] = S.p[a] + d[a] * a_t; }   // impl2:894
+    for (int a = 0; a < 6; a++) { S.dir[a] = d[a]; xt[a] = S.p[a] + d[a] * a_t; S.xt[a] = xt[a]; }   // impl2:894
     S.a_t = a_t;
+    S.phi0 = -S.score;                                                           // impl2:846
+    S.dphi0 = dphi0 >= 0 ? -dphi0 : dphi0;                                       // impl2:849, 860
     ndtm::pose_to_f32(xt, S.T, S.Rj);                                            // impl2:900
     for (int r = 0; r < 3; r++) {
       for (int c = 0; c < 4; c++) S.final_cm[c * 4 + r] = S.T[r * 4 + c];

@@ -61,7 +61,7 @@ SYMBOLS = [
     "mi355ndt_version", "mi355ndt_device_count", "mi355ndt_default_params", "mi355ndt_create", "mi355ndt_destroy",
     "mi355ndt_set_params", "mi355ndt_get_params", "mi355ndt_set_stream", "mi355ndt_last_error",
     "mi355ndt_set_target", "mi355ndt_set_source", "mi355ndt_align", "mi355ndt_get_aligned",
-    "mi355ndt_get_fitness_score", "mi355ndt_fitness_score_T", "mi355ndt_prefilter", "mi355ndt_use_prefiltered", "mi355ndt_derivatives", "mi355ndt_derivatives_T", "mi355ndt_get_grid", "mi355ndt_get_voxels",
+    "mi355ndt_get_fitness_score", "mi355ndt_fitness_score_T", "mi355ndt_prefilter", "mi355ndt_use_prefiltered", "mi355ndt_derivatives", "mi355ndt_compute_hessian", "mi355ndt_derivatives_T", "mi355ndt_get_grid", "mi355ndt_get_voxels",
     "mi355ndt_batch_reserve", "mi355ndt_batch_set_target", "mi355ndt_batch_set_source", "mi355ndt_batch_bind_device",
     "mi355ndt_batch_build_targets", "mi355ndt_batch_align", "mi355ndt_batch_size",
     "mi355ndt_profile_enable", "mi355ndt_profile_reset", "mi355ndt_profile_get", "mi355ndt_synchronize",
@@ -99,6 +99,7 @@ def load_library(path: str = LIB_PATH):
     L.mi355ndt_use_prefiltered.argtypes = [vp, i]
     L.mi355ndt_derivatives.argtypes = [vp, vp, vp, vp, vp, vp]
     L.mi355ndt_derivatives_T.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.mi355ndt_compute_hessian.argtypes = [vp, vp, vp]
     L.mi355ndt_get_grid.argtypes = [vp, i, vp, vp, vp, vp]
     L.mi355ndt_get_voxels.argtypes = [vp, i, vp, sz]
     L.mi355ndt_batch_reserve.argtypes = [vp, i, sz, sz]
@@ -240,6 +241,13 @@ class Engine:
         self._chk(self.lib.mi355ndt_derivatives(self.h, p.ctypes.data_as(C.c_void_p), C.byref(s), g.ctypes.data_as(C.c_void_p),
                                                 H.ctypes.data_as(C.c_void_p), C.byref(hits)), "derivatives")
         return s.value, g, H.reshape(6, 6), hits.value
+
+    def compute_hessian(self, p):
+        """computeHessian (ndt_omp_impl2.hpp:622-679) at tangent p -> H[6,6] f64."""
+        p = np.ascontiguousarray(p, np.float64)
+        H = np.zeros(36)
+        self._chk(self.lib.mi355ndt_compute_hessian(self.h, p.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p)), "compute_hessian")
+        return H.reshape(6, 6)
 
     def derivatives_T(self, T, Rj):
         t = _colmajor(T)

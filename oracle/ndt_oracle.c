@@ -649,6 +649,8 @@ long ora_derivatives(const ora_grid* g, const ora_params* prm,
       /* PCL 1.8 transformPointCloud scalar form */
       float xt[3];
       for (int a = 0; a < 3; a++) xt[a] = ((T[0 * 4 + a] * px + T[1 * 4 + a] * py) + T[2 * 4 + a] * pz) + T[3 * 4 + a];
+      if (!finite3(xt[0], xt[1], xt[2])) continue;   /* NaN pose (NaN More-Thuente trial value): the reference's float->int cast is
+                                                        UB there; canonical choice = such a point has no neighbours */
       /* impl2:507-508 : x_t = float(exp(p).matrix()) * (x,0) */
       float r[3];
       for (int a = 0; a < 3; a++) r[a] = (Rj[a * 3 + 0] * px + Rj[a * 3 + 1] * py) + Rj[a * 3 + 2] * pz;
@@ -716,15 +718,181 @@ long ora_derivatives_at(const ora_grid* g, const ora_params* prm,
   return ora_derivatives(g, prm, x, y, z, n, T, Rj, score, grad, hess);
 }
 
-/* computeTransformation, ndt_omp_impl2.hpp:87-188, with computeStepLengthMT's live
- * prefix (impl2:841-907) inlined.  `g` may be NULL (no target cells => zero hits). */
+/* computeHessian + updateHessian (ndt_omp_impl2.hpp:622-714): f64 throughout, kd-tree neighbourhoods whatever the search
+ * method is, point derivatives from the f64 overload (impl2:535-563: x_t = exp(p).matrix() * (x,0) in double).
+ * T = the f32 pose that produced trans_cloud, p = the tangent x_t handed to computeHessian.  Serial, point order. */
+void ora_compute_hessian(const ora_grid* g, const ora_params* prm,
+                         const float* x, const float* y, const float* z, size_t n,
+                         const float T[16], const double p[6], double H[36]) {
+  double gc[3];
+  ora_gauss_constants(prm->outlier_ratio, prm->resolution, gc);
+  const double d1 = gc[0], d2 = gc[1];
+  double M[16];
+  ora_se3_exp(p, M);
+  memset(H, 0, 36 * sizeof(double));
+  int finite_p = 1;
+  for (int a = 0; a < 6; a++) if (!isfinite(p[a])) finite_p = 0;
+  if (!finite_p) return;                                          /* NaN cloud: radiusSearch finds nothing */
+  for (size_t i = 0; i < n; i++) {
+    float px = x[i], py = y[i], pz = z[i];
+    if (!finite3(px, py, pz)) continue;
+    float xt[3];
+    for (int a = 0; a < 3; a++) xt[a] = ((T[0 * 4 + a] * px + T[1 * 4 + a] * py) + T[2 * 4 + a] * pz) + T[3 * 4 + a];
+    if (!finite3(xt[0], xt[1], xt[2])) continue;
+    const double X[3] = {(double)px, (double)py, (double)pz};
+    double r[3];
+    for (int a = 0; a < 3; a++) r[a] = (M[a * 4 + 0] * X[0] + M[a * 4 + 1] * X[1]) + M[a * 4 + 2] * X[2];
+    /* J (3x6): I | -[r]x pattern (impl2:544-549);  Hp(i,j) 3-vectors for i,j in 3..5 (impl2:555-563) */
+    double J[3][6] = {{1, 0, 0, 0, r[2], -r[1]}, {0, 1, 0, -r[2], 0, r[0]}, {0, 0, 1, r[1], -r[0], 0}};
+    double Hp[6][6][3];
+    memset(Hp, 0, sizeof Hp);
+    Hp[3][3][1] = -r[1]; Hp[3][3][2] = -r[2];
+    Hp[4][3][0] = r[1];
+    Hp[5][3][0] = r[2];
+    Hp[3][4][1] = r[0];
+    Hp[4][4][0] = -r[0]; Hp[4][4][2] = -r[2];
+    Hp[5][4][1] = r[2];
+    Hp[3][5][2] = r[0];
+    Hp[4][5][2] = r[1];
+    Hp[5][5][0] = -r[0]; Hp[5][5][1] = -r[1];
+    kd_hit hits[64];
+    int kh = radius_search(g, xt, (double)prm->resolution, hits, 64);
+    for (int k = 0; k < kh; k++) {
+      const ora_leaf* L = &g->leaves[hits[k].li];
+      double u[3];
+      for (int a = 0; a < 3; a++) u[a] = (double)xt[a] - L->mean[a];
+      const double* C = L->icov;
+      double Cu[3];
+      for (int a = 0; a < 3; a++) Cu[a] = (C[a * 3 + 0] * u[0] + C[a * 3 + 1] * u[1]) + C[a * 3 + 2] * u[2];
+      double e = d2 * exp(-d2 * ((u[0] * Cu[0] + u[1] * Cu[1]) + u[2] * Cu[2]) / 2);       /* impl2:691 */
+      if (e > 1 || e < 0 || e != e) continue;                                               /* impl2:694-695 */
+      e *= d1;
+      double CJ[6][3], uCJ[6];
+      for (int c = 0; c < 6; c++) {
+        for (int a = 0; a < 3; a++) CJ[c][a] = (C[a * 3 + 0] * J[0][c] + C[a * 3 + 1] * J[1][c]) + C[a * 3 + 2] * J[2][c];
+        uCJ[c] = (u[0] * CJ[c][0] + u[1] * CJ[c][1]) + u[2] * CJ[c][2];
+      }
+      for (int a = 0; a < 6; a++)
+        for (int b = 0; b < 6; b++) {
+          double CH[3];
+          for (int q = 0; q < 3; q++) CH[q] = (C[q * 3 + 0] * Hp[a][b][0] + C[q * 3 + 1] * Hp[a][b][1]) + C[q * 3 + 2] * Hp[a][b][2];
+          const double t2 = (u[0] * CH[0] + u[1] * CH[1]) + u[2] * CH[2];
+          const double t3 = (J[0][b] * CJ[a][0] + J[1][b] * CJ[a][1]) + J[2][b] * CJ[a][2];
+          H[a * 6 + b] += e * (-d2 * uCJ[a] * uCJ[b] + t2 + t3);                            /* impl2:709-711 */
+        }
+    }
+  }
+}
+
+/* std::min / std::max as the reference's libstdc++ evaluates them: a NaN first argument is returned unchanged */
+static double cmin(double a, double b) { return b < a ? b : a; }
+static double cmax(double a, double b) { return a < b ? b : a; }
+
+/* updateIntervalMT, impl2:717-755.  I = {a_l, f_l, g_l, a_u, f_u, g_u} */
+static int update_interval_mt(double I[6], double a_t, double f_t, double g_t) {
+  if (f_t > I[1]) { I[3] = a_t; I[4] = f_t; I[5] = g_t; return 0; }
+  if (g_t * (I[0] - a_t) > 0) { I[0] = a_t; I[1] = f_t; I[2] = g_t; return 0; }
+  if (g_t * (I[0] - a_t) < 0) { I[3] = I[0]; I[4] = I[1]; I[5] = I[2]; I[0] = a_t; I[1] = f_t; I[2] = g_t; return 0; }
+  return 1;
+}
+
+/* trialValueSelectionMT, impl2:758-838 */
+static double trial_value_mt(const double I[6], double a_t, double f_t, double g_t) {
+  const double a_l = I[0], f_l = I[1], g_l = I[2], a_u = I[3], f_u = I[4], g_u = I[5];
+  if (f_t > f_l) {
+    double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+    double w = sqrt(z * z - g_t * g_l);
+    double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    double a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t));
+    return fabs(a_c - a_l) < fabs(a_q - a_l) ? a_c : 0.5 * (a_q + a_c);
+  }
+  if (g_t * g_l < 0) {
+    double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+    double w = sqrt(z * z - g_t * g_l);
+    double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+    return fabs(a_c - a_t) >= fabs(a_s - a_t) ? a_c : a_s;
+  }
+  if (fabs(g_t) <= fabs(g_l)) {
+    double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+    double w = sqrt(z * z - g_t * g_l);
+    double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+    double a_n = fabs(a_c - a_t) < fabs(a_s - a_t) ? a_c : a_s;
+    return a_t > a_l ? cmin(a_t + 0.66 * (a_u - a_t), a_n) : cmax(a_t + 0.66 * (a_u - a_t), a_n);
+  }
+  double z = 3 * (f_t - f_u) / (a_t - a_u) - g_t - g_u;
+  double w = sqrt(z * z - g_t * g_u);
+  return a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w);
+}
+
+typedef struct {
+  const ora_grid* g; const ora_params* prm; const float *x, *y, *z; size_t n;
+  float* final_cm; long* hits; int* sweeps; int* mt_loops;
+} mt_ctx;
+
+/* computeStepLengthMT, impl2:841-1003, literal: every trial re-transforms and re-sweeps.  dir may be flipped in place. */
+static double step_length_mt(const mt_ctx* c, const double xv[6], double dir[6], double step_init, double step_max, double step_min,
+                             double* score, double grad[6], double H[36]) {
+  double phi_0 = -*score, d_phi_0 = 0;
+  for (int a = 0; a < 6; a++) d_phi_0 += grad[a] * dir[a];
+  d_phi_0 = -d_phi_0;                                             /* impl2:849 */
+  if (d_phi_0 >= 0) {
+    if (d_phi_0 == 0) return 0;                                   /* impl2:856-857: nothing re-evaluated */
+    d_phi_0 *= -1;
+    for (int a = 0; a < 6; a++) dir[a] *= -1;                     /* impl2:861-862 */
+  }
+  const double mu = 1.e-4, nu = 0.9;
+  /* auxilaryFunction_PsiMT(a, f_a, f_0, g_0, mu) = f_a - f_0 - mu*g_0*a ; dPsiMT(g_a, g_0, mu) = g_a - mu*g_0 (ndt_omp.h:480-496) */
+  double I[6] = {0, phi_0 - phi_0 - mu * d_phi_0 * 0.0, d_phi_0 - mu * d_phi_0, 0, phi_0 - phi_0 - mu * d_phi_0 * 0.0, d_phi_0 - mu * d_phi_0};
+  int interval_converged = (step_max - step_min) > 0, open_interval = 1;   /* impl2:888 */
+  double a_t = cmax(cmin(step_init, step_max), step_min);         /* impl2:890-892 */
+  double xt[6];
+  float T[16], Rj[9];
+  for (int a = 0; a < 6; a++) xt[a] = xv[a] + dir[a] * a_t;       /* impl2:894 */
+  pose_to_f32(xt, T, Rj);                                         /* impl2:900 */
+  memcpy(c->final_cm, T, sizeof T);
+  *c->hits = ora_derivatives(c->g, c->prm, c->x, c->y, c->z, c->n, T, Rj, score, grad, H);   /* impl2:903-907 */
+  (*c->sweeps)++;
+  double phi_t = -*score, d_phi_t = 0;
+  for (int a = 0; a < 6; a++) d_phi_t += grad[a] * dir[a];
+  d_phi_t = -d_phi_t;
+  double psi_t = phi_t - phi_0 - mu * d_phi_0 * a_t, d_psi_t = d_phi_t - mu * d_phi_0;
+  int step_iterations = 0;
+  while (!interval_converged && step_iterations < 10 && !(psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) {   /* impl2:920 */
+    a_t = open_interval ? trial_value_mt(I, a_t, psi_t, d_psi_t) : trial_value_mt(I, a_t, phi_t, d_phi_t);
+    a_t = cmax(cmin(a_t, step_max), step_min);                    /* impl2:936-937 */
+    for (int a = 0; a < 6; a++) xt[a] = xv[a] + dir[a] * a_t;
+    pose_to_f32(xt, T, Rj);
+    memcpy(c->final_cm, T, sizeof T);
+    *c->hits = ora_derivatives(c->g, c->prm, c->x, c->y, c->z, c->n, T, Rj, score, grad, H);  /* compute_hessian = false: */
+    memset(H, 0, 36 * sizeof(double));                                                        /* hessian.setZero() only   */
+    (*c->sweeps)++;
+    phi_t = -*score; d_phi_t = 0;
+    for (int a = 0; a < 6; a++) d_phi_t += grad[a] * dir[a];
+    d_phi_t = -d_phi_t;
+    psi_t = phi_t - phi_0 - mu * d_phi_0 * a_t; d_psi_t = d_phi_t - mu * d_phi_0;
+    if (open_interval && (psi_t <= 0 && d_psi_t >= 0)) {          /* impl2:963-974 */
+      open_interval = 0;
+      I[1] = I[1] + phi_0 - mu * d_phi_0 * I[0]; I[2] = I[2] + mu * d_phi_0;
+      I[4] = I[4] + phi_0 - mu * d_phi_0 * I[3]; I[5] = I[5] + mu * d_phi_0;
+    }
+    interval_converged = open_interval ? update_interval_mt(I, a_t, psi_t, d_psi_t) : update_interval_mt(I, a_t, phi_t, d_phi_t);
+    step_iterations++;
+  }
+  if (step_iterations) ora_compute_hessian(c->g, c->prm, c->x, c->y, c->z, c->n, T, xt, H);   /* impl2:999-1000 */
+  *c->mt_loops += step_iterations;
+  return a_t;
+}
+
+/* computeTransformation, ndt_omp_impl2.hpp:87-188 + computeStepLengthMT (impl2:841-1003; its loop and computeHessian are
+ * live iff step_size <= trans_epsilon/2). */
 int ora_align(const ora_grid* g, const ora_params* prm,
               const float* x, const float* y, const float* z, size_t n,
               const float guess[16], ora_result* out) {
   memset(out, 0, sizeof *out);
   const double eps = prm->trans_epsilon;
   const double step_max = prm->step_size, step_min = eps / 2;
-  if (!((step_max - step_min) > 0)) return -2;                     /* impl2:888: MT loop would be live */
   if (!g) return -3;
   /* final_transformation_ = guess (or Identity, same thing) impl2:102-108 */
   float T[16], Rj[9];
@@ -741,7 +909,8 @@ int ora_align(const ora_grid* g, const ora_params* prm,
   }
   double score, grad[6], H[36];
   long hits = ora_derivatives(g, prm, x, y, z, n, T, Rj, &score, grad, H);   /* impl2:129 */
-  int sweeps = 1, it = 0, converged = 0;
+  int sweeps = 1, it = 0, converged = 0, mt_loops = 0;
+  mt_ctx ctx = {g, prm, x, y, z, n, out->final_colmajor, &hits, &sweeps, &mt_loops};
   while (!converged) {
     double neg[6], dp[6];
     for (int a = 0; a < 6; a++) neg[a] = -grad[a];
@@ -752,29 +921,11 @@ int ora_align(const ora_grid* g, const ora_params* prm,
     if (nrm == 0 || nrm != nrm) {                                  /* impl2:147-152 */
       out->trans_probability = score / (double)n;
       out->converged = (nrm == nrm);
-      out->iterations = it; out->score = score; out->hits_last = hits; out->sweeps = sweeps;
+      out->iterations = it; out->score = score; out->hits_last = hits; out->sweeps = sweeps; out->mt_loops = mt_loops;
       return 0;
     }
     for (int a = 0; a < 6; a++) dp[a] /= nrm;                      /* normalize() impl2:154 */
-    /* computeStepLengthMT impl2:846-907 */
-    double dphi0 = 0;
-    for (int a = 0; a < 6; a++) dphi0 += grad[a] * dp[a];
-    dphi0 = -dphi0;
-    double a_t;
-    if (dphi0 >= 0 && dphi0 == 0) {
-      a_t = 0;                                                     /* impl2:856-857: return 0, nothing re-evaluated */
-    } else {
-      if (dphi0 >= 0) { for (int a = 0; a < 6; a++) dp[a] *= -1; } /* impl2:861-862 */
-      a_t = nrm;
-      a_t = a_t < step_max ? a_t : step_max;                       /* impl2:890-892 */
-      a_t = a_t > step_min ? a_t : step_min;
-      double xt[6];
-      for (int a = 0; a < 6; a++) xt[a] = p[a] + dp[a] * a_t;      /* impl2:894 */
-      pose_to_f32(xt, T, Rj);                                      /* impl2:900 */
-      memcpy(out->final_colmajor, T, sizeof T);
-      hits = ora_derivatives(g, prm, x, y, z, n, T, Rj, &score, grad, H);  /* impl2:903-907 */
-      sweeps++;
-    }
+    const double a_t = step_length_mt(&ctx, p, dp, nrm, step_max, step_min, &score, grad, H);   /* impl2:155 */
     for (int a = 0; a < 6; a++) dp[a] *= a_t;                      /* impl2:156 */
     double pn[6];
     ora_se3_compose_log(dp, p, pn);                                /* impl2:166 */
@@ -783,7 +934,7 @@ int ora_align(const ora_grid* g, const ora_params* prm,
     it++;
   }
   out->trans_probability = score / (double)n;                      /* impl2:187 */
-  out->converged = 1; out->iterations = it; out->score = score; out->hits_last = hits; out->sweeps = sweeps;
+  out->converged = 1; out->iterations = it; out->score = score; out->hits_last = hits; out->sweeps = sweeps; out->mt_loops = mt_loops;
   return 0;
 }
 

@@ -96,14 +96,19 @@ typedef struct {
   int    converged;            /* converged_ */
   long   hits_last;            /* hits in last sweep */
   int    sweeps;               /* number of computeDerivatives calls */
+  int    mt_loops;             /* total More-Thuente loop iterations (impl2:920-994); 0 unless step_size <= eps/2 */
 } ora_result;
 
-/* computeTransformation (ndt_omp_impl2.hpp:87-188) + the live part of
- * computeStepLengthMT (impl2:841-907).  Returns 0, or -2 if step_size <= eps/2
- * (the More-Thuente refinement would be live; not restated). */
+/* computeTransformation (ndt_omp_impl2.hpp:87-188) + computeStepLengthMT (impl2:841-1003), including its More-Thuente
+ * loop and computeHessian, which are live iff step_size <= trans_epsilon/2 (impl2:888).  Returns 0 (-3: no grid). */
 int ora_align(const ora_grid* g, const ora_params* prm,
               const float* x, const float* y, const float* z, size_t n,
               const float guess_colmajor[16], ora_result* out);
+
+/* computeHessian + updateHessian (impl2:622-714): f64, kd-tree neighbourhoods; T = f32 pose of the cloud, p = its tangent */
+void ora_compute_hessian(const ora_grid* g, const ora_params* prm,
+                         const float* x, const float* y, const float* z, size_t n,
+                         const float T_colmajor[16], const double p[6], double H[36]);
 
 /* Sophus a621ff2 (non-templated) SE3 exp/log, tangent order [upsilon; omega]. */
 void ora_se3_exp(const double p[6], double M_rowmajor[16]);

@@ -32,7 +32,7 @@ class Leaf(C.Structure):
 
 class Result(C.Structure):
     _fields_ = [("final_colmajor", C.c_float * 16), ("trans_probability", C.c_double), ("score", C.c_double),
-                ("iterations", C.c_int), ("converged", C.c_int), ("hits_last", C.c_long), ("sweeps", C.c_int)]
+                ("iterations", C.c_int), ("converged", C.c_int), ("hits_last", C.c_long), ("sweeps", C.c_int), ("mt_loops", C.c_int)]
 
 
 def build(force: bool = False) -> str:
@@ -66,6 +66,9 @@ def lib():
         L.ora_align.restype = C.c_int
         L.ora_align.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                 C.c_void_p, C.POINTER(Result)]
+        L.ora_compute_hessian.restype = None
+        L.ora_compute_hessian.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]
         L.ora_se3_exp.argtypes = [C.c_void_p, C.c_void_p]
         L.ora_se3_log.argtypes = [C.c_void_p, C.c_void_p]
         L.ora_se3_compose_log.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -167,6 +170,17 @@ def derivatives_at(grid: Grid, src: np.ndarray, p: np.ndarray):
     return s.value, g, H.reshape(6, 6), hits
 
 
+def compute_hessian(grid: Grid, src: np.ndarray, p: np.ndarray):
+    """ora_compute_hessian at tangent p (cloud moved by f32(exp(p))).  Returns H[6,6] f64."""
+    x, y, z = _soa(src)
+    p = np.ascontiguousarray(p, np.float64)
+    M = se3_exp(p)
+    Tc = np.asarray(M, np.float32).ravel(order="F").copy()
+    H = np.zeros(36)
+    lib().ora_compute_hessian(grid.h, C.byref(grid.prm), _p(x), _p(y), _p(z), len(src), _p(Tc), _p(p), _p(H))
+    return H.reshape(6, 6)
+
+
 def align(grid: Grid, src: np.ndarray, guess: np.ndarray):
     """ora_align; guess = 4x4 f32.  Returns dict(final[4,4] f32, trans_probability, score, iterations, converged, ...)."""
     x, y, z = _soa(src)
@@ -177,7 +191,7 @@ def align(grid: Grid, src: np.ndarray, guess: np.ndarray):
         raise RuntimeError(f"ora_align rc={rc}")
     return dict(final=np.array(r.final_colmajor, np.float32).reshape(4, 4, order="F"),
                 trans_probability=r.trans_probability, score=r.score, iterations=r.iterations,
-                converged=bool(r.converged), hits_last=r.hits_last, sweeps=r.sweeps)
+                converged=bool(r.converged), hits_last=r.hits_last, sweeps=r.sweeps, mt_loops=r.mt_loops)
 
 
 def se3_exp(p):

@@ -269,6 +269,8 @@ def sweep(grid, src, T32, M32, d1, d2, mode, pca=False):
         if not np.isfinite(p).all():
             continue
         xt = transform_point(T32, p)
+        if not np.isfinite(xt).all():        # NaN pose (only reachable through a NaN More-Thuente trial value): the reference's
+            continue                         # float->int cast is UB there; canonical choice = such a point has no neighbours
         s_pt, g_pt, H_pt = 0.0, np.zeros(6), np.zeros((6, 6))
         for L in neighbourhood(grid, xt, mode):
             x_trans = xt.astype(f64) - L.mean                          # omp:276-279
@@ -282,7 +284,186 @@ def sweep(grid, src, T32, M32, d1, d2, mode, pca=False):
     return score, g, H, hits
 
 
+def cmin(a, b):
+    """std::min(a, b) = (b < a) ? b : a  -- a NaN first argument is returned as is"""
+    return b if b < a else a
+
+
+def cmax(a, b):
+    """std::max(a, b) = (a < b) ? b : a"""
+    return b if a < b else a
+
+
+def update_interval_mt(I, a_t, f_t, g_t):
+    """updateIntervalMT, omp:717-755.  I = [a_l, f_l, g_l, a_u, f_u, g_u] updated in place; returns interval_converged."""
+    if f_t > I[1]:
+        I[3], I[4], I[5] = a_t, f_t, g_t
+        return False
+    if g_t * (I[0] - a_t) > 0:
+        I[0], I[1], I[2] = a_t, f_t, g_t
+        return False
+    if g_t * (I[0] - a_t) < 0:
+        I[3], I[4], I[5] = I[0], I[1], I[2]
+        I[0], I[1], I[2] = a_t, f_t, g_t
+        return False
+    return True
+
+
+def trial_value_selection_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, f_t, g_t):
+    """trialValueSelectionMT, omp:758-838 (IEEE semantics: sqrt of a negative and 0/0 give NaN, never an exception)."""
+    with np.errstate(all="ignore"):
+        a_l, f_l, g_l, a_u, f_u, g_u, a_t, f_t, g_t = (f64(v) for v in (a_l, f_l, g_l, a_u, f_u, g_u, a_t, f_t, g_t))
+        if f_t > f_l:
+            z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l
+            w = np.sqrt(z * z - g_t * g_l)
+            a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w)
+            a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t))
+            return float(a_c) if abs(a_c - a_l) < abs(a_q - a_l) else float(0.5 * (a_q + a_c))
+        if g_t * g_l < 0:
+            z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l
+            w = np.sqrt(z * z - g_t * g_l)
+            a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w)
+            a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l
+            return float(a_c) if abs(a_c - a_t) >= abs(a_s - a_t) else float(a_s)
+        if abs(g_t) <= abs(g_l):
+            z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l
+            w = np.sqrt(z * z - g_t * g_l)
+            a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w)
+            a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l
+            a_n = a_c if abs(a_c - a_t) < abs(a_s - a_t) else a_s
+            if a_t > a_l:
+                return float(cmin(a_t + 0.66 * (a_u - a_t), a_n))
+            return float(cmax(a_t + 0.66 * (a_u - a_t), a_n))
+        z = 3 * (f_t - f_u) / (a_t - a_u) - g_t - g_u
+        w = np.sqrt(z * z - g_t * g_u)
+        return float(a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w))
+
+
+def compute_hessian(grid, src, T32, xt_tangent, d1, d2):
+    """computeHessian + updateHessian, omp:622-714: f64 throughout, kd-tree neighbourhoods whatever the search method,
+    point derivatives from the f64 overload omp:535-563 (x_t = exp(p) * (x, 0) in double)."""
+    H = np.zeros((6, 6))
+    R = se3_exp(xt_tangent)[:3, :3]
+    for p in np.asarray(src, f32):
+        if not np.isfinite(p).all():
+            continue
+        xt = transform_point(T32, p)
+        if not np.isfinite(xt).all():
+            continue
+        x = p.astype(f64)
+        r = R @ x
+        J = np.zeros((3, 6)); J[:, :3] = np.eye(3)
+        J[1, 3] = -r[2]; J[2, 3] = r[1]; J[0, 4] = r[2]; J[2, 4] = -r[0]; J[0, 5] = -r[1]; J[1, 5] = r[0]
+        Hp = np.zeros((18, 6))
+        Hp[9:12, 3] = [0, -r[1], -r[2]]; Hp[12:15, 3] = [r[1], 0, 0]; Hp[15:18, 3] = [r[2], 0, 0]
+        Hp[9:12, 4] = [0, r[0], 0]; Hp[12:15, 4] = [-r[0], 0, -r[2]]; Hp[15:18, 4] = [0, r[2], 0]
+        Hp[9:12, 5] = [0, 0, r[0]]; Hp[12:15, 5] = [0, 0, r[1]]; Hp[15:18, 5] = [-r[0], -r[1], 0]
+        for L in radius_search(grid, xt, float(grid["leaf"])):
+            x_trans = xt.astype(f64) - L.mean
+            C = L.icov
+            with np.errstate(all="ignore"):
+                e = d2 * np.exp(-d2 * (x_trans @ (C @ x_trans)) / 2)
+            if e > 1 or e < 0 or e != e:
+                continue
+            e *= d1
+            for i in range(6):
+                cov_dxd = C @ J[:, i]
+                for j in range(6):
+                    H[i, j] += e * (-d2 * (x_trans @ cov_dxd) * (x_trans @ (C @ J[:, j])) +
+                                    x_trans @ (C @ Hp[3 * i:3 * i + 3, j]) + J[:, j] @ cov_dxd)
+    return H
+
+
+def step_length_mt(grid, src, x, dirn, step_init, step_max, step_min, score, g, H, prm, d1, d2):
+    """computeStepLengthMT omp:841-1003, literal (every trial re-sweeps).  Returns (a_t, dirn, score, g, H, final32, hits, info);
+    final32 is None when the function returned before touching final_transformation_ (omp:856-857)."""
+    mode, pca = prm["neighbor_mode"], prm["variant"] == 1
+    phi_0 = -score
+    d_phi_0 = -(g @ dirn)
+    if d_phi_0 >= 0:
+        if d_phi_0 == 0:
+            return 0.0, dirn, score, g, H, None, None, dict(step_iterations=0)
+        d_phi_0 *= -1
+        dirn = -dirn
+    mu, nu = 1.e-4, 0.9
+    psi = lambda a, f_a: f_a - phi_0 - mu * d_phi_0 * a              # auxilaryFunction_PsiMT  ndt_omp.h:480-483
+    dpsi = lambda g_a: g_a - mu * d_phi_0                            # auxilaryFunction_dPsiMT ndt_omp.h:493-496
+    I = [0.0, psi(0.0, phi_0), dpsi(d_phi_0), 0.0, psi(0.0, phi_0), dpsi(d_phi_0)]
+    interval_converged = (step_max - step_min) > 0
+    open_interval = True
+    a_t = cmax(cmin(step_init, step_max), step_min)
+    with np.errstate(all="ignore"):
+        x_t = x + dirn * a_t
+        final = se3_exp(x_t).astype(f32)
+    score, g, H, hits = sweep(grid, src, final, final, d1, d2, mode, pca)
+    phi_t, d_phi_t = -score, -(g @ dirn)
+    psi_t, d_psi_t = psi(a_t, phi_t), dpsi(d_phi_t)
+    it = 0
+    while not interval_converged and it < 10 and not (psi_t <= 0 and d_phi_t <= -nu * d_phi_0):
+        if open_interval:
+            a_t = trial_value_selection_mt(*I, a_t, psi_t, d_psi_t)
+        else:
+            a_t = trial_value_selection_mt(*I, a_t, phi_t, d_phi_t)
+        a_t = cmax(cmin(a_t, step_max), step_min)
+        with np.errstate(all="ignore"):
+            x_t = x + dirn * a_t
+            final = se3_exp(x_t).astype(f32) if np.isfinite(x_t).all() else np.full((4, 4), np.nan, f32)
+        score, g, _, hits = sweep(grid, src, final, final, d1, d2, mode, pca)     # compute_hessian = false: H comes back zero
+        H = np.zeros((6, 6))
+        phi_t, d_phi_t = -score, -(g @ dirn)
+        psi_t, d_psi_t = psi(a_t, phi_t), dpsi(d_phi_t)
+        if open_interval and (psi_t <= 0 and d_psi_t >= 0):
+            open_interval = False
+            I[1] = I[1] + phi_0 - mu * d_phi_0 * I[0]; I[2] = I[2] + mu * d_phi_0
+            I[4] = I[4] + phi_0 - mu * d_phi_0 * I[3]; I[5] = I[5] + mu * d_phi_0
+        if open_interval:
+            interval_converged = update_interval_mt(I, a_t, psi_t, d_psi_t)
+        else:
+            interval_converged = update_interval_mt(I, a_t, phi_t, d_phi_t)
+        it += 1
+    if it:
+        H = compute_hessian(grid, src, final, x_t, d1, d2)
+    return a_t, dirn, score, g, H, final, hits, dict(step_iterations=it)
+
+
 def align(grid, src, guess32, prm):
+    """computeTransformation omp:87-188 + computeStepLengthMT omp:841-1003 (its loop is live iff step_size <= eps/2)."""
+    if not (prm["step_size"] - prm["trans_epsilon"] / 2 > 0):
+        return align_mt_live(grid, src, guess32, prm)
+    return align_dead_mt(grid, src, guess32, prm)
+
+
+def align_mt_live(grid, src, guess32, prm):
+    d1, d2, _ = gauss_constants(prm["outlier_ratio"], prm["resolution"])
+    eps, step = prm["trans_epsilon"], prm["step_size"]
+    mode, pca = prm["neighbor_mode"], prm["variant"] == 1
+    final = np.array(guess32, f32)
+    p = se3_log(final.astype(f64))
+    score, g, H, hits = sweep(grid, src, final, se3_exp(p).astype(f32), d1, d2, mode, pca)
+    it, trace, mt_its = 0, [(score, g.copy(), H.copy())], []
+    while True:
+        U, S, Vt = np.linalg.svd(H)
+        rank = int((S >= max(S[0] * 6 * np.finfo(f64).eps, np.finfo(f64).tiny)).sum()) if S[0] > 0 else 0
+        dp = Vt[:rank].T @ ((U[:, :rank].T @ (-g)) / S[:rank])
+        n = np.linalg.norm(dp)
+        if n == 0 or n != n:
+            return dict(final=final, iterations=it, converged=bool(n == n), score=score, trace=trace, hits=hits, mt_its=mt_its)
+        dp = dp / n
+        a, dp, score, g, H, f2, h2, info = step_length_mt(grid, src, p, dp, n, step, eps / 2, score, g, H, prm, d1, d2)
+        if f2 is not None:
+            final, hits = f2, h2
+            trace.append((score, g.copy(), H.copy()))
+        mt_its.append(info["step_iterations"])
+        with np.errstate(all="ignore"):
+            dpv = dp * a
+            p = se3_log(se3_exp(dpv) @ se3_exp(p)) if np.isfinite(dpv).all() else np.full(6, np.nan)
+        conv = it > prm["max_iterations"] or (it and abs(a) < eps)
+        it += 1
+        if conv:
+            return dict(final=final, iterations=it, converged=True, score=score, trace=trace, hits=hits, mt_its=mt_its)
+
+
+def align_dead_mt(grid, src, guess32, prm):
     """computeTransformation omp:87-188 + the live prefix of computeStepLengthMT omp:841-907."""
     d1, d2, _ = gauss_constants(prm["outlier_ratio"], prm["resolution"])
     eps, step = prm["trans_epsilon"], prm["step_size"]
@@ -382,7 +563,42 @@ def se3_vectors():
     print("se3_vectors:", len(ps))
 
 
+def make_mt_case(name, pair, n_az, n_beams, mode, variant, n_src=400):
+    """step_size <= eps/2: the More-Thuente loop and computeHessian are live (omp:888, 920-1000)."""
+    from lv_slam_amd import synth
+    tgt, src, dT = synth.make_pair(pair, n_az, n_beams=n_beams)
+    tgt, src = tgt.numpy(), src.numpy()
+    base = dict(resolution=1.0, step_size=0.1, outlier_ratio=0.55, trans_epsilon=0.01, max_iterations=64,
+                neighbor_mode=mode, variant=variant, min_points_per_voxel=6, min_covar_eigvalue_mult=0.01)
+    live = dict(base, step_size=0.004)
+    grid = build_grid(tgt, 1.0, pca=(variant == 1))
+    d1, d2, _ = gauss_constants(0.55, 1.0)
+    s_al = src[:: max(1, len(src) // n_src)][:n_src]
+    g_far = synth.default_guess()
+    r0 = align(grid, s_al, g_far, base)                      # an ordinary registration: its result is the "near" guess
+    g_near = r0["final"]
+    g_over = g_near.copy()
+    g_over[0, 3] -= f32(0.002)                               # a hair off the optimum: the forced step eps/2 overshoots
+    out = dict(target=tgt, src_align=s_al, guess_far=g_far, guess_near=g_near, guess_over=g_over, params=np.array([1.0, 0.004, 0.55, 0.01, 64, mode, variant, 6, 0.01]))
+    for tag, G in (("far", g_far), ("near", g_near), ("over", g_over)):
+        r = align(grid, s_al, G, live)
+        out.update({f"{tag}_final": r["final"], f"{tag}_iterations": np.int64(r["iterations"]), f"{tag}_converged": np.int64(r["converged"]),
+                    f"{tag}_score": np.float64(r["score"]), f"{tag}_mt_its": np.array(r["mt_its"], np.int64),
+                    f"{tag}_trace_H": np.array([t[2] for t in r["trace"]]), f"{tag}_trace_g": np.array([t[1] for t in r["trace"]])})
+        print(f"{name}/{tag}: it {r['iterations']} conv {r['converged']} MT loop iterations {r['mt_its']} score {r['score']:.6f}")
+    p1 = se3_log(g_far.astype(f64)) + np.array([0.03, -0.02, 0.01, 0.004, -0.003, 0.01])
+    T1 = se3_exp(p1).astype(f32)
+    out.update(hess_p=p1, hess_H=compute_hessian(grid, s_al, T1, p1, d1, d2))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: -> {os.path.getsize(path)} B")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "mt":          # cases added after the first fixtures were frozen
+        make_mt_case("omp_direct7_mt", pair=15, n_az=128, n_beams=32, mode=DIRECT7, variant=0)
+        make_mt_case("pca_direct1_mt", pair=17, n_az=128, n_beams=32, mode=DIRECT1, variant=1)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "kdtree":      # only the case added after the first fixtures were frozen
         make_case("omp_kdtree_r1", pair=13, n_az=128, n_beams=32, resolution=1.0, mode=KDTREE, variant=0)
         sys.exit(0)

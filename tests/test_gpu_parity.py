@@ -163,6 +163,78 @@ def test_window_map_target_vs_oracle():
     assert n_in == n_o and abs(fs - fo) <= 1e-12 * max(1.0, abs(fo))
 
 
+MT_CASES = ["omp_direct7_mt", "pca_direct1_mt"]
+
+
+@pytest.mark.parametrize("name", MT_CASES)
+def test_golden_compute_hessian(golden_dir, name):
+    """computeHessian / updateHessian (impl2:622-714) through the parity hook, vs the NumPy fixture and the oracle."""
+    z, kw = golden(golden_dir, name)
+    gp, op = both_params(**kw)
+    eng = ndt.Engine(gp)
+    eng.set_target(z["target"])
+    eng.set_source(z["src_align"])
+    H = eng.compute_hessian(z["hess_p"])
+    Ho = O.compute_hessian(O.Grid(z["target"], op), z["src_align"], z["hess_p"])
+    scale = np.abs(Ho).max()
+    assert np.abs(H - Ho).max() <= 1e-11 * scale
+    assert np.abs(H - z["hess_H"]).max() <= 1e-10 * scale
+
+
+@pytest.mark.parametrize("name", MT_CASES)
+@pytest.mark.parametrize("tag", ["far", "near", "over"])
+def test_golden_align_live_more_thuente(golden_dir, name, tag):
+    """step_size <= eps/2 (impl2:888): More-Thuente loop + computeHessian live; fixtures cover Wolfe-at-first-trial (no loop),
+    loop at the second step only, and loop at the first step (its computeHessian result feeds the next Newton solve)."""
+    z, kw = golden(golden_dir, name)
+    gp, op = both_params(**kw)
+    eng = ndt.Engine(gp)
+    eng.set_target(z["target"])
+    eng.set_source(z["src_align"])
+    G = z["guess_" + tag]
+    r = eng.align(G)
+    ro = O.align(O.Grid(z["target"], op), z["src_align"], G)
+    assert r["iterations"] == ro["iterations"] == int(z[tag + "_iterations"])
+    assert r["converged"] == ro["converged"] == bool(z[tag + "_converged"])
+    assert r["sweeps"] == ro["sweeps"] == 1 + len(z[tag + "_mt_its"]) + int(z[tag + "_mt_its"].sum())
+    dt, dr = se3_err(ro["final"], r["final"])
+    assert dt < 1e-4 and dr < 1e-5, (dt, dr)
+    dt, dr = se3_err(z[tag + "_final"], r["final"])
+    assert dt < 1e-4 and dr < 1e-5, (dt, dr)
+    assert abs(r["score"] - ro["score"]) <= 1e-9 * abs(ro["score"])
+
+
+def test_full_size_live_more_thuente_vs_oracle():
+    """65,536-pt pair with step_size <= eps/2: batch of 3 guesses (far / converged / a hair off) == oracle, and switching the
+    same engine back to the shipped step size gives the ordinary result again (grid rebuilt without the f64 extras or with,
+    same voxels)."""
+    tgt, src, _ = synth.make_pair(1, 1024)
+    tgt, src = tgt.numpy(), src.numpy()
+    base = dict(trans_epsilon=0.01, max_iterations=64)
+    gp, op = both_params(**base)
+    eng = ndt.Engine(gp)
+    eng.set_target(tgt)
+    eng.set_source(src)
+    r0 = eng.align(synth.default_guess())
+    near = r0["final"].copy()
+    over = near.copy()
+    over[0, 3] -= np.float32(0.002)
+    gl, ol = both_params(step_size=0.004, **base)
+    eng.set_params(gl)
+    grid = O.Grid(tgt, ol)
+    loops = 0
+    for G in (synth.default_guess(), near, over):
+        r, ro = eng.align(G), O.align(grid, src, G)
+        assert r["iterations"] == ro["iterations"] and r["converged"] == ro["converged"] and r["sweeps"] == ro["sweeps"]
+        dt, dr = se3_err(ro["final"], r["final"])
+        assert dt < 1e-4 and dr < 1e-5, (dt, dr)
+        loops += ro["mt_loops"]
+    assert loops > 0                                   # the loop (and computeHessian) really ran
+    eng.set_params(gp)
+    r1 = eng.align(synth.default_guess())
+    assert r1["iterations"] == r0["iterations"] and np.array_equal(r1["final"], r0["final"])
+
+
 def test_identity_alignment_property():
     """identical clouds + identity guess => nothing to do: |delta| -> 0 within the 3-sweep minimum."""
     tgt, _, _ = synth.make_pair(2, 256)
@@ -211,10 +283,6 @@ def test_edge_cases():
         eng.set_source(s)
         check_sweep(eng.derivatives(p), O.derivatives_at(grid, s, p))
     # unsupported configurations fail loudly
-    with pytest.raises(ndt.NDTError) as e:
-        ndt.Engine(ndt.default_params(trans_epsilon=0.5, step_size=0.1)).align(G) if False else \
-            _align_with(ndt.default_params(trans_epsilon=0.5, step_size=0.1), tgt, src, G)
-    assert e.value.code == -6
     with pytest.raises(ndt.NDTError) as e:      # KDTREE is emulated for ndt_omp only (ndt_pca needs FLANN's result order)
         _align_with(ndt.default_params(neighbor_mode=ndt.KDTREE, variant=ndt.VARIANT_PCA), tgt, src, G)
     assert e.value.code == -6

@@ -119,6 +119,54 @@ def test_align(golden_dir, name):
     assert r["sweeps"] == len(z["align_trace_score"])
 
 
+MT_CASES = ["omp_direct7_mt", "pca_direct1_mt"]
+
+
+@pytest.mark.parametrize("name", MT_CASES)
+def test_compute_hessian(golden_dir, name):
+    """computeHessian/updateHessian (impl2:622-714): f64 pass over kd-tree neighbourhoods, vs the NumPy restatement."""
+    z, prm = load(golden_dir, name)
+    grid = O.Grid(z["target"], prm)
+    H = O.compute_hessian(grid, z["src_align"], z["hess_p"])
+    assert np.abs(H - z["hess_H"]).max() <= 1e-11 * np.abs(z["hess_H"]).max()
+
+
+@pytest.mark.parametrize("name", MT_CASES)
+@pytest.mark.parametrize("tag", ["far", "near", "over"])
+def test_align_live_more_thuente(golden_dir, name, tag):
+    """step_size <= eps/2 makes computeStepLengthMT's loop and computeHessian live (impl2:888, 920-1000)."""
+    z, prm = load(golden_dir, name)
+    assert not (prm.step_size - prm.trans_epsilon / 2 > 0)
+    grid = O.Grid(z["target"], prm)
+    r = O.align(grid, z["src_align"], z["guess_" + tag])
+    assert r["iterations"] == int(z[tag + "_iterations"]) and r["converged"] == bool(z[tag + "_converged"])
+    assert r["mt_loops"] == int(z[tag + "_mt_its"].sum())
+    dt, dr = se3_err(z[tag + "_final"], r["final"])
+    assert dt < 1e-6 and dr < 1e-6, (dt, dr)         # f32 pose entries may differ by an ulp between expm and the closed form
+    assert abs(r["score"] - float(z[tag + "_score"])) <= 1e-6 * abs(float(z[tag + "_score"]))
+
+
+def test_more_thuente_scalar_pieces():
+    """trialValueSelectionMT / updateIntervalMT / std::min,max NaN semantics, against the NumPy restatement."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    M = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(M)
+    assert np.isnan(M.cmin(float("nan"), 1.0)) and M.cmin(1.0, float("nan")) == 1.0
+    assert np.isnan(M.cmax(float("nan"), 1.0)) and M.cmax(1.0, float("nan")) == 1.0
+    # interval update: U1, U2, U3, converged
+    I = [0.0, 0.0, -1.0, 0.0, 0.0, -1.0]
+    assert M.update_interval_mt(I, 0.5, 0.1, 0.2) is False and I[3:] == [0.5, 0.1, 0.2]
+    I = [0.0, 0.0, -1.0, 0.0, 0.0, -1.0]
+    assert M.update_interval_mt(I, 0.5, -0.1, -0.2) is False and I[:3] == [0.5, -0.1, -0.2]
+    assert M.update_interval_mt(I, 0.5, -0.1, -0.2) is True                 # same point again: g_t * (a_l - a_t) == 0
+    I = [0.0, 0.0, -1.0, 1.0, 0.3, 0.4]
+    assert M.update_interval_mt(I, 0.5, -0.1, 0.2) is False and I == [0.5, -0.1, 0.2, 0.0, 0.0, -1.0]
+    # cubic/quadratic trial of case 1 on phi(a) = (a-1)^2 - 1 sampled at 0 and 3: minimiser of both interpolants is a = 1
+    a = M.trial_value_selection_mt(0.0, 0.0, -2.0, 0.0, 0.0, -2.0, 3.0, 3.0, 4.0)
+    assert abs(a - 1.0) < 1e-12
+
+
 def test_align_edge_cases():
     prm = O.default_params(trans_epsilon=0.01, max_iterations=64)
     rng = np.random.default_rng(3)
@@ -129,10 +177,10 @@ def test_align_edge_cases():
     G = np.eye(4, dtype=np.float32)
     r = O.align(g, src, G)
     assert r["converged"] and r["iterations"] == 0 and r["sweeps"] == 1 and np.array_equal(r["final"], G)
-    # step_size <= eps/2 would enable the More-Thuente loop: not restated, must refuse
+    # step_size <= eps/2 enables the More-Thuente loop; with zero hits it is never reached (delta_p == 0 returns first)
     prm2 = O.default_params(trans_epsilon=0.5, step_size=0.1)
-    with pytest.raises(RuntimeError):
-        O.align(O.Grid(tgt, prm2), src, G)
+    r2 = O.align(O.Grid(tgt, prm2), src, G)
+    assert r2["converged"] and r2["iterations"] == 0 and r2["mt_loops"] == 0
     # non-finite points are skipped
     tgt2 = tgt.copy()
     tgt2[::7] = np.nan
