@@ -62,8 +62,11 @@ __device__ __forceinline__ void eval_hit(const float u[3], const float r[3], con
       else if (j == 3) jcj = (-r[2]) * CJ[1][i] + r[1] * CJ[2][i];
       else if (j == 4) jcj = r[2] * CJ[0][i] + (-r[0]) * CJ[2][i];
       else jcj = (-r[1]) * CJ[0][i] + r[0] * CJ[1][i];
-      const float z = (i >= 3 && j >= 3) ? Z[i - 3][j - 3] : 0.f;
-      const float h = e * ((((-d2f) * v[i]) * v[j] + z) + jcj);                                // impl2:611-613
+      // z_i[j] is a structural zero outside the rotation block; "+ (+-0)" never changes a value that reaches the f64 sums
+      // (it can only turn a -0 term into +0, and adding either to an accumulator is a no-op), so the add is skipped there
+      float t = ((-d2f) * v[i]) * v[j];
+      if (i >= 3 && j >= 3) t = t + Z[i - 3][j - 3];
+      const float h = e * (t + jcj);                                                           // impl2:611-613
       NDT_ACC(7 + i * 6 + j, h);
     }
   }
