@@ -299,19 +299,39 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
       __builtin_amdgcn_wave_barrier();
       if (qcount > 0) drain(qcount);
     }
-    // fixed-order reduction of the wave: 64-lane butterfly -> one 44-double row per (chunk, quarter)
+    // Fixed-order reduction of the wave -> one 44-double row per (chunk, quarter).  Same pairwise tree as a 64-lane xor
+    // butterfly (distance 32, 16, 8, 4, 2, 1 -- so the same bits), but as a reduce-scatter: the distance-32 and -16
+    // levels use gfx950's v_permlane32_swap / v_permlane16_swap to exchange HALF of the values between lane halves /
+    // rows, so 43 -> 22 -> 11 values remain per lane before the in-row butterfly (66 swaps + 88 shuffles + 77 adds
+    // instead of 516 shuffles + 258 adds per item).
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    double P1[22], P2[11];
 #pragma unroll
-    for (int a = 0; a < 43; a++) {
-      double v = acc[a];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-      acc[a] = v;
+    for (int i = 0; i < 22; i++) {
+      const double a = acc[i], b2 = (i + 22 < 43) ? acc[i + 22] : 0.0;
+      const u2v lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b2), false, false);
+      const u2v hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b2), false, false);
+      // lanes 0..31: value i of lanes L and L+32;  lanes 32..63: value i+22 of lanes L-32 and L
+      P1[i] = __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
     }
-    if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 11; i++) {
+      const double a = P1[i], b2 = P1[i + 11];
+      const u2v lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b2), false, false);
+      const u2v hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b2), false, false);
+      // even rows: P1[i] of rows r and r+1;  odd rows: P1[i+11] of rows r-1 and r
+      double v = __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      P2[i] = v;
+    }
+    if ((lane & 15) == 0) {
+      // row 0 (lane 0) holds values 0..10, row 1: 11..21, row 2: 22..32, row 3: 33..42 (+ the pad)
+      const int row = lane >> 4, base = 11 * (row & 1) + 22 * (row >> 1);
       double* P = partials + (((size_t)b * chunks_per_pair + chunk) * QUARTERS + quarter) * NACC;
 #pragma unroll
-      for (int a = 0; a < 43; a++) P[a] = acc[a];
-      P[43] = (double)nhits;
+      for (int i = 0; i < 11; i++) if (base + i < 43) P[base + i] = P2[i];
+      if (lane == 0) P[43] = (double)nhits;
     }
   }
       item = __builtin_amdgcn_readfirstlane(next_item);
