@@ -8,9 +8,14 @@
 // Hessian patterns of computePointDerivatives_AngleAxisd (impl2:503-532) folded in (J and Hp are never
 // materialised).  f32 ops single, left to right; f64 accumulation.  `w` = weight multiplier of the hit
 // (ndt_pca compounding, applied as a suffix product; unused for ndt_omp).
-template <bool PCA>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `mid` runs between the gradient part and the 36 Hessian terms, where the fewest temporaries are live: the sweep uses it
+// to issue the NEXT batch's record loads so that their L2 latency overlaps the Hessian arithmetic.
+template <bool PCA, typename Mid = NoHook>
 __device__ __forceinline__ void eval_hit(const float u[3], const float r[3], const float C[9],
-                                         const double d1, const float d2f, const double w, const bool ok_in, double acc[43]) {
+                                         const double d1, const float d2f, const double w, const bool ok_in, double acc[43],
+                                         Mid mid = Mid()) {
   float y[3];
 #pragma unroll
   for (int j = 0; j < 3; j++) y[j] = (u[0] * C[j] + u[1] * C[3 + j]) + u[2] * C[6 + j];
@@ -52,6 +57,9 @@ __device__ __forceinline__ void eval_hit(const float u[3], const float r[3], con
   Z[0][2] = y[2] * r[0];
   Z[1][2] = y[2] * r[1];
   Z[2][2] = y[0] * (-r[0]) + y[1] * (-r[1]);
+  __builtin_amdgcn_sched_barrier(0);
+  mid();
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < 6; i++) {
 #pragma unroll
@@ -176,31 +184,56 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
     int q_old = 0;                                   // queued entries that reference the OTHER staging half (older tile)
     const int wbase = chunk * CHUNK_PTS + quarter * (CHUNK_PTS / QUARTERS);
 
-    // evaluate `m` queued hits (m <= 64), one per lane; lanes >= m re-read the last entry and contribute +0
-    auto drain = [&](int m) {
+    // One batch of queued hits (one per lane): queue entry + the voxel record it points at, in registers.
+    struct Batch { unsigned slot; double m0, m1, m2; float C[9]; int weight; double w; };
+    // read the `m` hits that sit `off` entries behind the queue head; lanes >= m re-read the last entry (and contribute +0)
+    auto fetch = [&](int off, int m, Batch& B) {
       const int k = lane < m ? lane : m - 1;
-      const unsigned ent = q_ent[wv][(qhead + k) & (Q_CAP - 1)];
-      const unsigned slot = ent >> ID_BITS, id = ent & ((1u << ID_BITS) - 1);
-      const float* sp = stage[wv][slot];
+      const unsigned ent = q_ent[wv][(qhead + off + k) & (Q_CAP - 1)];
+      B.slot = ent >> ID_BITS;
+      const VoxelRec& vr = R[ent & ((1u << ID_BITS) - 1)];
+      B.m0 = vr.mean[0]; B.m1 = vr.mean[1]; B.m2 = vr.mean[2];
+#pragma unroll
+      for (int a = 0; a < 9; a++) B.C[a] = vr.icov[a];
+      B.weight = vr.weight;
+      B.w = 1.0;
+      if (PCA) B.w = q_w[wv][(qhead + off + k) & (Q_CAP - 1)];
+    };
+    // evaluate a fetched batch (running `mid` half way through) and retire its `m` queue entries
+    auto eval_batch = [&](const Batch& B, int m, auto mid) {
+      const float* sp = stage[wv][B.slot];         // staged point: LDS, short latency
       const float xt0 = sp[0], xt1 = sp[1], xt2 = sp[2];
       float r[3] = {sp[3], sp[4], sp[5]};
-      const VoxelRec& vr = R[id];
-      const double m0 = vr.mean[0], m1 = vr.mean[1], m2 = vr.mean[2];
-      float Cf[9];
-#pragma unroll
-      for (int a = 0; a < 9; a++) Cf[a] = vr.icov[a];
-      double w = 1.0;
-      if (PCA) w = q_w[wv][(qhead + k) & (Q_CAP - 1)];
       // ndt_omp: leaves with nr_points = -1 (eigen / inverse failure) are not neighbours (impl:395): filtered here
-      const bool live = lane < m && (PCA || KD || vr.weight != VOX_DEAD);
-      float u[3] = {(float)((double)xt0 - m0), (float)((double)xt1 - m1), (float)((double)xt2 - m2)};   // impl2:276-279, 574
-      eval_hit<PCA>(u, r, Cf, sc.d1, sc.d2f, w, live, acc);
+      const bool live = lane < m && (PCA || KD || B.weight != VOX_DEAD);
+      float u[3] = {(float)((double)xt0 - B.m0), (float)((double)xt1 - B.m1), (float)((double)xt2 - B.m2)};   // impl2:276-279, 574
+      eval_hit<PCA>(u, r, B.C, sc.d1, sc.d2f, B.w, live, acc, mid);
       nhits += PCA ? (unsigned)m : (unsigned)__popcll(__ballot(live));
       qhead = (qhead + m) & (Q_CAP - 1);
       qcount -= m;
       q_old = q_old > m ? q_old - m : 0;
     };
-
+    // evaluate `m` queued hits (m <= 64), one per lane
+    auto drain = [&](int m) {
+      Batch B;
+      fetch(0, m, B);
+      eval_batch(B, m, NoHook());
+    };
+    // All full batches in the queue, software-pipelined: the next batch's record loads are issued in the middle of the
+    // current batch's arithmetic (before its 36 Hessian terms), so their L2 latency is off the critical path.
+    auto drain_full = [&]() {
+      if (qcount < 64) return;
+      Batch A;
+      fetch(0, 64, A);
+#pragma unroll 1
+      for (;;) {
+        const bool more = qcount >= 128;
+        Batch N;
+        eval_batch(A, 64, [&]() { if (more) fetch(64, 64, N); });
+        if (!more) break;
+        A = N;
+      }
+    };
     if (wbase < n && grid_ok) {
       // points of the next tile are fetched one tile ahead (HBM latency ~2 us would otherwise be exposed per tile)
       float nx = 0.f, ny = 0.f, nz = 0.f;
@@ -293,7 +326,7 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
             qcount += (int)__popcll(mask);
           }
           __builtin_amdgcn_wave_barrier();
-          while (qcount >= 64) drain(64);
+          drain_full();
         }
       }
       __builtin_amdgcn_wave_barrier();
