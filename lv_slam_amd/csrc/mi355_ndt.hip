@@ -80,7 +80,8 @@ struct mi355ndt_handle {
   mi355ndt_result* d_results = nullptr;
   int* d_active = nullptr;                      // per-round active counters
   int* d_active_list = nullptr;                 // pairs taking part in the next sweep (compacted by k_update)
-  SweepCtl* d_ctl = nullptr;
+  SweepCtl* d_ctl = nullptr;                      // two control blocks: the sweep reading one zeroes the other for the next round
+  int ctl_idx = 0;                                // block the NEXT sweep reads (k_init_state / k_update fill it)
   int n_cu = 256;
   int* h_pin_active = nullptr;
   hipEvent_t ev_burst[2] = {nullptr, nullptr};   // one per in-flight burst of align rounds
@@ -190,7 +191,7 @@ int mi355ndt_create(const mi355ndt_params* params, int device, mi355ndt_handle**
   if (hipHostMalloc((void**)&h->h_pin_u, 4 * sizeof(unsigned)) != hipSuccess ||
       hipHostMalloc((void**)&h->h_pin_active, 128 * sizeof(int)) != hipSuccess ||
       hipMalloc((void**)&h->d_active, 128 * sizeof(int)) != hipSuccess ||
-      hipMalloc((void**)&h->d_ctl, sizeof(SweepCtl)) != hipSuccess ||
+      hipMalloc((void**)&h->d_ctl, 2 * sizeof(SweepCtl)) != hipSuccess ||
       hipMalloc((void**)&h->d_hits, sizeof(unsigned long long)) != hipSuccess ||
       hipMalloc((void**)&h->d_hook, 64 * sizeof(double)) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_burst[0], hipEventDisableTiming) != hipSuccess ||
@@ -567,11 +568,12 @@ static int launch_sweep(mi355ndt_handle* h, const SweepConst& sc) {
   const dim3 grid((unsigned)(h->n_cu * SWEEP_WPE));
   if (h->prof) HIPCHK(h, ev_begin(h, h->ev_sweep));
 #define NDT_LAUNCH_SWEEP(P, KK) k_sweep<P, KK><<<grid, SWEEP_THREADS, 0, h->stream>>>(h->d_src, h->src_pitch, h->d_state, h->d_grid, \
-      h->d_words, h->d_recs, h->d_partials, h->chunks_per_pair, h->d_active_list, h->d_ctl, sc, h->d_cent)
+      h->d_words, h->d_recs, h->d_partials, h->chunks_per_pair, h->d_active_list, h->d_ctl + h->ctl_idx, h->d_ctl + (h->ctl_idx ^ 1), sc, h->d_cent)
   if (sc.pca) { if (sc.K == 1) NDT_LAUNCH_SWEEP(true, 1); else if (sc.K == 7) NDT_LAUNCH_SWEEP(true, 7); else NDT_LAUNCH_SWEEP(true, 26); }
   else        { if (sc.K == 1) NDT_LAUNCH_SWEEP(false, 1); else if (sc.K == 7) NDT_LAUNCH_SWEEP(false, 7); else if (sc.K == 26) NDT_LAUNCH_SWEEP(false, 26);
                 else NDT_LAUNCH_SWEEP(false, 27); }
 #undef NDT_LAUNCH_SWEEP
+  h->ctl_idx ^= 1;                                // the block this sweep zeroed is the one the next update fills
   if (h->prof) HIPCHK(h, ev_end(h, h->ev_sweep));
   return MI355NDT_OK;
 }
@@ -600,7 +602,8 @@ int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_resu
   make_sweep_const(h, sc);
   HIPCHK(h, hipMemcpyAsync(h->d_guess, guesses, (size_t)B * 16 * sizeof(float), hipMemcpyHostToDevice, s));
   HIPCHK(h, hipStreamSynchronize(s));           // guesses may be pageable caller memory
-  HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, sizeof(SweepCtl), s));
+  HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, 2 * sizeof(SweepCtl), s));
+  h->ctl_idx = 0;
   k_init_state<<<(B + 63) / 64, 64, 0, s>>>(h->d_state, h->d_guess, h->d_src_cnt, h->d_grid, B, h->d_active_list, h->d_ctl);
   rc = launch_sweep(h, sc);
   if (rc) return rc;
@@ -627,14 +630,13 @@ int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_resu
     int k = 0;
     for (; k < burst && round < max_rounds; k++, round++) {
       if (h->prof) HIPCHK(h, ev_begin(h, h->ev_update));
-      HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, sizeof(SweepCtl), s));
       k_update<<<B, 64, 0, s>>>(h->d_state, h->d_partials, h->chunks_per_pair, h->d_results, dact + k,
-                                h->d_active_list, h->d_ctl, h->prof ? h->d_hits : nullptr,
+                                h->d_active_list, h->d_ctl + h->ctl_idx, h->prof ? h->d_hits : nullptr,
                                 h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations, 0, mt_live ? 1 : 0);
       if (mt_live) {      // pairs whose More-Thuente loop iterated get their Hessian from computeHessian (impl2:999-1000)
         launch_hessian(h, sc);
         k_update<<<B, 64, 0, s>>>(h->d_state, h->d_partials, h->chunks_per_pair, h->d_results, dact + k,
-                                  h->d_active_list, h->d_ctl, nullptr,
+                                  h->d_active_list, h->d_ctl + h->ctl_idx, nullptr,
                                   h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations, 0, 2);
       }
       if (h->prof) HIPCHK(h, ev_end(h, h->ev_update));
@@ -806,7 +808,8 @@ int mi355ndt_derivatives(mi355ndt_handle* h, const double p[6], double* score, d
   double* dp = (double*)h->d_hook;
   HIPCHK(h, hipMemcpyAsync(dp, p, 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, sizeof(SweepCtl), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, 2 * sizeof(SweepCtl), h->stream));
+  h->ctl_idx = 0;
   k_set_pose_p<<<1, 1, 0, h->stream>>>(h->d_state, 0, dp, h->d_src_cnt, h->d_grid, h->d_active_list, h->d_ctl, 0);
   return run_hook_sweep(h, score, g, H, hits);
 }
@@ -826,7 +829,8 @@ int mi355ndt_compute_hessian(mi355ndt_handle* h, const double p[6], double H[36]
   double* dp = (double*)h->d_hook;
   HIPCHK(h, hipMemcpyAsync(dp, p, 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, sizeof(SweepCtl), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, 2 * sizeof(SweepCtl), h->stream));
+  h->ctl_idx = 0;
   k_set_pose_p<<<1, 1, 0, h->stream>>>(h->d_state, 0, dp, h->d_src_cnt, h->d_grid, h->d_active_list, h->d_ctl, 1);
   SweepConst sc;
   make_sweep_const(h, sc);
@@ -851,7 +855,8 @@ int mi355ndt_derivatives_T(mi355ndt_handle* h, const float T[16], const float Rj
   memcpy(buf + 16, Rj, 9 * sizeof(float));
   HIPCHK(h, hipMemcpyAsync(h->d_hook, buf, sizeof buf, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, sizeof(SweepCtl), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, 2 * sizeof(SweepCtl), h->stream));
+  h->ctl_idx = 0;
   k_set_pose<<<1, 1, 0, h->stream>>>(h->d_state, 0, h->d_hook, h->d_hook + 16, h->d_src_cnt, h->d_grid, h->d_active_list, h->d_ctl);
   return run_hook_sweep(h, score, g, H, hits);
 }

@@ -186,19 +186,26 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restri
   const KeyT* K = keys + (size_t)b * pitch;
   const unsigned* V = vals + (size_t)b * pitch;
   const float* X = tgt + (size_t)b * 3 * pitch;
-  for (int id = blockIdx.x * LS_WAVES + wv; id < g.n_voxels; id += gridDim.x * LS_WAVES) {
-    const size_t start = seg_start[g.rec_off + id];
-    const KeyT key = K[start];
+  const int id0 = blockIdx.x * LS_WAVES + wv, idstep = gridDim.x * LS_WAVES;
+  size_t start_next = id0 < g.n_voxels ? seg_start[g.rec_off + id0] : 0;
+  for (int id = id0; id < g.n_voxels; id += idstep) {
+    const size_t start = start_next;
+    if (id + idstep < g.n_voxels) start_next = seg_start[g.rec_off + id + idstep];   // next leaf's run start, one leaf ahead
     // accumulator order: S0 S1 S2 C00 C01 C02 C11 C12 C22 ; cov_ is seeded with Identity (voxel_grid_covariance_omp.h:101)
     double acc = (lane == 3 || lane == 6 || lane == 8) ? 1.0 : 0.0;
     float accf = 0.f;                            // lanes 9..11: leaf.centroid += pt (f32, impl:242-243)
     int cnt = 0;
+    KeyT key = 0;
     for (size_t j0 = start;; j0 += 64) {
       const size_t j = j0 + lane;
-      const bool in = j < pitch && K[j] == key;
+      const bool inb = j < pitch;
+      // key and point id of the run position are fetched together (the point id of a lane past the run's end is unused)
+      const KeyT kj = inb ? K[j] : (KeyT)0;
+      const unsigned pi = inb ? V[j] : 0u;
+      if (j0 == start) key = __shfl(kj, 0);      // the run's cell: its first entry
+      const bool in = inb && kj == key;
       const int m = (int)__popcll(__ballot(in));
       if (in) {
-        const unsigned pi = V[j];
         const double x = (double)X[pi], y = (double)X[pitch + pi], z = (double)X[2 * pitch + pi];
         double* t = term[wv][lane];
         t[0] = x; t[1] = y; t[2] = z;

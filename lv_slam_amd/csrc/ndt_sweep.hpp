@@ -105,7 +105,7 @@ __host__ __device__ constexpr int probe_off(int K, int q, int a) {
 //   chunk end: flush the queue tail, wave butterfly + fixed-order wave sum -> one 44-double partial row per chunk.
 // The partial rows depend only on (CHUNK_PTS, input order), never on the launch geometry, so single and batched
 // runs of one pair are bit-identical.
-struct SweepCtl {               // zeroed by the host before every k_update / k_init_state
+struct SweepCtl {               // 9 ints; two of them alternate: the sweep that reads one clears the other
   int n_active;                 // pairs whose next sweep is pending (entries of active_list)
   int next_item[8];             // per-XCD work-item cursors of the sweep
 };
@@ -115,7 +115,7 @@ template <bool PCA, int K>
 __global__ void __launch_bounds__(SWEEP_THREADS, SWEEP_WPE)
 k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict__ st,
         const GridDesc* __restrict__ gd, const BitWord* __restrict__ words, const VoxelRec* __restrict__ recs,
-        double* partials, int chunks_per_pair, const int* __restrict__ active_list, SweepCtl* ctl, SweepConst sc,
+        double* partials, int chunks_per_pair, const int* __restrict__ active_list, SweepCtl* ctl, SweepCtl* ctl_next, SweepConst sc,
         const float* __restrict__ cent) {
   // K == 27 is the KDTREE mode (ndt_omp_impl2.hpp:251-253): radiusSearch(point, resolution) over the f32 centroids of the
   // searchable leaves (voxel_grid_covariance_omp.h:505-534).  A centroid lies inside its own cell, so every centroid closer
@@ -137,6 +137,8 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
   __shared__ double q_w[PCA ? WAVES : 1][PCA ? Q_CAP : 1];
   __shared__ float stage[WAVES][128][6];           // two tiles of staged points: x'(3), R x (3)
 
+  // the control block of the NEXT round (k_update fills it after this kernel) is cleared here, not by a host memset
+  if (blockIdx.x == 0 && threadIdx.x < 9) reinterpret_cast<int*>(ctl_next)[threadIdx.x] = 0;
   if (n_active == 0) return;                       // nothing left to sweep (the loop's last, empty round)
   const int my_xcd = blockIdx.x & 7;
 #pragma unroll 1
