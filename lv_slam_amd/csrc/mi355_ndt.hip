@@ -493,6 +493,7 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
   }
   if (total_words) HIPCHK(h, hipMemsetAsync(h->d_words, 0, total_words * sizeof(BitWord), s));
   const int lb = std::max(1, std::min((int)((rpp + LS_WAVES - 1) / LS_WAVES), std::max(8, 8192 / B)));
+  const unsigned gx4 = (unsigned)((pitch + 256 * RUN_ILP - 1) / (256 * RUN_ILP));   // k_mark / k_segstart: RUN_ILP positions per thread
   const bool mt_live = mt_is_live(h->prm);
   const bool want_cent = h->prm.neighbor_mode == MI355NDT_KDTREE || mt_live;   // f32 leaf centroids: KDTREE probe, computeHessian
   h->cent_built = want_cent;
@@ -503,9 +504,9 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
     unsigned *ka = (unsigned*)h->d_keys_a, *kb = (unsigned*)h->d_keys_b;
     k_keys<unsigned><<<dim3(gx, B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_grid, ka, h->d_vals_a, cb);
     HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(h->d_tmp, tb, ka, kb, h->d_vals_a, h->d_vals_b, (int)total, 0, cb + pb, s));
-    k_mark<unsigned><<<dim3(gx, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, minpts, cb);
+    k_mark<unsigned><<<dim3(gx4, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, minpts, cb);
     k_rank<<<B, 256, 0, s>>>(h->d_grid, h->d_words);
-    k_segstart<unsigned><<<dim3(gx, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, h->d_seg_start, minpts, cb);
+    k_segstart<unsigned><<<dim3(gx4, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, h->d_seg_start, minpts, cb);
     if (want_cent) k_leafsum<unsigned, true><<<dim3(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start,
                                                                                     h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent);
     else k_leafsum<unsigned, false><<<dim3(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start,
@@ -514,9 +515,9 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
     typedef unsigned long long u64;
     k_keys<u64><<<dim3(gx, B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_grid, h->d_keys_a, h->d_vals_a, cb);
     HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(h->d_tmp, tb, h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, (int)total, 0, cb + pb, s));
-    k_mark<u64><<<dim3(gx, B), 256, 0, s>>>(h->d_keys_b, pitch, h->d_grid, h->d_words, minpts, cb);
+    k_mark<u64><<<dim3(gx4, B), 256, 0, s>>>(h->d_keys_b, pitch, h->d_grid, h->d_words, minpts, cb);
     k_rank<<<B, 256, 0, s>>>(h->d_grid, h->d_words);
-    k_segstart<u64><<<dim3(gx, B), 256, 0, s>>>(h->d_keys_b, pitch, h->d_grid, h->d_words, h->d_seg_start, minpts, cb);
+    k_segstart<u64><<<dim3(gx4, B), 256, 0, s>>>(h->d_keys_b, pitch, h->d_grid, h->d_words, h->d_seg_start, minpts, cb);
     if (want_cent) k_leafsum<u64, true><<<dim3(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, h->d_keys_b, h->d_vals_b, h->d_grid, h->d_seg_start,
                                                                                h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent);
     else k_leafsum<u64, false><<<dim3(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, h->d_keys_b, h->d_vals_b, h->d_grid, h->d_seg_start,

@@ -111,23 +111,43 @@ __global__ void __launch_bounds__(256) k_keys(const float* __restrict__ tgt, siz
 }
 
 // mark cells that hold >= min_points points (impl:297) in the occupancy bitmap
+// A sorted position i is the head of a searchable leaf's run iff its cell is binned, K[i-1] differs and K[i+min_points-1]
+// is still the same key.  One element per thread makes these streaming kernels latency bound (a wave issues three loads and
+// retires), so every thread tests RUN_ILP positions, one block stride apart, with all their loads in flight together.
+#define RUN_ILP 4
+template <typename KeyT>
+__device__ __forceinline__ void run_heads(const KeyT* __restrict__ K, size_t pitch, size_t i0, size_t stride, int min_points, unsigned cmask,
+                                          bool head[RUN_ILP], unsigned cell[RUN_ILP]) {
+  KeyT k0[RUN_ILP], km[RUN_ILP], kl[RUN_ILP];
+  const size_t span = (size_t)(min_points > 0 ? min_points - 1 : 0);
+#pragma unroll
+  for (int u = 0; u < RUN_ILP; u++) {
+    const size_t i = i0 + (size_t)u * stride;
+    const bool in = i < pitch;
+    k0[u] = in ? K[i] : (KeyT)cmask;
+    km[u] = (in && i != 0) ? K[i - 1] : ~(KeyT)0;
+    kl[u] = (in && i + span < pitch) ? K[i + span] : ~(KeyT)0;
+  }
+#pragma unroll
+  for (int u = 0; u < RUN_ILP; u++) {
+    const size_t i = i0 + (size_t)u * stride;
+    cell[u] = (unsigned)k0[u] & cmask;
+    head[u] = i < pitch && cell[u] != cmask && (i == 0 || km[u] != k0[u]) && (i + span < pitch) && kl[u] == k0[u];
+  }
+}
 template <typename KeyT>
 __global__ void __launch_bounds__(256) k_mark(const KeyT* __restrict__ keys, size_t pitch, const GridDesc* __restrict__ gd,
                                                BitWord* words, int min_points, int cb) {
   const int b = blockIdx.y;
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= pitch) return;
-  const KeyT* K = keys + (size_t)b * pitch;
-  const KeyT key = K[i];
-  const unsigned cmask = (1u << cb) - 1u;
-  const unsigned cell = (unsigned)key & cmask;
-  if (cell == cmask) return;
-  if (i != 0 && K[i - 1] == key) return;                       // not the head of its segment
-  const size_t last = i + (size_t)(min_points > 0 ? min_points - 1 : 0);
-  if (last >= pitch || K[last] != key) return;                 // fewer than min_points points
-  atomicOr(&words[gd[b].word_off + (cell >> 6)].bits, 1ull << (cell & 63));
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool head[RUN_ILP];
+  unsigned cell[RUN_ILP];
+  run_heads<KeyT>(keys + (size_t)b * pitch, pitch, i0, stride, min_points, (1u << cb) - 1u, head, cell);
+#pragma unroll
+  for (int u = 0; u < RUN_ILP; u++)
+    if (head[u]) atomicOr(&words[gd[b].word_off + (cell[u] >> 6)].bits, 1ull << (cell[u] & 63));
 }
-
 // exclusive popcount prefix over the bitmap words of each target: voxel id = rank in ascending cell order
 __global__ void __launch_bounds__(256) k_rank(GridDesc* gd, BitWord* words) {
   typedef hipcub::BlockScan<unsigned, 256> Scan;
@@ -152,20 +172,19 @@ template <typename KeyT>
 __global__ void __launch_bounds__(256) k_segstart(const KeyT* __restrict__ keys, size_t pitch, const GridDesc* __restrict__ gd,
                                                    const BitWord* __restrict__ words, unsigned* seg_start, int min_points, int cb) {
   const int b = blockIdx.y;
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= pitch) return;
-  const KeyT* K = keys + (size_t)b * pitch;
-  const KeyT key = K[i];
-  const unsigned cmask = (1u << cb) - 1u;
-  const unsigned cell = (unsigned)key & cmask;
-  if (cell == cmask) return;
-  if (i != 0 && K[i - 1] == key) return;
-  const size_t last = i + (size_t)(min_points > 0 ? min_points - 1 : 0);
-  if (last >= pitch || K[last] != key) return;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool head[RUN_ILP];
+  unsigned cell[RUN_ILP];
+  run_heads<KeyT>(keys + (size_t)b * pitch, pitch, i0, stride, min_points, (1u << cb) - 1u, head, cell);
   const GridDesc& g = gd[b];
-  const BitWord bw = words[g.word_off + (cell >> 6)];
-  const unsigned id = bw.prefix + (unsigned)__popcll(bw.bits & ((1ull << (cell & 63)) - 1ull));
-  seg_start[g.rec_off + id] = (unsigned)i;
+#pragma unroll
+  for (int u = 0; u < RUN_ILP; u++) {
+    if (!head[u]) continue;
+    const BitWord bw = words[g.word_off + (cell[u] >> 6)];
+    const unsigned id = bw.prefix + (unsigned)__popcll(bw.bits & ((1ull << (cell[u] & 63)) - 1ull));
+    seg_start[g.rec_off + id] = (unsigned)(i0 + (size_t)u * stride);
+  }
 }
 
 // leaf.mean_ += pt ; leaf.cov_ += pt pt^T (impl:233-237) for every searchable leaf: one WAVE per leaf.
