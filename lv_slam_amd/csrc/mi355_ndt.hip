@@ -24,6 +24,7 @@
 #include "ndt_math.hpp"
 #include "ndt_types.hpp"
 #include "ndt_build.hpp"
+#include "ndt_segsort.hpp"
 #include "ndt_sweep.hpp"
 #include "ndt_update.hpp"
 #include "ndt_hessian.hpp"
@@ -62,6 +63,7 @@ struct mi355ndt_handle {
   BitWord* d_words = nullptr; size_t words_cap = 0;
   VoxelRec* d_recs = nullptr; int *d_vox_idx = nullptr, *d_vox_n = nullptr;
   unsigned* d_seg_start = nullptr; double* d_sums = nullptr; float* d_cent = nullptr; double* d_icov64 = nullptr; size_t icov64_cap = 0;
+  unsigned* d_rs_hist = nullptr; unsigned* d_rs_offs = nullptr; size_t rs_cap = 0;   // segmented radix sort: tile histograms / offsets
   unsigned *d_cstart = nullptr, *d_cend = nullptr; size_t cell_cap = 0; bool cells_ready = false; int last_cb = 0;
   double* d_fit = nullptr; size_t fit_cap = 0;
   // prefilter workspace
@@ -210,7 +212,7 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
   void* ptrs[] = {h->d_tgt_own, h->d_src_own, h->d_tgt_cnt, h->d_src_cnt, h->d_minmax, h->d_grid, h->d_nwords, h->d_word_off,
                   h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, h->d_tmp, h->d_words, h->d_recs, h->d_vox_idx, h->d_vox_n,
                   h->d_state, h->d_partials, h->d_guess, h->d_results, h->d_active, h->d_hook, h->d_aligned, h->d_hits, h->d_seg_start, h->d_sums,
-                  h->d_cent, h->d_icov64, h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit, h->d_pf_in, h->d_pf_out, h->d_pf_keep, h->d_pf_keys,
+                  h->d_cent, h->d_icov64, h->d_rs_hist, h->d_rs_offs, h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit, h->d_pf_in, h->d_pf_out, h->d_pf_keep, h->d_pf_keys,
                   h->d_pf_vals, h->d_pf_flag, h->d_pf_pos, h->d_pf_mm, h->d_pf_grid, h->d_pf_tmp};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_pin_u) hipHostFree(h->h_pin_u);
@@ -502,8 +504,29 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
   tb = h->tmp_bytes;
   if (k32) {
     unsigned *ka = (unsigned*)h->d_keys_a, *kb = (unsigned*)h->d_keys_b;
-    k_keys<unsigned><<<dim3(gx, B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_grid, ka, h->d_vals_a, cb);
-    HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(h->d_tmp, tb, ka, kb, h->d_vals_a, h->d_vals_b, (int)total, 0, cb + pb, s));
+    // stable sort by cell inside every target's segment (ndt_segsort.hpp): ceil(cb / 8) passes, result in kb / d_vals_b
+    const int npass = (cb + RS_BITS - 1) / RS_BITS;
+    const int tiles = (int)((pitch + RS_TILE - 1) / RS_TILE);
+    {
+      const size_t need = (size_t)B * tiles * RS_NB;
+      if (need > h->rs_cap) {
+        size_t c1 = 0, c2 = 0;
+        if (h->d_rs_hist) { HIPCHK(h, hipFree(h->d_rs_hist)); h->d_rs_hist = nullptr; }
+        if (h->d_rs_offs) { HIPCHK(h, hipFree(h->d_rs_offs)); h->d_rs_offs = nullptr; }
+        HIPCHK(h, grow(h->d_rs_hist, c1, need)); HIPCHK(h, grow(h->d_rs_offs, c2, need));
+        h->rs_cap = need;
+      }
+    }
+    unsigned *kin = (npass & 1) ? ka : kb, *kout = (npass & 1) ? kb : ka;      // an odd number of hops must end in kb
+    unsigned *vin = (npass & 1) ? h->d_vals_a : h->d_vals_b, *vout = (npass & 1) ? h->d_vals_b : h->d_vals_a;
+    k_keys<unsigned><<<dim3(gx, B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_grid, kin, nullptr, cb);
+    for (int p = 0; p < npass; p++) {
+      k_rs_hist<<<dim3(tiles, B), RS_THREADS, 0, s>>>(kin, pitch, p * RS_BITS, h->d_rs_hist, tiles);
+      k_rs_scan<<<B, RS_NB, 0, s>>>(h->d_rs_hist, h->d_rs_offs, tiles);
+      if (p == 0) k_rs_scatter<true><<<dim3(tiles, B), RS_THREADS, 0, s>>>(kin, vin, kout, vout, pitch, p * RS_BITS, h->d_rs_offs, tiles);
+      else k_rs_scatter<false><<<dim3(tiles, B), RS_THREADS, 0, s>>>(kin, vin, kout, vout, pitch, p * RS_BITS, h->d_rs_offs, tiles);
+      std::swap(kin, kout); std::swap(vin, vout);
+    }
     k_mark<unsigned><<<dim3(gx4, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, minpts, cb);
     k_rank<<<B, 256, 0, s>>>(h->d_grid, h->d_words);
     k_segstart<unsigned><<<dim3(gx4, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, h->d_seg_start, minpts, cb);

@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256) k_keys(const float* __restrict__ tgt, siz
     }
   }
   keys[(size_t)b * pitch + i] = ((KeyT)b << cb) | (KeyT)cell;
-  vals[(size_t)b * pitch + i] = (unsigned)i;
+  if (vals) vals[(size_t)b * pitch + i] = (unsigned)i;      // the segmented sort derives the ids itself in its first pass
 }
 
 // mark cells that hold >= min_points points (impl:297) in the occupancy bitmap

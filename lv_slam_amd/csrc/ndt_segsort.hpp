@@ -1,0 +1,134 @@
+// ndt_segsort.hpp -- stable LSD radix sort of (cell key, point id) pairs INSIDE each target's segment.
+//
+// The target build needs every target's points grouped by voxel cell in input order (the leaf sums are added in that order to
+// stay bit-identical to the reference's sequential accumulation, voxel_grid_covariance_omp_impl.hpp:226-262).  A device-wide
+// radix sort of pair << cb | cell does that, but sorts bits it does not have to (the pair field is already in order) and
+// scatters every pass across the whole batch.  Here each pass moves a point only within its own target's segment
+// (65,536 points = 512 KB of keys + ids: the scatter stays in one XCD's L2), 8 bits per pass over the cell field only:
+// 3 passes for a 1 m KITTI-size grid instead of 4 device-wide ones.
+//   per pass:  k_rs_hist  (tile digit histograms)  ->  k_rs_scan (per segment, digit-major exclusive scan)  ->  k_rs_scatter
+// A tile is 2048 consecutive positions handled by 4 waves, each owning 512 consecutive positions in 8 rounds of 64, so the
+// order inside a tile is (wave, round, lane) = position order, which is what makes the pass stable.
+#pragma once
+#include "ndt_types.hpp"
+#include <hipcub/hipcub.hpp>
+
+#define RS_BITS    8
+#define RS_NB      (1 << RS_BITS)
+#define RS_THREADS 256
+#define RS_ROUNDS  8
+#define RS_TILE    (RS_THREADS * RS_ROUNDS)
+
+// lanes of the wave holding the same digit as this lane (valid lanes only); RS_BITS ballots
+__device__ __forceinline__ unsigned long long rs_match(unsigned d, bool valid) {
+  unsigned long long m = __ballot(valid);
+#pragma unroll
+  for (int bit = 0; bit < RS_BITS; bit++) {
+    const bool one = (d >> bit) & 1u;
+    const unsigned long long bb = __ballot(one);
+    m &= one ? bb : ~bb;
+  }
+  return valid ? m : 0ull;
+}
+
+// digit histogram of every tile: hist[(b * tiles + tile) * RS_NB + d]
+__global__ void __launch_bounds__(RS_THREADS) k_rs_hist(const unsigned* __restrict__ kin, size_t pitch, int shift, unsigned* hist, int tiles) {
+  __shared__ unsigned cnt[RS_THREADS / 64][RS_NB];
+  const int b = blockIdx.y, tile = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int d = threadIdx.x; d < (RS_THREADS / 64) * RS_NB; d += RS_THREADS) (&cnt[0][0])[d] = 0;
+  __syncthreads();
+  const unsigned* K = kin + (size_t)b * pitch;
+  const size_t wbase = (size_t)tile * RS_TILE + (size_t)w * (RS_TILE / 4);
+  unsigned key[RS_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; r++) {
+    const size_t i = wbase + r * 64 + lane;
+    key[r] = i < pitch ? K[i] : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; r++) {
+    const size_t i = wbase + r * 64 + lane;
+    const bool valid = i < pitch;
+    const unsigned d = (key[r] >> shift) & (RS_NB - 1);
+    const unsigned long long m = rs_match(d, valid);
+    // one lane per distinct digit adds the group's size: no two leaders of a wave touch the same counter
+    if (valid && (m & ((1ull << lane) - 1ull)) == 0) cnt[w][d] += (unsigned)__popcll(m);
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < RS_NB; d += RS_THREADS)
+    hist[((size_t)b * tiles + tile) * RS_NB + d] = ((cnt[0][d] + cnt[1][d]) + cnt[2][d]) + cnt[3][d];
+}
+
+// per segment: where does digit d of tile t start?  (digit-major, tile-minor exclusive scan; one block per segment)
+__global__ void __launch_bounds__(RS_NB) k_rs_scan(const unsigned* __restrict__ hist, unsigned* offs, int tiles) {
+  typedef hipcub::BlockScan<unsigned, RS_NB> Scan;
+  __shared__ typename Scan::TempStorage tmp;
+  const int b = blockIdx.x, d = threadIdx.x;
+  const unsigned* H = hist + (size_t)b * tiles * RS_NB;
+  unsigned* O = offs + (size_t)b * tiles * RS_NB;
+  unsigned tot = 0;
+  for (int t = 0; t < tiles; t++) tot += H[(size_t)t * RS_NB + d];
+  unsigned base;
+  Scan(tmp).ExclusiveSum(tot, base);
+  for (int t = 0; t < tiles; t++) {
+    O[(size_t)t * RS_NB + d] = base;
+    base += H[(size_t)t * RS_NB + d];
+  }
+}
+
+// stable scatter of one tile.  FIRST: the point id of position i is i itself (no id array to read yet).
+template <bool FIRST>
+__global__ void __launch_bounds__(RS_THREADS) k_rs_scatter(const unsigned* __restrict__ kin, const unsigned* __restrict__ vin,
+                                                            unsigned* kout, unsigned* vout, size_t pitch, int shift,
+                                                            const unsigned* __restrict__ offs, int tiles) {
+  __shared__ unsigned run[RS_THREADS / 64][RS_NB];
+  const int b = blockIdx.y, tile = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int d = threadIdx.x; d < (RS_THREADS / 64) * RS_NB; d += RS_THREADS) (&run[0][0])[d] = 0;
+  __syncthreads();
+  const unsigned* K = kin + (size_t)b * pitch;
+  const unsigned* V = vin + (size_t)b * pitch;
+  const size_t wbase = (size_t)tile * RS_TILE + (size_t)w * (RS_TILE / 4);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  unsigned key[RS_ROUNDS], val[RS_ROUNDS], info[RS_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; r++) {
+    const size_t i = wbase + r * 64 + lane;
+    key[r] = i < pitch ? K[i] : 0u;
+    val[r] = FIRST ? (unsigned)i : (i < pitch ? V[i] : 0u);
+  }
+  // phase 1: this wave's digit counts, and for every position its rank inside its (wave, round, digit) group
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; r++) {
+    const size_t i = wbase + r * 64 + lane;
+    const bool valid = i < pitch;
+    const unsigned d = (key[r] >> shift) & (RS_NB - 1);
+    const unsigned long long m = rs_match(d, valid);
+    const unsigned rank = (unsigned)__popcll(m & lt), c = (unsigned)__popcll(m);
+    const unsigned leader = valid ? (unsigned)__ffsll((long long)m) - 1u : (unsigned)lane;
+    if (valid && rank == 0) run[w][d] += c;
+    info[r] = rank | (leader << 8) | (c << 16);
+  }
+  __syncthreads();
+  // counts -> start offsets: digit d of this tile starts at offs[..][d]; waves follow each other in position order
+  for (int d = threadIdx.x; d < RS_NB; d += RS_THREADS) {
+    unsigned o = offs[((size_t)b * tiles + tile) * RS_NB + d];
+#pragma unroll
+    for (int w2 = 0; w2 < RS_THREADS / 64; w2++) { const unsigned c = run[w2][d]; run[w2][d] = o; o += c; }
+  }
+  __syncthreads();
+  // phase 2: rounds in order; the group leader advances the wave's running offset of its digit and broadcasts the old value
+  unsigned* KO = kout + (size_t)b * pitch;
+  unsigned* VO = vout + (size_t)b * pitch;
+#pragma unroll
+  for (int r = 0; r < RS_ROUNDS; r++) {
+    const size_t i = wbase + r * 64 + lane;
+    const bool valid = i < pitch;
+    const unsigned d = (key[r] >> shift) & (RS_NB - 1);
+    const unsigned rank = info[r] & 0xffu, leader = (info[r] >> 8) & 0xffu, c = info[r] >> 16;
+    unsigned prev = 0;
+    if (valid && rank == 0) { prev = run[w][d]; run[w][d] = prev + c; }
+    prev = __shfl(prev, (int)leader);
+    if (valid) { KO[prev + rank] = key[r]; VO[prev + rank] = val[r]; }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
