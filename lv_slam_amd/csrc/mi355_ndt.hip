@@ -96,6 +96,7 @@ struct mi355ndt_handle {
   bool prof = false;
   mi355ndt_profile P{};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_sweep, ev_update, ev_build;
+  std::vector<hipEvent_t> ev_pool;                // idle timing events (filled by mi355ndt_profile_enable)
 };
 
 #define HIPCHK(h, call)                                                                          \
@@ -218,6 +219,7 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
   if (h->h_pin_u) hipHostFree(h->h_pin_u);
   if (h->h_pin_active) hipHostFree(h->h_pin_active);
   for (hipEvent_t e : h->ev_burst) if (e) hipEventDestroy(e);
+  for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
   for (auto& e : h->ev_sweep) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   for (auto& e : h->ev_update) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   for (auto& e : h->ev_build) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -383,32 +385,50 @@ int mi355ndt_batch_bind_device(mi355ndt_handle* h, int n_pairs, const float* d_t
 }
 
 // ---- profiling helpers ------------------------------------------------------------------------
+// timing events come from a pool that mi355ndt_profile_enable fills up front: creating events inside a timed region can
+// stall for milliseconds when the runtime has to grow its signal pool
+static hipError_t ev_take(mi355ndt_handle* h, hipEvent_t* e) {
+  if (!h->ev_pool.empty()) { *e = h->ev_pool.back(); h->ev_pool.pop_back(); return hipSuccess; }
+  return hipEventCreate(e);
+}
 static hipError_t ev_begin(mi355ndt_handle* h, std::vector<std::pair<hipEvent_t, hipEvent_t>>& v) {
   hipEvent_t a, b;
-  hipError_t e = hipEventCreate(&a); if (e != hipSuccess) return e;
-  e = hipEventCreate(&b); if (e != hipSuccess) return e;
+  hipError_t e = ev_take(h, &a); if (e != hipSuccess) return e;
+  e = ev_take(h, &b); if (e != hipSuccess) return e;
   v.push_back({a, b});
   return hipEventRecord(a, h->stream);
 }
 static hipError_t ev_end(mi355ndt_handle* h, std::vector<std::pair<hipEvent_t, hipEvent_t>>& v) {
   return hipEventRecord(v.back().second, h->stream);
 }
-static void ev_collect(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, double& ms, long long& n) {
+static void ev_collect(mi355ndt_handle* h, std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, double& ms, long long& n) {
   for (auto& e : v) {
     float t = 0;
     if (hipEventElapsedTime(&t, e.first, e.second) == hipSuccess) { ms += t; n++; }
-    hipEventDestroy(e.first); hipEventDestroy(e.second);
+    h->ev_pool.push_back(e.first); h->ev_pool.push_back(e.second);
   }
   v.clear();
 }
 
-int mi355ndt_profile_enable(mi355ndt_handle* h, int on) { if (!h) return MI355NDT_ERR_BAD_HANDLE; h->prof = on != 0; return MI355NDT_OK; }
+int mi355ndt_profile_enable(mi355ndt_handle* h, int on) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  h->prof = on != 0;
+  if (h->prof) {
+    HIPCHK(h, hipSetDevice(h->device));
+    while (h->ev_pool.size() < 4096) {             // ~40 profiled steps of a 10-round batch align before the pool has to grow
+      hipEvent_t e;
+      HIPCHK(h, hipEventCreate(&e));
+      h->ev_pool.push_back(e);
+    }
+  }
+  return MI355NDT_OK;
+}
 int mi355ndt_profile_reset(mi355ndt_handle* h) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   double d; long long n;
-  ev_collect(h->ev_sweep, d, n); ev_collect(h->ev_update, d, n); ev_collect(h->ev_build, d, n);
+  ev_collect(h, h->ev_sweep, d, n); ev_collect(h, h->ev_update, d, n); ev_collect(h, h->ev_build, d, n);
   h->P = mi355ndt_profile{};
   return MI355NDT_OK;
 }
@@ -417,9 +437,9 @@ int mi355ndt_profile_get(mi355ndt_handle* h, mi355ndt_profile* out) {
   if (!out) return MI355NDT_ERR_BAD_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  ev_collect(h->ev_sweep, h->P.sweep_ms, h->P.sweep_launches);
-  ev_collect(h->ev_update, h->P.update_ms, h->P.update_launches);
-  ev_collect(h->ev_build, h->P.build_ms, h->P.build_launches);
+  ev_collect(h, h->ev_sweep, h->P.sweep_ms, h->P.sweep_launches);
+  ev_collect(h, h->ev_update, h->P.update_ms, h->P.update_launches);
+  ev_collect(h, h->ev_build, h->P.build_ms, h->P.build_launches);
   *out = h->P;
   return MI355NDT_OK;
 }
@@ -494,7 +514,8 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
     h->words_cap = c;
   }
   if (total_words) HIPCHK(h, hipMemsetAsync(h->d_words, 0, total_words * sizeof(BitWord), s));
-  const int lb = std::max(1, std::min((int)((rpp + LS_WAVES - 1) / LS_WAVES), std::max(8, 8192 / B)));
+  // leaf-sum workgroups per target: 64 keeps ~4 targets (3 MB of points) in flight per XCD, inside its 4 MB L2
+  const int lb = std::max(1, std::min((int)((rpp + LS_WAVES - 1) / LS_WAVES), 64));
   const unsigned gx4 = (unsigned)((pitch + 256 * RUN_ILP - 1) / (256 * RUN_ILP));   // k_mark / k_segstart: RUN_ILP positions per thread
   const bool mt_live = mt_is_live(h->prm);
   const bool want_cent = h->prm.neighbor_mode == MI355NDT_KDTREE || mt_live;   // f32 leaf centroids: KDTREE probe, computeHessian
@@ -521,19 +542,19 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
     unsigned *vin = (npass & 1) ? h->d_vals_a : h->d_vals_b, *vout = (npass & 1) ? h->d_vals_b : h->d_vals_a;
     k_keys<unsigned><<<dim3(gx, B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_grid, kin, nullptr, cb);
     for (int p = 0; p < npass; p++) {
-      k_rs_hist<<<dim3(tiles, B), RS_THREADS, 0, s>>>(kin, pitch, p * RS_BITS, h->d_rs_hist, tiles);
+      k_rs_hist<<<xcd_grid(tiles, B), RS_THREADS, 0, s>>>(kin, pitch, p * RS_BITS, h->d_rs_hist, tiles, B);
       k_rs_scan<<<B, RS_NB, 0, s>>>(h->d_rs_hist, h->d_rs_offs, tiles);
-      if (p == 0) k_rs_scatter<true><<<dim3(tiles, B), RS_THREADS, 0, s>>>(kin, vin, kout, vout, pitch, p * RS_BITS, h->d_rs_offs, tiles);
-      else k_rs_scatter<false><<<dim3(tiles, B), RS_THREADS, 0, s>>>(kin, vin, kout, vout, pitch, p * RS_BITS, h->d_rs_offs, tiles);
+      if (p == 0) k_rs_scatter<true><<<xcd_grid(tiles, B), RS_THREADS, 0, s>>>(kin, vin, kout, vout, pitch, p * RS_BITS, h->d_rs_offs, tiles, B);
+      else k_rs_scatter<false><<<xcd_grid(tiles, B), RS_THREADS, 0, s>>>(kin, vin, kout, vout, pitch, p * RS_BITS, h->d_rs_offs, tiles, B);
       std::swap(kin, kout); std::swap(vin, vout);
     }
     k_mark<unsigned><<<dim3(gx4, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, minpts, cb);
     k_rank<<<B, 256, 0, s>>>(h->d_grid, h->d_words);
     k_segstart<unsigned><<<dim3(gx4, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, h->d_seg_start, minpts, cb);
-    if (want_cent) k_leafsum<unsigned, true><<<dim3(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start,
-                                                                                    h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent);
-    else k_leafsum<unsigned, false><<<dim3(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start,
-                                                                          h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent);
+    if (want_cent) k_leafsum<unsigned, true><<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start,
+                                                                                    h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent, lb, B);
+    else k_leafsum<unsigned, false><<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start,
+                                                                          h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent, lb, B);
   } else {
     typedef unsigned long long u64;
     k_keys<u64><<<dim3(gx, B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_grid, h->d_keys_a, h->d_vals_a, cb);
@@ -541,10 +562,10 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
     k_mark<u64><<<dim3(gx4, B), 256, 0, s>>>(h->d_keys_b, pitch, h->d_grid, h->d_words, minpts, cb);
     k_rank<<<B, 256, 0, s>>>(h->d_grid, h->d_words);
     k_segstart<u64><<<dim3(gx4, B), 256, 0, s>>>(h->d_keys_b, pitch, h->d_grid, h->d_words, h->d_seg_start, minpts, cb);
-    if (want_cent) k_leafsum<u64, true><<<dim3(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, h->d_keys_b, h->d_vals_b, h->d_grid, h->d_seg_start,
-                                                                               h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent);
-    else k_leafsum<u64, false><<<dim3(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, h->d_keys_b, h->d_vals_b, h->d_grid, h->d_seg_start,
-                                                                     h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent);
+    if (want_cent) k_leafsum<u64, true><<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, h->d_keys_b, h->d_vals_b, h->d_grid, h->d_seg_start,
+                                                                               h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent, lb, B);
+    else k_leafsum<u64, false><<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, h->d_keys_b, h->d_vals_b, h->d_grid, h->d_seg_start,
+                                                                     h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent, lb, B);
   }
   k_voxels<<<dim3((unsigned)((rpp + 255) / 256), B), 256, 0, s>>>(h->d_grid, h->d_sums, h->d_recs, h->d_vox_n,
                                                                   h->prm.min_covar_eigvalue_mult, h->prm.variant == MI355NDT_VARIANT_PCA,

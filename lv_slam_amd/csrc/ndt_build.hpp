@@ -196,16 +196,18 @@ template <typename KeyT, bool CENT>
 __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restrict__ tgt, size_t pitch,
                                                            const KeyT* __restrict__ keys, const unsigned* __restrict__ vals,
                                                            const GridDesc* __restrict__ gd, const unsigned* __restrict__ seg_start,
-                                                           double* sums, int* vox_idx, int* vox_n, int cb, float* cent) {
+                                                           double* sums, int* vox_idx, int* vox_n, int cb, float* cent,
+                                                           int nx, int n_targets) {
   __shared__ double term[LS_WAVES][64][9];
   __shared__ float termf[CENT ? LS_WAVES : 1][64][3];
-  const int b = blockIdx.y;
+  int b, bx;
+  if (!xcd_map(nx, n_targets, bx, b)) return;    // one target's leaves on one XCD: the point gathers hit in its L2
   const GridDesc& g = gd[b];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const KeyT* K = keys + (size_t)b * pitch;
   const unsigned* V = vals + (size_t)b * pitch;
   const float* X = tgt + (size_t)b * 3 * pitch;
-  const int id0 = blockIdx.x * LS_WAVES + wv, idstep = gridDim.x * LS_WAVES;
+  const int id0 = bx * LS_WAVES + wv, idstep = nx * LS_WAVES;
   size_t start_next = id0 < g.n_voxels ? seg_start[g.rec_off + id0] : 0;
   for (int id = id0; id < g.n_voxels; id += idstep) {
     const size_t start = start_next;

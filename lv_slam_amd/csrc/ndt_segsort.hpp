@@ -32,9 +32,12 @@ __device__ __forceinline__ unsigned long long rs_match(unsigned d, bool valid) {
 }
 
 // digit histogram of every tile: hist[(b * tiles + tile) * RS_NB + d]
-__global__ void __launch_bounds__(RS_THREADS) k_rs_hist(const unsigned* __restrict__ kin, size_t pitch, int shift, unsigned* hist, int tiles) {
+__global__ void __launch_bounds__(RS_THREADS) k_rs_hist(const unsigned* __restrict__ kin, size_t pitch, int shift, unsigned* hist, int tiles,
+                                                        int n_targets) {
   __shared__ unsigned cnt[RS_THREADS / 64][RS_NB];
-  const int b = blockIdx.y, tile = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int b, tile;
+  if (!xcd_map(tiles, n_targets, tile, b)) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int d = threadIdx.x; d < (RS_THREADS / 64) * RS_NB; d += RS_THREADS) (&cnt[0][0])[d] = 0;
   __syncthreads();
   const unsigned* K = kin + (size_t)b * pitch;
@@ -80,9 +83,11 @@ __global__ void __launch_bounds__(RS_NB) k_rs_scan(const unsigned* __restrict__ 
 template <bool FIRST>
 __global__ void __launch_bounds__(RS_THREADS) k_rs_scatter(const unsigned* __restrict__ kin, const unsigned* __restrict__ vin,
                                                             unsigned* kout, unsigned* vout, size_t pitch, int shift,
-                                                            const unsigned* __restrict__ offs, int tiles) {
+                                                            const unsigned* __restrict__ offs, int tiles, int n_targets) {
   __shared__ unsigned run[RS_THREADS / 64][RS_NB];
-  const int b = blockIdx.y, tile = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int b, tile;
+  if (!xcd_map(tiles, n_targets, tile, b)) return;   // a target's tiles on one XCD: its scattered writes combine in that L2
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int d = threadIdx.x; d < (RS_THREADS / 64) * RS_NB; d += RS_THREADS) (&run[0][0])[d] = 0;
   __syncthreads();
   const unsigned* K = kin + (size_t)b * pitch;

@@ -85,3 +85,15 @@ __device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); retur
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
 __device__ __forceinline__ bool finite3(float x, float y, float z) { return isfinite(x) && isfinite(y) && isfinite(z); }
 
+// XCD-aware placement for kernels that give every target `nx` workgroups: a fresh launch hands workgroup L to XCD L % 8
+// (MI355X_MICROARCH.md), so the 1-D grid 8 * ceil(B / 8) * nx is read as  xcd = L & 7,  s = L >> 3,  target = xcd + 8 * (s / nx),
+// block-in-target = s % nx: all workgroups of one target run on ONE XCD (its points / keys stay in that XCD's 4 MB L2 and
+// scattered writes to one cache line meet in one L2), and an XCD walks through its targets in order.
+__device__ __forceinline__ bool xcd_map(int nx, int n_targets, int& bx, int& b) {
+  const int L = blockIdx.x, xcd = L & 7, s = L >> 3;
+  b = xcd + 8 * (s / nx);
+  bx = s % nx;
+  return b < n_targets;
+}
+static inline unsigned xcd_grid(int nx, int n_targets) { return 8u * (unsigned)((n_targets + 7) / 8) * (unsigned)nx; }
+
