@@ -1,0 +1,86 @@
+"""Turns the raw rocprofv3 output of tools/collect_profiles.sh (gpurun_out/final/) into the committed profile files.
+usage: python profiles/summarize.py [round_tag]   (default r01)"""
+import csv, glob, json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "final")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(SRC, pattern), recursive=True)
+    assert f, pattern
+    return f[0]
+
+
+# ---- kernel stats (engine kernels only; torch kernels of the synthetic data generator are summed into one line)
+rows = list(csv.DictReader(open(one("kt/**/*_kernel_stats.csv"))))
+ours, other_calls, other_ns = [], 0, 0.0
+for r in rows:
+    n = r["Name"]
+    if any(k in n for k in ("k_sweep", "k_update", "k_leafsum", "k_rs_", "k_keys", "k_mark", "k_segstart", "k_minmax", "k_voxels", "k_rank",
+                            "k_init_state", "k_griddesc", "k_set_word_off", "k_hessian", "k_fitness", "k_cellrange", "k_transform", "rocprim",
+                            "rocclr")):
+        ours.append(r)
+    else:
+        other_calls += int(r["Calls"]); other_ns += float(r["TotalDurationNs"])
+with open(os.path.join(OUT, f"{TAG}_final_kernel_stats.csv"), "w") as f:
+    f.write("kernel,calls,total_us,avg_us,min_us,max_us\n")
+    for r in ours:
+        f.write(f"\"{r['Name'][:110]}\",{r['Calls']},{float(r['TotalDurationNs']) / 1e3:.1f},{float(r['AverageNs']) / 1e3:.3f},"
+                f"{float(r['MinNs']) / 1e3:.2f},{float(r['MaxNs']) / 1e3:.2f}\n")
+    f.write(f"\"(torch kernels: synthetic data generation, outside the path)\",{other_calls},{other_ns / 1e3:.1f},,,\n")
+
+# ---- every sweep dispatch
+tr = list(csv.DictReader(open(one("kt/**/*_kernel_trace.csv"))))
+sw = [r for r in tr if "k_sweep" in r["Kernel_Name"]]
+sw.sort(key=lambda r: int(r["Start_Timestamp"]))
+with open(os.path.join(OUT, f"{TAG}_final_sweep_dispatches.csv"), "w") as f:
+    f.write("dispatch,duration_us,grid_size,vgpr,sgpr,lds_bytes,scratch\n")
+    for k, r in enumerate(sw):
+        f.write(f"{k},{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:.2f},{r.get('Grid_Size', r.get('Grid_Size_X', ''))},"
+                f"{r.get('VGPR_Count', '')},{r.get('SGPR_Count', '')},{r.get('LDS_Block_Size', '')},{r.get('Scratch_Size', '')}\n")
+
+
+# ---- PMC passes: FETCH_SIZE / WRITE_SIZE per sweep dispatch (rocprofv3 reports them in KB)
+def counter(dirname, name):
+    rows = list(csv.DictReader(open(one(f"{dirname}/**/*_counter_collection.csv"))))
+    rows = [r for r in rows if r["Counter_Name"] == name and "k_sweep" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    return [float(r["Counter_Value"]) for r in rows]
+
+
+fe, wr = counter("fetch", "FETCH_SIZE"), counter("write", "WRITE_SIZE")
+n = min(len(fe), len(wr))
+with open(os.path.join(OUT, f"{TAG}_final_pmc_sweep.csv"), "w") as f:
+    f.write("dispatch,FETCH_SIZE_KB,WRITE_SIZE_KB\n")
+    for k in range(n):
+        f.write(f"{k},{fe[k]},{wr[k]}\n")
+fe_avg, wr_avg = sum(fe[:n]) / n, sum(wr[:n]) / n
+kmax = max(range(n), key=lambda k: fe[k])
+bench = json.loads(open(os.path.join(SRC, "bench.json")).read())
+traffic = {
+    "kernel": "k_sweep", "workload": "bench.py defaults (271 pairs x 65536 pts, ndt_omp, 1.0 m, DIRECT7)",
+    "launches_counted": n, "fetch_size_kb_avg_per_launch": fe_avg, "write_size_kb_avg_per_launch": wr_avg, "fetch_correction": 2.0,
+    "traffic_bytes_per_launch": (2.0 * fe_avg + wr_avg) * 1024, "traffic_bytes_per_launch_uncorrected": (fe_avg + wr_avg) * 1024,
+    "full_launch": {"fetch_kb": fe[kmax], "write_kb": wr[kmax]},
+    "algorithmic_bytes_per_launch": bench["roofline"]["alg_bytes_per_launch"],
+    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --cpu-seconds 0 --steps 4 --warmup 1`, "
+              "--kernel-include-regex k_sweep, no trace domains; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE x2 is the gfx950 "
+              "half-counting correction of MI355X_MICROARCH.md (HBM section), calibrated on the compulsory traffic of a full launch "
+              "(source points 213 MB + records ~25 MB + bitmap ~11 MB).  The average runs over every sweep launch of the run, including "
+              "the empty speculative ones that close each align.",
+}
+json.dump(traffic, open(os.path.join(OUT, f"{TAG}_traffic.json"), "w"), indent=1)
+for src, dst in (("bench.json", f"{TAG}_final_bench.json"), ("bench_pca_d1.json", f"{TAG}_final_bench_pca_d1.json"),
+                 ("bench_cfg5.json", f"{TAG}_final_bench_cfg5.json"), ("bench_1536.json", f"{TAG}_final_bench_1536pairs.json"),
+                 ("kt_bench.json", f"{TAG}_final_bench_under_rocprof.json")):
+    p = os.path.join(SRC, src)
+    if os.path.exists(p) and os.path.getsize(p) > 10:
+        line = [l for l in open(p).read().splitlines() if l.startswith("{")][-1]
+        json.dump(json.loads(line), open(os.path.join(OUT, dst), "w"), indent=1)
+if os.path.exists(os.path.join(SRC, "latency.txt")):
+    open(os.path.join(OUT, f"{TAG}_final_latency.txt"), "w").write(open(os.path.join(SRC, "latency.txt")).read())
+print("sweep launches", len(sw), "avg us", sum((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) for r in sw) / 1e3 / max(1, len(sw)))
+print("traffic per launch MB", traffic["traffic_bytes_per_launch"] / 1e6, "full launch fetch/write KB", fe[kmax], wr[kmax])
