@@ -162,9 +162,23 @@ k_update(PairState* st, const double* __restrict__ partials, int chunks_per_pair
   if (lane < NACC && (mt != 2 || (lane >= 7 && lane < 43))) {
     double v = 0.0;
     const double* P = partials + (size_t)b * chunks_per_pair * QUARTERS * NACC + lane;
-    for (int c = 0; c < nchunks; c++) {                                          // impl2:298-302 (fixed order)
+    // impl2:298-302 (fixed order).  Eight chunks' rows are loaded together, then added in chunk order: the loop is a chain of
+    // dependent adds, but its 4 * nchunks loads do not have to wait for one another.
+    int c = 0;
+    for (; c + 8 <= nchunks; c += 8) {
+      double q[8][QUARTERS];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const double* Q = P + (size_t)(c + u) * QUARTERS * NACC;
+#pragma unroll
+        for (int k = 0; k < QUARTERS; k++) q[u][k] = Q[k * NACC];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) v += ((q[u][0] + q[u][1]) + q[u][2]) + q[u][3];   // the chunk's four wave-quarters, in order
+    }
+    for (; c < nchunks; c++) {
       const double* Q = P + (size_t)c * QUARTERS * NACC;
-      v += ((Q[0] + Q[NACC]) + Q[2 * NACC]) + Q[3 * NACC];                       // the chunk's four wave-quarters, in order
+      v += ((Q[0] + Q[NACC]) + Q[2 * NACC]) + Q[3 * NACC];
     }
     if (lane == 0) S.score = v;
     else if (lane < 7) S.g[lane - 1] = v;
