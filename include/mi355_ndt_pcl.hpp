@@ -12,6 +12,7 @@
 #include <pcl/registration/registration.h>
 #include <stdexcept>
 #include <limits>
+#include <vector>
 #include "mi355_ndt.h"
 
 namespace mi355ndt {
@@ -55,6 +56,16 @@ class NormalDistributionsTransform : public pcl::Registration<PointSource, Point
   inline void setNeighborhoodSearchMethod(NeighborSearchMethod m) { prm_.neighbor_mode = m; }
   inline double getTransformationProbability() const { return trans_probability_; }
   inline int getFinalNumIteration() const { return nr_iterations_; }
+  // pclpca's getTargetCells() (ndt_pca.h:129-133) hands out the VoxelGridCovariance itself; that container lives on the GPU here,
+  // so the accessor returns the searchable leaves (cell index, nr_points, mean, inverse covariance, pca weight) in std::map order
+  inline std::vector<mi355ndt_voxel> getTargetCells() const {
+    int mn[3], mx[3], dv[3], n = 0;
+    std::vector<mi355ndt_voxel> v;
+    if (mi355ndt_get_grid(h_, 0, mn, mx, dv, &n) != MI355NDT_OK || n <= 0) return v;
+    v.resize((size_t)n);
+    if (mi355ndt_get_voxels(h_, 0, v.data(), v.size()) != MI355NDT_OK) v.clear();
+    return v;
+  }
   // GPU version of pcl::Registration::getFitnessScore (non-virtual in PCL: reached when the caller holds the derived type,
   // e.g. boost::dynamic_pointer_cast<mi355ndt::NormalDistributionsTransform<PointT,PointT>>(registration) in
   // loop_detector.hpp:256; through a base pointer PCL's own CPU kd-tree version runs and gives the same number)

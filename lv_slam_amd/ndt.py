@@ -392,6 +392,10 @@ class NormalDistributionsTransform:
     def getTransformationProbability(self) -> float:
         return self._trans_probability
 
+    def getTargetCells(self) -> np.ndarray:
+        """pclpca getTargetCells() (ndt_pca.h:129-133): the searchable leaves of the target grid, in std::map order."""
+        return self._eng.get_voxels(0)
+
     def getFinalNumIteration(self) -> int:
         return self._nr_iterations
 

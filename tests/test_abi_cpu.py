@@ -78,3 +78,16 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in txt.replace("no oracle", ""), f"{f} mentions the oracle"
     assert "oracle" not in open(os.path.join(ROOT, "include", "mi355_ndt.h")).read()
+
+
+def test_mirror_has_reference_method_names():
+    """the host mirror answers to the reference's own method names (ndt_omp.h:109-203, ndt_pca.h:129-133, pcl::Registration)"""
+    names = ["setNumThreads", "setResolution", "getResolution", "setStepSize", "getStepSize", "setOulierRatio", "getOulierRatio",
+             "setNeighborhoodSearchMethod", "getTransformationProbability", "getFinalNumIteration", "getTargetCells",
+             "setInputTarget", "setInputSource", "align", "getFinalTransformation", "hasConverged", "getFitnessScore",
+             "setTransformationEpsilon", "setMaximumIterations"]
+    for n in names:
+        assert callable(getattr(ndt.NormalDistributionsTransform, n, None)), n
+    # enum order of ndt_omp.h:51-56
+    assert (ndt.KDTREE, ndt.DIRECT26, ndt.DIRECT7, ndt.DIRECT1) == (0, 1, 2, 3)
+

@@ -311,7 +311,7 @@ def test_set_resolution_revoxelises():
     n1 = reg.engine.get_grid()[3]
     reg.setResolution(2.0)                     # ndt_omp.h:126-136: re-init because a target is set
     n2 = reg.engine.get_grid()[3]
-    assert n1 != n2
+    assert n1 != n2 and len(reg.getTargetCells()) == n2            # ndt_pca.h:129-133 accessor
     check_voxels(reg.engine, O.Grid(tgt, O.default_params(resolution=2.0)))
     reg.setInputSource(src)
     out = reg.align(synth.default_guess())
@@ -377,6 +377,41 @@ def test_batch_matches_single_and_oracle():
     res2 = eng.batch_align(np.broadcast_to(G, (len(pairs), 4, 4)))
     for a, b in zip(res, res2):
         assert np.array_equal(a["final"], b["final"]) and a["score"] == b["score"]
+
+
+def test_wide_keys_fall_back_to_device_wide_sort():
+    """pair field + cell field > 32 bits (many pairs AND one very large grid): the build takes its 64-bit-key path (device-wide
+    radix sort instead of the segment-local one).  Same voxels as the oracle, same alignment as a single-pair engine."""
+    rng = np.random.default_rng(11)
+    t0, s0, _ = synth.make_pair(30, 64, n_beams=32)
+    t0, s0 = t0.numpy(), s0.numpy()
+    big = np.concatenate([t0, rng.uniform(-128, 128, (3000, 3)).astype(np.float32) * np.float32([1.0, 1.0, 0.9])])   # ~256^3 cells
+    B = 260                                                    # 9 pair bits + 25 cell bits
+    eng = ndt.Engine(ndt.default_params(trans_epsilon=0.01, max_iterations=64))
+    eng.batch_reserve(B, len(big), len(s0))
+    for k in range(B):
+        eng.batch_set_target(k, big if k == 0 else t0)
+        eng.batch_set_source(k, s0)
+    eng.batch_build_targets()
+    mn, mx, dv, nvox = eng.get_grid(0)
+    assert int(dv[0]) * int(dv[1]) * int(dv[2]) > (1 << 23)   # really the wide case
+    op = O.default_params(trans_epsilon=0.01, max_iterations=64)
+    g0 = O.Grid(big, op)
+    lv = g0.valid_leaves()
+    v = eng.get_voxels(0)
+    assert len(v) == len(lv) and np.array_equal(v["idx"], lv["idx"]) and np.array_equal(v["mean"], lv["mean"])
+    G = synth.default_guess()
+    res = eng.batch_align(np.broadcast_to(G, (B, 4, 4)))
+    single = ndt.Engine(ndt.default_params(trans_epsilon=0.01, max_iterations=64))
+    single.set_target(t0)
+    single.set_source(s0)
+    r1 = single.align(G)
+    for k in (1, 2, B - 1):
+        assert np.array_equal(res[k]["final"], r1["final"]) and res[k]["iterations"] == r1["iterations"]
+    ro = O.align(g0, s0, G)
+    assert res[0]["iterations"] == ro["iterations"]
+    dt, dr = se3_err(ro["final"], res[0]["final"])
+    assert dt < 1e-4 and dr < 1e-5
 
 
 def test_device_resident_batch_zero_copy():
