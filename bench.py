@@ -205,14 +205,20 @@ def main():
                                variant=1 if a.variant == "pca" else 0)
         g0 = O.Grid(tg0, op0)
         best = (1e9, 1)
+        align_ms_by_threads = {}
         for th in sorted({t for t in (4, 8, 16, 32, 64, 128, ncpu) if t <= ncpu}):
             O.lib().ora_set_threads(th)
             O.align(g0, sr0, G)
             c0 = time.perf_counter()
             O.align(g0, sr0, G)
             tt_ = time.perf_counter() - c0
+            align_ms_by_threads[str(th)] = round(1e3 * tt_, 2)
             if tt_ < best[0]:
                 best = (tt_, th)
+        try:
+            cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+        except Exception:
+            cpu_model = "unknown"
         cores = best[1]
         O.lib().ora_set_threads(cores)
         op = O.default_params(resolution=a.resolution, trans_epsilon=0.01, max_iterations=64, neighbor_mode=MODES[a.mode],
@@ -233,7 +239,9 @@ def main():
             done += 1
         cpu = {"value": round(done / t_cpu, 3), "unit": "registrations/s", "cores": cores, "kind": "port",
                "sample": f"first {done} of the {B} pairs of this workload (target build + align each), oracle/ndt_oracle.c with "
-                         f"OpenMP on {cores} threads (fastest of 4..{ncpu} on this host); CPU restatement of ndt_omp (reference not buildable in this environment)"}
+                         f"OpenMP on {cores} threads (fastest of 4..{ncpu} on this host); CPU restatement of ndt_omp (reference not buildable in this environment)",
+               "host": f"{cpu_model}, {ncpu} logical CPUs",
+               "align_ms_pair0_by_threads": align_ms_by_threads}   # 4 and 8 are the reference's own settings (nodelet / loop closure)
         parity = {"pairs_checked": done, "max_dtrans_m": worst[0], "max_drot_rad": worst[1], "iterations_equal": it_match,
                   "tolerance": "trans<1e-4 m, rot<1e-5 rad",
                   "note": "pairs that never converge (iterations = max_iterations + 2, e.g. ndt_pca with DIRECT26 where the compounding "
