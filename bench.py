@@ -194,7 +194,7 @@ def main():
     # ---- CPU baseline: the oracle (port of ndt_omp) on this box's host cores, bounded sample of the same pairs
     cpu = None
     parity = None
-    if a.cpu_seconds > 0:
+    if a.cpu_seconds > 0 and world == 1:          # the CPU leg runs on rank 0 of the single-GPU run only
         from oracle import oracle_py as O
         # pick the thread count that is fastest for this oracle on this box (4 and 8 are the reference's own settings,
         # scan_matching_odom_nodelet.cpp:110 / launch/dlo_lfa_ggo_kitti.launch:112); report the one used
