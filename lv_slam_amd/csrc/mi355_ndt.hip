@@ -466,7 +466,7 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
   }
   const int minpts = h->prm.min_points_per_voxel;
   const size_t rpp = pitch / (size_t)minpts + 1;
-  if (rpp > ((size_t)1 << ID_BITS)) { h->err = "target too large: voxel ids would not fit the sweep's 25-bit queue entries"; return MI355NDT_ERR_BAD_ARG; }
+  if (rpp > ((size_t)1 << ID_BITS)) { h->err = "target too large: voxel ids would not fit the sweep's queue entries"; return MI355NDT_ERR_BAD_ARG; }
   if ((size_t)B * rpp > h->recs_cap || rpp != h->recs_per_pair) {
     size_t need = (size_t)B * rpp, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
     if (h->d_recs) { HIPCHK(h, hipFree(h->d_recs)); h->d_recs = nullptr; }

@@ -2,6 +2,7 @@
 // include/ndt_omp/ndt_omp_impl2.hpp:196-305, 503-532, 566-619; voxel_grid_covariance_omp_impl.hpp:373-442).
 #pragma once
 #include "ndt_types.hpp"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------ derivative sweep
 // One (point, voxel) evaluation: updateDerivatives (ndt_omp_impl2.hpp:566-619) with the Jacobian /
@@ -90,9 +91,8 @@ __host__ __device__ constexpr int probe_off(int K, int q, int a) {
   return K == 1 ? 0 : (K == 7 ? o7[q][a] : (K == 26 ? o26[q][a] : (a == 0 ? q % 3 - 1 : (a == 1 ? (q / 3) % 3 - 1 : q / 9 - 1))));
 }
 
-#define Q_CAP   512                       // per-wave hit queue (entries); >= 63 + 7*64
 #define Q_GROUP 7                         // probes between queue drains
-#define ID_BITS 25                        // queue entry = slot << 25 | voxel id
+#define ID_BITS 23                        // queue entry = staging slot << 23 | voxel id
 #define WAVES   (SWEEP_THREADS / 64)
 
 // The sweep.  Work decomposition (MI355X-first):
@@ -133,9 +133,18 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
   const int n_active = ctl->n_active;
   const int items_per_pair = chunks_per_pair * QUARTERS;
 
+  // per-wave hit queue: must hold a leftover (< 64) plus everything one probe group can push: TP tiles x min(K, Q_GROUP) probes x 64
+  constexpr int Q_CAP = (K > 1 && K <= Q_GROUP) ? 1024 : 512;
   __shared__ unsigned q_ent[WAVES][Q_CAP];
-  __shared__ double q_w[PCA ? WAVES : 1][PCA ? Q_CAP : 1];
-  __shared__ float stage[WAVES][128][6];           // two tiles of staged points: x'(3), R x (3)
+  // ndt_pca weight of a queued hit: the suffix product (f64: up to ~150^7) -- for DIRECT1 just the leaf's own integer weight
+  typedef typename std::conditional<K == 1, int, double>::type QW;
+  __shared__ QW q_w[PCA ? WAVES : 1][PCA ? Q_CAP : 1];
+  // TP tiles of 64 points are probed together ("super-tile"): their point transforms, then ALL their bitmap loads, then all
+  // their ballots -- the probe stage costs a few L2 round trips per super-tile, not per tile.  DIRECT1 has one probe per point
+  // and ~0.9 hits, so it is probe-stage bound: 4 tiles at a time; DIRECT7: 2 (14 bitmap words in flight); the 26/27-cell
+  // searches already have 7-probe groups inside one tile.
+  constexpr int TP = (K == 1) ? 4 : (K <= Q_GROUP ? 2 : 1);
+  __shared__ float stage[WAVES][2 * 64 * TP][6];   // two super-tiles of staged points: x'(3), R x (3)
 
   // the control block of the NEXT round (k_update fills it after this kernel) is cleared here, not by a host memset
   if (blockIdx.x == 0 && threadIdx.x < 9) reinterpret_cast<int*>(ctl_next)[threadIdx.x] = 0;
@@ -199,7 +208,7 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
       for (int a = 0; a < 9; a++) B.C[a] = vr.icov[a];
       B.weight = vr.weight;
       B.w = 1.0;
-      if (PCA) B.w = q_w[wv][(qhead + off + k) & (Q_CAP - 1)];
+      if (PCA) B.w = (double)q_w[wv][(qhead + off + k) & (Q_CAP - 1)];
     };
     // evaluate a fetched batch (running `mid` half way through) and retire its `m` queue entries
     auto eval_batch = [&](const Batch& B, int m, auto mid) {
@@ -237,95 +246,120 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
       }
     };
     if (wbase < n && grid_ok) {
-      // points of the next tile are fetched one tile ahead (HBM latency ~2 us would otherwise be exposed per tile)
-      float nx = 0.f, ny = 0.f, nz = 0.f;
-      if (wbase + lane < n) { nx = X[wbase + lane]; ny = X[pitch + wbase + lane]; nz = X[2 * pitch + wbase + lane]; }
+      constexpr int NST = CHUNK_PTS / WAVES / 64 / TP;        // super-tiles per item
+      const unsigned e0 = (unsigned)(xb0 - mb0), e1 = (unsigned)(xb1 - mb1), e2 = (unsigned)(xb2 - mb2);
+      const unsigned empty_cell = (unsigned)(nwords - 1) << 6;
+      // points of the next super-tile are fetched one super-tile ahead (HBM latency ~2 us would otherwise be exposed each time)
+      float nx[TP], ny[TP], nz[TP];
+#pragma unroll
+      for (int p = 0; p < TP; p++) {
+        const int i = wbase + p * 64 + lane;
+        nx[p] = ny[p] = nz[p] = 0.f;
+        if (i < n) { nx[p] = X[i]; ny[p] = X[pitch + i]; nz[p] = X[2 * pitch + i]; }
+      }
 #pragma unroll 1
-      for (int t = 0; t < CHUNK_PTS / WAVES / 64; t++) {
-        const int i = wbase + t * 64 + lane;
-        if (wbase + t * 64 >= n) break;              // wave-uniform
-        // the staging area holds two tiles: entries of tile t-2 must be gone before tile t overwrites their half
+      for (int st = 0; st < NST; st++) {
+        if (wbase + st * TP * 64 >= n) break;        // wave-uniform
+        // the staging area holds two super-tiles: entries of super-tile st-2 must be gone before st overwrites their half
         // (only happens when hits are sparse; dense tiles are consumed by the regular 64-wide drains)
         if (q_old > 0) { __builtin_amdgcn_wave_barrier(); drain(q_old); }
         q_old = qcount;
-        const int slot = (t & 1) * 64 + lane;
-        bool valid = i < n;
-        const float px = nx, py = ny, pz = nz;
-        if (t + 1 < CHUNK_PTS / WAVES / 64 && i + 64 < n) { nx = X[i + 64]; ny = X[pitch + i + 64]; nz = X[2 * pitch + i + 64]; }
-        valid = valid && finite3(px, py, pz);
-        // PCL 1.8 transformPointCloud scalar form; Jacobian point r = R x (impl2:507-508)
-        float xt[3], r[3];
+        int r0[TP], r1[TP], r2[TP], cc[TP];
+        bool valid[TP];
+        float kx[TP], ky[TP], kz[TP];                // moved points (only the KDTREE distance test reads them again)
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
-          xt[a] = ((T[a * 4 + 0] * px + T[a * 4 + 1] * py) + T[a * 4 + 2] * pz) + T[a * 4 + 3];
-          r[a] = (Rj[a * 3 + 0] * px + Rj[a * 3 + 1] * py) + Rj[a * 3 + 2] * pz;
+        for (int p = 0; p < TP; p++) {
+          const int i = wbase + (st * TP + p) * 64 + lane;
+          const float px = nx[p], py = ny[p], pz = nz[p];
+          const int inext = i + TP * 64;
+          if (st + 1 < NST && inext < n) { nx[p] = X[inext]; ny[p] = X[pitch + inext]; nz[p] = X[2 * pitch + inext]; }
+          bool ok = i < n && finite3(px, py, pz);
+          // PCL 1.8 transformPointCloud scalar form; Jacobian point r = R x (impl2:507-508)
+          float xt[3], r[3];
+#pragma unroll
+          for (int a = 0; a < 3; a++) {
+            xt[a] = ((T[a * 4 + 0] * px + T[a * 4 + 1] * py) + T[a * 4 + 2] * pz) + T[a * 4 + 3];
+            r[a] = (Rj[a * 3 + 0] * px + Rj[a * 3 + 1] * py) + Rj[a * 3 + 2] * pz;
+          }
+          // a non-finite moved point (NaN pose: only reachable through a NaN More-Thuente trial value) has no neighbours;
+          // the reference's float->int cast is undefined there
+          ok = ok && finite3(xt[0], xt[1], xt[2]);
+          float* sp = stage[wv][((st & 1) * TP + p) * 64 + lane];
+          sp[0] = xt[0]; sp[1] = xt[1]; sp[2] = xt[2]; sp[3] = r[0]; sp[4] = r[1]; sp[5] = r[2];
+          kx[p] = xt[0]; ky[p] = xt[1]; kz[p] = xt[2];
+          // getNeighborhoodAtPoint (voxel_grid_covariance_omp_impl.hpp:379-399): cell of the point, f32 divide
+          // (x / 2^k is the same bits as x * 2^-k, so a power-of-two leaf takes the one-instruction path)
+          const int c0 = (int)floorf(sc.leaf_pow2 ? xt[0] * sc.inv_leaf : xt[0] / leaf);
+          const int c1 = (int)floorf(sc.leaf_pow2 ? xt[1] * sc.inv_leaf : xt[1] / leaf);
+          const int c2 = (int)floorf(sc.leaf_pow2 ? xt[2] * sc.inv_leaf : xt[2] / leaf);
+          // Branch-free probe stage.  Relative cell r = c - min_b; "inside the grid" (impl:382-392) is one unsigned
+          // compare per axis; a probe that falls outside (or belongs to an invalid lane) is redirected to the grid's
+          // spare all-zero bitmap word, so it misses without any flag having to be kept.
+          r0[p] = c0 - mb0; r1[p] = c1 - mb1; r2[p] = c2 - mb2;
+          cc[p] = r0[p] + r1[p] * mul1 + r2[p] * mul2;
+          valid[p] = ok;
         }
-        // a non-finite moved point (NaN pose: only reachable through a NaN More-Thuente trial value) has no neighbours;
-        // the reference's float->int cast is undefined there
-        valid = valid && finite3(xt[0], xt[1], xt[2]);
-        float* sp = stage[wv][slot];
-        sp[0] = xt[0]; sp[1] = xt[1]; sp[2] = xt[2]; sp[3] = r[0]; sp[4] = r[1]; sp[5] = r[2];
-        // getNeighborhoodAtPoint (voxel_grid_covariance_omp_impl.hpp:379-399): cell of the point, f32 divide
-        // (x / 2^k is the same bits as x * 2^-k, so a power-of-two leaf takes the one-instruction path)
-        const int c0 = (int)floorf(sc.leaf_pow2 ? xt[0] * sc.inv_leaf : xt[0] / leaf);
-        const int c1 = (int)floorf(sc.leaf_pow2 ? xt[1] * sc.inv_leaf : xt[1] / leaf);
-        const int c2 = (int)floorf(sc.leaf_pow2 ? xt[2] * sc.inv_leaf : xt[2] / leaf);
-        // Branch-free probe stage.  Relative cell r = c - min_b; "inside the grid" (impl:382-392) is one unsigned
-        // compare per axis; a probe that falls outside (or belongs to an invalid lane) is redirected to the grid's
-        // spare all-zero bitmap word, so it misses without any flag having to be kept.
-        const int r0 = c0 - mb0, r1 = c1 - mb1, r2 = c2 - mb2;
-        const unsigned e0 = (unsigned)(xb0 - mb0), e1 = (unsigned)(xb1 - mb1), e2 = (unsigned)(xb2 - mb2);
-        const int cc = r0 + r1 * mul1 + r2 * mul2;
-        const unsigned empty_cell = (unsigned)(nwords - 1) << 6;
         // probes run last-to-first so the ndt_pca weight of a hit (product of its own and all LATER hits' weights,
         // ndt_pca_impl2.hpp:295-296) is a running product; the order of the f64 additions is free anyway.
-        double suf = 1.0;
-        // Q_GROUP probes at a time: all bitmap loads of the group in flight together (then all ndt_pca weight loads),
-        // then the ballots -- one L2 round trip per stage instead of one per probe.
+        double suf[TP];
 #pragma unroll
-        for (int q1 = K; q1 > 0; q1 -= Q_GROUP) {      // compile-time groups: 1 for DIRECT1 / DIRECT7, 4 for DIRECT26
-          unsigned cellv[Q_GROUP];
-          uint4 bwv[Q_GROUP];                          // BitWord: bits lo, bits hi, prefix, pad
+        for (int p = 0; p < TP; p++) suf[p] = 1.0;
+        // Q_GROUP probes of every tile of the super-tile at a time: all their bitmap loads in flight together (then all
+        // ndt_pca weight loads), then the ballots -- one L2 round trip per stage.
 #pragma unroll
-          for (int j = 0; j < Q_GROUP; j++) {
-            const int q = q1 - 1 - j;                 // compile-time
-            cellv[j] = empty_cell;
-            if (q >= 0) {
+        for (int q1 = K; q1 > 0; q1 -= Q_GROUP) {      // compile-time groups: 1 for DIRECT1 / DIRECT7, 4 for DIRECT26 / KDTREE
+          unsigned cellv[TP][Q_GROUP];
+          uint4 bwv[TP][Q_GROUP];                      // BitWord: bits lo, bits hi, prefix, pad
+#pragma unroll
+          for (int p = 0; p < TP; p++) {
+#pragma unroll
+            for (int j = 0; j < Q_GROUP; j++) {
+              const int q = q1 - 1 - j;               // compile-time
+              if (q < 0) continue;
               const int o0 = probe_off(K, q, 0), o1 = probe_off(K, q, 1), o2 = probe_off(K, q, 2);
-              const bool inside = valid && (unsigned)(r0 + o0) <= e0 && (unsigned)(r1 + o1) <= e1 && (unsigned)(r2 + o2) <= e2;
-              if (inside) cellv[j] = (unsigned)(cc + o0 + o1 * mul1 + o2 * mul2);
-            }
-            bwv[j] = *reinterpret_cast<const uint4*>(W + (cellv[j] >> 6));
-          }
-          unsigned idv[Q_GROUP];
-          int wiv[Q_GROUP];
-#pragma unroll
-          for (int j = 0; j < Q_GROUP; j++) {
-            // shift the cell's bit to the top: sign = occupied, popcount = bits at or below it
-            const unsigned long long bits = ((unsigned long long)bwv[j].y << 32) | bwv[j].x;
-            const unsigned long long t = bits << (63u - (cellv[j] & 63u));
-            idv[j] = bwv[j].z + (unsigned)__popcll(t) - 1u;        // rank among the searchable leaves = voxel id
-            // occupied <=> the cell's bit (now the sign bit) is set; ndt_pca needs the weights now (suffix product),
-            // ndt_omp filters dead leaves in phase B instead and saves this dependent L2 round trip
-            wiv[j] = ((long long)t < 0) ? 1 : VOX_DEAD;
-            if (PCA) { if ((long long)t < 0) wiv[j] = R[idv[j]].weight; }
-            if (KD && (long long)t < 0) {                     // FLANN L2_Simple distance to the leaf's f32 centroid
-              const float* cp = cent + 3 * (size_t)(g.rec_off + idv[j]);
-              const float dx = xt[0] - cp[0], dy = xt[1] - cp[1], dz = xt[2] - cp[2];
-              if (!(((dx * dx + dy * dy) + dz * dz) < sc.kd_r2)) wiv[j] = VOX_DEAD;
+              const bool inside = valid[p] && (unsigned)(r0[p] + o0) <= e0 && (unsigned)(r1[p] + o1) <= e1 && (unsigned)(r2[p] + o2) <= e2;
+              cellv[p][j] = inside ? (unsigned)(cc[p] + o0 + o1 * mul1 + o2 * mul2) : empty_cell;
+              bwv[p][j] = *reinterpret_cast<const uint4*>(W + (cellv[p][j] >> 6));
             }
           }
+          unsigned idv[TP][Q_GROUP];
+          int wiv[TP][Q_GROUP];
 #pragma unroll
-          for (int j = 0; j < Q_GROUP; j++) {
-            const bool hit = wiv[j] != VOX_DEAD;     // empty cell, or nr_points == -1: not a neighbour (impl:395)
-            if (PCA && hit) suf *= (double)wiv[j];
-            const unsigned long long mask = __ballot(hit);
-            if (hit) {
-              const int pos = (qhead + qcount + (int)__popcll(mask & lt_mask)) & (Q_CAP - 1);
-              q_ent[wv][pos] = ((unsigned)slot << ID_BITS) | idv[j];
-              if (PCA) q_w[wv][pos] = suf;
+          for (int p = 0; p < TP; p++) {
+#pragma unroll
+            for (int j = 0; j < Q_GROUP; j++) {
+              if (q1 - 1 - j < 0) continue;
+              // shift the cell's bit to the top: sign = occupied, popcount = bits at or below it
+              const unsigned long long bits = ((unsigned long long)bwv[p][j].y << 32) | bwv[p][j].x;
+              const unsigned long long tb = bits << (63u - (cellv[p][j] & 63u));
+              idv[p][j] = bwv[p][j].z + (unsigned)__popcll(tb) - 1u;   // rank among the searchable leaves = voxel id
+              // occupied <=> the cell's bit (now the sign bit) is set; ndt_pca needs the weights now (suffix product),
+              // ndt_omp filters dead leaves in phase B instead and saves this dependent L2 round trip
+              wiv[p][j] = ((long long)tb < 0) ? 1 : VOX_DEAD;
+              if (PCA) { if ((long long)tb < 0) wiv[p][j] = R[idv[p][j]].weight; }
+              if (KD && (long long)tb < 0) {                     // FLANN L2_Simple distance to the leaf's f32 centroid
+                const float* cp = cent + 3 * (size_t)(g.rec_off + idv[p][j]);
+                const float dx = kx[p] - cp[0], dy = ky[p] - cp[1], dz = kz[p] - cp[2];
+                if (!(((dx * dx + dy * dy) + dz * dz) < sc.kd_r2)) wiv[p][j] = VOX_DEAD;
+              }
             }
-            qcount += (int)__popcll(mask);
+          }
+#pragma unroll
+          for (int p = 0; p < TP; p++) {
+            const int slot = ((st & 1) * TP + p) * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < Q_GROUP; j++) {
+              if (q1 - 1 - j < 0) continue;
+              const bool hit = wiv[p][j] != VOX_DEAD;     // empty cell, or nr_points == -1: not a neighbour (impl:395)
+              if (PCA && hit) suf[p] *= (double)wiv[p][j];
+              const unsigned long long mask = __ballot(hit);
+              if (hit) {
+                const int pos = (qhead + qcount + (int)__popcll(mask & lt_mask)) & (Q_CAP - 1);
+                q_ent[wv][pos] = ((unsigned)slot << ID_BITS) | idv[p][j];
+                if (PCA) q_w[wv][pos] = (QW)suf[p];
+              }
+              qcount += (int)__popcll(mask);
+            }
           }
           __builtin_amdgcn_wave_barrier();
           drain_full();
