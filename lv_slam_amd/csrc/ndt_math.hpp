@@ -196,6 +196,48 @@ __device__ inline void pose_to_f32(const double p[6], float T[12], float Rj[9]) 
   }
 }
 
+// ---- exp of an f32 argument, evaluated in f64 and rounded to f32 (the canonical choice for impl2:581) ----------
+// Table-driven: x = n*ln2/64 + r, exp(x) = 2^(n>>6) * 2^((n&63)/64) * exp(r), |r| <= ln2/128, exp(r) - 1 by its degree-5 Taylor
+// polynomial (truncation 3.5e-17).  Total error < 1 ulp of f64, like the device library's exp, but 12 instead of 28 f64-rate
+// instructions -- the sweep is VALU-issue bound and this exp was 12 % of it.  The table holds correctly rounded 2^(j/64).
+__constant__ double c_exp2_64[64] = {
+  0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+  0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+  0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+  0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+  0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+  0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+  0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+  0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+  0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+  0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+  0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+  0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+  0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+  0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+  0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+  0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0
+};
+#define NDT_EXP_INV   0x1.71547652b82fep+6      // 64 / ln 2
+#define NDT_EXP_C_HI  0x1.62e42fee00000p-7      // ln 2 / 64, low 21 significand bits zero: n * HI is exact for |n| < 2^21
+#define NDT_EXP_C_LO  0x1.a39ef35793c76p-39     // ln 2 / 64 - HI
+__device__ __forceinline__ float exp_f32arg(float a, const double* __restrict__ tab /* c_exp2_64, normally staged in LDS */) {
+  a = a < -800.f ? -800.f : a;                   // exp underflows / overflows f64 long before; NaN fails both tests and stays NaN
+  a = a > 800.f ? 800.f : a;
+  const double x = (double)a;
+  const double n = rint(x * NDT_EXP_INV);
+  double r = fma(n, -NDT_EXP_C_HI, x);
+  r = fma(n, -NDT_EXP_C_LO, r);
+  const int ni = (int)n;
+  const double t = tab[ni & 63];
+  double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  p = fma(r, p, 1.0 / 6.0);
+  p = fma(r, p, 0.5);
+  p = fma(r, p, 1.0);
+  p = r * p;                                     // exp(r) - 1
+  return (float)ldexp(fma(t, p, t), ni >> 6);
+}
+
 // Symmetric 3x3 eigen-decomposition (cyclic Jacobi; lower triangle read, ascending eigenvalues,
 // eigenvectors = columns of V).  Stands in for Eigen::SelfAdjointEigenSolver
 // (voxel_grid_covariance_omp_impl.hpp:333-335).

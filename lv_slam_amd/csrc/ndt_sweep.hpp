@@ -2,6 +2,7 @@
 // include/ndt_omp/ndt_omp_impl2.hpp:196-305, 503-532, 566-619; voxel_grid_covariance_omp_impl.hpp:373-442).
 #pragma once
 #include "ndt_types.hpp"
+#include "ndt_math.hpp"
 #include <type_traits>
 
 // ------------------------------------------------------------------------------------ derivative sweep
@@ -16,12 +17,12 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 template <bool PCA, typename Mid = NoHook>
 __device__ __forceinline__ void eval_hit(const float u[3], const float r[3], const float C[9],
                                          const double d1, const float d2f, const double w, const bool ok_in, double acc[43],
-                                         Mid mid = Mid()) {
+                                         const double* __restrict__ exp_tab, Mid mid = Mid()) {
   float y[3];
 #pragma unroll
   for (int j = 0; j < 3; j++) y[j] = (u[0] * C[j] + u[1] * C[3 + j]) + u[2] * C[6 + j];
   const float qf = (u[0] * y[0] + u[1] * y[1]) + u[2] * y[2];
-  const float e0 = (float)exp((double)((-d2f * qf) * 0.5f));                     // impl2:581
+  const float e0 = ndtm::exp_f32arg((-d2f * qf) * 0.5f, exp_tab);                // impl2:581: exp in f64 on the f32 argument, rounded to f32
   float s_inc = (float)(-d1 * (double)e0);                                       // impl2:583
   const float e1 = d2f * e0;                                                     // impl2:585
   // impl2:588-589, branch-free: a rejected hit (or an idle lane, ok_in = false) multiplies every term by e = 0 and so
@@ -146,6 +147,9 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
   constexpr int TP = (K == 1) ? 4 : (K <= Q_GROUP ? 2 : 1);
   __shared__ float stage[WAVES][2 * 64 * TP][6];   // two super-tiles of staged points: x'(3), R x (3)
 
+  __shared__ double exp_tab[64];                   // 2^(j/64) for ndtm::exp_f32arg
+  if (threadIdx.x < 64) exp_tab[threadIdx.x] = ndtm::c_exp2_64[threadIdx.x];
+  __syncthreads();                                 // (the only block barrier of the kernel, before the persistent loop)
   // the control block of the NEXT round (k_update fills it after this kernel) is cleared here, not by a host memset
   if (blockIdx.x == 0 && threadIdx.x < 9) reinterpret_cast<int*>(ctl_next)[threadIdx.x] = 0;
   if (n_active == 0) return;                       // nothing left to sweep (the loop's last, empty round)
@@ -218,7 +222,7 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
       // ndt_omp: leaves with nr_points = -1 (eigen / inverse failure) are not neighbours (impl:395): filtered here
       const bool live = lane < m && (PCA || KD || B.weight != VOX_DEAD);
       float u[3] = {(float)((double)xt0 - B.m0), (float)((double)xt1 - B.m1), (float)((double)xt2 - B.m2)};   // impl2:276-279, 574
-      eval_hit<PCA>(u, r, B.C, sc.d1, sc.d2f, B.w, live, acc, mid);
+      eval_hit<PCA>(u, r, B.C, sc.d1, sc.d2f, B.w, live, acc, exp_tab, mid);
       nhits += PCA ? (unsigned)m : (unsigned)__popcll(__ballot(live));
       qhead = (qhead + m) & (Q_CAP - 1);
       qcount -= m;
