@@ -48,6 +48,7 @@ struct mi355ndt_handle {
   const float *d_tgt = nullptr, *d_src = nullptr;
   int *d_tgt_cnt = nullptr, *d_src_cnt = nullptr;
   std::vector<int> h_tgt_cnt, h_src_cnt;
+  std::vector<int> up_tgt_cnt, up_src_cnt;        // what d_tgt_cnt / d_src_cnt currently hold (uploads are skipped when unchanged)
   bool targets_built = false, have_target = false, have_source = false;
   bool icov64_built = false;                      // ... and the f64 inverse covariances computeHessian reads (live More-Thuente)
   bool cent_built = false;                        // last target build also produced the f32 leaf centroids (KDTREE mode)
@@ -79,6 +80,7 @@ struct mi355ndt_handle {
   double* d_partials = nullptr; size_t partials_cap = 0;
   int chunks_per_pair = 0;
   float* d_guess = nullptr;
+  float* h_pin_guess = nullptr;                   // pinned staging copy of the caller's guesses (no sync needed after the upload)
   mi355ndt_result* d_results = nullptr;
   int* d_active = nullptr;                      // per-round active counters
   int* d_active_list = nullptr;                 // pairs taking part in the next sweep (compacted by k_update)
@@ -218,6 +220,7 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_pin_u) hipHostFree(h->h_pin_u);
   if (h->h_pin_active) hipHostFree(h->h_pin_active);
+  if (h->h_pin_guess) hipHostFree(h->h_pin_guess);
   for (hipEvent_t e : h->ev_burst) if (e) hipEventDestroy(e);
   for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
   for (auto& e : h->ev_sweep) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -271,12 +274,15 @@ static int ensure_pair_arrays(mi355ndt_handle* h, int n_pairs) {
   };
   HIPCHK(h, re((void**)&h->d_tgt_cnt, n_pairs * sizeof(int)));
   HIPCHK(h, re((void**)&h->d_src_cnt, n_pairs * sizeof(int)));
+  h->up_tgt_cnt.clear(); h->up_src_cnt.clear();       // fresh device arrays: nothing uploaded yet
   HIPCHK(h, re((void**)&h->d_minmax, n_pairs * 6 * sizeof(int)));
   HIPCHK(h, re((void**)&h->d_grid, n_pairs * sizeof(GridDesc)));
   HIPCHK(h, re((void**)&h->d_nwords, (n_pairs + 2) * sizeof(unsigned)));
   HIPCHK(h, re((void**)&h->d_word_off, (n_pairs + 1) * sizeof(unsigned)));
   HIPCHK(h, re((void**)&h->d_state, n_pairs * sizeof(PairState)));
   HIPCHK(h, re((void**)&h->d_guess, n_pairs * 16 * sizeof(float)));
+  if (h->h_pin_guess) { HIPCHK(h, hipHostFree(h->h_pin_guess)); h->h_pin_guess = nullptr; }
+  HIPCHK(h, hipHostMalloc((void**)&h->h_pin_guess, (size_t)n_pairs * 16 * sizeof(float)));
   HIPCHK(h, re((void**)&h->d_results, n_pairs * sizeof(mi355ndt_result)));
   HIPCHK(h, re((void**)&h->d_active_list, n_pairs * sizeof(int)));
   HIPCHK(h, hipMemsetAsync(h->d_grid, 0, n_pairs * sizeof(GridDesc), h->stream));
@@ -454,8 +460,11 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
   const size_t pitch = h->tgt_pitch;
   const size_t total = (size_t)B * pitch;
   hipStream_t s = h->stream;
-  HIPCHK(h, hipMemcpyAsync(h->d_tgt_cnt, h->h_tgt_cnt.data(), B * sizeof(int), hipMemcpyHostToDevice, s));
-  HIPCHK(h, hipStreamSynchronize(s));   // h_tgt_cnt is pageable
+  if (h->up_tgt_cnt != h->h_tgt_cnt) {
+    HIPCHK(h, hipMemcpyAsync(h->d_tgt_cnt, h->h_tgt_cnt.data(), B * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipStreamSynchronize(s));   // h_tgt_cnt is pageable
+    h->up_tgt_cnt = h->h_tgt_cnt;
+  }
 
   // workspace
   if (total > h->keys_cap) {
@@ -592,8 +601,11 @@ static int prep_align_ws(mi355ndt_handle* h) {
   h->chunks_per_pair = std::max(1, (maxn + CHUNK_PTS - 1) / CHUNK_PTS);
   size_t need = (size_t)B * h->chunks_per_pair * QUARTERS * NACC;
   HIPCHK(h, grow(h->d_partials, h->partials_cap, need));
-  HIPCHK(h, hipMemcpyAsync(h->d_src_cnt, h->h_src_cnt.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->up_src_cnt != h->h_src_cnt) {
+    HIPCHK(h, hipMemcpyAsync(h->d_src_cnt, h->h_src_cnt.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->up_src_cnt = h->h_src_cnt;
+  }
   return MI355NDT_OK;
 }
 
@@ -645,8 +657,9 @@ int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_resu
   hipStream_t s = h->stream;
   SweepConst sc;
   make_sweep_const(h, sc);
-  HIPCHK(h, hipMemcpyAsync(h->d_guess, guesses, (size_t)B * 16 * sizeof(float), hipMemcpyHostToDevice, s));
-  HIPCHK(h, hipStreamSynchronize(s));           // guesses may be pageable caller memory
+  // the engine's stream is idle here (every entry point returns synchronised), so the pinned staging copy is free to overwrite
+  memcpy(h->h_pin_guess, guesses, (size_t)B * 16 * sizeof(float));
+  HIPCHK(h, hipMemcpyAsync(h->d_guess, h->h_pin_guess, (size_t)B * 16 * sizeof(float), hipMemcpyHostToDevice, s));
   HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, 2 * sizeof(SweepCtl), s));
   h->ctl_idx = 0;
   k_init_state<<<(B + 63) / 64, 64, 0, s>>>(h->d_state, h->d_guess, h->d_src_cnt, h->d_grid, B, h->d_active_list, h->d_ctl);
