@@ -97,15 +97,16 @@ __host__ __device__ constexpr int probe_off(int K, int q, int a) {
 #define WAVES   (SWEEP_THREADS / 64)
 
 // The sweep.  Work decomposition (MI355X-first):
-//   block = 4 waves = one CHUNK_PTS chunk of one pair at a time; each wave owns CHUNK_PTS/4 consecutive points.
-//   phase A (probe, lane = point): transform the point (f32), probe its K neighbour cells in the rank-bitmap,
-//     and push every hit as a 4-byte entry into the wave's LDS queue (ballot + popcount compaction).
+//   work item = one wave-quarter (CHUNK_PTS/4 = 512 consecutive points) of one 2048-point chunk of one active pair, taken by
+//     ONE persistent wave from a per-XCD queue; a workgroup is just four such independent waves.
+//   phase A (probe, lane = point): transform the points of a super-tile (1, 2 or 4 tiles of 64) in f32, probe their K neighbour
+//     cells in the rank-bitmap, and push every hit as a 4-byte entry into the wave's LDS queue (ballot + popcount compaction).
 //   phase B (evaluate, lane = hit): lanes pull 64 queue entries at a time -- every lane busy no matter how the
 //     hits were distributed over points -- read the staged point (LDS) and the 64-B voxel record, and add the
-//     43 f64 terms into per-lane accumulators.
-//   chunk end: flush the queue tail, wave butterfly + fixed-order wave sum -> one 44-double partial row per chunk.
-// The partial rows depend only on (CHUNK_PTS, input order), never on the launch geometry, so single and batched
-// runs of one pair are bit-identical.
+//     43 f64 terms into per-lane accumulators; the next batch's records are fetched in the middle of the current evaluation.
+//   item end: flush the queue tail, fixed-tree wave reduction -> one 44-double partial row per (chunk, quarter).
+// The partial rows depend only on (CHUNK_PTS, input order), never on the launch geometry or on which wave ran the item, so
+// single and batched runs of one pair are bit-identical.
 struct SweepCtl {               // 9 ints; two of them alternate: the sweep that reads one clears the other
   int n_active;                 // pairs whose next sweep is pending (entries of active_list)
   int next_item[8];             // per-XCD work-item cursors of the sweep
