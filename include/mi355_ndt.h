@@ -40,7 +40,7 @@ extern "C" {
 #define MI355NDT_ERR_GRID        (-4)  /* target grid unusable: reference int32 guard
                                           (voxel_grid_covariance_omp_impl.hpp:75-84) or engine cell cap */
 #define MI355NDT_ERR_NO_DEVICE   (-5)
-#define MI355NDT_ERR_UNSUPPORTED (-6)  /* KDTREE neighbour search with ndt_pca (depends on FLANN's result order) */
+#define MI355NDT_ERR_UNSUPPORTED (-6)  /* reserved: every configuration of the reference classes is served at present */
 #define MI355NDT_ERR_STATE       (-7)  /* align/derivatives before target+source were set */
 
 /* pclomp::NeighborSearchMethod, include/ndt_omp/ndt_omp.h:51-56 (same enum order) */

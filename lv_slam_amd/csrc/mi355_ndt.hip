@@ -28,6 +28,7 @@
 #include "ndt_sweep.hpp"
 #include "ndt_update.hpp"
 #include "ndt_hessian.hpp"
+#include "ndt_sweep_kd.hpp"
 #include "ndt_fitness.hpp"
 #include "ndt_prefilter.hpp"
 
@@ -64,6 +65,7 @@ struct mi355ndt_handle {
   BitWord* d_words = nullptr; size_t words_cap = 0;
   VoxelRec* d_recs = nullptr; int *d_vox_idx = nullptr, *d_vox_n = nullptr;
   unsigned* d_seg_start = nullptr; double* d_sums = nullptr; float* d_cent = nullptr; double* d_icov64 = nullptr; size_t icov64_cap = 0;
+  int* d_kdw = nullptr; size_t kdw_cap = 0; bool kdw_built = false;   // per-leaf weights for ndt_pca + KDTREE (dead leaves included)
   unsigned* d_rs_hist = nullptr; unsigned* d_rs_offs = nullptr; size_t rs_cap = 0;   // segmented radix sort: tile histograms / offsets
   unsigned *d_cstart = nullptr, *d_cend = nullptr; size_t cell_cap = 0; bool cells_ready = false; int last_cb = 0;
   double* d_fit = nullptr; size_t fit_cap = 0;
@@ -215,7 +217,7 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
   void* ptrs[] = {h->d_tgt_own, h->d_src_own, h->d_tgt_cnt, h->d_src_cnt, h->d_minmax, h->d_grid, h->d_nwords, h->d_word_off,
                   h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, h->d_tmp, h->d_words, h->d_recs, h->d_vox_idx, h->d_vox_n,
                   h->d_state, h->d_partials, h->d_guess, h->d_results, h->d_active, h->d_hook, h->d_aligned, h->d_hits, h->d_seg_start, h->d_sums,
-                  h->d_cent, h->d_icov64, h->d_rs_hist, h->d_rs_offs, h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit, h->d_pf_in, h->d_pf_out, h->d_pf_keep, h->d_pf_keys,
+                  h->d_cent, h->d_icov64, h->d_kdw, h->d_rs_hist, h->d_rs_offs, h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit, h->d_pf_in, h->d_pf_out, h->d_pf_keep, h->d_pf_keys,
                   h->d_pf_vals, h->d_pf_flag, h->d_pf_pos, h->d_pf_mm, h->d_pf_grid, h->d_pf_tmp};
   for (void* p : ptrs) if (p) hipFree(p);
   if (h->h_pin_u) hipHostFree(h->h_pin_u);
@@ -454,7 +456,6 @@ int mi355ndt_profile_get(mi355ndt_handle* h, mi355ndt_profile* out) {
 int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   if (h->n_pairs <= 0 || !h->d_tgt) return MI355NDT_ERR_STATE;
-  if (h->prm.neighbor_mode == MI355NDT_KDTREE && h->prm.variant == MI355NDT_VARIANT_PCA) return MI355NDT_ERR_UNSUPPORTED;
   HIPCHK(h, hipSetDevice(h->device));
   const int B = h->n_pairs;
   const size_t pitch = h->tgt_pitch;
@@ -531,6 +532,9 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
   h->cent_built = want_cent;
   h->icov64_built = mt_live;
   if (mt_live) HIPCHK(h, grow(h->d_icov64, h->icov64_cap, h->recs_cap * 9));
+  const bool want_kdw = h->prm.neighbor_mode == MI355NDT_KDTREE && h->prm.variant == MI355NDT_VARIANT_PCA;
+  h->kdw_built = want_kdw;
+  if (want_kdw) HIPCHK(h, grow(h->d_kdw, h->kdw_cap, h->recs_cap));
   tb = h->tmp_bytes;
   if (k32) {
     unsigned *ka = (unsigned*)h->d_keys_a, *kb = (unsigned*)h->d_keys_b;
@@ -578,7 +582,7 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
   }
   k_voxels<<<dim3((unsigned)((rpp + 255) / 256), B), 256, 0, s>>>(h->d_grid, h->d_sums, h->d_recs, h->d_vox_n,
                                                                   h->prm.min_covar_eigvalue_mult, h->prm.variant == MI355NDT_VARIANT_PCA,
-                                                                  mt_live ? h->d_icov64 : nullptr);
+                                                                  mt_live ? h->d_icov64 : nullptr, want_kdw ? h->d_kdw : nullptr);
   HIPCHK(h, hipGetLastError());
   if (h->prof) {
     HIPCHK(h, ev_end(h, h->ev_build));
@@ -626,7 +630,11 @@ static int launch_sweep(mi355ndt_handle* h, const SweepConst& sc) {
   if (h->prof) HIPCHK(h, ev_begin(h, h->ev_sweep));
 #define NDT_LAUNCH_SWEEP(P, KK) k_sweep<P, KK><<<grid, SWEEP_THREADS, 0, h->stream>>>(h->d_src, h->src_pitch, h->d_state, h->d_grid, \
       h->d_words, h->d_recs, h->d_partials, h->chunks_per_pair, h->d_active_list, h->d_ctl + h->ctl_idx, h->d_ctl + (h->ctl_idx ^ 1), sc, h->d_cent)
-  if (sc.pca) { if (sc.K == 1) NDT_LAUNCH_SWEEP(true, 1); else if (sc.K == 7) NDT_LAUNCH_SWEEP(true, 7); else NDT_LAUNCH_SWEEP(true, 26); }
+  if (sc.pca && sc.K == 27) {                    // ndt_pca + KDTREE: order-dependent weights, the literal kernel (ndt_sweep_kd.hpp)
+    k_sweep_pca_kd<<<dim3((unsigned)h->chunks_per_pair, (unsigned)h->n_pairs), SWEEP_THREADS, 0, h->stream>>>(
+        h->d_src, h->src_pitch, h->d_state, h->d_grid, h->d_words, h->d_recs, h->d_cent, h->d_kdw, h->d_partials, h->chunks_per_pair,
+        h->d_active_list, h->d_ctl + h->ctl_idx, h->d_ctl + (h->ctl_idx ^ 1), sc);
+  } else if (sc.pca) { if (sc.K == 1) NDT_LAUNCH_SWEEP(true, 1); else if (sc.K == 7) NDT_LAUNCH_SWEEP(true, 7); else NDT_LAUNCH_SWEEP(true, 26); }
   else        { if (sc.K == 1) NDT_LAUNCH_SWEEP(false, 1); else if (sc.K == 7) NDT_LAUNCH_SWEEP(false, 7); else if (sc.K == 26) NDT_LAUNCH_SWEEP(false, 26);
                 else NDT_LAUNCH_SWEEP(false, 27); }
 #undef NDT_LAUNCH_SWEEP
@@ -647,10 +655,10 @@ int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_resu
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   if (!guesses || !out) return MI355NDT_ERR_BAD_ARG;
   if (h->n_pairs <= 0 || !h->d_tgt || !h->d_src) return MI355NDT_ERR_STATE;
-  if (h->prm.neighbor_mode == MI355NDT_KDTREE && h->prm.variant == MI355NDT_VARIANT_PCA) return MI355NDT_ERR_UNSUPPORTED;
   HIPCHK(h, hipSetDevice(h->device));
   const bool mt_live = mt_is_live(h->prm);                       // impl2:888: More-Thuente loop + computeHessian are live
-  if (!h->targets_built || (mt_live && !h->icov64_built)) { int rc = mi355ndt_batch_build_targets(h); if (rc) return rc; }
+  const bool pca_kd = h->prm.neighbor_mode == MI355NDT_KDTREE && h->prm.variant == MI355NDT_VARIANT_PCA;
+  if (!h->targets_built || (mt_live && !h->icov64_built) || (pca_kd && !h->kdw_built)) { int rc = mi355ndt_batch_build_targets(h); if (rc) return rc; }
   int rc = prep_align_ws(h);
   if (rc) return rc;
   const int B = h->n_pairs;
@@ -792,10 +800,11 @@ int mi355ndt_set_params(mi355ndt_handle* h, const mi355ndt_params* p) {
                       old.min_points_per_voxel != p->min_points_per_voxel ||
                       old.min_covar_eigvalue_mult != p->min_covar_eigvalue_mult ||
                       ((p->neighbor_mode == MI355NDT_KDTREE || mt_is_live(*p)) && !h->cent_built) ||   // centroids the build skipped
-                      (mt_is_live(*p) && !h->icov64_built);
+                      (mt_is_live(*p) && !h->icov64_built) ||
+                      (p->neighbor_mode == MI355NDT_KDTREE && p->variant == MI355NDT_VARIANT_PCA && !h->kdw_built);
   if (regrid && h->targets_built) {
     h->targets_built = false;
-    if (!(p->neighbor_mode == MI355NDT_KDTREE && p->variant == MI355NDT_VARIANT_PCA)) return mi355ndt_batch_build_targets(h);   // setResolution -> init() (ndt_omp.h:126-136)
+    return mi355ndt_batch_build_targets(h);   // setResolution -> init() (ndt_omp.h:126-136)
   }
   return MI355NDT_OK;
 }
@@ -852,9 +861,9 @@ static int run_hook_sweep(mi355ndt_handle* h, double* score, double g[6], double
 
 static int hook_ready(mi355ndt_handle* h) {
   if (h->n_pairs < 1 || !h->have_target || !h->have_source) return MI355NDT_ERR_STATE;
-  if (h->prm.neighbor_mode == MI355NDT_KDTREE && h->prm.variant == MI355NDT_VARIANT_PCA) return MI355NDT_ERR_UNSUPPORTED;
   HIPCHK(h, hipSetDevice(h->device));
-  if (!h->targets_built) { int rc = mi355ndt_batch_build_targets(h); if (rc) return rc; }
+  const bool pca_kd = h->prm.neighbor_mode == MI355NDT_KDTREE && h->prm.variant == MI355NDT_VARIANT_PCA;
+  if (!h->targets_built || (pca_kd && !h->kdw_built)) { int rc = mi355ndt_batch_build_targets(h); if (rc) return rc; }
   return prep_align_ws(h);
 }
 

@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restri
 
 // second pass of applyFilter (impl:282-367; pca impl:364-397): one thread per searchable leaf
 __global__ void __launch_bounds__(256) k_voxels(const GridDesc* __restrict__ gd, const double* __restrict__ sums,
-                                                 VoxelRec* recs, int* vox_n, double eig_mult, int pca, double* icov64) {
+                                                 VoxelRec* recs, int* vox_n, double eig_mult, int pca, double* icov64, int* kd_weight) {
   const int b = blockIdx.y;
   const GridDesc& g = gd[b];
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(256) k_voxels(const GridDesc* __restrict__ gd,
   r.mean[0] = mu[0]; r.mean[1] = mu[1]; r.mean[2] = mu[2];
   for (int a = 0; a < 9; a++) r.icov[a] = 0.f;
   r.weight = 1;
-  int n_out = cnt;
+  int n_out = cnt, kd_w = 0;
   if (ev[0] < 0 || ev[1] < 0 || ev[2] <= 0) {                                    // impl:337-341
     n_out = -1;
     r.weight = VOX_DEAD;
@@ -309,6 +309,7 @@ __global__ void __launch_bounds__(256) k_voxels(const GridDesc* __restrict__ gd,
       double scale = (label == 2) ? 1.25 : ((label == 1) ? 0.75 : 1.0);
       double d2d = scale * sqrt((mu[0] * mu[0] + mu[1] * mu[1]) + mu[2] * mu[2]);
       r.weight = (int)d2d;                                                       // getDimension2d() returns int (pca.h:222-226)
+      kd_w = r.weight;
     }
     double ic[9];
     ndtm::mat3_inverse(cov, ic);                                                 // impl:359
@@ -319,5 +320,8 @@ __global__ void __launch_bounds__(256) k_voxels(const GridDesc* __restrict__ gd,
   }
   recs[g.rec_off + id] = r;
   vox_n[g.rec_off + id] = n_out;
+  // ndt_pca + KDTREE reads the weight of EVERY leaf radiusSearch returns: (int)dimension_2d_ as computed (also when the
+  // inverse failed afterwards), and the constructor's 0 for an eigen-failed leaf (voxel_grid_covariance_pca.h:143)
+  if (kd_weight) kd_weight[g.rec_off + id] = kd_w;
 }
 

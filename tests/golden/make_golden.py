@@ -599,6 +599,9 @@ if __name__ == "__main__":
         make_mt_case("omp_direct7_mt", pair=15, n_az=128, n_beams=32, mode=DIRECT7, variant=0)
         make_mt_case("pca_direct1_mt", pair=17, n_az=128, n_beams=32, mode=DIRECT1, variant=1)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "pcakd":
+        make_case("pca_kdtree_r1", pair=21, n_az=128, n_beams=32, resolution=1.0, mode=KDTREE, variant=1, n_src_sweep=150, n_src_align=300)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "kdtree":      # only the case added after the first fixtures were frozen
         make_case("omp_kdtree_r1", pair=13, n_az=128, n_beams=32, resolution=1.0, mode=KDTREE, variant=0)
         sys.exit(0)
@@ -609,3 +612,4 @@ if __name__ == "__main__":
     make_case("pca_direct7_r1", pair=9, n_az=128, n_beams=32, resolution=1.0, mode=DIRECT7, variant=1)
     make_case("pca_direct1_r05", pair=11, n_az=256, n_beams=32, resolution=0.5, mode=DIRECT1, variant=1)
     make_case("omp_kdtree_r1", pair=13, n_az=128, n_beams=32, resolution=1.0, mode=KDTREE, variant=0)
+    make_case("pca_kdtree_r1", pair=21, n_az=128, n_beams=32, resolution=1.0, mode=KDTREE, variant=1, n_src_sweep=150, n_src_align=300)

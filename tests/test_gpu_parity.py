@@ -14,7 +14,7 @@ from oracle import oracle_py as O
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["omp_direct7_r1", "omp_direct1_r1", "omp_direct26_r2", "pca_direct7_r1", "pca_direct1_r05", "omp_kdtree_r1"]
+CASES = ["omp_direct7_r1", "omp_direct1_r1", "omp_direct26_r2", "pca_direct7_r1", "pca_direct1_r05", "omp_kdtree_r1", "pca_kdtree_r1"]
 FIELDS = ["resolution", "step_size", "outlier_ratio", "trans_epsilon", "max_iterations", "neighbor_mode", "variant",
           "min_points_per_voxel", "min_covar_eigvalue_mult"]
 
@@ -102,7 +102,7 @@ def test_golden_voxels_sweep_align(golden_dir, name):
     assert np.array_equal(out, exp.astype(np.float32))
 
 
-@pytest.mark.parametrize("mode,variant,res", [(ndt.DIRECT7, 0, 1.0), (ndt.DIRECT1, 1, 1.0), (ndt.DIRECT7, 1, 0.5), (ndt.KDTREE, 0, 1.0)])
+@pytest.mark.parametrize("mode,variant,res", [(ndt.DIRECT7, 0, 1.0), (ndt.DIRECT1, 1, 1.0), (ndt.DIRECT7, 1, 0.5), (ndt.KDTREE, 0, 1.0), (ndt.KDTREE, 1, 1.0)])
 def test_full_size_pair_vs_oracle(mode, variant, res):
     """BASELINE config 2 (65,536-pt pair, HIP path, SE(3) checked against the CPU restatement) + the nodelet's
     pca/DIRECT1 setting + config 5's 0.5 m pca grid."""
@@ -125,8 +125,11 @@ def test_full_size_pair_vs_oracle(mode, variant, res):
     dt, dr = se3_err(ro["final"], r["final"])
     assert dt < 1e-4 and dr < 1e-5, (dt, dr)
     # and the registration is physically right: recovered motion ~ true motion (scene-noise level)
-    dt, dr = se3_err(dT, r["final"])
-    assert dt < 0.1 and dr < 0.01, (dt, dr)
+    # (not for ndt_pca + KDTREE: the distance-ordered compounding of up to 27 integer weights lets a handful of points decide the
+    #  step, and the reference algorithm itself -- oracle and HIP alike -- lands metres away from the true motion)
+    if not (mode == ndt.KDTREE and variant == 1):
+        dt, dr = se3_err(dT, r["final"])
+        assert dt < 0.1 and dr < 0.01, (dt, dr)
 
 
 def test_window_map_target_vs_oracle():
@@ -282,10 +285,6 @@ def test_edge_cases():
         s = rng.uniform(-4, 4, (n, 3)).astype(np.float32)
         eng.set_source(s)
         check_sweep(eng.derivatives(p), O.derivatives_at(grid, s, p))
-    # unsupported configurations fail loudly
-    with pytest.raises(ndt.NDTError) as e:      # KDTREE is emulated for ndt_omp only (ndt_pca needs FLANN's result order)
-        _align_with(ndt.default_params(neighbor_mode=ndt.KDTREE, variant=ndt.VARIANT_PCA), tgt, src, G)
-    assert e.value.code == -6
     # stride: PointXYZI-style 32-byte records
     rec = np.zeros((len(tgt), 8), np.float32)
     rec[:, :3] = tgt

@@ -9,7 +9,7 @@ import pytest
 from oracle import oracle_py as O
 from conftest import se3_err
 
-CASES = ["omp_direct7_r1", "omp_direct1_r1", "omp_direct26_r2", "pca_direct7_r1", "pca_direct1_r05", "omp_kdtree_r1"]
+CASES = ["omp_direct7_r1", "omp_direct1_r1", "omp_direct26_r2", "pca_direct7_r1", "pca_direct1_r05", "omp_kdtree_r1", "pca_kdtree_r1"]
 
 
 def load(golden_dir, name):
