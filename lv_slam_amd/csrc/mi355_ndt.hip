@@ -176,6 +176,8 @@ int mi355ndt_default_params(mi355ndt_params* p) {
   return MI355NDT_OK;
 }
 
+int mi355ndt_destroy(mi355ndt_handle* h);
+
 int mi355ndt_create(const mi355ndt_params* params, int device, mi355ndt_handle** out) {
   if (!out) return MI355NDT_ERR_BAD_ARG;
   *out = nullptr;
@@ -203,7 +205,7 @@ int mi355ndt_create(const mi355ndt_params* params, int device, mi355ndt_handle**
       hipMalloc((void**)&h->d_hook, 64 * sizeof(double)) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_burst[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_burst[1], hipEventDisableTiming) != hipSuccess) {
-    delete h;
+    mi355ndt_destroy(h);                          // releases whatever was created before the failure
     return MI355NDT_ERR_HIP;
   }
   *out = h;
