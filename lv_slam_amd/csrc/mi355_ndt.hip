@@ -214,23 +214,23 @@ int mi355ndt_create(const mi355ndt_params* params, int device, mi355ndt_handle**
 
 int mi355ndt_destroy(mi355ndt_handle* h) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
-  hipSetDevice(h->device);
-  hipStreamSynchronize(h->stream);
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->d_tgt_own, h->d_src_own, h->d_tgt_cnt, h->d_src_cnt, h->d_minmax, h->d_grid, h->d_nwords, h->d_word_off,
                   h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, h->d_tmp, h->d_words, h->d_recs, h->d_vox_idx, h->d_vox_n,
                   h->d_state, h->d_partials, h->d_guess, h->d_results, h->d_active, h->d_hook, h->d_aligned, h->d_hits, h->d_seg_start, h->d_sums,
                   h->d_cent, h->d_icov64, h->d_kdw, h->d_rs_hist, h->d_rs_offs, h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit, h->d_pf_in, h->d_pf_out, h->d_pf_keep, h->d_pf_keys,
                   h->d_pf_vals, h->d_pf_flag, h->d_pf_pos, h->d_pf_mm, h->d_pf_grid, h->d_pf_tmp};
-  for (void* p : ptrs) if (p) hipFree(p);
-  if (h->h_pin_u) hipHostFree(h->h_pin_u);
-  if (h->h_pin_active) hipHostFree(h->h_pin_active);
-  if (h->h_pin_guess) hipHostFree(h->h_pin_guess);
-  for (hipEvent_t e : h->ev_burst) if (e) hipEventDestroy(e);
-  for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
-  for (auto& e : h->ev_sweep) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-  for (auto& e : h->ev_update) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-  for (auto& e : h->ev_build) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-  if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (h->h_pin_u) (void)hipHostFree(h->h_pin_u);
+  if (h->h_pin_active) (void)hipHostFree(h->h_pin_active);
+  if (h->h_pin_guess) (void)hipHostFree(h->h_pin_guess);
+  for (hipEvent_t e : h->ev_burst) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+  for (auto& e : h->ev_sweep) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto& e : h->ev_update) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto& e : h->ev_build) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return MI355NDT_OK;
 }
@@ -244,10 +244,10 @@ int mi355ndt_get_params(const mi355ndt_handle* h, mi355ndt_params* out) {
 
 int mi355ndt_set_stream(mi355ndt_handle* h, void* s) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
-  hipSetDevice(h->device);
-  hipStreamSynchronize(h->stream);
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
   if (s) {
-    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     h->stream = (hipStream_t)s;
     h->own_stream = false;
   } else if (!h->own_stream) {
@@ -435,8 +435,8 @@ int mi355ndt_profile_enable(mi355ndt_handle* h, int on) {
 }
 int mi355ndt_profile_reset(mi355ndt_handle* h) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
-  hipSetDevice(h->device);
-  hipStreamSynchronize(h->stream);
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
   double d; long long n;
   ev_collect(h, h->ev_sweep, d, n); ev_collect(h, h->ev_update, d, n); ev_collect(h, h->ev_build, d, n);
   h->P = mi355ndt_profile{};
