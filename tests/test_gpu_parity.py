@@ -238,6 +238,39 @@ def test_full_size_live_more_thuente_vs_oracle():
     assert r1["iterations"] == r0["iterations"] and np.array_equal(r1["final"], r0["final"])
 
 
+def test_full_size_sweep_properties():
+    """Size-independent properties of the derivative sweep at the full 65,536-pt size (no oracle involved):
+    additivity over a split of the source cloud, invariance under a permutation of the source points, and hit conservation."""
+    tgt, src, _ = synth.make_pair(5, 1024)
+    tgt, src = tgt.numpy(), src.numpy()
+    eng = ndt.Engine(ndt.default_params(trans_epsilon=0.01, max_iterations=64))
+    eng.set_target(tgt)
+    p = O.se3_log(synth.default_guess().astype(np.float64)) + np.array([0.02, -0.01, 0.0, 0.002, -0.001, 0.004])
+    eng.set_source(src)
+    s_all, g_all, H_all, h_all = eng.derivatives(p)
+    cut = 40000                                            # not a multiple of the 2048-pt reduction chunk
+    eng.set_source(src[:cut])
+    s_a, g_a, H_a, h_a = eng.derivatives(p)
+    eng.set_source(src[cut:])
+    s_b, g_b, H_b, h_b = eng.derivatives(p)
+    assert h_a + h_b == h_all
+    scale = np.abs(H_all).max()
+    assert abs((s_a + s_b) - s_all) <= 1e-11 * abs(s_all)
+    assert np.abs((g_a + g_b) - g_all).max() <= 1e-11 * max(1.0, np.abs(g_all).max())
+    assert np.abs((H_a + H_b) - H_all).max() <= 1e-11 * scale
+    perm = np.random.default_rng(3).permutation(len(src))
+    eng.set_source(np.ascontiguousarray(src[perm]))
+    s_p, g_p, H_p, h_p = eng.derivatives(p)
+    assert h_p == h_all
+    assert abs(s_p - s_all) <= 1e-11 * abs(s_all) and np.abs(H_p - H_all).max() <= 1e-11 * scale
+    # the target's leaves do not depend on the order of the target points beyond f64 summation rounding
+    eng2 = ndt.Engine(ndt.default_params(trans_epsilon=0.01, max_iterations=64))
+    eng2.set_target(np.ascontiguousarray(tgt[np.random.default_rng(4).permutation(len(tgt))]))
+    v1, v2 = eng.get_voxels(0), eng2.get_voxels(0)
+    assert np.array_equal(v1["idx"], v2["idx"]) and np.array_equal(v1["n"], v2["n"])
+    assert np.abs(v1["mean"] - v2["mean"]).max() <= 1e-12 * 128
+
+
 def test_identity_alignment_property():
     """identical clouds + identity guess => nothing to do: |delta| -> 0 within the 3-sweep minimum."""
     tgt, _, _ = synth.make_pair(2, 256)
