@@ -628,7 +628,7 @@ static void make_sweep_const(const mi355ndt_handle* h, SweepConst& sc) {
 
 static int launch_sweep(mi355ndt_handle* h, const SweepConst& sc) {
   // persistent waves: SWEEP_WPE workgroups per CU pull (pair, chunk, quarter) items until the per-XCD queues are dry
-  const dim3 grid((unsigned)(h->n_cu * SWEEP_WPE));
+  const dim3 grid((unsigned)(h->n_cu * sweep_wpe(sc.pca != 0, sc.K)));
   if (h->prof) HIPCHK(h, ev_begin(h, h->ev_sweep));
 #define NDT_LAUNCH_SWEEP(P, KK) k_sweep<P, KK><<<grid, SWEEP_THREADS, 0, h->stream>>>(h->d_src, h->src_pitch, h->d_state, h->d_grid, \
       h->d_words, h->d_recs, h->d_partials, h->chunks_per_pair, h->d_active_list, h->d_ctl + h->ctl_idx, h->d_ctl + (h->ctl_idx ^ 1), sc, h->d_cent)

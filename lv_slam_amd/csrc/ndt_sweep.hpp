@@ -113,8 +113,23 @@ struct SweepCtl {               // 9 ints; two of them alternate: the sweep that
 };
 #define QUARTERS WAVES          // a chunk is reduced as 4 wave-quarters of CHUNK_PTS/4 points
 
+// Per-instantiation tuning (measured with tools/sweep_only.py; none of it changes a result bit).  The sweep is VALU-issue
+// bound, so the only thing a third wave per SIMD can add is issue slots the other two leave empty -- it pays exactly where the
+// kernel fits 168 VGPRs WITHOUT spilling, which ndt_omp / DIRECT7 does once the mid-evaluation record prefetch (17 VGPRs) and
+// the two-tile probe group are dropped: 2.46-2.50 vs 2.55 ms for three full launches (1-3 %, box to box).  Every other instantiation is faster with
+// two waves, the prefetch and multi-tile probing (DIRECT1 is probe-stage bound; ndt_pca variants are LDS-limited to two
+// workgroups per CU anyway).
 template <bool PCA, int K>
-__global__ void __launch_bounds__(SWEEP_THREADS, SWEEP_WPE)
+struct SweepTune {
+  static constexpr bool LEAN = !PCA && K == 7;
+  static constexpr int  WPE  = LEAN ? 3 : SWEEP_WPE;                       // workgroups per CU = waves per SIMD
+  static constexpr bool PIPE = !LEAN;                                      // fetch batch k+1's records in the middle of batch k
+  static constexpr int  TP   = LEAN ? 1 : (K == 1 ? 4 : (K <= 7 ? 2 : 1));  // tiles probed together
+};
+static inline int sweep_wpe(bool pca, int K) { return (!pca && K == 7) ? 3 : SWEEP_WPE; }
+
+template <bool PCA, int K>
+__global__ void __launch_bounds__(SWEEP_THREADS, (SweepTune<PCA, K>::WPE))
 k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict__ st,
         const GridDesc* __restrict__ gd, const BitWord* __restrict__ words, const VoxelRec* __restrict__ recs,
         double* partials, int chunks_per_pair, const int* __restrict__ active_list, SweepCtl* ctl, SweepCtl* ctl_next, SweepConst sc,
@@ -145,7 +160,7 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
   // their ballots -- the probe stage costs a few L2 round trips per super-tile, not per tile.  DIRECT1 has one probe per point
   // and ~0.9 hits, so it is probe-stage bound: 4 tiles at a time; DIRECT7: 2 (14 bitmap words in flight); the 26/27-cell
   // searches already have 7-probe groups inside one tile.
-  constexpr int TP = (K == 1) ? 4 : (K <= Q_GROUP ? 2 : 1);
+  constexpr int TP = SweepTune<PCA, K>::TP;
   __shared__ float stage[WAVES][2 * 64 * TP][6];   // two super-tiles of staged points: x'(3), R x (3)
 
   __shared__ double exp_tab[64];                   // 2^(j/64) for ndtm::exp_f32arg
@@ -238,6 +253,10 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
     // All full batches in the queue, software-pipelined: the next batch's record loads are issued in the middle of the
     // current batch's arithmetic (before its 36 Hessian terms), so their L2 latency is off the critical path.
     auto drain_full = [&]() {
+      if (!SweepTune<PCA, K>::PIPE) {              // plain: one batch after the other
+        while (qcount >= 64) drain(64);
+        return;
+      }
       if (qcount < 64) return;
       Batch A;
       fetch(0, 64, A);
