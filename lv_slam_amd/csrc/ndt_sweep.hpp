@@ -113,20 +113,19 @@ struct SweepCtl {               // 9 ints; two of them alternate: the sweep that
 };
 #define QUARTERS WAVES          // a chunk is reduced as 4 wave-quarters of CHUNK_PTS/4 points
 
-// Per-instantiation tuning (measured with tools/sweep_only.py; none of it changes a result bit).  The sweep is VALU-issue
-// bound, so the only thing a third wave per SIMD can add is issue slots the other two leave empty -- it pays exactly where the
-// kernel fits 168 VGPRs WITHOUT spilling, which ndt_omp / DIRECT7 does once the mid-evaluation record prefetch (17 VGPRs) and
-// the two-tile probe group are dropped: 2.46-2.50 vs 2.55 ms for three full launches (1-3 %, box to box).  Every other instantiation is faster with
-// two waves, the prefetch and multi-tile probing (DIRECT1 is probe-stage bound; ndt_pca variants are LDS-limited to two
-// workgroups per CU anyway).
+// Per-instantiation tuning knobs (none of them changes a result bit).  LEAN = three waves per SIMD without spilling: possible
+// for DIRECT7 once the mid-evaluation record prefetch (17 VGPRs) and the two-tile probe group are dropped.  Measured
+// (tools/sweep_only.py, bench.py): ndt_omp at 1 m / 65,536 pts 1-3 % faster, but at 0.5 m / 131,072 pts (four times the voxel
+// records, fewer cache hits) 3 % slower, and ndt_pca 12 % slower there -- the prefetch matters as soon as records miss in L2,
+// so LEAN stays off.
 template <bool PCA, int K>
 struct SweepTune {
-  static constexpr bool LEAN = !PCA && K == 7;
+  static constexpr bool LEAN = false;
   static constexpr int  WPE  = LEAN ? 3 : SWEEP_WPE;                       // workgroups per CU = waves per SIMD
   static constexpr bool PIPE = !LEAN;                                      // fetch batch k+1's records in the middle of batch k
   static constexpr int  TP   = LEAN ? 1 : (K == 1 ? 4 : (K <= 7 ? 2 : 1));  // tiles probed together
 };
-static inline int sweep_wpe(bool pca, int K) { return (!pca && K == 7) ? 3 : SWEEP_WPE; }
+static inline int sweep_wpe(bool pca, int K) { (void)pca; (void)K; return SWEEP_WPE; }
 
 template <bool PCA, int K>
 __global__ void __launch_bounds__(SWEEP_THREADS, (SweepTune<PCA, K>::WPE))
