@@ -271,6 +271,36 @@ def test_full_size_sweep_properties():
     assert np.abs(v1["mean"] - v2["mean"]).max() <= 1e-12 * 128
 
 
+def test_two_engines_from_two_threads():
+    """Distinct handles are independent: two engines driven concurrently from two host threads give the
+    same bits as the same work done one after the other."""
+    import threading
+    jobs = []
+    for k in range(2):
+        t, s_, _ = synth.make_pair(40 + k, 256, n_beams=32)
+        jobs.append((t.numpy(), s_.numpy()))
+    G = synth.default_guess()
+    ref = []
+    for t, s_ in jobs:
+        e = ndt.Engine(ndt.default_params(trans_epsilon=0.01, max_iterations=64))
+        e.set_target(t); e.set_source(s_)
+        ref.append(e.align(G))
+    out = [None, None]
+
+    def work(k):
+        e = ndt.Engine(ndt.default_params(trans_epsilon=0.01, max_iterations=64))
+        for _ in range(5):                        # overlap for real: several build + align rounds per thread
+            e.set_target(jobs[k][0]); e.set_source(jobs[k][1])
+            out[k] = e.align(G)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for k in range(2):
+        assert np.array_equal(out[k]["final"], ref[k]["final"]) and out[k]["iterations"] == ref[k]["iterations"]
+        assert out[k]["score"] == ref[k]["score"]
+
+
 def test_identity_alignment_property():
     """identical clouds + identity guess => nothing to do: |delta| -> 0 within the 3-sweep minimum."""
     tgt, _, _ = synth.make_pair(2, 256)
