@@ -99,7 +99,10 @@ struct mi355ndt_handle {
   // profiling
   bool prof = false;
   mi355ndt_profile P{};
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_sweep, ev_update, ev_build;
+  struct EvSpan { hipEvent_t first, second; bool first_shared; };   // first_shared: `first` is the previous span's `second`
+  std::vector<EvSpan> ev_sweep, ev_update, ev_build;
+  hipEvent_t ev_last = nullptr;                   // end event of the span just closed, reusable as the next span's begin while
+  bool ev_last_fresh = false;                     // nothing else has been enqueued on the stream since
   std::vector<hipEvent_t> ev_pool;                // idle timing events (filled by mi355ndt_profile_enable)
 };
 
@@ -227,9 +230,8 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
   if (h->h_pin_guess) (void)hipHostFree(h->h_pin_guess);
   for (hipEvent_t e : h->ev_burst) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
-  for (auto& e : h->ev_sweep) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  for (auto& e : h->ev_update) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  for (auto& e : h->ev_build) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto* v : {&h->ev_sweep, &h->ev_update, &h->ev_build})
+    for (auto& e : *v) { if (!e.first_shared) (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return MI355NDT_OK;
@@ -401,25 +403,36 @@ static hipError_t ev_take(mi355ndt_handle* h, hipEvent_t* e) {
   if (!h->ev_pool.empty()) { *e = h->ev_pool.back(); h->ev_pool.pop_back(); return hipSuccess; }
   return hipEventCreate(e);
 }
-static hipError_t ev_begin(mi355ndt_handle* h, std::vector<std::pair<hipEvent_t, hipEvent_t>>& v) {
-  hipEvent_t a, b;
+// Back-to-back kernels share an event: the end of one span is the begin of the next (half the event records in the round loop).
+static hipError_t ev_begin(mi355ndt_handle* h, std::vector<mi355ndt_handle::EvSpan>& v) {
+  if (h->ev_last_fresh && h->ev_last) {
+    v.push_back({h->ev_last, nullptr, true});
+    h->ev_last_fresh = false;
+    return hipSuccess;
+  }
+  hipEvent_t a;
   hipError_t e = ev_take(h, &a); if (e != hipSuccess) return e;
-  e = ev_take(h, &b); if (e != hipSuccess) return e;
-  v.push_back({a, b});
+  v.push_back({a, nullptr, false});
   return hipEventRecord(a, h->stream);
 }
-static hipError_t ev_end(mi355ndt_handle* h, std::vector<std::pair<hipEvent_t, hipEvent_t>>& v) {
-  return hipEventRecord(v.back().second, h->stream);
+static hipError_t ev_end(mi355ndt_handle* h, std::vector<mi355ndt_handle::EvSpan>& v) {
+  hipEvent_t b;
+  hipError_t e = ev_take(h, &b); if (e != hipSuccess) return e;
+  v.back().second = b;
+  h->ev_last = b;
+  h->ev_last_fresh = true;
+  return hipEventRecord(b, h->stream);
 }
-static void ev_collect(mi355ndt_handle* h, std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, double& ms, long long& n) {
+static void ev_collect(mi355ndt_handle* h, std::vector<mi355ndt_handle::EvSpan>& v, double& ms, long long& n) {
   for (auto& e : v) {
     float t = 0;
-    if (hipEventElapsedTime(&t, e.first, e.second) == hipSuccess) { ms += t; n++; }
-    h->ev_pool.push_back(e.first); h->ev_pool.push_back(e.second);
+    if (e.second && hipEventElapsedTime(&t, e.first, e.second) == hipSuccess) { ms += t; n++; }
+    if (!e.first_shared) h->ev_pool.push_back(e.first);
+    if (e.second) h->ev_pool.push_back(e.second);
   }
   v.clear();
+  h->ev_last_fresh = false;
 }
-
 int mi355ndt_profile_enable(mi355ndt_handle* h, int on) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   h->prof = on != 0;
@@ -440,6 +453,8 @@ int mi355ndt_profile_reset(mi355ndt_handle* h) {
   double d; long long n;
   ev_collect(h, h->ev_sweep, d, n); ev_collect(h, h->ev_update, d, n); ev_collect(h, h->ev_build, d, n);
   h->P = mi355ndt_profile{};
+  (void)hipMemsetAsync(h->d_hits, 0, sizeof(unsigned long long), h->stream);
+  (void)hipStreamSynchronize(h->stream);
   return MI355NDT_OK;
 }
 int mi355ndt_profile_get(mi355ndt_handle* h, mi355ndt_profile* out) {
@@ -450,7 +465,11 @@ int mi355ndt_profile_get(mi355ndt_handle* h, mi355ndt_profile* out) {
   ev_collect(h, h->ev_sweep, h->P.sweep_ms, h->P.sweep_launches);
   ev_collect(h, h->ev_update, h->P.update_ms, h->P.update_launches);
   ev_collect(h, h->ev_build, h->P.build_ms, h->P.build_launches);
+  unsigned long long hh = 0;                      // (point, voxel) evaluations since the last reset, summed on the device
+  HIPCHK(h, hipMemcpy(&hh, h->d_hits, sizeof hh, hipMemcpyDeviceToHost));
   *out = h->P;
+  out->sweep_hits += (long long)hh;
+  out->sweep_alg_bytes += 64.0 * (double)hh;
   return MI355NDT_OK;
 }
 
@@ -505,6 +524,7 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
   }
   if (total >= ((size_t)1 << 31)) { h->err = "batch too large for one radix sort"; return MI355NDT_ERR_BAD_ARG; }
 
+  h->ev_last_fresh = false;
   if (h->prof) HIPCHK(h, ev_begin(h, h->ev_build));
   const int gx = (int)((pitch + 255) / 256);
   k_minmax_init<<<(B * 6 + 255) / 256, 256, 0, s>>>(h->d_minmax, B);
@@ -668,6 +688,7 @@ int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_resu
   SweepConst sc;
   make_sweep_const(h, sc);
   // the engine's stream is idle here (every entry point returns synchronised), so the pinned staging copy is free to overwrite
+  h->ev_last_fresh = false;
   memcpy(h->h_pin_guess, guesses, (size_t)B * 16 * sizeof(float));
   HIPCHK(h, hipMemcpyAsync(h->d_guess, h->h_pin_guess, (size_t)B * 16 * sizeof(float), hipMemcpyHostToDevice, s));
   HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, 2 * sizeof(SweepCtl), s));
@@ -680,7 +701,6 @@ int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_resu
   for (int b = 0; b < B; b++) pts_total += h->h_src_cnt[b];
   const double alg_static = pts_total * (12.0 + 4.0 * sc.K);   // every active pair streams its points + K table probes
   if (h->prof) {
-    HIPCHK(h, hipMemsetAsync(h->d_hits, 0, sizeof(unsigned long long), s));
     h->P.sweep_alg_bytes += alg_static;                          // the initial sweep covers all pairs
     h->P.sweep_points += (long long)pts_total;
   }
@@ -692,6 +712,7 @@ int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_resu
   int cnt[2] = {0, 0};                                           // rounds in the burst held by ring slot 0 / 1
   auto enqueue_burst = [&]() -> int {
     const int slot = n_enq & 1;
+    h->ev_last_fresh = false;                    // the burst bookkeeping below sits between the previous sweep and this update
     int* dact = h->d_active + slot * burst;
     hipError_t e = hipMemsetAsync(dact, 0, burst * sizeof(int), s);
     if (e != hipSuccess) return MI355NDT_ERR_HIP;
@@ -734,15 +755,8 @@ int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_resu
     }
     if (act[cnt[slot] - 1] == 0) break;
   }
-  if (h->prof) {
-    // one more reduction so the hits of the very last sweeps are counted is not needed: every sweep is
-    // followed by an update (the loop only exits after an update scheduled no further sweep)
-    unsigned long long hh = 0;
-    HIPCHK(h, hipMemcpyAsync(&hh, h->d_hits, sizeof hh, hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipStreamSynchronize(s));
-    h->P.sweep_hits += (long long)hh;
-    h->P.sweep_alg_bytes += 64.0 * (double)hh;
-  }
+  // (the device-side hit counter d_hits keeps accumulating; mi355ndt_profile_get reads it -- every sweep is followed by an
+  //  update, which is where the hits are added, so nothing is missing when the loop exits)
   HIPCHK(h, hipMemcpyAsync(out, h->d_results, (size_t)B * sizeof(mi355ndt_result), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
   HIPCHK(h, hipGetLastError());
@@ -862,6 +876,7 @@ static int run_hook_sweep(mi355ndt_handle* h, double* score, double g[6], double
 }
 
 static int hook_ready(mi355ndt_handle* h) {
+  h->ev_last_fresh = false;
   if (h->n_pairs < 1 || !h->have_target || !h->have_source) return MI355NDT_ERR_STATE;
   HIPCHK(h, hipSetDevice(h->device));
   const bool pca_kd = h->prm.neighbor_mode == MI355NDT_KDTREE && h->prm.variant == MI355NDT_VARIANT_PCA;
