@@ -48,14 +48,23 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_hist(const unsigned* __restri
     const size_t i = wbase + r * 64 + lane;
     key[r] = i < pitch ? K[i] : 0u;
   }
+  // Counting needs no ranks, only totals: equal digits mostly come in runs (neighbouring points of a scan fall into the same
+  // cell), so the head of each run adds the run's length with one LDS atomic -- a dozen instructions per round instead of the
+  // eight ballots of a full digit match.
 #pragma unroll
   for (int r = 0; r < RS_ROUNDS; r++) {
     const size_t i = wbase + r * 64 + lane;
-    const bool valid = i < pitch;
+    const bool valid = i < pitch;                              // valid lanes form a prefix of the wave
     const unsigned d = (key[r] >> shift) & (RS_NB - 1);
-    const unsigned long long m = rs_match(d, valid);
-    // one lane per distinct digit adds the group's size: no two leaders of a wave touch the same counter
-    if (valid && (m & ((1ull << lane) - 1ull)) == 0) cnt[w][d] += (unsigned)__popcll(m);
+    const unsigned prev = __shfl_up(d, 1);
+    const bool head = valid && (lane == 0 || d != prev);
+    const unsigned long long heads = __ballot(head);
+    const int nvalid = (int)__popcll(__ballot(valid));
+    if (head) {
+      const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+      const int next = above ? lane + 1 + ((int)__ffsll((long long)above) - 1) : nvalid;
+      atomicAdd(&cnt[w][d], (unsigned)(next - lane));
+    }
   }
   __syncthreads();
   for (int d = threadIdx.x; d < RS_NB; d += RS_THREADS)
