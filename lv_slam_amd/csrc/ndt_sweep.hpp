@@ -149,12 +149,16 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
   const int n_active = ctl->n_active;
   const int items_per_pair = chunks_per_pair * QUARTERS;
 
+  // ndt_pca's per-hit multiplier is the product of the hit's own weight and those of the point's LATER hits, known only in phase A.
+  // With one probe per point (DIRECT1) it is just the leaf's own weight, which phase B reads with the record anyway: no weight
+  // load in the probe stage, no weight queue, dead leaves filtered in phase B exactly as for ndt_omp.
+  constexpr bool PCAQ = PCA && K > 1;
   // per-wave hit queue: must hold a leftover (< 64) plus everything one probe group can push: TP tiles x min(K, Q_GROUP) probes x 64
   constexpr int Q_CAP = (K > 1 && K <= Q_GROUP) ? 1024 : 512;
   __shared__ unsigned q_ent[WAVES][Q_CAP];
   // ndt_pca weight of a queued hit: the suffix product (f64: up to ~150^7) -- for DIRECT1 just the leaf's own integer weight
   typedef typename std::conditional<K == 1, int, double>::type QW;
-  __shared__ QW q_w[PCA ? WAVES : 1][PCA ? Q_CAP : 1];
+  __shared__ QW q_w[PCAQ ? WAVES : 1][PCAQ ? Q_CAP : 1];
   // TP tiles of 64 points are probed together ("super-tile"): their point transforms, then ALL their bitmap loads, then all
   // their ballots -- the probe stage costs a few L2 round trips per super-tile, not per tile.  DIRECT1 has one probe per point
   // and ~0.9 hits, so it is probe-stage bound: 4 tiles at a time; DIRECT7: 2 (14 bitmap words in flight); the 26/27-cell
@@ -227,7 +231,8 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
       for (int a = 0; a < 9; a++) B.C[a] = vr.icov[a];
       B.weight = vr.weight;
       B.w = 1.0;
-      if (PCA) B.w = (double)q_w[wv][(qhead + off + k) & (Q_CAP - 1)];
+      if (PCAQ) B.w = (double)q_w[wv][(qhead + off + k) & (Q_CAP - 1)];
+      else if (PCA) B.w = (double)vr.weight;
     };
     // evaluate a fetched batch (running `mid` half way through) and retire its `m` queue entries
     auto eval_batch = [&](const Batch& B, int m, auto mid) {
@@ -235,10 +240,10 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
       const float xt0 = sp[0], xt1 = sp[1], xt2 = sp[2];
       float r[3] = {sp[3], sp[4], sp[5]};
       // ndt_omp: leaves with nr_points = -1 (eigen / inverse failure) are not neighbours (impl:395): filtered here
-      const bool live = lane < m && (PCA || KD || B.weight != VOX_DEAD);
+      const bool live = lane < m && (PCAQ || KD || B.weight != VOX_DEAD);
       float u[3] = {(float)((double)xt0 - B.m0), (float)((double)xt1 - B.m1), (float)((double)xt2 - B.m2)};   // impl2:276-279, 574
       eval_hit<PCA>(u, r, B.C, sc.d1, sc.d2f, B.w, live, acc, exp_tab, mid);
-      nhits += PCA ? (unsigned)m : (unsigned)__popcll(__ballot(live));
+      nhits += PCAQ ? (unsigned)m : (unsigned)__popcll(__ballot(live));
       qhead = (qhead + m) & (Q_CAP - 1);
       qcount -= m;
       q_old = q_old > m ? q_old - m : 0;
@@ -359,7 +364,7 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
               // occupied <=> the cell's bit (now the sign bit) is set; ndt_pca needs the weights now (suffix product),
               // ndt_omp filters dead leaves in phase B instead and saves this dependent L2 round trip
               wiv[p][j] = ((long long)tb < 0) ? 1 : VOX_DEAD;
-              if (PCA) { if ((long long)tb < 0) wiv[p][j] = R[idv[p][j]].weight; }
+              if (PCAQ) { if ((long long)tb < 0) wiv[p][j] = R[idv[p][j]].weight; }
               if (KD && (long long)tb < 0) {                     // FLANN L2_Simple distance to the leaf's f32 centroid
                 const float* cp = cent + 3 * (size_t)(g.rec_off + idv[p][j]);
                 const float dx = kx[p] - cp[0], dy = ky[p] - cp[1], dz = kz[p] - cp[2];
@@ -374,12 +379,12 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
             for (int j = 0; j < Q_GROUP; j++) {
               if (q1 - 1 - j < 0) continue;
               const bool hit = wiv[p][j] != VOX_DEAD;     // empty cell, or nr_points == -1: not a neighbour (impl:395)
-              if (PCA && hit) suf[p] *= (double)wiv[p][j];
+              if (PCAQ && hit) suf[p] *= (double)wiv[p][j];
               const unsigned long long mask = __ballot(hit);
               if (hit) {
                 const int pos = (qhead + qcount + (int)__popcll(mask & lt_mask)) & (Q_CAP - 1);
                 q_ent[wv][pos] = ((unsigned)slot << ID_BITS) | idv[p][j];
-                if (PCA) q_w[wv][pos] = (QW)suf[p];
+                if (PCAQ) q_w[wv][pos] = (QW)suf[p];
               }
               qcount += (int)__popcll(mask);
             }
