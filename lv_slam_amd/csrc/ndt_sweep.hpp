@@ -123,7 +123,7 @@ struct SweepTune {
   static constexpr bool LEAN = false;
   static constexpr int  WPE  = LEAN ? 3 : SWEEP_WPE;                       // workgroups per CU = waves per SIMD
   static constexpr bool PIPE = !LEAN;                                      // fetch batch k+1's records in the middle of batch k
-  static constexpr int  TP   = LEAN ? 1 : (K == 1 ? 4 : (K <= 7 ? 2 : 1));  // tiles probed together
+  static constexpr int  TP   = LEAN ? 1 : (K == 1 ? 8 : (K <= 7 ? 2 : 1));  // tiles probed together (8 = the whole work item)
 };
 static inline int sweep_wpe(bool pca, int K) { (void)pca; (void)K; return SWEEP_WPE; }
 
@@ -164,7 +164,8 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
   // and ~0.9 hits, so it is probe-stage bound: 4 tiles at a time; DIRECT7: 2 (14 bitmap words in flight); the 26/27-cell
   // searches already have 7-probe groups inside one tile.
   constexpr int TP = SweepTune<PCA, K>::TP;
-  __shared__ float stage[WAVES][2 * 64 * TP][6];   // two super-tiles of staged points: x'(3), R x (3)
+  constexpr int NBUF = (CHUNK_PTS / WAVES / 64 / TP > 1) ? 2 : 1;   // a super-tile that is the whole item needs no second buffer
+  __shared__ float stage[WAVES][NBUF * 64 * TP][6];   // (two) super-tiles of staged points: x'(3), R x (3)
 
   __shared__ double exp_tab[64];                   // 2^(j/64) for ndtm::exp_f32arg
   if (threadIdx.x < 64) exp_tab[threadIdx.x] = ndtm::c_exp2_64[threadIdx.x];
