@@ -344,6 +344,29 @@ def test_degenerate_geometry_vs_oracle(variant):
     assert dt < 1e-4 and dr < 1e-5, (dt, dr)
 
 
+def test_non_default_parameters_vs_oracle():
+    """Every tunable away from its constructor default at once: resolution, step size, outlier ratio, epsilon, iteration cap,
+    min_points_per_voxel (voxel_grid_covariance_omp.h:204) and the eigenvalue inflation factor (:205)."""
+    tgt, src, _ = synth.make_pair(60, 256, n_beams=32)
+    tgt, src = tgt.numpy(), src.numpy()
+    kw = dict(resolution=1.5, step_size=0.05, outlier_ratio=0.3, trans_epsilon=0.02, max_iterations=12, neighbor_mode=ndt.DIRECT7,
+              min_points_per_voxel=3, min_covar_eigvalue_mult=0.1)
+    gp, op = both_params(**kw)
+    eng = ndt.Engine(gp)
+    grid = O.Grid(tgt, op)
+    eng.set_target(tgt)
+    check_voxels(eng, grid)
+    eng.set_source(src)
+    G = synth.default_guess()
+    p0 = O.se3_log(G.astype(np.float64))
+    check_sweep(eng.derivatives(p0), O.derivatives_at(grid, src, p0))
+    r, ro = eng.align(G), O.align(grid, src, G)
+    assert r["iterations"] == ro["iterations"] and r["converged"] == ro["converged"] and r["sweeps"] == ro["sweeps"]
+    dt, dr = se3_err(ro["final"], r["final"])
+    assert dt < 1e-4 and dr < 1e-5, (dt, dr)
+    assert abs(r["trans_probability"] - ro["trans_probability"]) <= 1e-9 * max(1.0, abs(ro["trans_probability"]))
+
+
 def test_identity_alignment_property():
     """identical clouds + identity guess => nothing to do: |delta| -> 0 within the 3-sweep minimum."""
     tgt, _, _ = synth.make_pair(2, 256)
