@@ -130,6 +130,12 @@ int mi355ndt_align(mi355ndt_handle* h, const float guess_colmajor[16], mi355ndt_
  * Writes x,y,z into records `stride_bytes` apart. */
 int mi355ndt_get_aligned(mi355ndt_handle* h, void* out_pts, size_t stride_bytes);
 
+/* pcl::Registration::transformation_ / previous_transformation_ as the last align() left them: float(exp(delta_p)) of the
+ * last Newton step (ndt_omp_impl2.hpp:163; what getLastIncrementalTransformation() returns) and of the step before it
+ * (impl2:134); both Identity when no step was taken.  Column-major 4x4; either pointer may be NULL.  `pair` = batch slot
+ * (0 for the single-registration surface). */
+int mi355ndt_get_incremental(mi355ndt_handle* h, int pair, float transformation_colmajor[16], float previous_colmajor[16]);
+
 /* replaces pcl::Registration::getFitnessScore(max_range) as called by the loop-closure path
  * (include/global_graph/loop_detector.hpp:249-262; identical recipe in-tree:
  * src/global_graph/information_matrix_calculator.cpp:53-87): source moved by the final pose of the last align()

@@ -28,7 +28,7 @@ class NormalDistributionsTransform : public pcl::Registration<PointSource, Point
   typedef typename PointCloudTarget::ConstPtr PointCloudTargetConstPtr;
   using Base::reg_name_; using Base::input_; using Base::target_; using Base::nr_iterations_; using Base::max_iterations_;
   using Base::final_transformation_; using Base::transformation_; using Base::previous_transformation_;
-  using Base::transformation_epsilon_; using Base::converged_;
+  using Base::transformation_epsilon_; using Base::converged_; using Base::update_visualizer_;
 
  public:
   explicit NormalDistributionsTransform(int variant = MI355NDT_VARIANT_OMP, int device = 0) : h_(nullptr), trans_probability_(0) {
@@ -94,8 +94,18 @@ class NormalDistributionsTransform : public pcl::Registration<PointSource, Point
     nr_iterations_ = r.iterations;
     converged_ = r.converged != 0;
     trans_probability_ = r.trans_probability;
+    // transformation_ / previous_transformation_ as the reference's loop leaves them (ndt_omp_impl2.hpp:134, 163):
+    // pcl::Registration::getLastIncrementalTransformation() reads transformation_
+    float inc[16], prev[16];
+    if (mi355ndt_get_incremental(h_, 0, inc, prev) == MI355NDT_OK) {
+      transformation_ = Eigen::Map<const Eigen::Matrix4f>(inc);
+      previous_transformation_ = Eigen::Map<const Eigen::Matrix4f>(prev);
+    }
     output.points.resize(input_->points.size());
     mi355ndt_get_aligned(h_, output.points.data(), sizeof(PointSource));   // x,y,z of the moved source; other fields kept
+    // impl2:172-173 calls the visualizer hook once per iteration with the cloud at that iteration's pose; the Newton loop runs
+    // on the device without host round trips, so the hook (never set anywhere in lv_slam) fires once, with the final cloud
+    if (update_visualizer_ != 0) update_visualizer_(output, std::vector<int>(), *target_, std::vector<int>());
   }
 
   mi355ndt_handle* h_;

@@ -14,6 +14,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cstdio>
+#include <cstddef>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -115,6 +116,8 @@ struct mi355ndt_handle {
     }                                                                                            \
   } while (0)
 
+// several kernels carry the pair index in grid.y (HIP limit 65535)
+#define MAX_PAIRS 65535
 static int ceil_log2(unsigned v) { int b = 0; while ((1u << b) < v) b++; return b; }
 
 template <typename T>
@@ -274,6 +277,10 @@ int mi355ndt_batch_size(const mi355ndt_handle* h) { return h ? h->n_pairs : MI35
 static int ensure_pair_arrays(mi355ndt_handle* h, int n_pairs) {
   if (n_pairs <= h->cap_pairs) return MI355NDT_OK;
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  // the arrays are released and re-created one by one: until all of them exist again the engine holds no batch at all
+  // (a failure half way must not leave cap_pairs vouching for freed or undersized buffers)
+  h->cap_pairs = 0; h->n_pairs = 0;
+  h->targets_built = false; h->have_target = false; h->have_source = false;
   auto re = [&](void** p, size_t bytes) -> hipError_t {
     if (*p) { hipError_t e = hipFree(*p); *p = nullptr; if (e != hipSuccess) return e; }
     return hipMalloc(p, bytes);
@@ -316,7 +323,7 @@ static int alloc_side(mi355ndt_handle* h, bool tgt, int n_pairs, size_t pitch) {
 
 int mi355ndt_batch_reserve(mi355ndt_handle* h, int n_pairs, size_t max_tgt, size_t max_src) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
-  if (n_pairs <= 0 || max_tgt == 0 || max_src == 0 || n_pairs > (1 << 20)) return MI355NDT_ERR_BAD_ARG;
+  if (n_pairs <= 0 || max_tgt == 0 || max_src == 0 || n_pairs > MAX_PAIRS) return MI355NDT_ERR_BAD_ARG;
   if (max_tgt >= (1u << 31) || max_src >= (1u << 31)) return MI355NDT_ERR_BAD_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   // pitches padded to 64 floats so every row starts 256-B aligned
@@ -381,7 +388,7 @@ int mi355ndt_batch_set_source(mi355ndt_handle* h, int pair, const void* pts, siz
 int mi355ndt_batch_bind_device(mi355ndt_handle* h, int n_pairs, const float* d_t, const int* tc, size_t tp,
                                const float* d_s, const int* scnt, size_t sp) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
-  if (n_pairs <= 0 || !d_t || !d_s || !tc || !scnt || tp == 0 || sp == 0 || n_pairs > (1 << 20)) return MI355NDT_ERR_BAD_ARG;
+  if (n_pairs <= 0 || !d_t || !d_s || !tc || !scnt || tp == 0 || sp == 0 || n_pairs > MAX_PAIRS) return MI355NDT_ERR_BAD_ARG;
   if (tp >= (1u << 31) || sp >= (1u << 31)) return MI355NDT_ERR_BAD_ARG;
   for (int b = 0; b < n_pairs; b++) if (tc[b] < 0 || (size_t)tc[b] > tp || scnt[b] < 0 || (size_t)scnt[b] > sp) return MI355NDT_ERR_BAD_ARG;
   HIPCHK(h, hipSetDevice(h->device));
@@ -482,10 +489,10 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
   const size_t pitch = h->tgt_pitch;
   const size_t total = (size_t)B * pitch;
   hipStream_t s = h->stream;
-  if (h->up_tgt_cnt != h->h_tgt_cnt) {
+  if (h->up_tgt_cnt.size() != (size_t)B || !std::equal(h->up_tgt_cnt.begin(), h->up_tgt_cnt.end(), h->h_tgt_cnt.begin())) {
     HIPCHK(h, hipMemcpyAsync(h->d_tgt_cnt, h->h_tgt_cnt.data(), B * sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHK(h, hipStreamSynchronize(s));   // h_tgt_cnt is pageable
-    h->up_tgt_cnt = h->h_tgt_cnt;
+    h->up_tgt_cnt.assign(h->h_tgt_cnt.begin(), h->h_tgt_cnt.begin() + B);   // exactly what the device now holds
   }
 
   // workspace
@@ -627,10 +634,10 @@ static int prep_align_ws(mi355ndt_handle* h) {
   h->chunks_per_pair = std::max(1, (maxn + CHUNK_PTS - 1) / CHUNK_PTS);
   size_t need = (size_t)B * h->chunks_per_pair * QUARTERS * NACC;
   HIPCHK(h, grow(h->d_partials, h->partials_cap, need));
-  if (h->up_src_cnt != h->h_src_cnt) {
+  if (h->up_src_cnt.size() != (size_t)B || !std::equal(h->up_src_cnt.begin(), h->up_src_cnt.end(), h->h_src_cnt.begin())) {
     HIPCHK(h, hipMemcpyAsync(h->d_src_cnt, h->h_src_cnt.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->up_src_cnt = h->h_src_cnt;
+    h->up_src_cnt.assign(h->h_src_cnt.begin(), h->h_src_cnt.begin() + B);
   }
   return MI355NDT_OK;
 }
@@ -820,7 +827,9 @@ int mi355ndt_set_params(mi355ndt_handle* h, const mi355ndt_params* p) {
                       (p->neighbor_mode == MI355NDT_KDTREE && p->variant == MI355NDT_VARIANT_PCA && !h->kdw_built);
   if (regrid && h->targets_built) {
     h->targets_built = false;
-    return mi355ndt_batch_build_targets(h);   // setResolution -> init() (ndt_omp.h:126-136)
+    rc = mi355ndt_batch_build_targets(h);     // setResolution -> init() (ndt_omp.h:126-136)
+    if (rc) h->prm = old;                     // the grids were not rebuilt: keep the parameters they were (last) built with;
+    return rc;                                // targets_built stays false, so the next align re-voxelises
   }
   return MI355NDT_OK;
 }
@@ -854,6 +863,19 @@ int mi355ndt_get_aligned(mi355ndt_handle* h, void* out_pts, size_t stride) {
     float v[3] = {tmp[i], tmp[(size_t)n + i], tmp[(size_t)2 * n + i]};
     memcpy(o + (size_t)i * stride, v, 12);
   }
+  return MI355NDT_OK;
+}
+
+int mi355ndt_get_incremental(mi355ndt_handle* h, int pair, float last[16], float prev[16]) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (pair < 0 || pair >= h->n_pairs) return MI355NDT_ERR_BAD_ARG;
+  if (!h->d_state) return MI355NDT_ERR_STATE;
+  HIPCHK(h, hipSetDevice(h->device));
+  float buf[32];
+  HIPCHK(h, hipMemcpyAsync(buf, (const char*)(h->d_state + pair) + offsetof(PairState, inc_cm), sizeof buf, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (last) memcpy(last, buf, 16 * sizeof(float));
+  if (prev) memcpy(prev, buf + 16, 16 * sizeof(float));
   return MI355NDT_OK;
 }
 

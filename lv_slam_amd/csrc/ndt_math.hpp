@@ -301,6 +301,16 @@ __device__ inline void eigen_sym3(const double Ain[9], double evals[3], double V
 // x = pinv(H) b with Eigen::JacobiSVD<6x6>::solve semantics (ndt_omp_impl2.hpp:138-140):
 // rank = #{sigma_i >= max(sigma_max * 6 eps, DBL_MIN)}.  One-sided (Hestenes) Jacobi.
 __device__ inline void svd_solve6(const double* H, const double b[6], double x[6]) {
+  // A non-finite entry in H or b: Eigen 3.3's JacobiSVD keeps rank = 6 (NaN singular values fail the `< threshold` test of
+  // SVDBase::rank()) and solve() multiplies through, so every component of the answer is NaN -- which computeTransformation
+  // reports as converged_ = false (impl2:147-151).  A thresholded pseudo-inverse written with `!(sigma >= thr)` would
+  // return 0 (= "converged") instead.
+  {
+    bool fin = true;
+    for (int i = 0; i < 36; i++) fin = fin && isfinite(H[i]);
+    for (int i = 0; i < 6; i++) fin = fin && isfinite(b[i]);
+    if (!fin) { for (int i = 0; i < 6; i++) x[i] = __longlong_as_double(0x7ff8000000000000ll); return; }
+  }
   double A[6][6], V[6][6];
 #pragma unroll
   for (int i = 0; i < 6; i++)

@@ -14,10 +14,16 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
 // `mid` runs between the gradient part and the 36 Hessian terms, where the fewest temporaries are live: the sweep uses it
 // to issue the NEXT batch's record loads so that their L2 latency overlaps the Hessian arithmetic.
-template <bool PCA, typename Mid = NoHook>
-__device__ __forceinline__ void eval_hit(const float u[3], const float r[3], const float C[9],
+// SAN (KDTREE modes only): radiusSearch also returns leaves whose inverse covariance is non-finite (no nr_points re-check,
+// voxel_grid_covariance_omp.h:505-534); the reference rejects such a hit before touching the sums (impl2:588-589), so the
+// operands of a rejected hit are zeroed first -- "e = 0" alone would still add 0 * NaN.
+template <bool PCA, typename Mid = NoHook, bool SAN = false>
+__device__ __forceinline__ void eval_hit(const float u_in[3], const float r[3], const float C_in[9],
                                          const double d1, const float d2f, const double w, const bool ok_in, double acc[43],
                                          const double* __restrict__ exp_tab, Mid mid = Mid()) {
+  float u[3] = {u_in[0], u_in[1], u_in[2]}, C[9];
+#pragma unroll
+  for (int a = 0; a < 9; a++) C[a] = C_in[a];
   float y[3];
 #pragma unroll
   for (int j = 0; j < 3; j++) y[j] = (u[0] * C[j] + u[1] * C[3 + j]) + u[2] * C[6 + j];
@@ -31,6 +37,12 @@ __device__ __forceinline__ void eval_hit(const float u[3], const float r[3], con
   float e = (float)((double)e1 * d1);                                            // impl2:592
   e = ok ? e : 0.f;
   s_inc = ok ? s_inc : 0.f;
+  if (SAN) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) { u[a] = ok ? u[a] : 0.f; y[a] = ok ? y[a] : 0.f; }
+#pragma unroll
+    for (int a = 0; a < 9; a++) C[a] = ok ? C[a] : 0.f;
+  }
   // CJ = c_inv4 * point_gradient4 (impl2:594): columns 0..2 are C itself
   float CJ[3][6];
 #pragma unroll
@@ -243,7 +255,7 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
       // ndt_omp: leaves with nr_points = -1 (eigen / inverse failure) are not neighbours (impl:395): filtered here
       const bool live = lane < m && (PCAQ || KD || B.weight != VOX_DEAD);
       float u[3] = {(float)((double)xt0 - B.m0), (float)((double)xt1 - B.m1), (float)((double)xt2 - B.m2)};   // impl2:276-279, 574
-      eval_hit<PCA>(u, r, B.C, sc.d1, sc.d2f, B.w, live, acc, exp_tab, mid);
+      eval_hit<PCA, decltype(mid), KD>(u, r, B.C, sc.d1, sc.d2f, B.w, live, acc, exp_tab, mid);
       nhits += PCAQ ? (unsigned)m : (unsigned)__popcll(__ballot(live));
       qhead = (qhead + m) & (Q_CAP - 1);
       qcount -= m;

@@ -58,6 +58,9 @@ struct PairState {
   // live More-Thuente case only (step_size <= eps/2, impl2:888): tangent of the pending trial, phi(0), phi'(0)
   double xt[6], phi0, dphi0;
   int    mt_loops, pad_;
+  // pcl::Registration::transformation_ / previous_transformation_ as computeTransformation leaves them (impl2:134, 163):
+  // float(exp(delta_p)) of the last and of the one-before-last Newton step, column-major
+  float  inc_cm[16], prev_inc_cm[16];
 };
 
 struct SweepConst {

@@ -22,6 +22,17 @@ __device__ void finalize_pair(PairState& S, mi355ndt_result* res, int converged)
   *res = o;
 }
 
+// transformation_ = (Sophus::SE3::exp(delta_p).matrix()).cast<float>() (impl2:163)
+__device__ inline void set_increment(PairState& S, const double dp[6]) {
+  float T[12], Rj[9];
+  ndtm::pose_to_f32(dp, T, Rj);
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 4; c++) S.inc_cm[c * 4 + r] = T[r * 4 + c];
+    S.inc_cm[r * 4 + 3] = 0.f;
+  }
+  S.inc_cm[15] = 1.f;
+}
+
 // p = SE3(R,t).log(); first sweep moves the cloud by the caller's f32 guess itself (impl2:102-129)
 __global__ void k_init_state(PairState* st, const float* __restrict__ guess_cm, const int* __restrict__ src_cnt,
                              const GridDesc* __restrict__ gd, int n_pairs, int* active_list, SweepCtl* ctl) {
@@ -42,6 +53,7 @@ __global__ void k_init_state(PairState* st, const float* __restrict__ guess_cm, 
   float Tdummy[12];
   ndtm::pose_to_f32(S.p, Tdummy, S.Rj);
   S.it = 0; S.phase = PH_SWEEP0; S.converged = 0; S.sweeps = 1; S.a_t = 0; S.hits = 0; S.score = 0; S.mt_loops = 0;
+  for (int a = 0; a < 16; a++) S.inc_cm[a] = S.prev_inc_cm[a] = (a % 5 == 0) ? 1.f : 0.f;    // align(): transformation_ = previous_ = I
   S.n_src = src_cnt[b];
   S.grid_status = gd[b].status;
 }
@@ -216,6 +228,7 @@ k_update(PairState* st, const double* __restrict__ partials, int chunks_per_pair
   if (S.phase == PH_STEP) {
     double dp[6], pn[6];
     for (int a = 0; a < 6; a++) dp[a] = S.dir[a] * S.a_t;                        // impl2:156
+    set_increment(S, dp);                                                        // impl2:163
     ndtm::se3_log(ndtm::se3_mul(ndtm::se3_exp(dp), ndtm::se3_exp(S.p)), pn);     // impl2:166
     for (int a = 0; a < 6; a++) S.p[a] = pn[a];
     const bool conv = (S.it > max_iterations) || (S.it && (fabs(S.a_t) < eps));  // impl2:175-179
@@ -223,11 +236,16 @@ k_update(PairState* st, const double* __restrict__ partials, int chunks_per_pair
     if (conv) { finalize_pair(S, &results[b], 1); return; }
   }
   for (int guard = 0; guard < 4; guard++) {
+    for (int a = 0; a < 16; a++) S.prev_inc_cm[a] = S.inc_cm[a];                 // impl2:134
     double neg[6], d[6];
     for (int a = 0; a < 6; a++) neg[a] = -S.g[a];
     // impl2:138-140: JacobiSVD(H).solve(-g).  Well-conditioned H: exact LU solve (same answer to rounding);
     // anything else (rank-deficient, H = 0, ill-conditioned): the thresholded pseudo-inverse itself.
-    if (!ndtm::lu_solve6(S.H, neg, d)) ndtm::svd_solve6(S.H, neg, d);
+    // (non-finite g or H: the SVD route answers NaN, as Eigen's does, and the pair ends with converged = 0)
+    bool fin = true;
+    for (int a = 0; a < 36; a++) fin = fin && isfinite(S.H[a]);
+    for (int a = 0; a < 6; a++) fin = fin && isfinite(S.g[a]);
+    if (!fin || !ndtm::lu_solve6(S.H, neg, d)) ndtm::svd_solve6(S.H, neg, d);
     double nrm = 0;
     for (int a = 0; a < 6; a++) nrm += d[a] * d[a];
     nrm = sqrt(nrm);
@@ -239,6 +257,7 @@ k_update(PairState* st, const double* __restrict__ partials, int chunks_per_pair
     if (dphi0 >= 0 && dphi0 == 0) {
       // impl2:856-857: step length 0, nothing re-evaluated
       double z[6] = {0, 0, 0, 0, 0, 0}, pn[6];
+      set_increment(S, z);
       ndtm::se3_log(ndtm::se3_mul(ndtm::se3_exp(z), ndtm::se3_exp(S.p)), pn);
       for (int a = 0; a < 6; a++) S.p[a] = pn[a];
       const bool conv = (S.it > max_iterations) || (S.it && (0.0 < eps));

@@ -60,7 +60,7 @@ class Profile(C.Structure):
 SYMBOLS = [
     "mi355ndt_version", "mi355ndt_device_count", "mi355ndt_default_params", "mi355ndt_create", "mi355ndt_destroy",
     "mi355ndt_set_params", "mi355ndt_get_params", "mi355ndt_set_stream", "mi355ndt_last_error",
-    "mi355ndt_set_target", "mi355ndt_set_source", "mi355ndt_align", "mi355ndt_get_aligned",
+    "mi355ndt_set_target", "mi355ndt_set_source", "mi355ndt_align", "mi355ndt_get_aligned", "mi355ndt_get_incremental",
     "mi355ndt_get_fitness_score", "mi355ndt_fitness_score_T", "mi355ndt_prefilter", "mi355ndt_use_prefiltered", "mi355ndt_derivatives", "mi355ndt_compute_hessian", "mi355ndt_derivatives_T", "mi355ndt_get_grid", "mi355ndt_get_voxels",
     "mi355ndt_batch_reserve", "mi355ndt_batch_set_target", "mi355ndt_batch_set_source", "mi355ndt_batch_bind_device",
     "mi355ndt_batch_build_targets", "mi355ndt_batch_align", "mi355ndt_batch_size",
@@ -93,6 +93,7 @@ def load_library(path: str = LIB_PATH):
     L.mi355ndt_set_source.argtypes = [vp, vp, sz, sz]
     L.mi355ndt_align.argtypes = [vp, vp, C.POINTER(Result)]
     L.mi355ndt_get_aligned.argtypes = [vp, vp, sz]
+    L.mi355ndt_get_incremental.argtypes = [vp, i, vp, vp]
     L.mi355ndt_get_fitness_score.argtypes = [vp, C.c_double, vp, vp]
     L.mi355ndt_fitness_score_T.argtypes = [vp, vp, C.c_double, vp, vp]
     L.mi355ndt_prefilter.argtypes = [vp, vp, sz, sz, i, C.c_double, C.c_double, C.c_float, vp, sz, sz, C.POINTER(sz)]
@@ -201,6 +202,12 @@ class Engine:
         out = np.zeros((self._n_src, 3), np.float32)
         self._chk(self.lib.mi355ndt_get_aligned(self.h, out.ctypes.data_as(C.c_void_p), 12), "get_aligned")
         return out
+
+    def get_incremental(self, pair: int = 0):
+        """(transformation_, previous_transformation_) of the last align: f32 exp(delta_p) of the last two Newton steps."""
+        a, b = np.zeros(16, np.float32), np.zeros(16, np.float32)
+        self._chk(self.lib.mi355ndt_get_incremental(self.h, pair, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)), "get_incremental")
+        return a.reshape(4, 4).T.copy(), b.reshape(4, 4).T.copy()
 
     def fitness_score(self, max_range: float = float("inf"), T=None):
         """getFitnessScore(max_range); T = explicit 4x4 transform (default: final pose of the last align)."""
@@ -425,6 +432,10 @@ class NormalDistributionsTransform:
 
     def getFinalTransformation(self) -> np.ndarray:
         return self._final.copy()
+
+    def getLastIncrementalTransformation(self) -> np.ndarray:
+        """pcl::Registration::getLastIncrementalTransformation(): transformation_ = f32 exp(delta_p) of the last step (impl2:163)."""
+        return self._eng.get_incremental(0)[0] if self._last is not None else np.eye(4, dtype=np.float32)
 
     def hasConverged(self) -> bool:
         return bool(self._converged)

@@ -34,6 +34,12 @@
 static int g_threads = 0;
 void ora_set_threads(int n) { g_threads = n; }
 
+/* the exp of updateDerivatives as this oracle evaluates it (impl2:581; canonical choice): glibc's double exp of
+ * the f32 argument, rounded to f32.  Exposed so a test can hold the device's table-driven exp against it argument by argument. */
+void ora_exp_f32arg(const float* a, float* out, size_t n) {
+  for (size_t i = 0; i < n; i++) out[i] = (float)exp((double)a[i]);
+}
+
 /* ------------------------------------------------------------------ params */
 void ora_default_params(ora_params* p) {
   /* ndt_omp_impl2.hpp:53-83 (ctor); voxel_grid_covariance_omp.h:202-205 */
@@ -146,6 +152,14 @@ void ora_eigen_sym3(const double Ain[9], double evals[3], double evecs[9]) {
  * rank = #{ sigma_i >= max(sigma_max * 6*eps, DBL_MIN) } (ndt_omp_impl2.hpp:138-140).
  * Algorithm here: one-sided (Hestenes) Jacobi. */
 void ora_svd_solve6(const double H[36], const double b[6], double x[6]) {
+  /* non-finite input: Eigen 3.3 JacobiSVD keeps rank 6 (NaN singular values fail `sigma < threshold` in SVDBase::rank())
+   * and solve() propagates NaN into every component, which impl2:147-151 reports as converged_ = false */
+  {
+    int fin = 1;
+    for (int i = 0; i < 36; i++) fin = fin && isfinite(H[i]);
+    for (int i = 0; i < 6; i++) fin = fin && isfinite(b[i]);
+    if (!fin) { for (int i = 0; i < 6; i++) x[i] = NAN; return; }
+  }
   double A[6][6], V[6][6];
   for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { A[i][j] = H[i * 6 + j]; V[i][j] = (i == j); }
   for (int sweep = 0; sweep < 60; sweep++) {
@@ -911,7 +925,10 @@ int ora_align(const ora_grid* g, const ora_params* prm,
   long hits = ora_derivatives(g, prm, x, y, z, n, T, Rj, &score, grad, H);   /* impl2:129 */
   int sweeps = 1, it = 0, converged = 0, mt_loops = 0;
   mt_ctx ctx = {g, prm, x, y, z, n, out->final_colmajor, &hits, &sweeps, &mt_loops};
+  /* pcl::Registration::align(): transformation_ = previous_transformation_ = Identity before computeTransformation */
+  for (int a = 0; a < 16; a++) out->inc_colmajor[a] = out->prev_inc_colmajor[a] = (a % 5 == 0) ? 1.f : 0.f;
   while (!converged) {
+    memcpy(out->prev_inc_colmajor, out->inc_colmajor, sizeof out->inc_colmajor);   /* impl2:134 */
     double neg[6], dp[6];
     for (int a = 0; a < 6; a++) neg[a] = -grad[a];
     ora_svd_solve6(H, neg, dp);                                    /* impl2:138-140 */
@@ -927,6 +944,11 @@ int ora_align(const ora_grid* g, const ora_params* prm,
     for (int a = 0; a < 6; a++) dp[a] /= nrm;                      /* normalize() impl2:154 */
     const double a_t = step_length_mt(&ctx, p, dp, nrm, step_max, step_min, &score, grad, H);   /* impl2:155 */
     for (int a = 0; a < 6; a++) dp[a] *= a_t;                      /* impl2:156 */
+    {                                                              /* transformation_ = float(exp(delta_p)), impl2:163 */
+      float Ti[16], Ri[9];
+      pose_to_f32(dp, Ti, Ri);
+      memcpy(out->inc_colmajor, Ti, sizeof Ti);
+    }
     double pn[6];
     ora_se3_compose_log(dp, p, pn);                                /* impl2:166 */
     memcpy(p, pn, sizeof pn);

@@ -97,6 +97,8 @@ typedef struct {
   long   hits_last;            /* hits in last sweep */
   int    sweeps;               /* number of computeDerivatives calls */
   int    mt_loops;             /* total More-Thuente loop iterations (impl2:920-994); 0 unless step_size <= eps/2 */
+  float  inc_colmajor[16];     /* transformation_ = float(exp(delta_p)) of the last step (impl2:163) */
+  float  prev_inc_colmajor[16];/* previous_transformation_ (impl2:134) */
 } ora_result;
 
 /* computeTransformation (ndt_omp_impl2.hpp:87-188) + computeStepLengthMT (impl2:841-1003), including its More-Thuente
@@ -131,6 +133,8 @@ size_t ora_prefilter(const float* x, const float* y, const float* z, size_t n, i
                      float* ox, float* oy, float* oz);
 
 void ora_set_threads(int n);
+/* (float)exp((double)a[i]) -- the exp of impl2:581 as eval_hit evaluates it */
+void ora_exp_f32arg(const float* a, float* out, size_t n);
 
 #ifdef __cplusplus
 }

@@ -32,7 +32,8 @@ class Leaf(C.Structure):
 
 class Result(C.Structure):
     _fields_ = [("final_colmajor", C.c_float * 16), ("trans_probability", C.c_double), ("score", C.c_double),
-                ("iterations", C.c_int), ("converged", C.c_int), ("hits_last", C.c_long), ("sweeps", C.c_int), ("mt_loops", C.c_int)]
+                ("iterations", C.c_int), ("converged", C.c_int), ("hits_last", C.c_long), ("sweeps", C.c_int), ("mt_loops", C.c_int),
+                ("inc_colmajor", C.c_float * 16), ("prev_inc_colmajor", C.c_float * 16)]
 
 
 def build(force: bool = False) -> str:
@@ -77,6 +78,7 @@ def lib():
         L.ora_gauss_constants.argtypes = [C.c_double, C.c_float, C.c_void_p]
         L.ora_default_params.argtypes = [C.POINTER(Params)]
         L.ora_set_threads.argtypes = [C.c_int]
+        L.ora_exp_f32arg.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.ora_prefilter.restype = C.c_size_t
         L.ora_prefilter.argtypes = [C.c_void_p] * 3 + [C.c_size_t, C.c_int, C.c_double, C.c_double, C.c_float] + [C.c_void_p] * 3
         L.ora_fitness_score.restype = C.c_double
@@ -191,7 +193,9 @@ def align(grid: Grid, src: np.ndarray, guess: np.ndarray):
         raise RuntimeError(f"ora_align rc={rc}")
     return dict(final=np.array(r.final_colmajor, np.float32).reshape(4, 4, order="F"),
                 trans_probability=r.trans_probability, score=r.score, iterations=r.iterations,
-                converged=bool(r.converged), hits_last=r.hits_last, sweeps=r.sweeps, mt_loops=r.mt_loops)
+                converged=bool(r.converged), hits_last=r.hits_last, sweeps=r.sweeps, mt_loops=r.mt_loops,
+                transformation=np.array(r.inc_colmajor, np.float32).reshape(4, 4, order="F"),
+                previous_transformation=np.array(r.prev_inc_colmajor, np.float32).reshape(4, 4, order="F"))
 
 
 def se3_exp(p):

@@ -1,0 +1,58 @@
+// TEST INFRASTRUCTURE: drives include/mi355_ndt_pcl.hpp the way lv_slam's odometry nodelet drives its registration object
+// (scan_matching_odom_nodelet.cpp:109-119, 197, 220-226), against tests/pcl_stub's stand-in for pcl::Registration.
+//   adaptor_main <target.f32> <source.f32> <n_target> <n_source> <variant> <mode> <resolution>
+// clouds are raw float32 x,y,z triples; prints one line of numbers (final 16, last-increment 16, previous 16, iterations,
+// converged, trans_probability, visualizer calls, fitness score) and the first 4 output points.
+#include <cstdio>
+#include <cstdlib>
+#include "mi355_ndt_pcl.hpp"
+
+typedef pcl::PointXYZI PointT;
+
+static pcl::PointCloud<PointT>::Ptr load(const char* path, size_t n) {
+  pcl::PointCloud<PointT>::Ptr c(new pcl::PointCloud<PointT>());
+  c->points.resize(n);
+  FILE* f = fopen(path, "rb");
+  if (!f) { perror(path); exit(2); }
+  for (size_t i = 0; i < n; i++) {
+    float v[3];
+    if (fread(v, sizeof(float), 3, f) != 3) { fprintf(stderr, "short read\n"); exit(2); }
+    c->points[i].x = v[0]; c->points[i].y = v[1]; c->points[i].z = v[2]; c->points[i].data[3] = 1.f; c->points[i].intensity = (float)i;
+  }
+  fclose(f);
+  c->width = (unsigned)n;
+  return c;
+}
+
+static int g_vis_calls = 0;
+
+int main(int argc, char** argv) {
+  if (argc < 8) return 2;
+  const size_t nt = strtoul(argv[3], 0, 10), ns = strtoul(argv[4], 0, 10);
+  pcl::PointCloud<PointT>::Ptr tgt = load(argv[1], nt), src = load(argv[2], ns);
+  mi355ndt::NormalDistributionsTransform<PointT, PointT> reg(atoi(argv[5]));
+  // the nodelet's set-up sequence (scan_matching_odom_nodelet.cpp:109-119)
+  reg.setNumThreads(4);
+  reg.setTransformationEpsilon(0.01);
+  reg.setMaximumIterations(64);
+  reg.setResolution((float)atof(argv[7]));
+  reg.setNeighborhoodSearchMethod((mi355ndt::NeighborSearchMethod)atoi(argv[6]));
+  std::function<void(const pcl::PointCloud<PointT>&, const std::vector<int>&, const pcl::PointCloud<PointT>&, const std::vector<int>&)> cb =
+      [](const pcl::PointCloud<PointT>&, const std::vector<int>&, const pcl::PointCloud<PointT>&, const std::vector<int>&) { g_vis_calls++; };
+  reg.registerVisualizationCallback(cb);
+  reg.setInputTarget(tgt);
+  reg.setInputSource(src);
+  Eigen::Matrix4f guess = Eigen::Matrix4f::Identity();
+  guess(0, 3) = 1.0f;
+  pcl::PointCloud<PointT> out;
+  reg.align(out, guess);
+  const Eigen::Matrix4f F = reg.getFinalTransformation(), L = reg.getLastIncrementalTransformation();
+  for (int i = 0; i < 16; i++) printf("%.9g ", F.data()[i]);
+  for (int i = 0; i < 16; i++) printf("%.9g ", L.data()[i]);
+  printf("%d %d %.17g %d %.17g\n", reg.getFinalNumIteration(), (int)reg.hasConverged(), reg.getTransformationProbability(), g_vis_calls,
+         reg.getFitnessScore(4.0));
+  for (int i = 0; i < 4 && i < (int)out.points.size(); i++)
+    printf("%.9g %.9g %.9g %.9g %.9g\n", out.points[i].x, out.points[i].y, out.points[i].z, out.points[i].data[3], out.points[i].intensity);
+  printf("%zu\n", reg.getTargetCells().size());
+  return 0;
+}

@@ -271,3 +271,31 @@ def test_prefilter_vs_numpy():
     # leaf far too small for the extent: PCL warns and returns the (filtered) input
     assert np.array_equal(O.prefilter(pts, near, far, 1e-4), f)
     assert len(O.prefilter(np.zeros((0, 3), np.float32))) == 0
+
+
+def test_svd_solve_non_finite_input_gives_nan():
+    """Eigen 3.3 JacobiSVD keeps rank 6 on NaN singular values, solve() propagates NaN, and computeTransformation reports
+    converged_ = false (ndt_omp_impl2.hpp:147-151); a thresholded pseudo-inverse must not answer 0 (= "converged") there."""
+    H = np.eye(6)
+    b = np.ones(6)
+    for bad in (np.nan, np.inf, -np.inf):
+        Hb = H.copy(); Hb[2, 3] = bad
+        assert np.isnan(O.svd_solve6(Hb, b)).all()
+        bb = b.copy(); bb[4] = bad
+        assert np.isnan(O.svd_solve6(H, bb)).all()
+    assert np.array_equal(O.svd_solve6(np.zeros((6, 6)), np.zeros(6)), np.zeros(6))      # H = 0, g = 0 stays the exact-zero case (P14)
+
+
+def test_align_reports_incremental_transforms():
+    """transformation_ = float(exp(delta_p)) of the last step, previous_transformation_ = the one before (impl2:134, 163)."""
+    from lv_slam_amd import synth
+    tgt, src, dT = synth.make_pair(2, 128, n_beams=32)
+    tgt, src = tgt.numpy(), src.numpy()
+    prm = O.default_params(trans_epsilon=0.01, max_iterations=64)
+    r = O.align(O.Grid(tgt, prm), src, synth.default_guess())
+    assert r["iterations"] >= 2
+    for M in (r["transformation"], r["previous_transformation"]):
+        assert np.allclose(M[3], [0, 0, 0, 1]) and np.allclose(M[:3, :3] @ M[:3, :3].T, np.eye(3), atol=1e-6)
+    # the last step is the shorter one (the loop ends when |a| < eps)
+    step = lambda M: np.linalg.norm(M[:3, 3])
+    assert step(r["transformation"]) < 0.011 and step(r["transformation"]) <= step(r["previous_transformation"]) + 1e-9
