@@ -1,0 +1,92 @@
+"""GPU (-m gpu): the BASELINE.json configurations at their full sizes, through mi355ndt_batch_bind_device (device-resident
+SoA buffers, the path bench.py times), every pair checked against the oracle: voxel grids bit-exact, same iteration count and
+converged flag, SE(3) inside the north-star tolerance (trans < 1e-4 m, rot < 1e-5 rad).
+
+  config 3 shape : a batch of 65,536-pt pairs, ndt_omp, 1 m, DIRECT7
+  config 5       : 131,072-pt pairs, ndt_pca, 0.5 m, DIRECT7 and DIRECT1 (DIRECT1 = what the live nodelet sets,
+                   scan_matching_odom_nodelet.cpp:109-119; weighting ndt_pca_impl2.hpp:294-296; gate ndt_omp_impl2.hpp:581-589)
+"""
+import numpy as np
+import pytest
+
+from conftest import se3_err
+from lv_slam_amd import ndt, synth
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+
+def resident_batch(pair_ids, naz):
+    import torch
+    dev = torch.device("cuda:0")
+    n = naz * 64
+    T = torch.empty(len(pair_ids), 3, n, device=dev)
+    S = torch.empty(len(pair_ids), 3, n, device=dev)
+    host = []
+    for k, pid in enumerate(pair_ids):
+        t, s, dT = synth.make_pair(pid, naz, device=dev)
+        T[k] = t.T
+        S[k] = s.T
+        host.append((t.cpu().numpy(), s.cpu().numpy(), dT))
+    torch.cuda.synchronize()
+    return T, S, host, n
+
+
+def run_and_check(pair_ids, naz, kw, check_motion=True):
+    T, S, host, n = resident_batch(pair_ids, naz)
+    B = len(pair_ids)
+    eng = ndt.Engine(ndt.default_params(**kw))
+    eng.batch_bind_device(T.data_ptr(), [n] * B, n, S.data_ptr(), [n] * B, n)
+    eng.batch_build_targets()
+    G = synth.default_guess()
+    res = eng.batch_align(G)
+    op = O.default_params(**kw)
+    worst = [0.0, 0.0]
+    for k in range(B):
+        tgt, src, dT = host[k]
+        grid = O.Grid(tgt, op)
+        # voxel grid of this pair: bounds, cells, counts, f64 means, f32 inverse covariances, pca weights -- bit-exact
+        mn, mx, dv, nv = eng.get_grid(k)
+        omn, omx, odv = grid.bounds()
+        assert np.array_equal(mn, omn) and np.array_equal(mx, omx) and np.array_equal(dv, odv)
+        lv = grid.leaves()
+        sel = lv[(lv["n"] >= op.min_points_per_voxel) | (lv["n"] == -1)]
+        v = eng.get_voxels(k)
+        assert nv == len(sel) and np.array_equal(v["idx"], sel["idx"]) and np.array_equal(v["n"], sel["n"])
+        live = sel["n"] >= op.min_points_per_voxel
+        assert np.array_equal(v["mean"], sel["mean"])
+        assert np.array_equal(v["icov"][live], sel["icov"][live].astype(np.float32))
+        if kw.get("variant", 0) == 1:
+            assert np.array_equal(v["weight"][live], sel["weight"][live])
+        ro = O.align(grid, src, G)
+        r = res[k]
+        assert r["iterations"] == ro["iterations"] and r["converged"] == ro["converged"] and r["sweeps"] == ro["sweeps"], (k, r, ro)
+        assert r["hits_last"] == ro["hits_last"]
+        dt, dr = se3_err(ro["final"], r["final"])
+        assert dt < 1e-4 and dr < 1e-5, (k, dt, dr)
+        worst = [max(worst[0], dt), max(worst[1], dr)]
+        assert abs(r["score"] - ro["score"]) <= 1e-9 * max(1.0, abs(ro["score"]))
+        if check_motion:                      # and the registration is physically right (scene-noise level)
+            dt, dr = se3_err(dT, r["final"])
+            assert dt < 0.1 and dr < 0.01, (k, dt, dr)
+    # the batch is deterministic run to run
+    res2 = eng.batch_align(G)
+    for a, b in zip(res, res2):
+        assert np.array_equal(a["final"], b["final"]) and a["score"] == b["score"]
+    return worst
+
+
+def test_config3_shaped_batch_vs_oracle():
+    """16 consecutive 65,536-pt pairs (pairs 0..15 of config 3), ndt_omp, 1 m, DIRECT7."""
+    run_and_check(list(range(16)), 1024, dict(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=ndt.DIRECT7, variant=0))
+
+
+@pytest.mark.parametrize("mode", [ndt.DIRECT7, ndt.DIRECT1])
+def test_config5_full_size_vs_oracle(mode):
+    """config 5: 131,072-pt clouds, ndt_pca, 0.5 m voxels; three pairs in one device-resident batch."""
+    run_and_check([0, 1, 7], 2048, dict(resolution=0.5, trans_epsilon=0.01, max_iterations=64, neighbor_mode=mode, variant=1))
+
+
+def test_nodelet_configuration_batch_vs_oracle():
+    """what the live nodelet sets (scan_matching_odom_nodelet.cpp:109-119): ndt_pca, DIRECT1, 1 m -- 65,536-pt pairs."""
+    run_and_check([0, 5, 11, 270], 1024, dict(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=ndt.DIRECT1, variant=1))
