@@ -11,7 +11,6 @@
 // the host side of the C-ABI (one translation unit).  Data layout in HBM: DESIGN.md.  Built with -ffp-contract=off: every f32/f64 step of the
 // reference recipe is a separately rounded operation.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <cstdio>
 #include <cstddef>
@@ -59,9 +58,8 @@ struct mi355ndt_handle {
   int* d_minmax = nullptr;
   GridDesc* d_grid = nullptr;
   unsigned *d_nwords = nullptr, *d_word_off = nullptr;
-  unsigned long long *d_keys_a = nullptr, *d_keys_b = nullptr;
+  unsigned *d_keys_a = nullptr, *d_keys_b = nullptr;      // cell key per target point: unsorted / sorted (segment-local radix sort)
   unsigned *d_vals_a = nullptr, *d_vals_b = nullptr;
-  void* d_tmp = nullptr; size_t tmp_bytes = 0;
   size_t keys_cap = 0;
   BitWord* d_words = nullptr; size_t words_cap = 0;
   VoxelRec* d_recs = nullptr; int *d_vox_idx = nullptr, *d_vox_n = nullptr;
@@ -223,7 +221,7 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->d_tgt_own, h->d_src_own, h->d_tgt_cnt, h->d_src_cnt, h->d_minmax, h->d_grid, h->d_nwords, h->d_word_off,
-                  h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, h->d_tmp, h->d_words, h->d_recs, h->d_vox_idx, h->d_vox_n,
+                  h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, h->d_words, h->d_recs, h->d_vox_idx, h->d_vox_n,
                   h->d_state, h->d_partials, h->d_guess, h->d_results, h->d_active, h->d_hook, h->d_aligned, h->d_hits, h->d_seg_start, h->d_sums,
                   h->d_cent, h->d_icov64, h->d_kdw, h->d_rs_hist, h->d_rs_offs, h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit, h->d_pf_in, h->d_pf_out, h->d_pf_keep, h->d_pf_keys,
                   h->d_pf_vals, h->d_pf_flag, h->d_pf_pos, h->d_pf_mm, h->d_pf_grid, h->d_pf_tmp};
@@ -518,35 +516,18 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
     { size_t c6 = 0; HIPCHK(h, grow(h->d_cent, c6, need * 3)); }
     h->recs_cap = need; h->recs_per_pair = rpp;
   }
-  const int pb = ceil_log2((unsigned)B);
-  size_t need_tmp = 0, need_tmp32 = 0, need_scan = 0;
-  HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(nullptr, need_tmp, h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, (int)total, 0, 64, s));
-  HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(nullptr, need_tmp32, (unsigned*)h->d_keys_a, (unsigned*)h->d_keys_b, h->d_vals_a, h->d_vals_b, (int)total, 0, 32, s));
-  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(nullptr, need_scan, h->d_nwords, h->d_word_off, B + 1, s));
-  need_tmp = std::max(std::max(need_tmp, need_tmp32), need_scan);
-  if (need_tmp > h->tmp_bytes) {
-    if (h->d_tmp) { HIPCHK(h, hipFree(h->d_tmp)); h->d_tmp = nullptr; }
-    HIPCHK(h, hipMalloc(&h->d_tmp, need_tmp));
-    h->tmp_bytes = need_tmp;
-  }
-  if (total >= ((size_t)1 << 31)) { h->err = "batch too large for one radix sort"; return MI355NDT_ERR_BAD_ARG; }
-
   h->ev_last_fresh = false;
   if (h->prof) HIPCHK(h, ev_begin(h, h->ev_build));
   const int gx = (int)((pitch + 255) / 256);
   k_minmax_init<<<(B * 6 + 255) / 256, 256, 0, s>>>(h->d_minmax, B);
   k_minmax<<<dim3(std::min(gx, 16), B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_minmax);
-  HIPCHK(h, hipMemsetAsync(h->d_nwords, 0, (B + 2) * sizeof(unsigned), s));
+  HIPCHK(h, hipMemsetAsync(h->d_word_off, 0, 2 * sizeof(unsigned), s));
   k_griddesc<<<(B + 63) / 64, 64, 0, s>>>(h->d_minmax, h->d_grid, h->d_nwords, h->prm.resolution, B, (unsigned)rpp);
-  size_t tb = h->tmp_bytes;
-  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(h->d_tmp, tb, h->d_nwords, h->d_word_off, B + 1, s));
-  k_set_word_off<<<(B + 63) / 64, 64, 0, s>>>(h->d_grid, h->d_word_off, B, h->d_nwords + B + 1);
-  HIPCHK(h, hipMemcpyAsync(h->h_pin_u, h->d_word_off + B, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-  HIPCHK(h, hipMemcpyAsync(h->h_pin_u + 1, h->d_nwords + B + 1, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  k_word_offsets<<<1, 1024, 0, s>>>(h->d_grid, h->d_nwords, B, h->d_word_off);   // d_word_off[0] = total words, [1] = largest grid
+  HIPCHK(h, hipMemcpyAsync(h->h_pin_u, h->d_word_off, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));           // total bitmap words -> size the pool; largest grid -> key width
   const size_t total_words = h->h_pin_u[0];
   const int cb = std::max(1, ceil_log2(h->h_pin_u[1] + 1u));   // cell field: every cell index + the all-ones "not binned" value
-  const bool k32 = cb + pb <= 32;
   if (total_words > h->words_cap) {
     size_t c = h->words_cap;
     HIPCHK(h, grow(h->d_words, c, std::max(total_words, (size_t)1024)));
@@ -564,9 +545,8 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
   const bool want_kdw = h->prm.neighbor_mode == MI355NDT_KDTREE && h->prm.variant == MI355NDT_VARIANT_PCA;
   h->kdw_built = want_kdw;
   if (want_kdw) HIPCHK(h, grow(h->d_kdw, h->kdw_cap, h->recs_cap));
-  tb = h->tmp_bytes;
-  if (k32) {
-    unsigned *ka = (unsigned*)h->d_keys_a, *kb = (unsigned*)h->d_keys_b;
+  {
+    unsigned *ka = h->d_keys_a, *kb = h->d_keys_b;
     // stable sort by cell inside every target's segment (ndt_segsort.hpp): ceil(cb / 8) passes, result in kb / d_vals_b
     const int npass = (cb + RS_BITS - 1) / RS_BITS;
     const int tiles = (int)((pitch + RS_TILE - 1) / RS_TILE);
@@ -597,17 +577,6 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
                                                                                     h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent, lb, B);
     else k_leafsum<unsigned, false><<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start,
                                                                           h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent, lb, B);
-  } else {
-    typedef unsigned long long u64;
-    k_keys<u64><<<dim3(gx, B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_grid, h->d_keys_a, h->d_vals_a, cb);
-    HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(h->d_tmp, tb, h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, (int)total, 0, cb + pb, s));
-    k_mark<u64><<<dim3(gx4, B), 256, 0, s>>>(h->d_keys_b, pitch, h->d_grid, h->d_words, minpts, cb);
-    k_rank<<<B, 256, 0, s>>>(h->d_grid, h->d_words);
-    k_segstart<u64><<<dim3(gx4, B), 256, 0, s>>>(h->d_keys_b, pitch, h->d_grid, h->d_words, h->d_seg_start, minpts, cb);
-    if (want_cent) k_leafsum<u64, true><<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, h->d_keys_b, h->d_vals_b, h->d_grid, h->d_seg_start,
-                                                                               h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent, lb, B);
-    else k_leafsum<u64, false><<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, h->d_keys_b, h->d_vals_b, h->d_grid, h->d_seg_start,
-                                                                     h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent, lb, B);
   }
   k_voxels<<<dim3((unsigned)((rpp + 255) / 256), B), 256, 0, s>>>(h->d_grid, h->d_sums, h->d_recs, h->d_vox_n,
                                                                   h->prm.min_covar_eigvalue_mult, h->prm.variant == MI355NDT_VARIANT_PCA,
@@ -1033,7 +1002,7 @@ int mi355ndt_fitness_score_T(mi355ndt_handle* h, const float T_colmajor[16], dou
     }
     HIPCHK(h, hipMemsetAsync(h->d_cstart, 0, nc * sizeof(unsigned), s));
     HIPCHK(h, hipMemsetAsync(h->d_cend, 0, nc * sizeof(unsigned), s));
-    k_cellrange<unsigned><<<(unsigned)((h->tgt_pitch + 255) / 256), 256, 0, s>>>((const unsigned*)h->d_keys_b, h->tgt_pitch, h->last_cb,
+    k_cellrange<unsigned><<<(unsigned)((h->tgt_pitch + 255) / 256), 256, 0, s>>>(h->d_keys_b, h->tgt_pitch, h->last_cb,
                                                                                 h->d_cstart, h->d_cend);
     h->cells_ready = true;
   }
@@ -1096,14 +1065,24 @@ int mi355ndt_prefilter(mi355ndt_handle* h, const void* pts, size_t n, size_t str
   if (rc) return rc;
   const int gx = (int)((pitch + 255) / 256);
   unsigned *ka = h->d_pf_keys, *kb = h->d_pf_keys + pitch, *va = h->d_pf_vals, *vb = h->d_pf_vals + pitch;
-  size_t t1 = 0, t2 = 0;
-  HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(nullptr, t1, ka, kb, va, vb, (int)pitch, 0, 31, s));
-  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(nullptr, t2, h->d_pf_flag, h->d_pf_pos, (int)pitch, s));
-  t1 = std::max(t1, t2);
-  if (t1 > h->pf_tmp_bytes) {
-    if (h->d_pf_tmp) { HIPCHK(h, hipFree(h->d_pf_tmp)); h->d_pf_tmp = nullptr; }
-    HIPCHK(h, hipMalloc(&h->d_pf_tmp, t1));
-    h->pf_tmp_bytes = t1;
+  // workspace of the segment sort (one segment = the whole cloud) and of the emit-position scan
+  const int pf_tiles = (int)((pitch + RS_TILE - 1) / RS_TILE);
+  const int pf_chunks = (int)((pitch + PF_SCAN_CHUNK - 1) / PF_SCAN_CHUNK);
+  {
+    const size_t need = (size_t)pf_tiles * RS_NB;
+    if (need > h->rs_cap) {
+      size_t c1 = 0, c2 = 0;
+      if (h->d_rs_hist) { HIPCHK(h, hipFree(h->d_rs_hist)); h->d_rs_hist = nullptr; }
+      if (h->d_rs_offs) { HIPCHK(h, hipFree(h->d_rs_offs)); h->d_rs_offs = nullptr; }
+      HIPCHK(h, grow(h->d_rs_hist, c1, need)); HIPCHK(h, grow(h->d_rs_offs, c2, need));
+      h->rs_cap = need;
+    }
+    const size_t nb = (size_t)pf_chunks * sizeof(unsigned);
+    if (nb > h->pf_tmp_bytes) {
+      if (h->d_pf_tmp) { HIPCHK(h, hipFree(h->d_pf_tmp)); h->d_pf_tmp = nullptr; }
+      HIPCHK(h, hipMalloc(&h->d_pf_tmp, nb));
+      h->pf_tmp_bytes = nb;
+    }
   }
   k_minmax_init<<<1, 64, 0, s>>>(h->d_pf_mm, 1);
   k_pf_flag<<<std::min(gx, 256), 256, 0, s>>>(h->d_pf_in, pitch, (int)n, use_distance_filter, distance_near, distance_far, h->d_pf_keep, h->d_pf_mm);
@@ -1120,14 +1099,21 @@ int mi355ndt_prefilter(mi355ndt_handle* h, const void* pts, size_t n, size_t str
       downsample = 0;
     } else {
       k_pf_keys<<<gx, 256, 0, s>>>(h->d_pf_in, pitch, (int)n, h->d_pf_keep, h->d_pf_grid, ka, va);
-      size_t tb = h->pf_tmp_bytes;
-      HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(h->d_pf_tmp, tb, ka, kb, va, vb, (int)pitch, 0, 31, s));
-      keys_sorted = kb; vals_sorted = vb;
+      // stable sort by voxel index: the target build's segment sort with the whole cloud as its one segment, 31 key bits
+      unsigned *kin = ka, *kout = kb, *vin = va, *vout = vb;
+      for (int p = 0; p < 4; p++) {
+        k_rs_hist<<<xcd_grid(pf_tiles, 1), RS_THREADS, 0, s>>>(kin, pitch, p * RS_BITS, h->d_rs_hist, pf_tiles, 1);
+        k_rs_scan<<<1, RS_NB, 0, s>>>(h->d_rs_hist, h->d_rs_offs, pf_tiles);
+        k_rs_scatter<false><<<xcd_grid(pf_tiles, 1), RS_THREADS, 0, s>>>(kin, vin, kout, vout, pitch, p * RS_BITS, h->d_rs_offs, pf_tiles, 1);
+        std::swap(kin, kout); std::swap(vin, vout);
+      }
+      keys_sorted = kin; vals_sorted = vin;      // four hops: back in ka / va
     }
   }
   k_pf_heads<<<gx, 256, 0, s>>>(keys_sorted, h->d_pf_keep, (int)n, pitch, downsample, h->d_pf_flag);
-  size_t tb = h->pf_tmp_bytes;
-  HIPCHK(h, hipcub::DeviceScan::ExclusiveSum(h->d_pf_tmp, tb, h->d_pf_flag, h->d_pf_pos, (int)pitch, s));
+  k_pf_scan_totals<<<pf_chunks, 1024, 0, s>>>(h->d_pf_flag, pitch, (unsigned*)h->d_pf_tmp);
+  k_pf_scan_offsets<<<1, 1024, 0, s>>>((unsigned*)h->d_pf_tmp, pf_chunks);
+  k_pf_scan_apply<<<pf_chunks, 1024, 0, s>>>(h->d_pf_flag, pitch, (const unsigned*)h->d_pf_tmp, h->d_pf_pos);
   k_pf_emit<<<gx, 256, 0, s>>>(h->d_pf_in, pitch, keys_sorted, vals_sorted, h->d_pf_flag, h->d_pf_pos, downsample, h->d_pf_out, pitch);
   int last_pos = 0, last_flag = 0;
   HIPCHK(h, hipMemcpyAsync(&last_pos, h->d_pf_pos + (pitch - 1), sizeof(int), hipMemcpyDeviceToHost, s));

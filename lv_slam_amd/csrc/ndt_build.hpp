@@ -82,9 +82,20 @@ __global__ void k_griddesc(const int* __restrict__ mm, GridDesc* gd, unsigned* n
   nwords[b] = (unsigned)g.nwords;
 }
 
-__global__ void k_set_word_off(GridDesc* gd, const unsigned* __restrict__ off, int n_pairs, unsigned* max_ncells) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < n_pairs) { gd[b].word_off = off[b]; atomicMax(max_ncells, (unsigned)gd[b].ncells); }
+// bitmap-pool offsets of the targets (exclusive scan of their word counts, one block) and the largest grid of the batch
+__global__ void __launch_bounds__(1024) k_word_offsets(GridDesc* gd, const unsigned* __restrict__ nwords, int n_pairs, unsigned* out /* total words, max cells */) {
+  __shared__ unsigned sm[17];
+  unsigned base = 0, mx = 0;
+  for (int b0 = 0; b0 < n_pairs; b0 += 1024) {
+    const int b = b0 + threadIdx.x;
+    const unsigned v = b < n_pairs ? nwords[b] : 0u;
+    unsigned tot;
+    const unsigned ex = block_exscan<1024>(v, &tot, sm);
+    if (b < n_pairs) { gd[b].word_off = base + ex; mx = max(mx, (unsigned)gd[b].ncells); }
+    base += tot;
+  }
+  if (mx) atomicMax(&out[1], mx);
+  if (threadIdx.x == 0) out[0] = base;
 }
 
 // first pass of applyFilter: cell index per point (impl:218-223)
@@ -106,7 +117,7 @@ __global__ void __launch_bounds__(256) k_keys(const float* __restrict__ tgt, siz
       cell = (unsigned)(i0 + i1 * g.mul1 + i2 * g.mul2);
     }
   }
-  keys[(size_t)b * pitch + i] = ((KeyT)b << cb) | (KeyT)cell;
+  keys[(size_t)b * pitch + i] = (KeyT)cell;      // the sort is segment-local: the pair index is no part of the key
   if (vals) vals[(size_t)b * pitch + i] = (unsigned)i;      // the segmented sort derives the ids itself in its first pass
 }
 
@@ -150,156 +161,110 @@ __global__ void __launch_bounds__(256) k_mark(const KeyT* __restrict__ keys, siz
 }
 // exclusive popcount prefix over the bitmap words of each target: voxel id = rank in ascending cell order
 __global__ void __launch_bounds__(256) k_rank(GridDesc* gd, BitWord* words) {
-  typedef hipcub::BlockScan<unsigned, 256> Scan;
-  __shared__ typename Scan::TempStorage tmp;
+  __shared__ unsigned sm[5];
   const int b = blockIdx.x;
   BitWord* W = words + gd[b].word_off;
   const int nw = gd[b].nwords;
   unsigned base = 0;
   for (int w0 = 0; w0 < nw; w0 += 256) {
     int w = w0 + threadIdx.x;
-    unsigned c = (w < nw) ? (unsigned)__popcll(W[w].bits) : 0u, ex, tot;
-    Scan(tmp).ExclusiveSum(c, ex, tot);
+    unsigned c = (w < nw) ? (unsigned)__popcll(W[w].bits) : 0u, tot;
+    const unsigned ex = block_exscan<256>(c, &tot, sm);
     if (w < nw) W[w].prefix = base + ex;
     base += tot;
-    __syncthreads();
   }
   if (threadIdx.x == 0) gd[b].n_voxels = (int)base;
 }
 
-// Which sorted positions [start, end) hold the points of searchable leaf `id`?  A position whose key differs from its
-// predecessor's is the head of a run and, at the same time, one past the end of the previous run: the head side writes
-// seg[id].x (and the leaf's cell index), the boundary side looks the PREVIOUS run's cell up in the bitmap and writes seg[id'].y.
+// where does the point run of searchable leaf `id` start in the sorted order?
 template <typename KeyT>
 __global__ void __launch_bounds__(256) k_segstart(const KeyT* __restrict__ keys, size_t pitch, const GridDesc* __restrict__ gd,
-                                                   const BitWord* __restrict__ words, uint2* seg, int* vox_idx, int min_points, int cb) {
+                                                   const BitWord* __restrict__ words, unsigned* seg_start, int min_points, int cb) {
   const int b = blockIdx.y;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const KeyT* K = keys + (size_t)b * pitch;
-  const unsigned cmask = (1u << cb) - 1u;
-  const size_t span = (size_t)(min_points > 0 ? min_points - 1 : 0);
-  KeyT k0[RUN_ILP], km[RUN_ILP], kl[RUN_ILP];
-#pragma unroll
-  for (int u = 0; u < RUN_ILP; u++) {              // all loads of the RUN_ILP positions in flight together
-    const size_t i = i0 + (size_t)u * stride;
-    const bool in = i < pitch;
-    k0[u] = in ? K[i] : (KeyT)cmask;
-    km[u] = (in && i != 0) ? K[i - 1] : ~(KeyT)0;
-    kl[u] = (in && i + span < pitch) ? K[i + span] : ~(KeyT)0;
-  }
+  bool head[RUN_ILP];
+  unsigned cell[RUN_ILP];
+  run_heads<KeyT>(keys + (size_t)b * pitch, pitch, i0, stride, min_points, (1u << cb) - 1u, head, cell);
   const GridDesc& g = gd[b];
-  const BitWord* W = words + g.word_off;
 #pragma unroll
   for (int u = 0; u < RUN_ILP; u++) {
-    const size_t i = i0 + (size_t)u * stride;
-    if (i >= pitch) continue;
-    const unsigned cell = (unsigned)k0[u] & cmask, pcell = (unsigned)km[u] & cmask;
-    const bool boundary = i == 0 || km[u] != k0[u];
-    if (boundary && cell != cmask && i + span < pitch && kl[u] == k0[u]) {          // head of a searchable leaf's run
-      const BitWord bw = W[cell >> 6];
-      const unsigned id = bw.prefix + (unsigned)__popcll(bw.bits & ((1ull << (cell & 63)) - 1ull));
-      seg[g.rec_off + id].x = (unsigned)i;
-      vox_idx[g.rec_off + id] = (int)cell;
-    }
-    if (boundary && i != 0 && pcell != cmask) {                                      // the previous run ends here
-      const BitWord bw = W[pcell >> 6];
-      if ((bw.bits >> (pcell & 63)) & 1ull)
-        seg[g.rec_off + bw.prefix + (unsigned)__popcll(bw.bits & ((1ull << (pcell & 63)) - 1ull))].y = (unsigned)i;
-    }
-    if (i == pitch - 1 && cell != cmask) {                                           // a run that reaches the segment's last position
-      const BitWord bw = W[cell >> 6];
-      if ((bw.bits >> (cell & 63)) & 1ull)
-        seg[g.rec_off + bw.prefix + (unsigned)__popcll(bw.bits & ((1ull << (cell & 63)) - 1ull))].y = (unsigned)pitch;
-    }
+    if (!head[u]) continue;
+    const BitWord bw = words[g.word_off + (cell[u] >> 6)];
+    const unsigned id = bw.prefix + (unsigned)__popcll(bw.bits & ((1ull << (cell[u] & 63)) - 1ull));
+    seg_start[g.rec_off + id] = (unsigned)(i0 + (size_t)u * stride);
   }
 }
 
-// leaf.mean_ += pt ; leaf.cov_ += pt pt^T (impl:233-237) for every searchable leaf.  The sums must be added strictly in input
-// order (the radix sort is stable, so a leaf's run is in input order) to stay bit-identical to the reference's sequential
-// accumulation -- a chain of dependent f64 adds per accumulator.  One wave therefore works on LS_GROUP = 7 consecutive leaves at
-// once: lane 9 l + a owns accumulator a (S0 S1 S2 C00 C01 C02 C11 C12 C22) of leaf l, 63 chains advance together.  The wave
-// stages LS_WIN consecutive sorted positions at a time in LDS as (x, y, z, 1) -- coalesced id loads, all point gathers in
-// flight together -- and every lane then walks the part of its leaf's run that lies in the window: term = p * q with
-// (p, q) two of the four staged floats ((x,1) (y,1) (z,1) (x,x) (x,y) ...; the f64 product of two f32 values is exact).
+// leaf.mean_ += pt ; leaf.cov_ += pt pt^T (impl:233-237) for every searchable leaf: one WAVE per leaf.
+// The wave gathers 64 points of the leaf's run at a time (the radix sort is stable, so the run is in input
+// order), parks the nine f64 terms of each point in LDS, and lanes 0..8 -- one per accumulator -- add them
+// strictly in input order, which keeps the sums bit-identical to the reference's sequential accumulation.
 #define LS_WAVES 4
-#define LS_GROUP 7
-#define LS_WIN   512
-template <bool CENT>
-__global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restrict__ tgt, size_t pitch, const unsigned* __restrict__ vals,
-                                                           const GridDesc* __restrict__ gd, const uint2* __restrict__ seg,
-                                                           double* sums, int* vox_n, float* cent, int nx, int n_targets) {
-  __shared__ float4 stage[LS_WAVES][LS_WIN];
+template <typename KeyT, bool CENT>
+__global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restrict__ tgt, size_t pitch,
+                                                           const KeyT* __restrict__ keys, const unsigned* __restrict__ vals,
+                                                           const GridDesc* __restrict__ gd, const unsigned* __restrict__ seg_start,
+                                                           double* sums, int* vox_idx, int* vox_n, int cb, float* cent,
+                                                           int nx, int n_targets) {
+  __shared__ double term[LS_WAVES][64][9];
+  __shared__ float termf[CENT ? LS_WAVES : 1][64][3];
   int b, bx;
   if (!xcd_map(nx, n_targets, bx, b)) return;    // one target's leaves on one XCD: the point gathers hit in its L2
   const GridDesc& g = gd[b];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const KeyT* K = keys + (size_t)b * pitch;
   const unsigned* V = vals + (size_t)b * pitch;
   const float* X = tgt + (size_t)b * 3 * pitch;
-  const int l = lane / 9, a = lane - 9 * l;
-  // staged components read by accumulator a: S0..S2 = (x|y|z) * 1, C00 C01 C02 C11 C12 C22
-  const int cp = (a < 3) ? a : (a < 6 ? 0 : (a < 8 ? 1 : 2));
-  const int cq = (a < 3) ? 3 : (a < 6 ? a - 3 : (a < 8 ? a - 5 : 2));
-  const int ngroups = (g.n_voxels + LS_GROUP - 1) / LS_GROUP;
-  const float* sf = reinterpret_cast<const float*>(&stage[wv][0]);
-  for (int gi = bx * LS_WAVES + wv; gi < ngroups; gi += nx * LS_WAVES) {
-    const int id = gi * LS_GROUP + l;
-    const bool mine = lane < 9 * LS_GROUP && id < g.n_voxels;
-    uint2 se = make_uint2(0u, 0u);
-    if (mine) se = seg[g.rec_off + id];
-    // cov_ is seeded with Identity (voxel_grid_covariance_omp.h:101)
-    double acc = (a == 3 || a == 6 || a == 8) ? 1.0 : 0.0;
-    float accf = 0.f;                              // leaf.centroid += pt (f32, impl:242-243): accumulators 0..2 carry it along
-    unsigned cur = se.x;
-    const unsigned wfirst = (unsigned)__shfl((int)se.x, 0);           // the group's first position (leaf 0 always exists)
-    unsigned wlast = mine ? se.y : 0u;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wlast = max(wlast, (unsigned)__shfl_xor((int)wlast, o));
-    for (unsigned wpos = wfirst; wpos < wlast; wpos += LS_WIN) {
-      unsigned pi[LS_WIN / 64];
-#pragma unroll
-      for (int r = 0; r < LS_WIN / 64; r++) {
-        const unsigned j = wpos + r * 64 + lane;
-        pi[r] = (j < wlast) ? V[j] : 0u;
-      }
-#pragma unroll
-      for (int r = 0; r < LS_WIN / 64; r++) {
-        const unsigned j = wpos + r * 64 + lane;
-        float4 v = make_float4(0.f, 0.f, 0.f, 1.f);
-        if (j < wlast) { v.x = X[pi[r]]; v.y = X[pitch + pi[r]]; v.z = X[2 * pitch + pi[r]]; }
-        stage[wv][r * 64 + lane] = v;
+  const int id0 = bx * LS_WAVES + wv, idstep = nx * LS_WAVES;
+  size_t start_next = id0 < g.n_voxels ? seg_start[g.rec_off + id0] : 0;
+  for (int id = id0; id < g.n_voxels; id += idstep) {
+    const size_t start = start_next;
+    if (id + idstep < g.n_voxels) start_next = seg_start[g.rec_off + id + idstep];   // next leaf's run start, one leaf ahead
+    // accumulator order: S0 S1 S2 C00 C01 C02 C11 C12 C22 ; cov_ is seeded with Identity (voxel_grid_covariance_omp.h:101)
+    double acc = (lane == 3 || lane == 6 || lane == 8) ? 1.0 : 0.0;
+    float accf = 0.f;                            // lanes 9..11: leaf.centroid += pt (f32, impl:242-243)
+    int cnt = 0;
+    KeyT key = 0;
+    for (size_t j0 = start;; j0 += 64) {
+      const size_t j = j0 + lane;
+      const bool inb = j < pitch;
+      // key and point id of the run position are fetched together (the point id of a lane past the run's end is unused)
+      const KeyT kj = inb ? K[j] : (KeyT)0;
+      const unsigned pi = inb ? V[j] : 0u;
+      if (j0 == start) key = __shfl(kj, 0);      // the run's cell: its first entry
+      const bool in = inb && kj == key;
+      const int m = (int)__popcll(__ballot(in));
+      if (in) {
+        const double x = (double)X[pi], y = (double)X[pitch + pi], z = (double)X[2 * pitch + pi];
+        double* t = term[wv][lane];
+        t[0] = x; t[1] = y; t[2] = z;
+        t[3] = x * x; t[4] = x * y; t[5] = x * z; t[6] = y * y; t[7] = y * z; t[8] = z * z;
+        if (CENT) { termf[wv][lane][0] = X[pi]; termf[wv][lane][1] = X[pitch + pi]; termf[wv][lane][2] = X[2 * pitch + pi]; }
       }
       __builtin_amdgcn_wave_barrier();
-      // the part of this lane's run inside the window
-      const unsigned lo = max(cur, wpos), hi = min(se.y, wpos + LS_WIN);
-      const int c = (mine && hi > lo) ? (int)(hi - lo) : 0;
-      int cmax = c;
+      if (lane < 9) {                            // strictly sequential adds (input order); the LDS reads are batched ahead of them
+        int l = 0;
+        for (; l + 8 <= m; l += 8) {
+          double t[8];
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
-      const float* base = sf + (size_t)(lo - wpos) * 4;
-      for (int t = 0; t < cmax; t += 8) {           // LDS reads batched ahead of the strictly ordered adds
-        float p[8], q[8];
+          for (int u = 0; u < 8; u++) t[u] = term[wv][l + u][lane];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const int k = (t + u < c) ? t + u : 0;
-          p[u] = base[k * 4 + cp]; q[u] = base[k * 4 + cq];
+          for (int u = 0; u < 8; u++) acc += t[u];
         }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const double term = (double)p[u] * (double)q[u];
-          const double nacc = acc + term;
-          acc = (t + u < c) ? nacc : acc;
-          if (CENT) { const float nf = accf + p[u]; accf = (t + u < c) ? nf : accf; }
-        }
+        for (; l < m; l++) acc += term[wv][l][lane];
+      } else if (CENT && lane < 12) {
+        for (int l = 0; l < m; l++) accf += termf[wv][l][lane - 9];
       }
-      cur = max(cur, hi);
       __builtin_amdgcn_wave_barrier();
+      cnt += m;
+      if (m < 64) break;
     }
-    if (mine) {
-      const int cnt = (int)(se.y - se.x);
-      sums[(size_t)(g.rec_off + id) * 9 + a] = acc;
-      if (CENT && a < 3) cent[(size_t)(g.rec_off + id) * 3 + a] = accf / (float)cnt;   // centroid /= nr_points (impl:289)
-      if (a == 0) vox_n[g.rec_off + id] = cnt;
+    if (lane < 9) sums[(size_t)(g.rec_off + id) * 9 + lane] = acc;
+    else if (CENT && lane < 12) cent[(size_t)(g.rec_off + id) * 3 + (lane - 9)] = accf / (float)cnt;   // centroid /= nr_points (impl:289)
+    if (lane == 0) {
+      vox_idx[g.rec_off + id] = (int)((unsigned)key & ((1u << cb) - 1u));
+      vox_n[g.rec_off + id] = cnt;
     }
   }
 }

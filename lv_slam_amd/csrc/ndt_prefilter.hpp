@@ -104,3 +104,40 @@ __global__ void __launch_bounds__(256) k_pf_emit(const float* __restrict__ X, si
   out[o] = sx; out[out_pitch + o] = sy; out[2 * out_pitch + o] = sz;
 }
 
+
+// Exclusive prefix sum of n ints (the emit positions of the kept points / voxel heads): block totals of 4096-element chunks,
+// one block scanning those totals, then every chunk scans itself again on top of its offset.
+#define PF_SCAN_CHUNK 4096
+__global__ void __launch_bounds__(1024) k_pf_scan_totals(const int* __restrict__ in, size_t n, unsigned* totals) {
+  __shared__ unsigned sm[17];
+  const size_t i0 = (size_t)blockIdx.x * PF_SCAN_CHUNK + (size_t)threadIdx.x * 4;
+  unsigned v = 0;
+#pragma unroll
+  for (int u = 0; u < 4; u++) if (i0 + u < n) v += (unsigned)in[i0 + u];
+  unsigned tot;
+  (void)block_exscan<1024>(v, &tot, sm);
+  if (threadIdx.x == 0) totals[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(1024) k_pf_scan_offsets(unsigned* totals, int nchunks) {
+  __shared__ unsigned sm[17];
+  unsigned base = 0;
+  for (int c0 = 0; c0 < nchunks; c0 += 1024) {
+    const int c = c0 + threadIdx.x;
+    const unsigned v = c < nchunks ? totals[c] : 0u;
+    unsigned tot;
+    const unsigned ex = block_exscan<1024>(v, &tot, sm);
+    if (c < nchunks) totals[c] = base + ex;
+    base += tot;
+  }
+}
+__global__ void __launch_bounds__(1024) k_pf_scan_apply(const int* __restrict__ in, size_t n, const unsigned* __restrict__ offs, int* out) {
+  __shared__ unsigned sm[17];
+  const size_t i0 = (size_t)blockIdx.x * PF_SCAN_CHUNK + (size_t)threadIdx.x * 4;
+  unsigned e[4], v = 0;
+#pragma unroll
+  for (int u = 0; u < 4; u++) { e[u] = i0 + u < n ? (unsigned)in[i0 + u] : 0u; v += e[u]; }
+  unsigned tot;
+  unsigned ex = block_exscan<1024>(v, &tot, sm) + offs[blockIdx.x];
+#pragma unroll
+  for (int u = 0; u < 4; u++) { if (i0 + u < n) out[i0 + u] = (int)ex; ex += e[u]; }
+}

@@ -11,7 +11,6 @@
 // order inside a tile is (wave, round, lane) = position order, which is what makes the pass stable.
 #pragma once
 #include "ndt_types.hpp"
-#include <hipcub/hipcub.hpp>
 
 #define RS_BITS    8
 #define RS_NB      (1 << RS_BITS)
@@ -73,15 +72,14 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_hist(const unsigned* __restri
 
 // per segment: where does digit d of tile t start?  (digit-major, tile-minor exclusive scan; one block per segment)
 __global__ void __launch_bounds__(RS_NB) k_rs_scan(const unsigned* __restrict__ hist, unsigned* offs, int tiles) {
-  typedef hipcub::BlockScan<unsigned, RS_NB> Scan;
-  __shared__ typename Scan::TempStorage tmp;
+  __shared__ unsigned sm[RS_NB / 64 + 1];
   const int b = blockIdx.x, d = threadIdx.x;
   const unsigned* H = hist + (size_t)b * tiles * RS_NB;
   unsigned* O = offs + (size_t)b * tiles * RS_NB;
   unsigned tot = 0;
   for (int t = 0; t < tiles; t++) tot += H[(size_t)t * RS_NB + d];
-  unsigned base;
-  Scan(tmp).ExclusiveSum(tot, base);
+  unsigned all;
+  unsigned base = block_exscan<RS_NB>(tot, &all, sm);
   for (int t = 0; t < tiles; t++) {
     O[(size_t)t * RS_NB + d] = base;
     base += H[(size_t)t * RS_NB + d];

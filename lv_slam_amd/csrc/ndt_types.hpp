@@ -100,3 +100,28 @@ __device__ __forceinline__ bool xcd_map(int nx, int n_targets, int& bx, int& b) 
 }
 static inline unsigned xcd_grid(int nx, int n_targets) { return 8u * (unsigned)((n_targets + 7) / 8) * (unsigned)nx; }
 
+
+// Exclusive prefix sum over the NT threads of a block (NT a multiple of 64, <= 1024): wave-level shuffle scan, the wave totals
+// scanned by wave 0 through `sm` (NT / 64 + 1 entries of LDS).  Returns the thread's exclusive prefix; *total = block sum.
+template <int NT>
+__device__ __forceinline__ unsigned block_exscan(unsigned v, unsigned* total, unsigned* sm) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+  if (lane == 63) sm[w] = inc;
+  __syncthreads();
+  if (w == 0) {
+    const unsigned s = lane < NT / 64 ? sm[lane] : 0u;
+    unsigned si = s;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { const unsigned t = __shfl_up(si, o); if (lane >= o) si += t; }
+    if (lane < NT / 64) sm[lane] = si - s;
+    if (lane == NT / 64 - 1) sm[NT / 64] = si;
+  }
+  __syncthreads();
+  const unsigned ex = inc - v + sm[w];
+  *total = sm[NT / 64];
+  __syncthreads();                               // `sm` may be reused by the caller's next round
+  return ex;
+}
