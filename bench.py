@@ -3,21 +3,27 @@
 
 A "step" is one pass of the hot path over one batch of synthetic scan pairs resident in HBM:
 voxelise every target (setInputTarget) + align every pair (align), then -- for N > 1 -- one RCCL
-all-gather of the 96-byte pose records.  Pairs are sharded round-robin over ranks (pair index
-i -> rank i mod N), every rank owns `--pairs` pairs (weak scaling), no data-path collective.
+all-gather of the 96-byte pose records, packed on the device by the engine (no host hop).
+Pairs are sharded round-robin over ranks (pair index i -> rank i mod N), no data-path collective.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel:
-the derivative sweep, algorithmic bytes / HIP-event time, peak 8 TB/s HBM) and `cpu_baseline`
-(the oracle = CPU restatement of ndt_omp, timed on this box's host cores on a bounded sample;
-the reference itself cannot be built here).
+  default            : weak scaling, every rank owns `--pairs` pairs (BASELINE config 3 per GPU: 271)
+  --total-pairs 4541 : BASELINE config 4 as worded -- a fixed job of T pairs over the N ranks (strong scaling,
+                       shards differ by at most one pair; the shorter ones pad their record block with pair_id = -1)
+  --host-clouds      : adds the drop-in path's rate (host AoS clouds in, PCIe inclusive) as `value_host_clouds`
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel: the derivative
+sweep, algorithmic bytes / HIP-event time, peak 8 TB/s HBM), `roofline_valu` (what actually bounds the sweep) and
+`cpu_baseline` (the oracle = CPU restatement of ndt_omp, timed on this box's host cores on a bounded sample, in the
+reference-shaped arrangement of SURVEY.md 8(d) and as the optimised port; the reference itself cannot be built here).
 """
 import argparse
-import ctypes
 import gc
 import json
 import os
 import sys
 import time
+
+os.environ.setdefault("OMP_PROC_BIND", "close")      # SURVEY 8(d): pinned OpenMP threads for the CPU leg (read when libgomp starts)
 
 import numpy as np
 import torch
@@ -34,15 +40,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=271, help="pairs per GPU per step (BASELINE config 3: 271)")
+    ap.add_argument("--pairs", type=int, default=271, help="pairs per GPU per step (BASELINE config 3: 271); weak scaling")
+    ap.add_argument("--total-pairs", type=int, default=0,
+                    help="fixed job of this many pairs over all ranks (BASELINE config 4: 4541); strong scaling; overrides --pairs")
     ap.add_argument("--azimuth", type=int, default=1024, help="firings per revolution; x64 beams = points per cloud")
     ap.add_argument("--mode", default="direct7", choices=sorted(MODES))
     ap.add_argument("--variant", default="omp", choices=["omp", "pca"])
     ap.add_argument("--resolution", type=float, default=1.0)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
-    ap.add_argument("--traffic", type=float, default=None,
-                    help="HBM bytes per sweep launch from separate rocprofv3 --pmc passes (default: profiles/r01_traffic.json "
-                         "when the workload is the default one)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time of the parity/port sample of the cpu_baseline leg (0 = skip the leg)")
+    ap.add_argument("--host-clouds", action="store_true", help="also time the drop-in path: host AoS clouds in (PCIe inclusive)")
+    ap.add_argument("--traffic", type=float, default=None, help="HBM bytes per sweep launch from separate rocprofv3 --pmc passes")
     return ap.parse_args()
 
 
@@ -50,6 +57,110 @@ def se3_err(A, B):
     E = np.linalg.inv(np.asarray(A, np.float64)) @ np.asarray(B, np.float64)
     w = np.array([E[2, 1] - E[1, 2], E[0, 2] - E[2, 0], E[1, 0] - E[0, 1]]) / 2.0
     return float(np.linalg.norm(E[:3, 3])), float(np.arctan2(np.linalg.norm(w), min(1.0, max(-1.0, (np.trace(E[:3, :3]) - 1) / 2))))
+
+
+def host_info():
+    model, phys = "unknown", None
+    try:
+        lines = open("/proc/cpuinfo").read().split("\n")
+        model = [l.split(":", 1)[1].strip() for l in lines if l.startswith("model name")][0]
+        cores = {}
+        pid = None
+        for l in lines:
+            if l.startswith("physical id"):
+                pid = l.split(":")[1].strip()
+            elif l.startswith("core id") and pid is not None:
+                cores[(pid, l.split(":")[1].strip())] = 1
+        phys = len(cores) or None
+    except Exception:
+        pass
+    return model, phys, os.cpu_count() or 1
+
+
+def static_profile(name, workload_key):
+    """A measurement that cannot be taken inside the timed run (PMC counters need their own rocprofv3 passes): read the committed
+    file under profiles/ -- only when it was taken on this very workload -- and say so in the JSON line."""
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        d = json.load(open(path))
+        if d.get("workload_key") == workload_key:
+            return d, "static: profiles/" + name
+    except Exception:
+        pass
+    return None, None
+
+
+def cpu_leg(a, T, S, G, res_np, B):
+    """(1) the reference-shaped arrangement on pair 0 at 4 threads (the nodelet's setting,
+    scan_matching_odom_nodelet.cpp:110,116), 8 (launch/dlo_lfa_ggo_kitti.launch:112) and all physical cores: 3 warm-ups, then
+    median / p10 / p90 over 20 repeats, target build and align separately; (2) the optimised port the same way; (3) a bounded
+    batch sample with the port (total wall / count) that doubles as the pose-by-pose parity check of the GPU results."""
+    from oracle import oracle_py as O
+    model, phys, logical = host_info()
+    kw = dict(resolution=a.resolution, trans_epsilon=0.01, max_iterations=64, neighbor_mode=MODES[a.mode], variant=1 if a.variant == "pca" else 0)
+    op = O.default_params(**kw)
+    tg0 = T[0].T.contiguous().cpu().numpy()
+    sr0 = S[0].T.contiguous().cpu().numpy()
+    refshape_ok = a.mode != "kdtree"
+
+    def stats(v):
+        v = np.asarray(v) * 1e3
+        return {"median_ms": round(float(np.median(v)), 3), "p10_ms": round(float(np.percentile(v, 10)), 3), "p90_ms": round(float(np.percentile(v, 90)), 3)}
+
+    def protocol(make_grid, align, threads, reps=20, warm=3):
+        O.lib().ora_set_threads(threads)
+        tb, ta = [], []
+        for r in range(warm + reps):
+            c0 = time.perf_counter()
+            g = make_grid()
+            c1 = time.perf_counter()
+            align(g)
+            c2 = time.perf_counter()
+            if r >= warm:
+                tb.append(c1 - c0)
+                ta.append(c2 - c1)
+        reg_s = 1.0 / (np.median(tb) + np.median(ta))
+        return {"build": stats(tb), "align": stats(ta), "registrations_per_s": round(float(reg_s), 3)}
+
+    settings = sorted({t for t in (4, 8, phys or logical) if t <= logical})
+    shaped, port = {}, {}
+    for th in settings:
+        if refshape_ok:
+            shaped[str(th)] = protocol(lambda: O.RefGrid(tg0, op), lambda g: O.ref_align(g, sr0, G), th)
+        port[str(th)] = protocol(lambda: O.Grid(tg0, op), lambda g: O.align(g, sr0, G), th, reps=10, warm=2)
+    best_port = max(port, key=lambda k: port[k]["registrations_per_s"])
+    best_shaped = max(shaped, key=lambda k: shaped[k]["registrations_per_s"]) if shaped else None
+    # (3) batch sample with the port at its best thread count; pose-by-pose parity of the GPU results
+    O.lib().ora_set_threads(int(best_port))
+    done, t_cpu, worst, it_match = 0, 0.0, (0.0, 0.0), 0
+    while done < B and (done < 3 or t_cpu < a.cpu_seconds):
+        tg = T[done].T.contiguous().cpu().numpy()
+        sr = S[done].T.contiguous().cpu().numpy()
+        c0 = time.perf_counter()
+        ro = O.align(O.Grid(tg, op), sr, G)
+        t_cpu += time.perf_counter() - c0
+        e = se3_err(ro["final"], res_np["final"][done].reshape(4, 4).T)
+        worst = (max(worst[0], e[0]), max(worst[1], e[1]))
+        it_match += int(ro["iterations"] == int(res_np["it"][done]))
+        done += 1
+    O.lib().ora_set_threads(0)
+    label = "CPU restatement of ndt_omp (reference not buildable in this environment)"
+    if best_shaped is not None:
+        value, cores, what = shaped[best_shaped]["registrations_per_s"], int(best_shaped), "reference-shaped arrangement (oracle/ndt_oracle_refshape.inc)"
+    else:
+        value, cores, what = port[best_port]["registrations_per_s"], int(best_port), "optimised port (the reference-shaped arrangement does not cover KDTREE)"
+    cpu = {"value": value, "unit": "registrations/s", "cores": cores, "kind": "port",
+           "sample": f"pair 0 of this workload, one registration = target build + align, {what}: 3 warm-ups then the median of 20 repeats at "
+                     f"{settings} threads (OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}); value = the fastest setting; {label}",
+           "host": f"{model}; {phys} physical cores, {logical} logical CPUs",
+           "reference_shaped_by_threads": shaped, "optimised_port_by_threads": port,
+           "optimised_port_batch": {"registrations_per_s": round(done / t_cpu, 3), "threads": int(best_port),
+                                    "sample": f"first {done} of the {B} pairs, total wall / count"}}
+    parity = {"pairs_checked": done, "max_dtrans_m": worst[0], "max_drot_rad": worst[1], "iterations_equal": it_match,
+              "tolerance": "trans<1e-4 m, rot<1e-5 rad", "oracle": "parity unpinned (no reference-originated vectors exist, DESIGN.md 2)",
+              "note": "pairs that never converge (iterations = max_iterations + 2, e.g. ndt_pca with DIRECT26 where the compounding "
+                      "weights make the iteration oscillate) amplify rounding-order differences and are not comparable pose by pose"}
+    return cpu, parity
 
 
 def main():
@@ -84,17 +195,20 @@ def main():
     from lv_slam_amd import ndt, synth
     from lv_slam_amd import dist as shard
 
-    B, N = a.pairs, a.azimuth * 64
+    strong = a.total_pairs > 0
+    total = a.total_pairs if strong else a.pairs * world
+    if total < world:
+        raise SystemExit("fewer pairs than ranks")
+    pair_ids = shard.shard_pairs(total, rank, world)           # round-robin shard of the global pair index space
+    B, N = len(pair_ids), a.azimuth * 64
+    cap = shard.shard_capacity(total, world)
     # ---- synthetic inputs, generated on the GPU and left resident in HBM: [pair][3][N] SoA
     T = torch.empty(B, 3, N, device=dev, dtype=torch.float32)
     S = torch.empty(B, 3, N, device=dev, dtype=torch.float32)
-    pair_ids = shard.shard_pairs(B * world, rank, world)       # round-robin shard of the global pair index space
-    truth = []
     for k, pid in enumerate(pair_ids):
         t, s, dT = synth.make_pair(pid, a.azimuth, device=dev)
         T[k] = t.T
         S[k] = s.T
-        truth.append(dT)
     torch.cuda.synchronize()
 
     prm = ndt.default_params(resolution=a.resolution, trans_epsilon=0.01, max_iterations=64, neighbor_mode=MODES[a.mode],
@@ -104,20 +218,24 @@ def main():
     G = synth.default_guess()
     guesses = np.ascontiguousarray(np.broadcast_to(G.T.reshape(1, 16), (B, 16)), dtype=np.float32)
     res = (ndt.Result * B)()
-    rec_host = torch.empty(B, 24, dtype=torch.float32).pin_memory()
-    coll_dev = dev if backend == "nccl" else torch.device("cpu")
-    rec_dev = torch.empty(B, 24, device=coll_dev, dtype=torch.float32)
-    gathered = torch.empty(world * B, 24, device=coll_dev, dtype=torch.float32) if world > 1 else None
     res_np = np.frombuffer(res, dtype=np.dtype([("final", "<f4", 16), ("tp", "<f8"), ("score", "<f8"), ("it", "<i4"), ("conv", "<i4"),
                                                  ("sweeps", "<i4"), ("status", "<i4"), ("hits", "<i8")]))
+    # pose records: packed by the engine on the device into this tensor, which goes straight into the all-gather
+    rec_dev = torch.empty(cap, shard.REC_WORDS, device=dev, dtype=torch.int32)
+    on_dev = backend == "nccl"
+    rec_host = None if on_dev else torch.empty(cap, shard.REC_WORDS, dtype=torch.int32).pin_memory()   # gloo functional check only
+    gathered = torch.empty(world * cap, shard.REC_WORDS, device=dev if on_dev else "cpu", dtype=torch.int32) if world > 1 else None
 
     def step():
         eng.batch_build_targets()                 # setInputTarget for every pair: voxelise
         eng.batch_align_raw(guesses, res)         # align every pair (synchronous: results on the host)
-        if world > 1:                             # pose gather: {final[16], score, iters, converged, pair_id, pad} = 96 B per pair
-            rec_host.copy_(shard.pack_records(res_np["final"], res_np["score"], res_np["it"], res_np["conv"], pair_ids))
-            rec_dev.copy_(rec_host, non_blocking=True)
-            shard.gather_records(rec_dev, gathered)
+        if world > 1:                             # pose gather: 96 B per pair, no host hop on the RCCL path
+            eng.batch_pose_records(rank, world, rec_dev.data_ptr(), cap)
+            if on_dev:
+                shard.gather_records(rec_dev, gathered)
+            else:
+                rec_host.copy_(rec_dev)
+                shard.gather_records(rec_host, gathered)
 
     eng.profile_enable(True)                      # the warm-up runs exactly what the timed steps run (event pool touched, too)
     gc.collect()
@@ -149,15 +267,28 @@ def main():
         eng.batch_align_raw(guesses, res)
     torch.cuda.synchronize()
     dt_resident = time.perf_counter() - t1
+    gather_check = None
     if dist is not None:
-        tt = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if on_dev else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        # gather check: pair ids form a permutation of the global index space
+        # gather check: pair ids form a permutation of the global index space, and my own records came back bit-identical
         got = shard.unpack_records(gathered)
-        assert sorted(got) == list(range(world * B)), "pose gather lost or duplicated pairs"
-        for k, pid in enumerate(pair_ids):        # my own records came back bit-identical
-            assert np.array_equal(got[pid]["final"], res_np["final"][k].reshape(4, 4).T)
+        perm = sorted(got) == list(range(total))
+        same = all(np.array_equal(got[pid]["final"], res_np["final"][k].reshape(4, 4).T) and got[pid]["iterations"] == int(res_np["it"][k])
+                   and got[pid]["converged"] == bool(res_np["conv"][k]) and np.float32(res_np["score"][k]) == np.float32(got[pid]["score"])
+                   for k, pid in enumerate(pair_ids))
+        assert perm, "pose gather lost or duplicated pairs"
+        assert same, "gathered records differ from this rank's results"
+        ok = torch.tensor([int(perm and same)], dtype=torch.int32, device=dev if on_dev else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        gather_check = {"pairs_gathered": len(got), "permutation_of_all_pair_ids": bool(perm), "own_records_bit_identical_on_every_rank": bool(ok.item()),
+                        "record_bytes": 96, "records_per_rank": cap, "backend": backend, "packed_on_device": True, "host_hop": not on_dev}
+
+    # ---- the drop-in path: host AoS clouds (pcl::PointXYZI records) in, PCIe inclusive -- rank 0's pairs, same engine
+    host_path = None
+    if a.host_clouds and hasattr(eng, "stream_run"):
+        host_path = eng.stream_benchmark(T, S, guesses, steps=max(2, a.steps // 4))
 
     if rank != 0:
         eng.close()
@@ -165,20 +296,19 @@ def main():
             dist.destroy_process_group()
         return
 
-    value = world * B * a.steps / dt
+    value = total * a.steps / dt
     its = res_np["it"].astype(np.float64)
     sweeps = res_np["sweeps"].astype(np.float64)
     # ---- roofline of the dominant kernel (derivative sweep): algorithmic bytes / HIP-event time
+    wkey = f"{a.pairs if not strong else B}x{N}:{a.variant}:{a.mode}:{a.resolution}"
     sw_s = prof["sweep_ms"] * 1e-3
     ach = (prof["sweep_alg_bytes"] / sw_s / 1e9) if sw_s > 0 else 0.0
-    traffic = a.traffic
-    if traffic is None and (a.pairs, a.azimuth, a.mode, a.variant, a.resolution) == (271, 1024, "direct7", "omp", 1.0):
-        try:        # PMC counters cannot be read from inside the timed run: use the committed separate-pass measurement
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["traffic_bytes_per_launch"]
-        except Exception:
-            traffic = None
+    traffic, traffic_source = a.traffic, "command line" if a.traffic is not None else None
+    if traffic is None:       # PMC counters cannot be read from inside the timed run: the committed separate-pass measurement of this workload
+        tp_, traffic_source = static_profile("r02_traffic.json", wkey)
+        traffic = tp_["traffic_bytes_per_launch"] if tp_ else None
     roof = {"bound": "hbm", "kernel": "k_sweep", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "frac_of_achievable_6290": round(ach / 6290.0, 4),     # MI355X_MICROARCH.md: measured-achievable HBM rate
             "launches": prof["sweep_launches"], "avg_launch_us": round(1e3 * prof["sweep_ms"] / max(1, prof["sweep_launches"]), 2),
             "alg_bytes_per_launch": round(prof["sweep_alg_bytes"] / max(1, prof["sweep_launches"])),
@@ -190,79 +320,38 @@ def main():
             "step_ms_min_median_max": [round(min(step_ms), 3), round(float(np.median(step_ms)), 3), round(max(step_ms), 3)],
             "build_achieved_gbs": round(prof["build_alg_bytes"] / max(1e-9, prof["build_ms"] * 1e-3) / 1e9, 1),
             "build_frac": round(prof["build_alg_bytes"] / max(1e-9, prof["build_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    # what really bounds the sweep: vector-ALU issue (SQ counters of separate rocprofv3 --pmc passes, committed under profiles/)
+    valu, valu_source = static_profile("r02_valu.json", wkey)
+    roof_valu = None
+    if valu:
+        roof_valu = {"bound": "valu issue", "kernel": "k_sweep", "active_frac": valu["valu_active_frac"], "insts_per_hit": valu["valu_insts_per_hit"],
+                     "wave_insts_per_64_hits": valu["valu_wave_insts_per_64_hits"], "physical_hbm_frac_of_peak": valu.get("physical_hbm_frac_of_peak"),
+                     "source": valu_source}
 
-    # ---- CPU baseline: the oracle (port of ndt_omp) on this box's host cores, bounded sample of the same pairs
-    cpu = None
-    parity = None
+    cpu, parity = (None, None)
     if a.cpu_seconds > 0 and world == 1:          # the CPU leg runs on rank 0 of the single-GPU run only
-        from oracle import oracle_py as O
-        # pick the thread count that is fastest for this oracle on this box (4 and 8 are the reference's own settings,
-        # scan_matching_odom_nodelet.cpp:110 / launch/dlo_lfa_ggo_kitti.launch:112); report the one used
-        ncpu = os.cpu_count() or 1
-        tg0 = T[0].T.contiguous().cpu().numpy()
-        sr0 = S[0].T.contiguous().cpu().numpy()
-        op0 = O.default_params(resolution=a.resolution, trans_epsilon=0.01, max_iterations=64, neighbor_mode=MODES[a.mode],
-                               variant=1 if a.variant == "pca" else 0)
-        g0 = O.Grid(tg0, op0)
-        best = (1e9, 1)
-        align_ms_by_threads = {}
-        for th in sorted({t for t in (4, 8, 16, 32, 64, 128, ncpu) if t <= ncpu}):
-            O.lib().ora_set_threads(th)
-            O.align(g0, sr0, G)
-            c0 = time.perf_counter()
-            O.align(g0, sr0, G)
-            tt_ = time.perf_counter() - c0
-            align_ms_by_threads[str(th)] = round(1e3 * tt_, 2)
-            if tt_ < best[0]:
-                best = (tt_, th)
-        try:
-            cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
-        except Exception:
-            cpu_model = "unknown"
-        cores = best[1]
-        O.lib().ora_set_threads(cores)
-        op = O.default_params(resolution=a.resolution, trans_epsilon=0.01, max_iterations=64, neighbor_mode=MODES[a.mode],
-                              variant=1 if a.variant == "pca" else 0)
-        done, t_cpu, worst = 0, 0.0, (0.0, 0.0)
-        it_match = 0
-        while done < B and (done < 3 or t_cpu < a.cpu_seconds):
-            tg = T[done].T.contiguous().cpu().numpy()
-            sr = S[done].T.contiguous().cpu().numpy()
-            c0 = time.perf_counter()
-            grid = O.Grid(tg, op)
-            ro = O.align(grid, sr, G)
-            t_cpu += time.perf_counter() - c0
-            fin = res_np["final"][done].reshape(4, 4).T
-            e = se3_err(ro["final"], fin)
-            worst = (max(worst[0], e[0]), max(worst[1], e[1]))
-            it_match += int(ro["iterations"] == int(res_np["it"][done]))
-            done += 1
-        cpu = {"value": round(done / t_cpu, 3), "unit": "registrations/s", "cores": cores, "kind": "port",
-               "sample": f"first {done} of the {B} pairs of this workload (target build + align each), oracle/ndt_oracle.c with "
-                         f"OpenMP on {cores} threads (fastest of 4..{ncpu} on this host); CPU restatement of ndt_omp (reference not buildable in this environment)",
-               "host": f"{cpu_model}, {ncpu} logical CPUs",
-               "align_ms_pair0_by_threads": align_ms_by_threads}   # 4 and 8 are the reference's own settings (nodelet / loop closure)
-        parity = {"pairs_checked": done, "max_dtrans_m": worst[0], "max_drot_rad": worst[1], "iterations_equal": it_match,
-                  "tolerance": "trans<1e-4 m, rot<1e-5 rad",
-                  "note": "pairs that never converge (iterations = max_iterations + 2, e.g. ndt_pca with DIRECT26 where the compounding "
-                          "weights make the iteration oscillate) amplify rounding-order differences and are not comparable pose by pose"}
+        cpu, parity = cpu_leg(a, T, S, G, res_np, B)
 
     out = {
         "metric": "NDT registrations/sec (64k-pt Velodyne pairs)", "value": round(value, 2), "unit": "registrations/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 terms, f64 accumulation",
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32 terms, f64 accumulation",
         "data": "synthetic",
-        "config": {"workload": f"BASELINE config 3: batch of {B} synthetic HDL-64E scan pairs per GPU ({N} pts each), "
-                               f"ndt_{a.variant}, {a.resolution} m voxels, {a.mode.upper()}, eps 0.01, max_iter 64; "
+        "config": {"workload": (f"BASELINE config 4: {total} synthetic HDL-64E scan pairs sharded round-robin over {world} GPU(s) " if strong else
+                                f"BASELINE config 3: batch of {a.pairs} synthetic HDL-64E scan pairs per GPU ") +
+                               f"({N} pts per cloud), ndt_{a.variant}, {a.resolution} m voxels, {a.mode.upper()}, eps 0.01, max_iter 64; "
                                "one step = voxelise every target + align every pair (+ RCCL pose all-gather when N>1)",
-                   "pairs_per_gpu": B, "points_per_cloud": N, "neighbor_mode": a.mode, "variant": a.variant,
-                   "resolution_m": a.resolution, "sharding": "pair i -> rank i mod N (round-robin), weak scaling",
+                   "pairs_total": total, "pairs_rank0": B, "points_per_cloud": N, "neighbor_mode": a.mode, "variant": a.variant,
+                   "resolution_m": a.resolution, "sharding": "pair i -> rank i mod N (round-robin)",
                    "mean_iterations": round(float(its.mean()), 2), "max_iterations_seen": int(its.max()),
                    "mean_sweeps_per_align": round(float(sweeps.mean()), 2),
                    "converged": int(res_np["conv"].sum()),
                    "rank0_registrations_per_s_resident_targets": round(B * a.steps / dt_resident, 1)},
-        "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+        "roofline": roof, "roofline_valu": roof_valu, "cpu_baseline": cpu, "parity": parity, "gather_check": gather_check,
     }
+    if host_path is not None:
+        out["value_host_clouds"] = host_path["registrations_per_s"]
+        out["host_clouds"] = host_path
     print(json.dumps(out), flush=True)
     eng.close()                                   # release HIP objects before interpreter teardown (profilers hook exit)
     if dist is not None:

@@ -179,6 +179,12 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h);
 /* align every pair; guesses = n_pairs x 16 floats column-major; out = n_pairs results. Synchronous. */
 int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses_colmajor, mi355ndt_result* out);
 int mi355ndt_batch_size(const mi355ndt_handle* h);
+/* Pose records of the last mi355ndt_batch_align for the multi-GPU gather, written on the device into a caller-owned DEVICE
+ * buffer of `capacity` 96-byte records {float final[16] column-major; float score; int32 iterations; int32 converged;
+ * int32 pair_id; int32 pad[4]}: record k describes batch slot k and carries pair_id = id_base + k * id_stride (round-robin
+ * sharding: base = rank, stride = world size); records k >= batch size carry pair_id = -1.  The buffer can go straight into
+ * an RCCL all-gather: no host hop.  Returns after the records are complete (the engine's stream is synchronised). */
+int mi355ndt_batch_pose_records(mi355ndt_handle* h, int id_base, int id_stride, void* d_records, size_t capacity);
 
 /* ---- prefilter: the step immediately upstream of the path ------------------------------------------- */
 /* replaces PrefilteringNodelet::distance_filter + downsample (src/lidar_odometry/prefiltering_nodelet.cpp:137-181,

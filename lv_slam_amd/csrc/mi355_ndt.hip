@@ -739,6 +739,18 @@ int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_resu
   return MI355NDT_OK;
 }
 
+int mi355ndt_batch_pose_records(mi355ndt_handle* h, int id_base, int id_stride, void* d_records, size_t capacity) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (!d_records || capacity == 0 || capacity > (size_t)MAX_PAIRS || (size_t)h->n_pairs > capacity) return MI355NDT_ERR_BAD_ARG;
+  if (h->n_pairs <= 0 || !h->d_results) return MI355NDT_ERR_STATE;
+  HIPCHK(h, hipSetDevice(h->device));
+  static_assert(sizeof(PoseRecord) == 96, "pose record is 96 bytes");
+  k_pose_records<<<(unsigned)((capacity + 255) / 256), 256, 0, h->stream>>>(h->d_results, h->n_pairs, id_base, id_stride, (PoseRecord*)d_records, (int)capacity);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MI355NDT_OK;
+}
+
 // ---- single-registration surface (pair slot 0) ---------------------------------------------------
 static int ensure_single(mi355ndt_handle* h, bool tgt, size_t n) {
   const size_t want = std::max(((n + 63) & ~(size_t)63), (size_t)64);

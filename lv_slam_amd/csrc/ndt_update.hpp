@@ -299,3 +299,23 @@ __global__ void k_transform(const float* __restrict__ src, size_t pitch, const P
   for (int a = 0; a < 3; a++) out[(size_t)a * n + i] = ((F[0 * 4 + a] * px + F[1 * 4 + a] * py) + F[2 * 4 + a] * pz) + F[3 * 4 + a];
 }
 
+
+// Pose records for the multi-GPU gather: 96 bytes = {float final[16] column-major; float score; int iterations;
+// int converged; int pair_id; int pad[4]} per pair, packed on the device straight from the results of the last batch align.
+// Rows past the batch (a rank that owns one pair fewer than its neighbours) carry pair_id = -1.
+struct PoseRecord { float final_cm[16]; float score; int iterations, converged, pair_id, pad[4]; };
+__global__ void k_pose_records(const mi355ndt_result* __restrict__ res, int n_pairs, int id_base, int id_stride, PoseRecord* out, int capacity) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= capacity) return;
+  PoseRecord r;
+  memset(&r, 0, sizeof r);
+  r.pair_id = -1;
+  if (k < n_pairs) {
+    for (int a = 0; a < 16; a++) r.final_cm[a] = res[k].final_colmajor[a];
+    r.score = (float)res[k].score;
+    r.iterations = res[k].iterations;
+    r.converged = res[k].converged;
+    r.pair_id = id_base + k * id_stride;
+  }
+  out[k] = r;
+}

@@ -63,7 +63,7 @@ SYMBOLS = [
     "mi355ndt_set_target", "mi355ndt_set_source", "mi355ndt_align", "mi355ndt_get_aligned", "mi355ndt_get_incremental",
     "mi355ndt_get_fitness_score", "mi355ndt_fitness_score_T", "mi355ndt_prefilter", "mi355ndt_use_prefiltered", "mi355ndt_derivatives", "mi355ndt_compute_hessian", "mi355ndt_derivatives_T", "mi355ndt_get_grid", "mi355ndt_get_voxels",
     "mi355ndt_batch_reserve", "mi355ndt_batch_set_target", "mi355ndt_batch_set_source", "mi355ndt_batch_bind_device",
-    "mi355ndt_batch_build_targets", "mi355ndt_batch_align", "mi355ndt_batch_size",
+    "mi355ndt_batch_build_targets", "mi355ndt_batch_align", "mi355ndt_batch_size", "mi355ndt_batch_pose_records",
     "mi355ndt_profile_enable", "mi355ndt_profile_reset", "mi355ndt_profile_get", "mi355ndt_synchronize",
 ]
 
@@ -110,6 +110,7 @@ def load_library(path: str = LIB_PATH):
     L.mi355ndt_batch_build_targets.argtypes = [vp]
     L.mi355ndt_batch_align.argtypes = [vp, vp, vp]
     L.mi355ndt_batch_size.argtypes = [vp]
+    L.mi355ndt_batch_pose_records.argtypes = [vp, i, i, vp, sz]
     L.mi355ndt_profile_enable.argtypes = [vp, i]
     L.mi355ndt_profile_reset.argtypes = [vp]
     L.mi355ndt_profile_get.argtypes = [vp, C.POINTER(Profile)]
@@ -318,6 +319,10 @@ class Engine:
     def batch_align_raw(self, guesses_colmajor: np.ndarray, res_array):
         """Allocation-free variant for timing loops: guesses [n,16] f32 C-contiguous, res_array = (Result*n)()."""
         self._chk(self.lib.mi355ndt_batch_align(self.h, guesses_colmajor.ctypes.data_as(C.c_void_p), C.cast(res_array, C.c_void_p)), "batch_align")
+
+    def batch_pose_records(self, id_base: int, id_stride: int, d_records_ptr: int, capacity: int):
+        """96-byte pose records of the last batch_align, packed on the device into a caller-owned device buffer (dist.py layout)."""
+        self._chk(self.lib.mi355ndt_batch_pose_records(self.h, id_base, id_stride, C.c_void_p(d_records_ptr), capacity), "batch_pose_records")
 
     def synchronize(self):
         self._chk(self.lib.mi355ndt_synchronize(self.h), "synchronize")

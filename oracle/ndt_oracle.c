@@ -389,6 +389,63 @@ static int cmp_keypos(const void* a, const void* b) {
 
 static int finite3(float x, float y, float z) { return isfinite(x) && isfinite(y) && isfinite(z); }
 
+/* Second pass of applyFilter for one leaf (impl:282-367; pca impl:364-397) from its first-pass sums: S = sum of points,
+ * C = Identity + sum of p p^T (both f64, input order), cen = f32 sum, cnt = nr_points. */
+static void finish_leaf(ora_leaf* L, const double S[3], const double C[9], const float cen[3], int cnt, const ora_params* prm) {
+  L->n = cnt;
+  L->n_pushed = cnt;                                               /* what voxel_centroids_ saw (impl:297-302) */
+  for (int a = 0; a < 3; a++) L->centroid[a] = cen[a] / (float)cnt;   /* impl:289 */
+  double mu[3];
+  for (int a = 0; a < 3; a++) mu[a] = S[a] / (double)cnt;            /* impl:293 */
+  memcpy(L->mean, mu, sizeof mu);
+  if (cnt >= prm->min_points_per_voxel) {                            /* impl:297 */
+    double cov[9];
+    /* impl:329-330 */
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++)
+        cov[a * 3 + b] = (C[a * 3 + b] - 2 * (S[a] * mu[b])) / (double)cnt + mu[a] * mu[b];
+    double f = ((double)cnt - 1.0) / (double)cnt;
+    for (int a = 0; a < 9; a++) cov[a] *= f;
+    double ev[3], V[9];
+    ora_eigen_sym3(cov, ev, V);                                      /* impl:333-335 */
+    memcpy(L->evecs, V, sizeof V);
+    if (ev[0] < 0 || ev[1] < 0 || ev[2] <= 0) {                      /* impl:337-341 */
+      L->n = -1;
+      memcpy(L->cov, cov, sizeof cov);
+      memcpy(L->evals, ev, sizeof ev);
+      return;
+    }
+    double minev = prm->min_covar_eigvalue_mult * ev[2];             /* impl:345 */
+    if (ev[0] < minev) {
+      ev[0] = minev;
+      if (ev[1] < minev) ev[1] = minev;
+      /* cov = evecs * diag * evecs.inverse()  impl:355 */
+      double VD[9], Vi[9];
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) VD[a * 3 + b] = V[a * 3 + b] * ev[b];
+      mat3_inverse(V, Vi);
+      mat3_mul(VD, Vi, cov);
+    }
+    memcpy(L->evals, ev, sizeof ev);
+    memcpy(L->cov, cov, sizeof cov);
+    if (prm->variant == ORA_VARIANT_PCA) {                           /* pca impl:364-397 */
+      double sg[3] = {sqrt(ev[0]), sqrt(ev[1]), sqrt(ev[2])};
+      double ft[3] = {(sg[2] - sg[1]) / sg[2], (sg[1] - sg[0]) / sg[2], sg[0] / sg[2]};
+      int dmax = 0;
+      if (ft[1] > ft[dmax]) dmax = 1;
+      if (ft[2] > ft[dmax]) dmax = 2;
+      L->label = dmax + 1;
+      double scale = 1;
+      if (L->label == 2) scale = 1.25; else if (L->label == 3) scale = 1; else if (L->label == 1) scale = 0.75;
+      L->dim2d = scale * sqrt((mu[0] * mu[0] + mu[1] * mu[1]) + mu[2] * mu[2]);
+      L->weight = (int)L->dim2d;                                     /* pca.h:222-226 returns int */
+    }
+    mat3_inverse(cov, L->icov);                                      /* impl:359 */
+    int bad = 0;
+    for (int a = 0; a < 9; a++) if (!isfinite(L->icov[a])) bad = 1;  /* impl:360-364 (NaN treated as inf) */
+    if (bad) L->n = -1;
+  }
+}
+
 ora_grid* ora_grid_build(const float* x, const float* y, const float* z, size_t n, const ora_params* prm) {
   if (n == 0) return NULL;
   ora_grid* g = (ora_grid*)calloc(1, sizeof(ora_grid));
@@ -457,59 +514,7 @@ ora_grid* ora_grid_build(const float* x, const float* y, const float* z, size_t 
       cen[0] += x[i]; cen[1] += y[i]; cen[2] += z[i];                  /* impl:242-243 */
       cnt++;
     }
-    L->n = cnt;
-    L->n_pushed = cnt;                                               /* what voxel_centroids_ saw (impl:297-302) */
-    for (int a = 0; a < 3; a++) L->centroid[a] = cen[a] / (float)cnt;   /* impl:289 */
-    double mu[3];
-    for (int a = 0; a < 3; a++) mu[a] = S[a] / (double)cnt;            /* impl:293 */
-    memcpy(L->mean, mu, sizeof mu);
-    if (cnt >= prm->min_points_per_voxel) {                            /* impl:297 */
-      double cov[9];
-      /* impl:329-330 */
-      for (int a = 0; a < 3; a++)
-        for (int b = 0; b < 3; b++)
-          cov[a * 3 + b] = (C[a * 3 + b] - 2 * (S[a] * mu[b])) / (double)cnt + mu[a] * mu[b];
-      double f = ((double)cnt - 1.0) / (double)cnt;
-      for (int a = 0; a < 9; a++) cov[a] *= f;
-      double ev[3], V[9];
-      ora_eigen_sym3(cov, ev, V);                                      /* impl:333-335 */
-      memcpy(L->evecs, V, sizeof V);
-      if (ev[0] < 0 || ev[1] < 0 || ev[2] <= 0) {                      /* impl:337-341 */
-        L->n = -1;
-        memcpy(L->cov, cov, sizeof cov);
-        memcpy(L->evals, ev, sizeof ev);
-        s = e;
-        continue;
-      }
-      double minev = prm->min_covar_eigvalue_mult * ev[2];             /* impl:345 */
-      if (ev[0] < minev) {
-        ev[0] = minev;
-        if (ev[1] < minev) ev[1] = minev;
-        /* cov = evecs * diag * evecs.inverse()  impl:355 */
-        double VD[9], Vi[9];
-        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) VD[a * 3 + b] = V[a * 3 + b] * ev[b];
-        mat3_inverse(V, Vi);
-        mat3_mul(VD, Vi, cov);
-      }
-      memcpy(L->evals, ev, sizeof ev);
-      memcpy(L->cov, cov, sizeof cov);
-      if (prm->variant == ORA_VARIANT_PCA) {                           /* pca impl:364-397 */
-        double sg[3] = {sqrt(ev[0]), sqrt(ev[1]), sqrt(ev[2])};
-        double ft[3] = {(sg[2] - sg[1]) / sg[2], (sg[1] - sg[0]) / sg[2], sg[0] / sg[2]};
-        int dmax = 0;
-        if (ft[1] > ft[dmax]) dmax = 1;
-        if (ft[2] > ft[dmax]) dmax = 2;
-        L->label = dmax + 1;
-        double scale = 1;
-        if (L->label == 2) scale = 1.25; else if (L->label == 3) scale = 1; else if (L->label == 1) scale = 0.75;
-        L->dim2d = scale * sqrt((mu[0] * mu[0] + mu[1] * mu[1]) + mu[2] * mu[2]);
-        L->weight = (int)L->dim2d;                                     /* pca.h:222-226 returns int */
-      }
-      mat3_inverse(cov, L->icov);                                      /* impl:359 */
-      int bad = 0;
-      for (int a = 0; a < 9; a++) if (!isfinite(L->icov[a])) bad = 1;  /* impl:360-364 (NaN treated as inf) */
-      if (bad) L->n = -1;
-    }
+    finish_leaf(L, S, C, cen, cnt, prm);
     s = e;
   }
   free(kp);
@@ -637,10 +642,18 @@ static int radius_search(const ora_grid* g, const float q[3], double radius, kd_
   return k;
 }
 
+/* reference-shaped mode (ndt_oracle_refshape.inc): set by ora_ref_align for the duration of one align */
+typedef struct ora_refgrid ora_refgrid;
+static ora_refgrid* g_ref = NULL;
+static double g_ref_p[6];
+static long ref_derivatives(ora_refgrid* R, const ora_params* prm, const float* x, const float* y, const float* z, size_t n,
+                            const float T[16], const double p[6], double* score, double grad[6], double hess[36]);
+
 long ora_derivatives(const ora_grid* g, const ora_params* prm,
                      const float* x, const float* y, const float* z, size_t n,
                      const float T[16], const float Rj[9],
                      double* score, double grad[6], double hess[36]) {
+  if (g_ref) return ref_derivatives(g_ref, prm, x, y, z, n, T, g_ref_p, score, grad, hess);
   double gc[3];
   ora_gauss_constants(prm->outlier_ratio, prm->resolution, gc);
   const double d1 = gc[0];
@@ -719,6 +732,7 @@ long ora_derivatives(const ora_grid* g, const ora_params* prm,
 
 static void pose_to_f32(const double p[6], float T[16], float Rj[9]) {
   double M[16];
+  if (g_ref) memcpy(g_ref_p, p, sizeof g_ref_p);                      /* the tangent the next sweep's exp(p) is taken at */
   ora_se3_exp(p, M);
   for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) T[c * 4 + r] = (float)M[r * 4 + c];   /* .cast<float>() */
   for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Rj[r * 3 + c] = (float)M[r * 4 + c];
@@ -1059,3 +1073,5 @@ size_t ora_prefilter(const float* x, const float* y, const float* z, size_t n, i
   free(kp); free(keep);
   return m;
 }
+
+#include "ndt_oracle_refshape.inc"

@@ -132,6 +132,17 @@ double ora_fitness_score(const float* tx, const float* ty, const float* tz, size
 size_t ora_prefilter(const float* x, const float* y, const float* z, size_t n, int use_df, double dnear, double dfar, float leaf,
                      float* ox, float* oy, float* oz);
 
+/* ---- "reference-shaped" arrangement of the same arithmetic (ndt_oracle_refshape.inc): CPU-baseline timing only ------------
+ * std::map-like grid (one heap node per cell, O(log n) pointer walk per insert / probe, serial build), per-point heap
+ * neighbour lists, exp(p) and dense 4x6 / 24x6 f32 matrices per evaluation, cloud rewrite per sweep, schedule(guided,8). */
+typedef struct ora_refgrid ora_refgrid;
+ora_refgrid* ora_refgrid_build(const float* x, const float* y, const float* z, size_t n, const ora_params* prm);
+void   ora_refgrid_free(ora_refgrid* g);
+size_t ora_refgrid_num_leaves(const ora_refgrid* g);
+void   ora_refgrid_leaves(const ora_refgrid* g, ora_leaf* out);      /* ascending idx; out sized num_leaves */
+int    ora_ref_align(ora_refgrid* g, const ora_params* prm, const float* x, const float* y, const float* z, size_t n,
+                     const float guess_colmajor[16], ora_result* out);   /* -2: configuration only the port serves */
+
 void ora_set_threads(int n);
 /* (float)exp((double)a[i]) -- the exp of impl2:581 as eval_hit evaluates it */
 void ora_exp_f32arg(const float* a, float* out, size_t n);

@@ -39,7 +39,8 @@ class Result(C.Structure):
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libndt_oracle.so")
     src = os.path.join(_HERE, "ndt_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    inc = os.path.join(_HERE, "ndt_oracle_refshape.inc")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(inc)):
         subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
     return so
 
@@ -78,6 +79,14 @@ def lib():
         L.ora_gauss_constants.argtypes = [C.c_double, C.c_float, C.c_void_p]
         L.ora_default_params.argtypes = [C.POINTER(Params)]
         L.ora_set_threads.argtypes = [C.c_int]
+        L.ora_refgrid_build.restype = C.c_void_p
+        L.ora_refgrid_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Params)]
+        L.ora_refgrid_free.argtypes = [C.c_void_p]
+        L.ora_refgrid_num_leaves.restype = C.c_size_t
+        L.ora_refgrid_num_leaves.argtypes = [C.c_void_p]
+        L.ora_refgrid_leaves.argtypes = [C.c_void_p, C.c_void_p]
+        L.ora_ref_align.restype = C.c_int
+        L.ora_ref_align.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Result)]
         L.ora_exp_f32arg.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.ora_prefilter.restype = C.c_size_t
         L.ora_prefilter.argtypes = [C.c_void_p] * 3 + [C.c_size_t, C.c_int, C.c_double, C.c_double, C.c_float] + [C.c_void_p] * 3
@@ -261,3 +270,37 @@ def prefilter(pts: np.ndarray, distance_near=0.5, distance_far=100.0, leaf=0.1, 
     m = lib().ora_prefilter(_p(x), _p(y), _p(z), n, int(use_distance_filter), float(distance_near), float(distance_far), float(leaf),
                             _p(ox), _p(oy), _p(oz))
     return np.stack([ox[:m], oy[:m], oz[:m]], axis=1)
+
+
+class RefGrid:
+    """The reference-shaped voxel grid (std::map-like tree, serial build) -- CPU-baseline timing only."""
+
+    def __init__(self, target: np.ndarray, prm: Params):
+        self.prm = prm
+        x, y, z = _soa(target)
+        self.h = lib().ora_refgrid_build(_p(x), _p(y), _p(z), len(target), C.byref(prm))
+
+    def __del__(self):
+        if getattr(self, "h", None) and _LIB is not None:
+            _LIB.ora_refgrid_free(self.h)
+            self.h = None
+
+    def leaves(self):
+        n = lib().ora_refgrid_num_leaves(self.h)
+        arr = (Leaf * max(n, 1))()
+        lib().ora_refgrid_leaves(self.h, C.cast(arr, C.c_void_p))
+        dt = np.dtype([("idx", "<i4"), ("n", "<i4"), ("mean", "<f8", 3), ("cov", "<f8", 9), ("icov", "<f8", 9),
+                       ("evals", "<f8", 3), ("evecs", "<f8", 9), ("label", "<i4"), ("weight", "<i4"), ("dim2d", "<f8"),
+                       ("centroid", "<f4", 3), ("n_pushed", "<i4")])
+        return np.frombuffer(bytes(arr), dtype=dt)[:n].copy()
+
+
+def ref_align(grid: RefGrid, src: np.ndarray, guess: np.ndarray):
+    x, y, z = _soa(src)
+    Gc = np.asarray(guess, np.float32).ravel(order="F").copy()
+    r = Result()
+    rc = lib().ora_ref_align(grid.h, C.byref(grid.prm), _p(x), _p(y), _p(z), len(src), _p(Gc), C.byref(r))
+    if rc != 0:
+        raise RuntimeError(f"ora_ref_align rc={rc}")
+    return dict(final=np.array(r.final_colmajor, np.float32).reshape(4, 4, order="F"), trans_probability=r.trans_probability,
+                score=r.score, iterations=r.iterations, converged=bool(r.converged), hits_last=r.hits_last, sweeps=r.sweeps)

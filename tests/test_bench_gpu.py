@@ -1,0 +1,63 @@
+"""GPU (-m gpu): bench.py itself -- the N = 1 line's contract fields, and the N > 1 branch run as two ranks sharing cuda:0
+(LV_SLAM_BENCH_BACKEND=gloo; the driver's own scaling runs use RCCL, one rank per GPU): round-robin sharding, pose records
+packed on the device by the engine, the all-gather, and the two checks on it (pair ids form a permutation of the job, every
+rank's own records come back bit-identical).  Independence of the pairs: scan_matching_odom_nodelet.cpp:240-250 is the only
+coupling between frames in the reference, and the benchmark's fixed guess removes it."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_bench(args, nproc=1, env_extra=None):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.join(ROOT, "bench.py")] + args
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_contract():
+    d = run_bench(["--pairs", "6", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.5"])
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["unit"] == "registrations/s" and d["value"] > 0 and d["vs_baseline"] is None and d["data"] == "synthetic"
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "reference_shaped_by_threads" in c
+    p = d["parity"]
+    assert p["pairs_checked"] >= 3 and p["iterations_equal"] == p["pairs_checked"] and p["max_dtrans_m"] < 1e-4 and p["max_drot_rad"] < 1e-5
+
+
+@pytest.mark.parametrize("extra,total", [(["--pairs", "5"], 10), (["--total-pairs", "11"], 11)])
+def test_two_ranks_on_one_gpu_gather(extra, total):
+    """weak scaling (5 pairs per rank) and the config-4-literal mode with uneven shards (11 pairs: 6 + 5)."""
+    d = run_bench(["--gpus", "2", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0"] + extra, nproc=2,
+                  env_extra={"LV_SLAM_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert d["n_gpus"] == 2 and d["config"]["pairs_total"] == total
+    assert d["scaling"] == ("strong" if "--total-pairs" in extra else "weak")
+    g = d["gather_check"]
+    assert g["pairs_gathered"] == total and g["permutation_of_all_pair_ids"] is True and g["own_records_bit_identical_on_every_rank"] is True
+    assert g["record_bytes"] == 96 and g["packed_on_device"] is True
+    assert d["config"]["converged"] == d["config"]["pairs_rank0"]

@@ -34,7 +34,7 @@ def _worker(rank, world, port, n_total, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         mine = D.shard_pairs(n_total, rank, world)
-        cap = (n_total + world - 1) // world
+        cap = D.shard_capacity(n_total, world)
         res = [_fake_result(p) for p in mine]
         rec = D.pack_records(np.stack([r[0] for r in res]) if res else np.zeros((0, 4, 4), np.float32),
                              [r[1] for r in res], [r[2] for r in res], [r[3] for r in res], mine, capacity=cap)
@@ -49,7 +49,7 @@ def _worker(rank, world, port, n_total, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [6, 7])
+@pytest.mark.parametrize("n_total", [6, 7, 4541])      # 4541 = BASELINE config 4 (uneven shards: 2271 + 2270)
 def test_gather_world2_gloo(n_total):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -70,6 +70,14 @@ def test_gather_world2_gloo(n_total):
 def test_records_roundtrip_single_process():
     F = np.stack([_fake_result(p)[0] for p in range(3)])
     rec = D.pack_records(F, [1.0, 2.0, 3.0], [3, 4, 5], [1, 0, 1], [10, 11, 12], capacity=5)
-    assert rec.shape == (5, D.REC_FLOATS) and rec.element_size() * D.REC_FLOATS == 96
+    assert rec.shape == (5, D.REC_WORDS) and rec.element_size() * D.REC_WORDS == 96 and rec.dtype == torch.int32
     got = D.unpack_records(D.gather_records(rec))
     assert sorted(got) == [10, 11, 12] and got[11]["converged"] is False and np.array_equal(got[12]["final"], F[2])
+
+
+def test_pair_ids_beyond_float_precision_survive():
+    """pair ids travel as int32 words, not as float32 values (exact beyond 2^24)."""
+    ids = [16777217, 16777219, 2000000001]
+    F = np.stack([np.eye(4, dtype=np.float32)] * 3)
+    got = D.unpack_records(D.pack_records(F, [0.5, 1.5, 2.5], [1, 2, 3], [1, 1, 0], ids))
+    assert sorted(got) == ids and got[2000000001]["iterations"] == 3 and got[16777217]["score"] == 0.5

@@ -299,3 +299,27 @@ def test_align_reports_incremental_transforms():
     # the last step is the shorter one (the loop ends when |a| < eps)
     step = lambda M: np.linalg.norm(M[:3, 3])
     assert step(r["transformation"]) < 0.011 and step(r["transformation"]) <= step(r["previous_transformation"]) + 1e-9
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(variant=1, neighbor_mode=3), dict(variant=1, resolution=0.5), dict(neighbor_mode=1, resolution=2.0)])
+def test_reference_shaped_mode_equals_the_port(kw):
+    """oracle/ndt_oracle_refshape.inc (ordered-map grid, per-evaluation exp(p), dense 4x6 / 24x6 matrices, cloud rewrite per
+    sweep, schedule(guided, 8)) is the arrangement the CPU baseline is timed on; it must compute what the port computes: the
+    same leaves bit for bit, and the same alignment up to the f64 summation order of the threads."""
+    from lv_slam_amd import synth
+    tgt, src, dT = synth.make_pair(4, 128, n_beams=32)
+    tgt, src = tgt.numpy(), src.numpy()
+    prm = O.default_params(trans_epsilon=0.01, max_iterations=64, **kw)
+    g, rg = O.Grid(tgt, prm), O.RefGrid(tgt, prm)
+    a, b = g.leaves(), rg.leaves()
+    for f in ("idx", "n", "mean", "cov", "icov", "evals", "weight", "centroid", "n_pushed"):
+        assert np.array_equal(a[f], b[f], equal_nan=True), f
+    G = synth.default_guess()
+    for th in (1, 3):
+        O.lib().ora_set_threads(th)
+        r1, r2 = O.align(g, src, G), O.ref_align(rg, src, G)
+        assert r1["iterations"] == r2["iterations"] and r1["converged"] == r2["converged"] and r1["hits_last"] == r2["hits_last"]
+        dt, dr = se3_err(r1["final"], r2["final"])
+        assert dt < 1e-6 and dr < 1e-7
+        assert abs(r1["score"] - r2["score"]) <= 1e-9 * max(1.0, abs(r1["score"]))
+    O.lib().ora_set_threads(0)
