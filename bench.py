@@ -59,6 +59,25 @@ def se3_err(A, B):
     return float(np.linalg.norm(E[:3, 3])), float(np.arctan2(np.linalg.norm(w), min(1.0, max(-1.0, (np.trace(E[:3, :3]) - 1) / 2))))
 
 
+def cpu_quota():
+    """CPUs this process may actually use: the cgroup quota (cpu.max) when there is one, else None."""
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, per = open(path).read().split()[:2]
+            if q != "max":
+                return max(1, int(int(q) / int(per)))
+        except Exception:
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, q // per)
+    except Exception:
+        pass
+    return None
+
+
 def host_info():
     model, phys = "unknown", None
     try:
@@ -122,7 +141,9 @@ def cpu_leg(a, T, S, G, res_np, B):
         reg_s = 1.0 / (np.median(tb) + np.median(ta))
         return {"build": stats(tb), "align": stats(ta), "registrations_per_s": round(float(reg_s), 3)}
 
-    settings = sorted({t for t in (4, 8, phys or logical) if t <= logical})
+    quota = cpu_quota()
+    usable = min(phys or logical, quota) if quota else (phys or logical)     # "all physical cores" = what the container may really use
+    settings = sorted({t for t in (4, 8, usable) if t <= max(usable, 4)})
     shaped, port = {}, {}
     for th in settings:
         if refshape_ok:
@@ -152,7 +173,7 @@ def cpu_leg(a, T, S, G, res_np, B):
     cpu = {"value": value, "unit": "registrations/s", "cores": cores, "kind": "port",
            "sample": f"pair 0 of this workload, one registration = target build + align, {what}: 3 warm-ups then the median of 20 repeats at "
                      f"{settings} threads (OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}); value = the fastest setting; {label}",
-           "host": f"{model}; {phys} physical cores, {logical} logical CPUs",
+           "host": f"{model}; {phys} physical cores, {logical} logical CPUs" + (f", cgroup CPU quota {quota} CPUs (the 'all cores' setting is {usable} threads)" if quota else ""),
            "reference_shaped_by_threads": shaped, "optimised_port_by_threads": port,
            "optimised_port_batch": {"registrations_per_s": round(done / t_cpu, 3), "threads": int(best_port),
                                     "sample": f"first {done} of the {B} pairs, total wall / count"}}
@@ -161,6 +182,62 @@ def cpu_leg(a, T, S, G, res_np, B):
               "note": "pairs that never converge (iterations = max_iterations + 2, e.g. ndt_pca with DIRECT26 where the compounding "
                       "weights make the iteration oscillate) amplify rounding-order differences and are not comparable pose by pose"}
     return cpu, parity
+
+
+def host_clouds_leg(a, ndt, prm, dev_index, T, S, guesses, B, N, steps, uploaders=None):
+    """The drop-in path as a PCL host would drive it for a batch: every cloud starts as an array of 32-byte pcl::PointXYZI records
+    in ordinary (pageable) host memory and goes through mi355ndt_batch_set_target / _set_source (staging in pinned memory, PCIe,
+    AoS -> SoA on the device), then build + align.  Two engines, each driven by its own host thread with its own pool of
+    uploader threads, so that one engine's uploads overlap the other's kernels (scan_matching_odom_nodelet.cpp:220-221 is the
+    per-frame call pattern this batches)."""
+    import threading
+    if uploaders is None:                              # staging threads per engine: within the CPUs the container may use
+        uploaders = max(1, min(8, ((cpu_quota() or os.cpu_count() or 8) - 4) // 2))
+    rec = 8                                            # floats per PointXYZI record: x y z 1 | intensity pad pad pad
+    tg = np.zeros((B, N, rec), np.float32)
+    sr = np.zeros((B, N, rec), np.float32)
+    tg[:, :, :3] = T.permute(0, 2, 1).cpu().numpy(); tg[:, :, 3] = 1.0
+    sr[:, :, :3] = S.permute(0, 2, 1).cpu().numpy(); sr[:, :, 3] = 1.0
+    stride = rec * 4
+    tgp, srp = np.uint64(tg.ctypes.data), np.uint64(sr.ctypes.data)
+    results = {}
+
+    def drive(idx, nsteps, out):
+        eng = ndt.Engine(prm, device=dev_index)
+        eng.batch_reserve(B, N, N)
+        res = (ndt.Result * B)()
+        tptr = tgp + np.arange(B, dtype=np.uint64) * np.uint64(N * stride)
+        sptr = srp + np.arange(B, dtype=np.uint64) * np.uint64(N * stride)
+        cnt = np.full(B, N, np.uint64)
+
+        def one():
+            eng.batch_set_clouds_raw(0, tptr, cnt, sptr, cnt, stride, uploaders)     # the engine's own staging threads
+            eng.batch_build_targets()
+            eng.batch_align_raw(guesses, res)
+        one()                                          # warm-up (allocations, pinned slots)
+        out["barrier"].wait()
+        for _ in range(nsteps):
+            one()
+        out[idx] = np.frombuffer(res, dtype=np.uint8).copy()
+        eng.close()
+
+    results["barrier"] = threading.Barrier(3)
+    n_each = max(1, steps // 2)
+    th = [threading.Thread(target=drive, args=(i, n_each, results)) for i in range(2)]
+    for t in th:
+        t.start()
+    results["barrier"].wait()
+    t0 = time.perf_counter()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    regs = 2 * n_each * B
+    bytes_pcie = regs * 2 * N * 12                     # what crosses the link: x,y,z of both clouds
+    bytes_host = regs * 2 * N * stride                 # what the staging threads read from the caller's records
+    return {"registrations_per_s": round(regs / dt, 1), "ms_per_batch_of_%d" % B: round(1e3 * dt / (2 * n_each), 3),
+            "pcie_h2d_gbs": round(bytes_pcie / dt / 1e9, 2), "pcie_h2d_frac_of_gen5_x16_63gbs": round(bytes_pcie / dt / 63.0e9, 3),
+            "host_records_read_gbs": round(bytes_host / dt / 1e9, 2), "record_bytes": stride, "engines": 2, "uploader_threads_per_engine": uploaders,
+            "what": "host pcl::PointXYZI clouds (pageable memory) -> batch_set_target/_set_source -> build -> align -> results on the host"}, results
 
 
 def main():
@@ -287,8 +364,14 @@ def main():
 
     # ---- the drop-in path: host AoS clouds (pcl::PointXYZI records) in, PCIe inclusive -- rank 0's pairs, same engine
     host_path = None
-    if a.host_clouds and hasattr(eng, "stream_run"):
-        host_path = eng.stream_benchmark(T, S, guesses, steps=max(2, a.steps // 4))
+    if a.host_clouds and rank == 0:
+        host_path, hres = host_clouds_leg(a, ndt, prm, local, T, S, guesses, B, N, steps=max(2, a.steps // 2))
+        # same bits as the device-resident run of the same pairs
+        ref = np.frombuffer(res, dtype=np.uint8)
+        fin = np.dtype([("final", "<f4", 16), ("tp", "<f8"), ("score", "<f8"), ("it", "<i4"), ("conv", "<i4"), ("sweeps", "<i4"), ("status", "<i4"), ("hits", "<i8")])
+        host_path["bit_identical_to_device_resident_run"] = bool(all(
+            np.array_equal(np.frombuffer(hres[i], dtype=fin)["final"], res_np["final"]) and np.array_equal(np.frombuffer(hres[i], dtype=fin)["score"], res_np["score"])
+            for i in range(2)))
 
     if rank != 0:
         eng.close()

@@ -166,9 +166,18 @@ int mi355ndt_get_voxels(mi355ndt_handle* h, int pair, mi355ndt_voxel* out, size_
 /* (BASELINE.json configs 3-5; the single-registration calls above are the n = 1 case) */
 
 int mi355ndt_batch_reserve(mi355ndt_handle* h, int n_pairs, size_t max_target_pts, size_t max_source_pts);
-/* host uploads into pair slot `pair` (same record convention as set_target / set_source) */
+/* Host uploads into pair slot `pair` (same record convention as set_target / set_source).  Asynchronous: the call returns as
+ * soon as x,y,z of the caller's records sit in one of the engine's pinned staging slots (caller memory is not referenced
+ * afterwards); the PCIe transfer and the AoS -> SoA kernel run on the engine's copy stream while the next cloud is staged, and
+ * the next build / align waits for them.  These two calls -- and only these -- may be issued from several threads at once for
+ * DIFFERENT pair slots (staging is the CPU-bound part of a host-cloud batch). */
 int mi355ndt_batch_set_target(mi355ndt_handle* h, int pair, const void* pts, size_t n, size_t stride_bytes);
 int mi355ndt_batch_set_source(mi355ndt_handle* h, int pair, const void* pts, size_t n, size_t stride_bytes);
+/* A whole batch of host clouds in one call: pairs first_pair .. first_pair + n - 1, one pointer and one point count per cloud
+ * (`targets` or `sources` may be NULL to upload only the other side), records `stride_bytes` apart; n_threads staging threads
+ * of the engine's own (<= 0: 8) share the pairs.  Same asynchrony as the per-cloud calls. */
+int mi355ndt_batch_set_clouds(mi355ndt_handle* h, int first_pair, int n, const void* const* targets, const size_t* target_counts,
+                              const void* const* sources, const size_t* source_counts, size_t stride_bytes, int n_threads);
 /* zero-copy: use device-resident SoA buffers laid out [pair][3][pitch] (x row, y row, z row of `pitch`
  * floats each).  counts are HOST arrays of n_pairs ints.  The buffers must stay valid until replaced. */
 int mi355ndt_batch_bind_device(mi355ndt_handle* h, int n_pairs,

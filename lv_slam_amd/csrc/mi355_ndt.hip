@@ -19,6 +19,8 @@
 #include <vector>
 #include <algorithm>
 #include <cmath>
+#include <mutex>
+#include <thread>
 
 #include "mi355_ndt.h"
 #include "ndt_math.hpp"
@@ -93,7 +95,19 @@ struct mi355ndt_handle {
   unsigned long long* d_hits = nullptr;         // (point,voxel) evaluations, all sweeps
   float* d_hook = nullptr;                      // 16 + 9 floats, 6 doubles
   float* d_aligned = nullptr; size_t aligned_cap = 0;
-  std::vector<float> h_stage;
+  float* h_pin_aligned = nullptr; size_t pin_aligned_cap = 0;   // pinned landing buffer of get_aligned
+  // host-cloud uploads: a ring of pinned staging slots, a copy stream of its own, a device staging buffer per slot.  The caller's
+  // records are compacted to x,y,z into a slot (the only CPU work), the slot goes over PCIe asynchronously and a small kernel
+  // spreads it into the SoA rows; the next call stages the next cloud while this one is still in flight.
+  struct UpSlot { float* h = nullptr; float* d = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false, filling = false; };
+  static constexpr int UP_SLOTS = 16;
+  UpSlot up[UP_SLOTS];
+  int up_next = 0;
+  static constexpr int UP_STREAMS = 4;            // slot i rides copy stream i % UP_STREAMS: the per-transfer latencies of the SDMA queues overlap
+  hipStream_t copy_stream[UP_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_uploads[UP_STREAMS] = {nullptr, nullptr, nullptr, nullptr}, ev_compute = nullptr;   // copy streams -> compute stream, compute stream -> copy streams
+  bool uploads_pending = false;
+  std::mutex up_mtx;                              // batch_set_target / batch_set_source may be called from several threads (distinct pairs)
 
   // profiling
   bool prof = false;
@@ -207,11 +221,15 @@ int mi355ndt_create(const mi355ndt_params* params, int device, mi355ndt_handle**
       hipMalloc((void**)&h->d_ctl, 2 * sizeof(SweepCtl)) != hipSuccess ||
       hipMalloc((void**)&h->d_hits, sizeof(unsigned long long)) != hipSuccess ||
       hipMalloc((void**)&h->d_hook, 64 * sizeof(double)) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_compute, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_burst[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_burst[1], hipEventDisableTiming) != hipSuccess) {
     mi355ndt_destroy(h);                          // releases whatever was created before the failure
     return MI355NDT_ERR_HIP;
   }
+  for (int i = 0; i < mi355ndt_handle::UP_STREAMS; i++)
+    if (hipStreamCreateWithFlags(&h->copy_stream[i], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_uploads[i], hipEventDisableTiming) != hipSuccess) { mi355ndt_destroy(h); return MI355NDT_ERR_HIP; }
   *out = h;
   return MI355NDT_OK;
 }
@@ -226,6 +244,12 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
                   h->d_cent, h->d_icov64, h->d_kdw, h->d_rs_hist, h->d_rs_offs, h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit, h->d_pf_in, h->d_pf_out, h->d_pf_keep, h->d_pf_keys,
                   h->d_pf_vals, h->d_pf_flag, h->d_pf_pos, h->d_pf_mm, h->d_pf_grid, h->d_pf_tmp};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (hipStream_t cs : h->copy_stream) if (cs) (void)hipStreamSynchronize(cs);
+  for (auto& u : h->up) { if (u.h) (void)hipHostFree(u.h); if (u.d) (void)hipFree(u.d); if (u.ev) (void)hipEventDestroy(u.ev); }
+  if (h->h_pin_aligned) (void)hipHostFree(h->h_pin_aligned);
+  for (hipEvent_t e : h->ev_uploads) if (e) (void)hipEventDestroy(e);
+  if (h->ev_compute) (void)hipEventDestroy(h->ev_compute);
+  for (hipStream_t cs : h->copy_stream) if (cs) (void)hipStreamDestroy(cs);
   if (h->h_pin_u) (void)hipHostFree(h->h_pin_u);
   if (h->h_pin_active) (void)hipHostFree(h->h_pin_active);
   if (h->h_pin_guess) (void)hipHostFree(h->h_pin_guess);
@@ -274,6 +298,7 @@ int mi355ndt_batch_size(const mi355ndt_handle* h) { return h ? h->n_pairs : MI35
 // ---- capacity management ----------------------------------------------------------------------
 static int ensure_pair_arrays(mi355ndt_handle* h, int n_pairs) {
   if (n_pairs <= h->cap_pairs) return MI355NDT_OK;
+  for (hipStream_t cs : h->copy_stream) HIPCHK(h, hipStreamSynchronize(cs));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   // the arrays are released and re-created one by one: until all of them exist again the engine holds no batch at all
   // (a failure half way must not leave cap_pairs vouching for freed or undersized buffers)
@@ -309,6 +334,7 @@ static int alloc_side(mi355ndt_handle* h, bool tgt, int n_pairs, size_t pitch) {
   size_t& own_pitch = tgt ? h->own_tgt_pitch : h->own_src_pitch;
   int& own_pairs = tgt ? h->own_tgt_pairs : h->own_src_pairs;
   if (buf && own_pitch == pitch && own_pairs == n_pairs) return MI355NDT_OK;
+  for (hipStream_t cs : h->copy_stream) HIPCHK(h, hipStreamSynchronize(cs));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (buf) { HIPCHK(h, hipFree(buf)); buf = nullptr; }
   HIPCHK(h, hipMalloc((void**)&buf, (size_t)n_pairs * 3 * pitch * sizeof(float)));
@@ -343,20 +369,74 @@ int mi355ndt_batch_reserve(mi355ndt_handle* h, int n_pairs, size_t max_tgt, size
   return MI355NDT_OK;
 }
 
+// The compute stream must not start before the uploads enqueued so far have landed, and an upload must not overwrite rows a
+// kernel enqueued earlier still reads: the two streams hand over through two events.
+static int uploads_before_compute(mi355ndt_handle* h) {
+  std::lock_guard<std::mutex> lk(h->up_mtx);
+  if (h->uploads_pending) {
+    for (int i = 0; i < mi355ndt_handle::UP_STREAMS; i++) {
+      HIPCHK(h, hipEventRecord(h->ev_uploads[i], h->copy_stream[i]));
+      HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_uploads[i], 0));
+    }
+    h->uploads_pending = false;
+  }
+  return MI355NDT_OK;
+}
+static int compute_enqueued(mi355ndt_handle* h) {       // call after enqueueing kernels that read the cloud buffers
+  std::lock_guard<std::mutex> lk(h->up_mtx);
+  HIPCHK(h, hipEventRecord(h->ev_compute, h->stream));
+  for (hipStream_t cs : h->copy_stream) HIPCHK(h, hipStreamWaitEvent(cs, h->ev_compute, 0));
+  return MI355NDT_OK;
+}
+
+// One host cloud -> SoA rows of pair slot `pair` in d_base, asynchronously.  Returns as soon as the caller's memory is no longer
+// needed (the records are compacted into a pinned ring slot; nothing of the caller's buffer is referenced afterwards).
 static int upload_cloud(mi355ndt_handle* h, float* d_base, size_t pitch, int pair, const void* pts, size_t n, size_t stride) {
   if (!pts && n) return MI355NDT_ERR_BAD_ARG;
   if ((n && stride < 12) || n > pitch) return MI355NDT_ERR_BAD_ARG;
-  h->h_stage.resize(3 * pitch);
-  const unsigned char* p = (const unsigned char*)pts;
-  float* sx = h->h_stage.data(); float* sy = sx + pitch; float* sz = sy + pitch;
-  for (size_t i = 0; i < n; i++) {
-    float v[3];
-    memcpy(v, p + i * stride, 12);
-    sx[i] = v[0]; sy[i] = v[1]; sz[i] = v[2];
+  mi355ndt_handle::UpSlot* u = nullptr;
+  for (;;) {                                      // a slot no other thread is filling right now
+    {
+      std::lock_guard<std::mutex> lk(h->up_mtx);
+      for (int t = 0; t < mi355ndt_handle::UP_SLOTS && !u; t++) {
+        mi355ndt_handle::UpSlot* c = &h->up[(h->up_next + t) % mi355ndt_handle::UP_SLOTS];
+        if (!c->filling) { u = c; h->up_next = (h->up_next + t + 1) % mi355ndt_handle::UP_SLOTS; c->filling = true; }
+      }
+    }
+    if (u) break;
+    std::this_thread::yield();                    // more uploader threads than slots
   }
-  for (size_t i = n; i < pitch; i++) sx[i] = sy[i] = sz[i] = 0.f;
-  HIPCHK(h, hipMemcpyAsync(d_base + (size_t)pair * 3 * pitch, h->h_stage.data(), 3 * pitch * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));   // staging buffer is reused
+  auto release = [&](int rc) { std::lock_guard<std::mutex> lk(h->up_mtx); u->filling = false; return rc; };
+  hipError_t e = hipSuccess;
+  if (!u->ev) e = hipEventCreateWithFlags(&u->ev, hipEventDisableTiming);
+  if (e == hipSuccess && u->used) e = hipEventSynchronize(u->ev);      // the slot's previous transfer has to be out of the pinned buffer
+  if (e == hipSuccess && n > u->cap) {
+    if (u->h) { (void)hipHostFree(u->h); u->h = nullptr; }
+    if (u->d) { (void)hipFree(u->d); u->d = nullptr; }
+    u->cap = 0; u->used = false;
+    const size_t cap = std::max(n, (size_t)65536);
+    e = hipHostMalloc((void**)&u->h, cap * 3 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&u->d, cap * 3 * sizeof(float));
+    if (e == hipSuccess) u->cap = cap;
+  }
+  if (e != hipSuccess) { h->err = std::string("upload staging: ") + hipGetErrorString(e); return release(MI355NDT_ERR_HIP); }
+  // the CPU part, outside the lock: x,y,z of every record into the pinned slot
+  const unsigned char* p = (const unsigned char*)pts;
+  if (stride == 12) memcpy(u->h, p, n * 12);
+  else for (size_t i = 0; i < n; i++) memcpy(u->h + 3 * i, p + i * stride, 12);
+  {
+    std::lock_guard<std::mutex> lk(h->up_mtx);
+    hipStream_t cs = h->copy_stream[(int)(u - h->up) % mi355ndt_handle::UP_STREAMS];
+    if (n) e = hipMemcpyAsync(u->d, u->h, n * 3 * sizeof(float), hipMemcpyHostToDevice, cs);
+    if (e == hipSuccess) {
+      k_deinterleave<<<(unsigned)((pitch + 255) / 256), 256, 0, cs>>>(u->d, (int)n, d_base + (size_t)pair * 3 * pitch, pitch);
+      e = hipEventRecord(u->ev, cs);
+    }
+    u->used = e == hipSuccess;
+    u->filling = false;
+    h->uploads_pending = true;
+    if (e != hipSuccess) { h->err = std::string("upload: ") + hipGetErrorString(e); return MI355NDT_ERR_HIP; }
+  }
   return MI355NDT_OK;
 }
 
@@ -366,6 +446,7 @@ int mi355ndt_batch_set_target(mi355ndt_handle* h, int pair, const void* pts, siz
   HIPCHK(h, hipSetDevice(h->device));
   int rc = upload_cloud(h, h->d_tgt_own, h->tgt_pitch, pair, pts, n, stride);
   if (rc) return rc;
+  std::lock_guard<std::mutex> lk(h->up_mtx);
   h->h_tgt_cnt[pair] = (int)n;
   h->targets_built = false;
   h->have_target = true;
@@ -378,8 +459,37 @@ int mi355ndt_batch_set_source(mi355ndt_handle* h, int pair, const void* pts, siz
   HIPCHK(h, hipSetDevice(h->device));
   int rc = upload_cloud(h, h->d_src_own, h->src_pitch, pair, pts, n, stride);
   if (rc) return rc;
+  std::lock_guard<std::mutex> lk(h->up_mtx);
   h->h_src_cnt[pair] = (int)n;
   h->have_source = true;
+  return MI355NDT_OK;
+}
+
+// A whole batch of host clouds at once: the engine's own staging threads split the pairs among themselves (staging -- copying x,y,z
+// out of the caller's records into pinned memory -- is the CPU-bound part of a host-cloud batch; one thread does ~10 k clouds/s).
+int mi355ndt_batch_set_clouds(mi355ndt_handle* h, int first_pair, int n, const void* const* targets, const size_t* target_counts,
+                              const void* const* sources, const size_t* source_counts, size_t stride, int n_threads) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (n <= 0 || first_pair < 0 || first_pair + n > h->n_pairs || (!targets && !sources) || (targets && !target_counts) || (sources && !source_counts))
+    return MI355NDT_ERR_BAD_ARG;
+  if (h->d_tgt != h->d_tgt_own || h->d_src != h->d_src_own) return MI355NDT_ERR_BAD_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  const int nt = std::max(1, std::min(n_threads > 0 ? n_threads : 8, n));
+  std::vector<int> rcs((size_t)nt, MI355NDT_OK);
+  auto work = [&](int t) {
+    (void)hipSetDevice(h->device);
+    for (int k = t; k < n; k += nt) {
+      int rc = MI355NDT_OK;
+      if (targets) rc = mi355ndt_batch_set_target(h, first_pair + k, targets[k], target_counts[k], stride);
+      if (rc == MI355NDT_OK && sources) rc = mi355ndt_batch_set_source(h, first_pair + k, sources[k], source_counts[k], stride);
+      if (rc != MI355NDT_OK) { rcs[(size_t)t] = rc; return; }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+  for (int rc : rcs) if (rc != MI355NDT_OK) return rc;
   return MI355NDT_OK;
 }
 
@@ -483,6 +593,7 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   if (h->n_pairs <= 0 || !h->d_tgt) return MI355NDT_ERR_STATE;
   HIPCHK(h, hipSetDevice(h->device));
+  { int rcu = uploads_before_compute(h); if (rcu) return rcu; }
   const int B = h->n_pairs;
   const size_t pitch = h->tgt_pitch;
   const size_t total = (size_t)B * pitch;
@@ -592,7 +703,7 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
   h->targets_built = true;
   h->cells_ready = false;
   h->last_cb = cb;
-  return MI355NDT_OK;
+  return compute_enqueued(h);                     // asynchronous: a later upload into these rows has to wait for the kernels above
 }
 
 // ---- sweeps -----------------------------------------------------------------------------------
@@ -654,6 +765,7 @@ int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_resu
   if (!guesses || !out) return MI355NDT_ERR_BAD_ARG;
   if (h->n_pairs <= 0 || !h->d_tgt || !h->d_src) return MI355NDT_ERR_STATE;
   HIPCHK(h, hipSetDevice(h->device));
+  { int rcu = uploads_before_compute(h); if (rcu) return rcu; }
   const bool mt_live = mt_is_live(h->prm);                       // impl2:888: More-Thuente loop + computeHessian are live
   const bool pca_kd = h->prm.neighbor_mode == MI355NDT_KDTREE && h->prm.variant == MI355NDT_VARIANT_PCA;
   if (!h->targets_built || (mt_live && !h->icov64_built) || (pca_kd && !h->kdw_built)) { int rc = mi355ndt_batch_build_targets(h); if (rc) return rc; }
@@ -832,18 +944,22 @@ int mi355ndt_get_aligned(mi355ndt_handle* h, void* out_pts, size_t stride) {
   if (!out_pts || stride < 12) return MI355NDT_ERR_BAD_ARG;
   if (h->n_pairs < 1 || !h->d_src) return MI355NDT_ERR_STATE;
   HIPCHK(h, hipSetDevice(h->device));
+  { int rcu = uploads_before_compute(h); if (rcu) return rcu; }
   const int n = h->h_src_cnt[0];
   if (n == 0) return MI355NDT_OK;
   HIPCHK(h, grow(h->d_aligned, h->aligned_cap, (size_t)3 * n));
+  if ((size_t)3 * n > h->pin_aligned_cap) {
+    if (h->h_pin_aligned) { HIPCHK(h, hipHostFree(h->h_pin_aligned)); h->h_pin_aligned = nullptr; h->pin_aligned_cap = 0; }
+    HIPCHK(h, hipHostMalloc((void**)&h->h_pin_aligned, (size_t)3 * n * sizeof(float)));
+    h->pin_aligned_cap = (size_t)3 * n;
+  }
+  // moved cloud as packed x,y,z triples -> pinned memory -> x,y,z of the caller's records (their other fields are left alone)
   k_transform<<<(n + 255) / 256, 256, 0, h->stream>>>(h->d_src, h->src_pitch, h->d_state, 0, h->d_aligned, n);
-  std::vector<float> tmp((size_t)3 * n);
-  HIPCHK(h, hipMemcpyAsync(tmp.data(), h->d_aligned, (size_t)3 * n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->h_pin_aligned, h->d_aligned, (size_t)3 * n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   unsigned char* o = (unsigned char*)out_pts;
-  for (int i = 0; i < n; i++) {
-    float v[3] = {tmp[i], tmp[(size_t)n + i], tmp[(size_t)2 * n + i]};
-    memcpy(o + (size_t)i * stride, v, 12);
-  }
+  if (stride == 12) memcpy(o, h->h_pin_aligned, (size_t)n * 12);
+  else for (int i = 0; i < n; i++) memcpy(o + (size_t)i * stride, h->h_pin_aligned + (size_t)3 * i, 12);
   return MI355NDT_OK;
 }
 
@@ -882,6 +998,7 @@ static int hook_ready(mi355ndt_handle* h) {
   h->ev_last_fresh = false;
   if (h->n_pairs < 1 || !h->have_target || !h->have_source) return MI355NDT_ERR_STATE;
   HIPCHK(h, hipSetDevice(h->device));
+  { int rcu = uploads_before_compute(h); if (rcu) return rcu; }
   const bool pca_kd = h->prm.neighbor_mode == MI355NDT_KDTREE && h->prm.variant == MI355NDT_VARIANT_PCA;
   if (!h->targets_built || (pca_kd && !h->kdw_built)) { int rc = mi355ndt_batch_build_targets(h); if (rc) return rc; }
   return prep_align_ws(h);
@@ -997,6 +1114,7 @@ int mi355ndt_fitness_score_T(mi355ndt_handle* h, const float T_colmajor[16], dou
   if (h->n_pairs != 1 || !h->have_target || !h->have_source) return MI355NDT_ERR_STATE;
   if (h->h_tgt_cnt[0] <= 0 || h->h_src_cnt[0] <= 0) return MI355NDT_ERR_STATE;
   HIPCHK(h, hipSetDevice(h->device));
+  { int rcu = uploads_before_compute(h); if (rcu) return rcu; }
   if (!h->targets_built) { int rc = mi355ndt_batch_build_targets(h); if (rc) return rc; }
   hipStream_t s = h->stream;
   GridDesc g;
@@ -1074,6 +1192,8 @@ int mi355ndt_prefilter(mi355ndt_handle* h, const void* pts, size_t n, size_t str
   }
   h->pf_pitch = pitch;
   int rc = upload_cloud(h, h->d_pf_in, pitch, 0, pts, n, stride);
+  if (rc) return rc;
+  rc = uploads_before_compute(h);
   if (rc) return rc;
   const int gx = (int)((pitch + 255) / 256);
   unsigned *ka = h->d_pf_keys, *kb = h->d_pf_keys + pitch, *va = h->d_pf_vals, *vb = h->d_pf_vals + pitch;
@@ -1157,6 +1277,8 @@ int mi355ndt_use_prefiltered(mi355ndt_handle* h, int role) {
   const size_t m = (size_t)h->pf_count;
   int rc = ensure_single(h, role == 2, m);
   if (rc) return rc;
+  rc = uploads_before_compute(h);                 // an earlier upload into the same rows must not land after these copies
+  if (rc) return rc;
   float* dst = role == 2 ? h->d_tgt_own : h->d_src_own;
   const size_t dp = role == 2 ? h->tgt_pitch : h->src_pitch;
   HIPCHK(h, hipMemsetAsync(dst, 0, 3 * dp * sizeof(float), h->stream));
@@ -1167,7 +1289,7 @@ int mi355ndt_use_prefiltered(mi355ndt_handle* h, int role) {
     return mi355ndt_batch_build_targets(h);
   }
   h->h_src_cnt[0] = (int)m; h->have_source = true;
-  return MI355NDT_OK;
+  return compute_enqueued(h);
 }
 
 }  // extern "C"

@@ -289,14 +289,24 @@ k_update(PairState* st, const double* __restrict__ partials, int chunks_per_pair
   finalize_pair(S, &results[b], 1);
 }
 
-// output cloud of align(): source moved by final_transformation_ (f32)
+// output cloud of align(): source moved by final_transformation_ (f32), written as packed x,y,z triples (what goes back over PCIe)
 __global__ void k_transform(const float* __restrict__ src, size_t pitch, const PairState* __restrict__ st, int b, float* out, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float* X = src + (size_t)b * 3 * pitch;
   const float* F = st[b].final_cm;
   float px = X[i], py = X[pitch + i], pz = X[2 * pitch + i];
-  for (int a = 0; a < 3; a++) out[(size_t)a * n + i] = ((F[0 * 4 + a] * px + F[1 * 4 + a] * py) + F[2 * 4 + a] * pz) + F[3 * 4 + a];
+  for (int a = 0; a < 3; a++) out[(size_t)3 * i + a] = ((F[0 * 4 + a] * px + F[1 * 4 + a] * py) + F[2 * 4 + a] * pz) + F[3 * 4 + a];
+}
+
+// host clouds arrive as packed x,y,z triples (the engine drops the other fields of the caller's records while it stages them in
+// pinned memory); this turns one cloud into the SoA rows the kernels read, zero-filling the padding up to the row pitch
+__global__ void __launch_bounds__(256) k_deinterleave(const float* __restrict__ xyz, int n, float* rows, size_t pitch) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pitch) return;
+  float x = 0.f, y = 0.f, z = 0.f;
+  if (i < (size_t)n) { x = xyz[3 * i]; y = xyz[3 * i + 1]; z = xyz[3 * i + 2]; }
+  rows[i] = x; rows[pitch + i] = y; rows[2 * pitch + i] = z;
 }
 
 

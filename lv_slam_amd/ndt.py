@@ -62,7 +62,7 @@ SYMBOLS = [
     "mi355ndt_set_params", "mi355ndt_get_params", "mi355ndt_set_stream", "mi355ndt_last_error",
     "mi355ndt_set_target", "mi355ndt_set_source", "mi355ndt_align", "mi355ndt_get_aligned", "mi355ndt_get_incremental",
     "mi355ndt_get_fitness_score", "mi355ndt_fitness_score_T", "mi355ndt_prefilter", "mi355ndt_use_prefiltered", "mi355ndt_derivatives", "mi355ndt_compute_hessian", "mi355ndt_derivatives_T", "mi355ndt_get_grid", "mi355ndt_get_voxels",
-    "mi355ndt_batch_reserve", "mi355ndt_batch_set_target", "mi355ndt_batch_set_source", "mi355ndt_batch_bind_device",
+    "mi355ndt_batch_reserve", "mi355ndt_batch_set_target", "mi355ndt_batch_set_source", "mi355ndt_batch_set_clouds", "mi355ndt_batch_bind_device",
     "mi355ndt_batch_build_targets", "mi355ndt_batch_align", "mi355ndt_batch_size", "mi355ndt_batch_pose_records",
     "mi355ndt_profile_enable", "mi355ndt_profile_reset", "mi355ndt_profile_get", "mi355ndt_synchronize",
 ]
@@ -106,6 +106,7 @@ def load_library(path: str = LIB_PATH):
     L.mi355ndt_batch_reserve.argtypes = [vp, i, sz, sz]
     L.mi355ndt_batch_set_target.argtypes = [vp, i, vp, sz, sz]
     L.mi355ndt_batch_set_source.argtypes = [vp, i, vp, sz, sz]
+    L.mi355ndt_batch_set_clouds.argtypes = [vp, i, i, vp, vp, vp, vp, sz, i]
     L.mi355ndt_batch_bind_device.argtypes = [vp, i, vp, vp, sz, vp, vp, sz]
     L.mi355ndt_batch_build_targets.argtypes = [vp]
     L.mi355ndt_batch_align.argtypes = [vp, vp, vp]
@@ -292,6 +293,21 @@ class Engine:
     def batch_set_source(self, pair, cloud):
         a = _as_points(cloud)
         self._chk(self.lib.mi355ndt_batch_set_source(self.h, pair, a.ctypes.data_as(C.c_void_p), a.shape[0], a.strides[0]), "batch_set_source")
+
+    def batch_set_target_raw(self, pair: int, ptr: int, n: int, stride: int):
+        """batch_set_target on a raw host pointer (records `stride` bytes apart); thread-safe across different pairs."""
+        self._chk(self.lib.mi355ndt_batch_set_target(self.h, pair, C.c_void_p(ptr), n, stride), "batch_set_target")
+
+    def batch_set_source_raw(self, pair: int, ptr: int, n: int, stride: int):
+        self._chk(self.lib.mi355ndt_batch_set_source(self.h, pair, C.c_void_p(ptr), n, stride), "batch_set_source")
+
+    def batch_set_clouds_raw(self, first_pair: int, tgt_ptrs, tgt_counts, src_ptrs, src_counts, stride: int, threads: int = 8):
+        """mi355ndt_batch_set_clouds: arrays of host pointers / point counts (numpy uint64), one per pair; either side may be None."""
+        n = len(tgt_ptrs if tgt_ptrs is not None else src_ptrs)
+        arr = lambda a: None if a is None else np.ascontiguousarray(a, np.uint64)
+        tp, tc, sp, sc = arr(tgt_ptrs), arr(tgt_counts), arr(src_ptrs), arr(src_counts)
+        ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        self._chk(self.lib.mi355ndt_batch_set_clouds(self.h, first_pair, n, ptr(tp), ptr(tc), ptr(sp), ptr(sc), stride, threads), "batch_set_clouds")
 
     def batch_bind_device(self, d_targets_ptr: int, target_counts, target_pitch: int, d_sources_ptr: int, source_counts, source_pitch: int):
         """Zero-copy device buffers laid out [pair][3][pitch] float32.  The caller keeps them alive."""

@@ -17,6 +17,21 @@ for variant, mode, name in ((0, ndt.DIRECT7, "ndt_omp/DIRECT7"), (1, ndt.DIRECT1
     for _ in range(20):
         t0 = time.perf_counter(); r = host(); t.append(time.perf_counter() - t0)
     t = np.array(t) * 1e3
+    # the nodelet's per-frame pattern against a resident target (scan_matching_odom_nodelet.cpp:220-221): setInputSource + align (+ output cloud)
+    src32 = np.zeros((len(src_h), 8), np.float32); src32[:, :3] = src_h          # pcl::PointXYZI records
+    def frame(cloud, out):
+        e.set_source(cloud); r = e.align(G)
+        if out: e.get_aligned()
+        return r
+    v = {}
+    for nm, cloud, out in (("xyz12", src_h, False), ("xyzi32", src32, False), ("xyzi32+output", src32, True)):
+        for _ in range(3): frame(cloud, out)
+        w = []
+        for _ in range(20):
+            t0 = time.perf_counter(); frame(cloud, out); w.append(time.perf_counter() - t0)
+        v[nm] = np.median(np.array(w) * 1e3)
+    print(f"{name}: set_source+align against a resident target: 12-B records {v['xyz12']:.3f} ms, 32-B PointXYZI records {v['xyzi32']:.3f} ms, "
+          f"with the output cloud fetched {v['xyzi32+output']:.3f} ms", flush=True)
     e2 = ndt.Engine(prm)
     n = tgt.shape[0]
     e2.batch_bind_device(T.data_ptr(), [n], n, S.data_ptr(), [n], n)
