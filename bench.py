@@ -23,6 +23,9 @@ import os
 import sys
 import time
 
+if os.environ.get("LV_SLAM_CPUS"):                   # e.g. "0-63": keep the process (and the memory it first touches) on one socket
+    lo, hi = os.environ["LV_SLAM_CPUS"].split("-")
+    os.sched_setaffinity(0, range(int(lo), int(hi) + 1))
 os.environ.setdefault("OMP_PROC_BIND", "close")      # pinned OpenMP threads for the CPU leg (read when libgomp starts)
 
 import numpy as np
@@ -49,6 +52,7 @@ def parse():
     ap.add_argument("--resolution", type=float, default=1.0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time of the parity/port sample of the cpu_baseline leg (0 = skip the leg)")
     ap.add_argument("--host-clouds", action="store_true", help="also time the drop-in path: host AoS clouds in (PCIe inclusive)")
+    ap.add_argument("--uploaders", type=int, default=0, help="staging threads per engine of the --host-clouds leg (0 = from the CPU quota)")
     ap.add_argument("--traffic", type=float, default=None, help="HBM bytes per sweep launch from separate rocprofv3 --pmc passes")
     return ap.parse_args()
 
@@ -76,6 +80,34 @@ def cpu_quota():
     except Exception:
         pass
     return None
+
+
+def pin_to_gpu_numa_node(dev_index):
+    """Keep this process -- its staging threads and the host memory it first touches -- on the NUMA node the GPU hangs off.
+    On the 2-socket hosts of this pool a staging thread that reads the clouds across the socket link halves the host-cloud rate."""
+    if os.environ.get("LV_SLAM_CPUS"):
+        return os.environ["LV_SLAM_CPUS"]
+    try:
+        from lv_slam_amd import ndt
+        node = ndt.load_library().mi355ndt_host_numa_node(dev_index)      # hipDeviceAttributeHostNumaId, else the PCI device's sysfs entry
+        if node < 0:                                   # containers often hide the PCI tree: ask the SMI
+            import re
+            import subprocess
+            txt = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showtoponuma", "-d", str(dev_index)], capture_output=True, text=True, timeout=90).stdout
+            m = re.search(r"Numa Node:\s*(-?\d+)", txt)
+            node = int(m.group(1)) if m else -1
+        if node < 0:
+            print("bench: the GPU's NUMA node is unknown, process not pinned", file=sys.stderr)
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        os.sched_setaffinity(0, cpus & os.sched_getaffinity(0))
+        return f"numa node {node} ({len(cpus)} CPUs)"
+    except Exception as e:
+        print("bench: not pinned to the GPU's NUMA node:", repr(e), file=sys.stderr)
+        return None
 
 
 def host_info():
@@ -237,6 +269,7 @@ def host_clouds_leg(a, ndt, prm, dev_index, T, S, guesses, B, N, steps, uploader
     return {"registrations_per_s": round(regs / dt, 1), "ms_per_batch_of_%d" % B: round(1e3 * dt / (2 * n_each), 3),
             "pcie_h2d_gbs": round(bytes_pcie / dt / 1e9, 2), "pcie_h2d_frac_of_gen5_x16_63gbs": round(bytes_pcie / dt / 63.0e9, 3),
             "host_records_read_gbs": round(bytes_host / dt / 1e9, 2), "record_bytes": stride, "engines": 2, "uploader_threads_per_engine": uploaders,
+            "cpu_quota": cpu_quota(), "bound": "host-side staging (reading the caller's 32-byte records with the CPUs the container may use), not PCIe",
             "what": "host pcl::PointXYZI clouds (pageable memory) -> batch_set_target/_set_source -> build -> align -> results on the host"}, results
 
 
@@ -255,6 +288,7 @@ def main():
     local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    pinned_to = pin_to_gpu_numa_node(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -365,7 +399,7 @@ def main():
     # ---- the drop-in path: host AoS clouds (pcl::PointXYZI records) in, PCIe inclusive -- rank 0's pairs, same engine
     host_path = None
     if a.host_clouds and rank == 0:
-        host_path, hres = host_clouds_leg(a, ndt, prm, local, T, S, guesses, B, N, steps=max(2, a.steps // 2))
+        host_path, hres = host_clouds_leg(a, ndt, prm, local, T, S, guesses, B, N, steps=max(2, a.steps // 2), uploaders=a.uploaders or None)
         # same bits as the device-resident run of the same pairs
         ref = np.frombuffer(res, dtype=np.uint8)
         fin = np.dtype([("final", "<f4", 16), ("tp", "<f8"), ("score", "<f8"), ("it", "<i4"), ("conv", "<i4"), ("sweeps", "<i4"), ("status", "<i4"), ("hits", "<i8")])
@@ -433,6 +467,7 @@ def main():
         "roofline": roof, "roofline_valu": roof_valu, "cpu_baseline": cpu, "parity": parity, "gather_check": gather_check,
     }
     if host_path is not None:
+        host_path["process_pinned_to"] = pinned_to
         out["value_host_clouds"] = host_path["registrations_per_s"]
         out["host_clouds"] = host_path
     print(json.dumps(out), flush=True)

@@ -99,6 +99,10 @@ typedef struct mi355ndt_handle mi355ndt_handle;
 
 const char* mi355ndt_version(void);
 int mi355ndt_device_count(void);                       /* number of usable HIP devices (0 on a CPU-only box) */
+/* NUMA node of the host CPUs closest to `device` (-1 = unknown).  Host clouds are staged by CPU threads: on a two-socket host
+ * a staging thread that reads the clouds across the socket link runs at half the rate, so keep the threads that own the
+ * clouds (and call set_source / set_target) on this node; the engine's own staging threads pin themselves to it. */
+int mi355ndt_host_numa_node(int device);
 
 /* ctor defaults of NormalDistributionsTransform() (ndt_omp_impl2.hpp:53-83) */
 int mi355ndt_default_params(mi355ndt_params* p);

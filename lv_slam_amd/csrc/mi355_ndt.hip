@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstddef>
 #include <cstring>
 #include <string>
@@ -21,6 +22,8 @@
 #include <cmath>
 #include <mutex>
 #include <thread>
+#include <sched.h>
+#include <fstream>
 
 #include "mi355_ndt.h"
 #include "ndt_math.hpp"
@@ -178,6 +181,71 @@ int mi355ndt_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+// NUMA node of the host CPUs closest to `device` (-1: unknown) -- staging threads and the clouds they read belong there
+int mi355ndt_host_numa_node(int device) {
+  int node = -1;
+  if (hipDeviceGetAttribute(&node, hipDeviceAttributeHostNumaId, device) != hipSuccess) {
+    (void)hipGetLastError();                      // not every runtime answers this attribute: leave no sticky error behind
+    // fall back to the PCI device's sysfs entry
+    char bdf[64];
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char* c = bdf; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+    std::ifstream f(std::string("/sys/bus/pci/devices/") + bdf + "/numa_node");
+    if (f && (f >> node)) return node;
+    // containers usually hide the PCI tree but show the KFD topology: find the GPU node by its PCI location, then the CPU node
+    // that has an io_link to it (KFD numbers its CPU nodes like the NUMA nodes)
+    unsigned dom = 0, bus = 0, dv = 0, fn = 0;
+    if (sscanf(bdf, "%x:%x:%x.%x", &dom, &bus, &dv, &fn) != 4) return -1;
+    const long want = (long)((bus << 8) | (dv << 3) | fn);
+    auto prop = [](const std::string& path, const char* key, long& out) {
+      std::ifstream pf(path);
+      std::string k; long v;
+      while (pf >> k >> v) if (k == key) { out = v; return true; }
+      return false;
+    };
+    const std::string top = "/sys/class/kfd/kfd/topology/nodes/";
+    int gpu_node = -1;
+    for (int n = 0; n < 64 && gpu_node < 0; n++) {
+      long loc = -1, simd = 0;
+      if (prop(top + std::to_string(n) + "/properties", "simd_count", simd) && simd > 0 &&
+          prop(top + std::to_string(n) + "/properties", "location_id", loc) && loc == want) gpu_node = n;
+    }
+    if (gpu_node < 0) return -1;
+    node = -1;
+    for (int n = 0; n < 64 && node < 0; n++) {
+      long cores = 0;
+      if (!prop(top + std::to_string(n) + "/properties", "cpu_cores_count", cores) || cores <= 0) continue;
+      for (int l = 0; l < 64; l++) {
+        long to = -1;
+        if (!prop(top + std::to_string(n) + "/io_links/" + std::to_string(l) + "/properties", "node_to", to)) break;
+        if (to == gpu_node) { node = n; break; }
+      }
+    }
+  }
+  return node;
+}
+
+// CPUs of a NUMA node as an affinity mask (empty on failure)
+static bool numa_cpus(int node, cpu_set_t* set) {
+  CPU_ZERO(set);
+  if (node < 0) return false;
+  std::ifstream f("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist");
+  std::string txt;
+  if (!f || !std::getline(f, txt)) return false;
+  bool any = false;
+  size_t pos = 0;
+  while (pos < txt.size()) {
+    size_t comma = txt.find(',', pos);
+    std::string part = txt.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+    size_t dash = part.find('-');
+    int lo = atoi(part.c_str()), hi = dash == std::string::npos ? lo : atoi(part.c_str() + dash + 1);
+    for (int c = lo; c <= hi && c < CPU_SETSIZE; c++) { CPU_SET(c, set); any = true; }
+    if (comma == std::string::npos) break;
+    pos = comma + 1;
+  }
+  return any;
 }
 
 int mi355ndt_default_params(mi355ndt_params* p) {
@@ -476,8 +544,11 @@ int mi355ndt_batch_set_clouds(mi355ndt_handle* h, int first_pair, int n, const v
   HIPCHK(h, hipSetDevice(h->device));
   const int nt = std::max(1, std::min(n_threads > 0 ? n_threads : 8, n));
   std::vector<int> rcs((size_t)nt, MI355NDT_OK);
+  cpu_set_t near;
+  const bool pin = numa_cpus(mi355ndt_host_numa_node(h->device), &near);
   auto work = [&](int t) {
     (void)hipSetDevice(h->device);
+    if (pin && t > 0) (void)sched_setaffinity(0, sizeof near, &near);   // the engine's own threads stage next to the GPU (t = 0 is the caller's thread)
     for (int k = t; k < n; k += nt) {
       int rc = MI355NDT_OK;
       if (targets) rc = mi355ndt_batch_set_target(h, first_pair + k, targets[k], target_counts[k], stride);

@@ -58,7 +58,7 @@ class Profile(C.Structure):
 
 # every symbol include/mi355_ndt.h declares
 SYMBOLS = [
-    "mi355ndt_version", "mi355ndt_device_count", "mi355ndt_default_params", "mi355ndt_create", "mi355ndt_destroy",
+    "mi355ndt_version", "mi355ndt_device_count", "mi355ndt_host_numa_node", "mi355ndt_default_params", "mi355ndt_create", "mi355ndt_destroy",
     "mi355ndt_set_params", "mi355ndt_get_params", "mi355ndt_set_stream", "mi355ndt_last_error",
     "mi355ndt_set_target", "mi355ndt_set_source", "mi355ndt_align", "mi355ndt_get_aligned", "mi355ndt_get_incremental",
     "mi355ndt_get_fitness_score", "mi355ndt_fitness_score_T", "mi355ndt_prefilter", "mi355ndt_use_prefiltered", "mi355ndt_derivatives", "mi355ndt_compute_hessian", "mi355ndt_derivatives_T", "mi355ndt_get_grid", "mi355ndt_get_voxels",
@@ -84,6 +84,7 @@ def load_library(path: str = LIB_PATH):
     L.mi355ndt_last_error.restype = C.c_char_p
     L.mi355ndt_last_error.argtypes = [vp]
     L.mi355ndt_default_params.argtypes = [C.POINTER(Params)]
+    L.mi355ndt_host_numa_node.argtypes = [i]
     L.mi355ndt_create.argtypes = [C.POINTER(Params), i, C.POINTER(vp)]
     L.mi355ndt_destroy.argtypes = [vp]
     L.mi355ndt_set_params.argtypes = [vp, C.POINTER(Params)]

@@ -90,3 +90,63 @@ def test_config5_full_size_vs_oracle(mode):
 def test_nodelet_configuration_batch_vs_oracle():
     """what the live nodelet sets (scan_matching_odom_nodelet.cpp:109-119): ndt_pca, DIRECT1, 1 m -- 65,536-pt pairs."""
     run_and_check([0, 5, 11, 270], 1024, dict(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=ndt.DIRECT1, variant=1))
+
+
+def test_host_cloud_batch_upload_paths_agree():
+    """The drop-in host path for a batch: pcl::PointXYZI-style 32-byte records in ordinary host memory, staged by the engine's
+    own threads (mi355ndt_batch_set_clouds), by several caller threads (batch_set_target / batch_set_source on different pairs)
+    and one cloud at a time -- ragged cloud sizes -- all give the bits of the device-resident run of the same pairs
+    (the call pattern being batched: scan_matching_odom_nodelet.cpp:220-221)."""
+    import threading
+    kw = dict(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=ndt.DIRECT7, variant=0)
+    pairs = []
+    for k in range(6):
+        t, s, dT = synth.make_pair(40 + k, 256 if k % 2 else 192)
+        t, s = t.numpy(), s.numpy()[: len(s) - 1000 * k - 1]
+        t32 = np.zeros((len(t), 8), np.float32); t32[:, :3] = t; t32[:, 3] = 1.0; t32[:, 4] = 7.0
+        s32 = np.zeros((len(s), 8), np.float32); s32[:, :3] = s; s32[:, 3] = 1.0; s32[:, 4] = 9.0
+        pairs.append((t32, s32))
+    B = len(pairs)
+    G = synth.default_guess()
+    mt, ms = max(len(p[0]) for p in pairs), max(len(p[1]) for p in pairs)
+
+    def run(fill):
+        eng = ndt.Engine(ndt.default_params(**kw))
+        eng.batch_reserve(B, mt, ms)
+        fill(eng)
+        eng.batch_build_targets()
+        r = eng.batch_align(G)
+        v = eng.get_voxels(B - 1)
+        eng.close()
+        return r, v
+
+    def one_by_one(eng):
+        for k, (t, s) in enumerate(pairs):
+            eng.batch_set_target(k, t)
+            eng.batch_set_source(k, s)
+
+    def own_threads(eng):
+        tp = np.array([p[0].ctypes.data for p in pairs], np.uint64); tc = np.array([len(p[0]) for p in pairs], np.uint64)
+        sp = np.array([p[1].ctypes.data for p in pairs], np.uint64); sc = np.array([len(p[1]) for p in pairs], np.uint64)
+        eng.batch_set_clouds_raw(0, tp, tc, sp, sc, 32, threads=4)
+
+    def caller_threads(eng):
+        def up(w):
+            for k in range(w, B, 3):
+                eng.batch_set_source_raw(k, pairs[k][1].ctypes.data, len(pairs[k][1]), 32)
+                eng.batch_set_target_raw(k, pairs[k][0].ctypes.data, len(pairs[k][0]), 32)
+        th = [threading.Thread(target=up, args=(w,)) for w in range(3)]
+        [t.start() for t in th]; [t.join() for t in th]
+
+    ref, vref = run(one_by_one)
+    for fill in (own_threads, caller_threads):
+        got, v = run(fill)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a["final"], b["final"]) and a["score"] == b["score"] and a["iterations"] == b["iterations"]
+        assert np.array_equal(v["mean"], vref["mean"]) and np.array_equal(v["icov"], vref["icov"])
+    # and against the oracle
+    for k in (0, B - 1):
+        ro = O.align(O.Grid(pairs[k][0][:, :3].copy(), O.default_params(**kw)), pairs[k][1][:, :3].copy(), G)
+        assert ref[k]["iterations"] == ro["iterations"]
+        dt, dr = se3_err(ro["final"], ref[k]["final"])
+        assert dt < 1e-4 and dr < 1e-5
