@@ -61,3 +61,18 @@ def test_two_ranks_on_one_gpu_gather(extra, total):
     assert g["pairs_gathered"] == total and g["permutation_of_all_pair_ids"] is True and g["own_records_bit_identical_on_every_rank"] is True
     assert g["record_bytes"] == 96 and g["packed_on_device"] is True
     assert d["config"]["converged"] == d["config"]["pairs_rank0"]
+
+
+def test_default_workload_parity_leg_covers_the_whole_batch():
+    """BASELINE config 3 as bench.py runs it by default (271 pairs x 65,536 pts, ndt_omp, 1 m, DIRECT7): the line's parity leg
+    checks every pair of the batch against the oracle -- same iteration counts, SE(3) inside the north-star tolerance -- and the
+    roofline block is internally consistent."""
+    d = run_bench(["--steps", "5", "--warmup", "2", "--cpu-seconds", "20"])
+    p = d["parity"]
+    assert p["pairs_checked"] == 271 and p["iterations_equal"] == 271 and p["max_dtrans_m"] < 1e-4 and p["max_drot_rad"] < 1e-5
+    assert d["config"]["converged"] == 271 and d["config"]["pairs_total"] == 271
+    r = d["roofline"]
+    assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3 and r["hits_per_point"] > 3.5
+    assert abs(r["alg_bytes_per_launch"] * r["launches"] / (r["sweep_ms_per_step"] * 1e-3 * d["steps"]) / 1e9 - r["achieved"]) < 0.02 * r["achieved"]
+    c = d["cpu_baseline"]
+    assert set(c["reference_shaped_by_threads"]) == set(c["optimised_port_by_threads"]) and c["value"] > 0
