@@ -474,7 +474,6 @@ static int upload_cloud(mi355ndt_handle* h, float* d_base, size_t pitch, int pai
     if (u) break;
     std::this_thread::yield();                    // more uploader threads than slots
   }
-  auto release = [&](int rc) { std::lock_guard<std::mutex> lk(h->up_mtx); u->filling = false; return rc; };
   hipError_t e = hipSuccess;
   if (!u->ev) e = hipEventCreateWithFlags(&u->ev, hipEventDisableTiming);
   if (e == hipSuccess && u->used) e = hipEventSynchronize(u->ev);      // the slot's previous transfer has to be out of the pinned buffer
@@ -487,7 +486,12 @@ static int upload_cloud(mi355ndt_handle* h, float* d_base, size_t pitch, int pai
     if (e == hipSuccess) e = hipMalloc((void**)&u->d, cap * 3 * sizeof(float));
     if (e == hipSuccess) u->cap = cap;
   }
-  if (e != hipSuccess) { h->err = std::string("upload staging: ") + hipGetErrorString(e); return release(MI355NDT_ERR_HIP); }
+  if (e != hipSuccess) {
+    std::lock_guard<std::mutex> lk(h->up_mtx);
+    h->err = std::string("upload staging: ") + hipGetErrorString(e);
+    u->filling = false;
+    return MI355NDT_ERR_HIP;
+  }
   // the CPU part, outside the lock: x,y,z of every record into the pinned slot
   const unsigned char* p = (const unsigned char*)pts;
   if (stride == 12) memcpy(u->h, p, n * 12);
