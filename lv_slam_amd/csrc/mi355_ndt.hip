@@ -93,6 +93,7 @@ struct mi355ndt_handle {
   SweepCtl* d_ctl = nullptr;                      // two control blocks: the sweep reading one zeroes the other for the next round
   int ctl_idx = 0;                                // block the NEXT sweep reads (k_init_state / k_update fill it)
   int n_cu = 256;
+  int dyn_shift = -1;                             // < 0: per search mode (make_sweep_const); MI355NDT_SWEEP_DYN_SHIFT overrides (tuning runs)
   int* h_pin_active = nullptr;
   hipEvent_t ev_burst[2] = {nullptr, nullptr};   // one per in-flight burst of align rounds
   unsigned long long* d_hits = nullptr;         // (point,voxel) evaluations, all sweeps
@@ -279,6 +280,7 @@ int mi355ndt_create(const mi355ndt_params* params, int device, mi355ndt_handle**
   h->device = device;
   h->prm = p;
   { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
+  if (const char* e = std::getenv("MI355NDT_SWEEP_DYN_SHIFT")) { const int v = std::atoi(e); if (v >= 0 && v <= 30) h->dyn_shift = v; }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
     return MI355NDT_ERR_HIP;
@@ -806,6 +808,7 @@ static void make_sweep_const(const mi355ndt_handle* h, SweepConst& sc) {
   { int ex; float mant = std::frexp(h->prm.resolution, &ex); sc.leaf_pow2 = (mant == 0.5f) && ex > -100 && ex < 100; sc.inv_leaf = 1.0f / h->prm.resolution; }
   sc.kd_r2 = (float)((double)h->prm.resolution * (double)h->prm.resolution);   // KdTreeFLANN::radiusSearch: float(radius * radius)
   build_offsets(h->prm.neighbor_mode, sc);
+  sc.dyn_shift = h->dyn_shift >= 0 ? h->dyn_shift : (sc.K == 1 ? 3 : 2);
 }
 
 static int launch_sweep(mi355ndt_handle* h, const SweepConst& sc) {
@@ -1369,3 +1372,13 @@ int mi355ndt_use_prefiltered(mi355ndt_handle* h, int role) {
 
 }  // extern "C"
 
+
+#ifdef NDT_TIMELINE
+extern "C" int mi355ndt_debug_timeline(unsigned long long* out) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tl), sizeof(z)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_tl), z, sizeof(z)) != hipSuccess) return -1;
+  return 0;
+}
+#endif

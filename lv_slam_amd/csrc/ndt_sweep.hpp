@@ -119,6 +119,14 @@ __host__ __device__ constexpr int probe_off(int K, int q, int a) {
 //   item end: flush the queue tail, fixed-tree wave reduction -> one 44-double partial row per (chunk, quarter).
 // The partial rows depend only on (CHUNK_PTS, input order), never on the launch geometry or on which wave ran the item, so
 // single and batched runs of one pair are bit-identical.
+// -DNDT_TIMELINE: per-phase shader-clock stamps of every work item, summed over all waves into g_tl (read back through
+// mi355ndt_debug_timeline; tools/sweep_timeline.py).  Costs ~10 % and is never part of the shipped library.
+#ifdef NDT_TIMELINE
+__device__ unsigned long long g_tl[8];
+#define TL_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); tl[k] += t_ - tl_last; tl_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TL_STAMP(k) do {} while (0)
+#endif
 struct SweepCtl {               // 9 ints; two of them alternate: the sweep that reads one clears the other
   int n_active;                 // pairs whose next sweep is pending (entries of active_list)
   int next_item[8];             // per-XCD work-item cursors of the sweep
@@ -186,25 +194,46 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
   if (blockIdx.x == 0 && threadIdx.x < 9) reinterpret_cast<int*>(ctl_next)[threadIdx.x] = 0;
   if (n_active == 0) return;                       // nothing left to sweep (the loop's last, empty round)
   const int my_xcd = blockIdx.x & 7;
+  // Items of a queue are handed out in two ways.  The first `n_static` rounds are STATIC: wave `wx` of the XCD's `xw` waves takes
+  // items wx, wx + xw, ...; only the rest of the queue is claimed with an atomic.  Why: VMEM operations of a wave complete in
+  // order (vmcnt), so every load issued after a returning atomic -- an agent-scope atomic takes ~4 us here -- waits for it;
+  // with one claim per item the point loads of every item sat behind one (measured with -DNDT_TIMELINE: 10 k cycles per item).
+  // The dynamic tail (1 / 2^sc.dyn_shift of the queue, more when that is no whole round) absorbs the imbalance.
+  const int xw = (int)(gridDim.x >> 3) * WAVES;  // waves per XCD
+  const int wx = (int)(blockIdx.x >> 3) * WAVES + wv;
+#ifdef NDT_TIMELINE
+  unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tl_last = __builtin_readcyclecounter();
+#endif
 #pragma unroll 1
   for (int probe = 0; probe < 8; probe++) {        // own XCD first, then steal
     const int xcd = (my_xcd + probe) & 7;
     const int pairs_here = n_active > xcd ? (n_active - xcd + 7) / 8 : 0;
     const int items_here = pairs_here * items_per_pair;
     if (items_here == 0) continue;
-    // a drained queue is recognised with a plain (L2) load; only a queue that still has items costs an atomic
-    if (__hip_atomic_load(&ctl->next_item[xcd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= items_here) continue;
+    // static rounds of this queue (the same number for every wave; none when the grid is no multiple of 8 or for a thief)
+    const int n_static = ((gridDim.x & 7) == 0) ? (items_here - (items_here >> sc.dyn_shift)) / xw : 0;
+    const int dyn0 = n_static * xw;               // first item of the dynamic tail
+    int round = 0;
+    const bool own = (probe == 0) && n_static > 0;
     int item = 0;
-    if (lane == 0) item = atomicAdd(&ctl->next_item[xcd], 1);
-    item = __builtin_amdgcn_readfirstlane(item);
+    if (own) item = wx;
+    else {
+      // a drained queue is recognised with a plain (L2) load; only a queue that still has items costs an atomic
+      if (dyn0 + __hip_atomic_load(&ctl->next_item[xcd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= items_here) continue;
+      if (lane == 0) item = dyn0 + atomicAdd(&ctl->next_item[xcd], 1);
+      item = __builtin_amdgcn_readfirstlane(item);
+    }
 #pragma unroll 1
     while (item < items_here) {
-      // claim the NEXT item now; the atomic's round trip is hidden behind this item's work
+      // the next item: static while rounds are left, else claimed NOW (the atomic's round trip is hidden behind this item's work)
+      const bool next_static = own && (round + 1 < n_static);
       int next_item = 0;
-      if (lane == 0) next_item = atomicAdd(&ctl->next_item[xcd], 1);
+      if (!next_static && lane == 0) next_item = dyn0 + atomicAdd(&ctl->next_item[xcd], 1);
       const int b = active_list[xcd + 8 * (item / items_per_pair)];
       const int rem = item % items_per_pair;
       const int chunk = rem / QUARTERS, quarter = rem % QUARTERS;
+      TL_STAMP(0);
 
   const PairState& S = st[b];
   const int n = S.n_src;
@@ -298,6 +327,7 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
         nx[p] = ny[p] = nz[p] = 0.f;
         if (i < n) { nx[p] = X[i]; ny[p] = X[pitch + i]; nz[p] = X[2 * pitch + i]; }
       }
+      TL_STAMP(1);
 #pragma unroll 1
       for (int st = 0; st < NST; st++) {
         if (wbase + st * TP * 64 >= n) break;        // wave-uniform
@@ -342,6 +372,7 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
         }
         // probes run last-to-first so the ndt_pca weight of a hit (product of its own and all LATER hits' weights,
         // ndt_pca_impl2.hpp:295-296) is a running product; the order of the f64 additions is free anyway.
+        TL_STAMP(2);
         double suf[TP];
 #pragma unroll
         for (int p = 0; p < TP; p++) suf[p] = 1.0;
@@ -363,6 +394,7 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
               bwv[p][j] = *reinterpret_cast<const uint4*>(W + (cellv[p][j] >> 6));
             }
           }
+          TL_STAMP(3);
           unsigned idv[TP][Q_GROUP];
           int wiv[TP][Q_GROUP];
 #pragma unroll
@@ -403,11 +435,14 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
             }
           }
           __builtin_amdgcn_wave_barrier();
+          TL_STAMP(4);
           drain_full();
+          TL_STAMP(5);
         }
       }
       __builtin_amdgcn_wave_barrier();
       if (qcount > 0) drain(qcount);
+      TL_STAMP(5);
     }
     // Fixed-order reduction of the wave -> one 44-double row per (chunk, quarter).  Same pairwise tree as a 64-lane xor
     // butterfly (distance 32, 16, 8, 4, 2, 1 -- so the same bits), but as a reduce-scatter: the distance-32 and -16
@@ -443,9 +478,16 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
       for (int i = 0; i < 11; i++) if (base + i < 43) P[base + i] = P2[i];
       if (lane == 0) P[43] = (double)nhits;
     }
+    TL_STAMP(6);
+#ifdef NDT_TIMELINE
+    tl[7] += 1;
+#endif
   }
-      item = __builtin_amdgcn_readfirstlane(next_item);
+      if (next_static) { round++; item = wx + round * xw; }
+      else item = __builtin_amdgcn_readfirstlane(next_item);
     }
   }
+#ifdef NDT_TIMELINE
+  if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_tl[k], tl[k]);
+#endif
 }
-

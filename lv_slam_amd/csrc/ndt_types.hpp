@@ -72,6 +72,7 @@ struct SweepConst {
   float  kd_r2;                // KDTREE: float(resolution * resolution), the squared search radius
   int    leaf_pow2;            // resolution is a power of two: x / leaf == x * inv_leaf bit for bit
   float  inv_leaf;
+  int    dyn_shift;            // the sweep claims 1 / 2^dyn_shift of every work queue dynamically, the rest is dealt statically
 };
 
 // Neighbour offsets in the reference's probe order.  DIRECT1: voxel_grid_covariance_omp_impl.hpp:441;

@@ -15,7 +15,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355ndt.so")
+# MI355NDT_LIB: another build of the same library (A/B runs of kernel variants)
+LIB_PATH = os.environ.get("MI355NDT_LIB") or os.path.join(_HERE, "libmi355ndt.so")
 
 # pclomp::NeighborSearchMethod (include/ndt_omp/ndt_omp.h:51-56)
 KDTREE, DIRECT26, DIRECT7, DIRECT1 = 0, 1, 2, 3
