@@ -92,6 +92,36 @@ def test_nodelet_configuration_batch_vs_oracle():
     run_and_check([0, 5, 11, 270], 1024, dict(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=ndt.DIRECT1, variant=1))
 
 
+@pytest.mark.parametrize("mode,variant", [(ndt.DIRECT7, 0), (ndt.DIRECT1, 1)])
+def test_results_do_not_depend_on_how_work_items_are_dealt(mode, variant, monkeypatch):
+    """The sweep deals most of every per-XCD work queue statically and claims only the tail with atomics.  Which
+    wave runs an item must not change a bit of the result: all-dynamic (shift 0), half, the shipped setting and almost-all-static
+    (shift 6) give identical poses, scores and hit counts for a batch big enough (24 x 65,536 pts = 3,072 items) to have static
+    rounds."""
+    ids = list(range(100, 124))
+    T, S, host, n = resident_batch(ids, 1024)
+    B = len(ids)
+    G = synth.default_guess()
+    kw = dict(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=mode, variant=variant)
+    ref = None
+    for shift in ("0", "1", None, "6"):
+        if shift is None:
+            monkeypatch.delenv("MI355NDT_SWEEP_DYN_SHIFT", raising=False)
+        else:
+            monkeypatch.setenv("MI355NDT_SWEEP_DYN_SHIFT", shift)
+        eng = ndt.Engine(ndt.default_params(**kw))          # the knob is read when the engine is created
+        eng.batch_bind_device(T.data_ptr(), [n] * B, n, S.data_ptr(), [n] * B, n)
+        eng.batch_build_targets()
+        res = eng.batch_align(G)
+        eng.close()
+        if ref is None:
+            ref = res
+            continue
+        for a, b in zip(ref, res):
+            assert np.array_equal(a["final"], b["final"]) and a["score"] == b["score"] and a["iterations"] == b["iterations"]
+            assert a["hits_last"] == b["hits_last"] and a["sweeps"] == b["sweeps"]
+
+
 def test_host_cloud_batch_upload_paths_agree():
     """The drop-in host path for a batch: pcl::PointXYZI-style 32-byte records in ordinary host memory, staged by the engine's
     own threads (mi355ndt_batch_set_clouds), by several caller threads (batch_set_target / batch_set_source on different pairs)
