@@ -27,6 +27,10 @@ if os.environ.get("LV_SLAM_CPUS"):                   # e.g. "0-63": keep the pro
     lo, hi = os.environ["LV_SLAM_CPUS"].split("-")
     os.sched_setaffinity(0, range(int(lo), int(hi) + 1))
 os.environ.setdefault("OMP_PROC_BIND", "close")      # pinned OpenMP threads for the CPU leg (read when libgomp starts)
+# ... and a libgomp that starts with OMP_PROC_BIND set binds the thread that loaded it to ONE cpu, which every thread created
+# later inherits: remember what the process may use, and give it back to the threads that are not OpenMP's (apply_affinity)
+ALLOWED_CPUS = set(os.sched_getaffinity(0))
+PIN_CPUS = None
 
 import numpy as np
 import torch
@@ -103,11 +107,22 @@ def pin_to_gpu_numa_node(dev_index):
         for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
             lo, _, hi = part.partition("-")
             cpus.update(range(int(lo), int(hi or lo) + 1))
-        os.sched_setaffinity(0, cpus & os.sched_getaffinity(0))
-        return f"numa node {node} ({len(cpus)} CPUs)"
+        global PIN_CPUS
+        PIN_CPUS = (cpus & ALLOWED_CPUS) or set(ALLOWED_CPUS)
+        os.sched_setaffinity(0, PIN_CPUS)
+        return f"numa node {node} ({len(PIN_CPUS)} CPUs)"
     except Exception as e:
         print("bench: not pinned to the GPU's NUMA node:", repr(e), file=sys.stderr)
         return None
+
+
+def apply_affinity():
+    """(Re-)apply the process-wide CPU set to the calling thread: the GPU's NUMA node if known, else everything allowed."""
+    try:
+        os.sched_setaffinity(0, PIN_CPUS or ALLOWED_CPUS)
+    except OSError:
+        pass
+    return len(os.sched_getaffinity(0))
 
 
 def host_info():
@@ -223,6 +238,7 @@ def host_clouds_leg(a, ndt, prm, dev_index, T, S, guesses, B, N, steps, uploader
     uploader threads, so that one engine's uploads overlap the other's kernels (scan_matching_odom_nodelet.cpp:220-221 is the
     per-frame call pattern this batches)."""
     import threading
+    main_cpus_before = len(os.sched_getaffinity(0))
     if uploaders is None:                              # staging threads per engine: within the CPUs the container may use
         uploaders = max(1, min(8, ((cpu_quota() or os.cpu_count() or 8) - 4) // 2))
     rec = 8                                            # floats per PointXYZI record: x y z 1 | intensity pad pad pad
@@ -235,6 +251,7 @@ def host_clouds_leg(a, ndt, prm, dev_index, T, S, guesses, B, N, steps, uploader
     results = {}
 
     def drive(idx, nsteps, out):
+        out["cpus%d" % idx] = apply_affinity()        # not the one cpu an OpenMP runtime may have bound the main thread to
         eng = ndt.Engine(prm, device=dev_index)
         eng.batch_reserve(B, N, N)
         res = (ndt.Result * B)()
@@ -242,14 +259,22 @@ def host_clouds_leg(a, ndt, prm, dev_index, T, S, guesses, B, N, steps, uploader
         sptr = srp + np.arange(B, dtype=np.uint64) * np.uint64(N * stride)
         cnt = np.full(B, N, np.uint64)
 
+        phases = []
+
         def one():
+            t0 = time.perf_counter()
             eng.batch_set_clouds_raw(0, tptr, cnt, sptr, cnt, stride, uploaders)     # the engine's own staging threads
+            t1 = time.perf_counter()
             eng.batch_build_targets()
             eng.batch_align_raw(guesses, res)
+            phases.append((t1 - t0, time.perf_counter() - t1))
         one()                                          # warm-up (allocations, pinned slots)
+        phases.clear()
         out["barrier"].wait()
         for _ in range(nsteps):
             one()
+        out["t_end%d" % idx] = time.perf_counter()  # before the teardown (freeing the pinned ring takes milliseconds)
+        out["phases%d" % idx] = phases
         out[idx] = np.frombuffer(res, dtype=np.uint8).copy()
         eng.close()
 
@@ -262,13 +287,16 @@ def host_clouds_leg(a, ndt, prm, dev_index, T, S, guesses, B, N, steps, uploader
     t0 = time.perf_counter()
     for t in th:
         t.join()
-    dt = time.perf_counter() - t0
+    dt = max(results.pop("t_end0"), results.pop("t_end1")) - t0
     regs = 2 * n_each * B
+    ph = np.array(results.pop("phases0") + results.pop("phases1"))
+    results.pop("cpus1")
     bytes_pcie = regs * 2 * N * 12                     # what crosses the link: x,y,z of both clouds
     bytes_host = regs * 2 * N * stride                 # what the staging threads read from the caller's records
     return {"registrations_per_s": round(regs / dt, 1), "ms_per_batch_of_%d" % B: round(1e3 * dt / (2 * n_each), 3),
             "pcie_h2d_gbs": round(bytes_pcie / dt / 1e9, 2), "pcie_h2d_frac_of_gen5_x16_63gbs": round(bytes_pcie / dt / 63.0e9, 3),
-            "host_records_read_gbs": round(bytes_host / dt / 1e9, 2), "record_bytes": stride, "engines": 2, "uploader_threads_per_engine": uploaders,
+            "host_records_read_gbs": round(bytes_host / dt / 1e9, 2), "record_bytes": stride, "engines": 2, "cpus_of_the_driving_threads": results.pop("cpus0"), "cpus_of_the_main_thread": main_cpus_before,
+            "staging_ms_per_batch_median": round(1e3 * float(np.median(ph[:, 0])), 2), "build_align_ms_per_batch_median": round(1e3 * float(np.median(ph[:, 1])), 2), "uploader_threads_per_engine": uploaders,
             "cpu_quota": cpu_quota(), "bound": "host-side staging (reading the caller's 32-byte records with the CPUs the container may use), not PCIe",
             "what": "host pcl::PointXYZI clouds (pageable memory) -> batch_set_target/_set_source -> build -> align -> results on the host"}, results
 

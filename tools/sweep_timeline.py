@@ -1,11 +1,12 @@
 """Where a sweep work item spends its time: per-phase shader-clock totals from a library built with -DNDT_TIMELINE
 (hipcc <the flags of __graft_entry__.HIP_FLAGS> -DNDT_TIMELINE ... -o lv_slam_amd/libexp_tl.so; MI355NDT_LIB=<that file>).
-MODE=direct1|direct7 VARIANT=omp|pca PAIRS=271.  The shipped library has no such hook."""
+MODE=direct1|direct7 VARIANT=omp|pca PAIRS=271 AZIMUTH=1024 RESOLUTION=1.0.  The shipped library has no such hook."""
 import sys, os, ctypes
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lv_slam_amd import ndt, synth
-B, NAZ = int(os.environ.get("PAIRS", 271)), 1024
+B, NAZ = int(os.environ.get("PAIRS", 271)), int(os.environ.get("AZIMUTH", 1024))
+RES = float(os.environ.get("RESOLUTION", 1.0))
 MODE = {"direct7": ndt.DIRECT7, "direct1": ndt.DIRECT1}[os.environ.get("MODE", "direct7")]
 VAR = 1 if os.environ.get("VARIANT", "omp") == "pca" else 0
 dev = torch.device("cuda:0")
@@ -14,7 +15,7 @@ T = torch.empty(B, 3, N, device=dev); S = torch.empty(B, 3, N, device=dev)
 for b in range(B):
     t, s, _ = synth.make_pair(b, NAZ, device=dev)
     T[b] = t.T; S[b] = s.T
-eng = ndt.Engine(ndt.default_params(trans_epsilon=0.01, max_iterations=0, neighbor_mode=MODE, variant=VAR), device=0)
+eng = ndt.Engine(ndt.default_params(resolution=RES, trans_epsilon=0.01, max_iterations=0, neighbor_mode=MODE, variant=VAR), device=0)
 eng.batch_bind_device(T.data_ptr(), [N] * B, N, S.data_ptr(), [N] * B, N)
 G = synth.default_guess()
 guesses = np.ascontiguousarray(np.broadcast_to(G.T.reshape(1, 16), (B, 16)), dtype=np.float32)
