@@ -9,7 +9,8 @@ Pairs are sharded round-robin over ranks (pair index i -> rank i mod N), no data
   default            : weak scaling, every rank owns `--pairs` pairs (BASELINE config 3 per GPU: 271)
   --total-pairs 4541 : BASELINE config 4 as worded -- a fixed job of T pairs over the N ranks (strong scaling,
                        shards differ by at most one pair; the shorter ones pad their record block with pair_id = -1)
-  --host-clouds      : adds the drop-in path's rate (host AoS clouds in, PCIe inclusive) as `value_host_clouds`
+  (N = 1)            : also reports the drop-in path's rate (host AoS clouds in, PCIe inclusive) as `value_host_clouds`;
+                       --no-host-clouds skips that leg, --host-clouds forces it for N > 1 (rank 0)
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel: the derivative
 sweep, algorithmic bytes / HIP-event time, peak 8 TB/s HBM), `roofline_valu` (what actually bounds the sweep) and
@@ -55,7 +56,8 @@ def parse():
     ap.add_argument("--variant", default="omp", choices=["omp", "pca"])
     ap.add_argument("--resolution", type=float, default=1.0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time of the parity/port sample of the cpu_baseline leg (0 = skip the leg)")
-    ap.add_argument("--host-clouds", action="store_true", help="also time the drop-in path: host AoS clouds in (PCIe inclusive)")
+    ap.add_argument("--host-clouds", action="store_true", help="time the drop-in path (host AoS clouds in, PCIe inclusive) also when N > 1")
+    ap.add_argument("--no-host-clouds", action="store_true", help="skip the drop-in path's leg (on by default in the single-GPU run)")
     ap.add_argument("--uploaders", type=int, default=0, help="staging threads per engine of the --host-clouds leg (0 = from the CPU quota)")
     ap.add_argument("--traffic", type=float, default=None, help="HBM bytes per sweep launch from separate rocprofv3 --pmc passes")
     return ap.parse_args()
@@ -238,6 +240,8 @@ def host_clouds_leg(a, ndt, prm, dev_index, T, S, guesses, B, N, steps, uploader
     uploader threads, so that one engine's uploads overlap the other's kernels (scan_matching_odom_nodelet.cpp:220-221 is the
     per-frame call pattern this batches)."""
     import threading
+    B = min(B, 271)                                    # one config-3 batch at most: the leg holds every cloud twice in host memory
+    T, S, guesses = T[:B], S[:B], guesses[:B]
     main_cpus_before = len(os.sched_getaffinity(0))
     if uploaders is None:                              # staging threads per engine: within the CPUs the container may use
         uploaders = max(1, min(8, ((cpu_quota() or os.cpu_count() or 8) - 4) // 2))
@@ -426,13 +430,15 @@ def main():
 
     # ---- the drop-in path: host AoS clouds (pcl::PointXYZI records) in, PCIe inclusive -- rank 0's pairs, same engine
     host_path = None
-    if a.host_clouds and rank == 0:
+    if rank == 0 and not a.no_host_clouds and (a.host_clouds or world == 1):
         host_path, hres = host_clouds_leg(a, ndt, prm, local, T, S, guesses, B, N, steps=max(2, a.steps // 2), uploaders=a.uploaders or None)
         # same bits as the device-resident run of the same pairs
         ref = np.frombuffer(res, dtype=np.uint8)
         fin = np.dtype([("final", "<f4", 16), ("tp", "<f8"), ("score", "<f8"), ("it", "<i4"), ("conv", "<i4"), ("sweeps", "<i4"), ("status", "<i4"), ("hits", "<i8")])
+        nh = len(np.frombuffer(hres[0], dtype=fin))      # the leg's pairs: the first min(B, 271) of the batch
+        host_path["pairs_per_batch"] = nh
         host_path["bit_identical_to_device_resident_run"] = bool(all(
-            np.array_equal(np.frombuffer(hres[i], dtype=fin)["final"], res_np["final"]) and np.array_equal(np.frombuffer(hres[i], dtype=fin)["score"], res_np["score"])
+            np.array_equal(np.frombuffer(hres[i], dtype=fin)["final"], res_np["final"][:nh]) and np.array_equal(np.frombuffer(hres[i], dtype=fin)["score"], res_np["score"][:nh])
             for i in range(2)))
 
     if rank != 0:

@@ -48,6 +48,12 @@ def test_single_gpu_line_contract():
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "reference_shaped_by_threads" in c
     p = d["parity"]
     assert p["pairs_checked"] >= 3 and p["iterations_equal"] == p["pairs_checked"] and p["max_dtrans_m"] < 1e-4 and p["max_drot_rad"] < 1e-5
+    # the drop-in path's leg (host AoS clouds in, PCIe inclusive) is part of the default single-GPU line, and never `value`
+    h = d["host_clouds"]
+    assert d["value_host_clouds"] == h["registrations_per_s"] > 0 and h["bit_identical_to_device_resident_run"] is True
+    assert h["pairs_per_batch"] == 6 and h["record_bytes"] == 32
+    assert "value_host_clouds" not in run_bench(["--pairs", "4", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0",
+                                                 "--no-host-clouds"])
 
 
 @pytest.mark.parametrize("extra,total", [(["--pairs", "5"], 10), (["--total-pairs", "11"], 11)])

@@ -17,7 +17,7 @@ cd $R
 timeout 500 tools/pmc_kernel.sh k_sweep sq_direct7 > $O/pmc_sq_direct7.txt 2>&1
 timeout 500 tools/pmc_kernel.sh k_sweep sq_pca_direct1 --variant pca --mode direct1 > $O/pmc_sq_pca_direct1.txt 2>&1
 # bench lines (CPU baseline + pose-by-pose parity legs on)
-timeout 600 python bench.py --host-clouds 2> $O/bench.log | tail -1 > $O/bench.json
+timeout 600 python bench.py 2> $O/bench.log | tail -1 > $O/bench.json
 timeout 400 python bench.py --variant pca --mode direct1 2>> $O/bench.log | tail -1 > $O/bench_pca_d1.json
 timeout 400 python bench.py --variant pca --mode direct7 --resolution 0.5 --azimuth 2048 --pairs 128 2>> $O/bench.log | tail -1 > $O/bench_cfg5.json
 timeout 400 python bench.py --variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128 2>> $O/bench.log | tail -1 > $O/bench_cfg5_d1.json
