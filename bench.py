@@ -322,9 +322,13 @@ def main():
     dev = torch.device("cuda", local)
     pinned_to = pin_to_gpu_numa_node(local)
     dist = None
-    if world > 1:
+    # LV_SLAM_BENCH_FORCE_DIST=1: a single rank still goes through the process group, the device-packed records and the RCCL
+    # all-gather -- the N > 1 code path on a one-GPU box (tests/test_bench_gpu.py)
+    use_dist = world > 1 or bool(os.environ.get("LV_SLAM_BENCH_FORCE_DIST"))
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")   # (torch.distributed.run sets both; the forced single-rank mode may not)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -367,12 +371,12 @@ def main():
     rec_dev = torch.empty(cap, shard.REC_WORDS, device=dev, dtype=torch.int32)
     on_dev = backend == "nccl"
     rec_host = None if on_dev else torch.empty(cap, shard.REC_WORDS, dtype=torch.int32).pin_memory()   # gloo functional check only
-    gathered = torch.empty(world * cap, shard.REC_WORDS, device=dev if on_dev else "cpu", dtype=torch.int32) if world > 1 else None
+    gathered = torch.empty(world * cap, shard.REC_WORDS, device=dev if on_dev else "cpu", dtype=torch.int32) if use_dist else None
 
     def step():
         eng.batch_build_targets()                 # setInputTarget for every pair: voxelise
         eng.batch_align_raw(guesses, res)         # align every pair (synchronous: results on the host)
-        if world > 1:                             # pose gather: 96 B per pair, no host hop on the RCCL path
+        if use_dist:                              # pose gather: 96 B per pair, no host hop on the RCCL path
             eng.batch_pose_records(rank, world, rec_dev.data_ptr(), cap)
             if on_dev:
                 shard.gather_records(rec_dev, gathered)

@@ -54,9 +54,12 @@ def pack_records(finals: np.ndarray, scores, iterations, converged, pair_ids, ca
 def gather_records(rec: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
     """All-gather the per-rank record blocks (same shape on every rank).  Returns [world*cap, 24] on rec.device."""
     import torch.distributed as dist
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
-        return rec.clone()
+    if not dist.is_initialized():                  # no process group: the block is the result
+        if out is None:
+            return rec.clone()
+        out.copy_(rec)
+        return out
+    world = dist.get_world_size()                  # (a group of one rank still goes through the collective)
     if out is None:
         out = torch.empty(world * rec.shape[0], rec.shape[1], dtype=rec.dtype, device=rec.device)
     if dist.get_backend() == "gloo":

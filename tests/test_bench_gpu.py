@@ -69,6 +69,17 @@ def test_two_ranks_on_one_gpu_gather(extra, total):
     assert d["config"]["converged"] == d["config"]["pairs_rank0"]
 
 
+def test_single_rank_through_rccl():
+    """The N > 1 code path with the backend the driver's scaling runs use (nccl = RCCL), as far as one GPU can take it: a single
+    rank made to go through the process group, the records packed on the device and all_gather_into_tensor on device memory."""
+    d = run_bench(["--pairs", "7", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-host-clouds"],
+                  env_extra={"LV_SLAM_BENCH_FORCE_DIST": "1", "MASTER_PORT": str(free_port()), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    g = d["gather_check"]
+    assert g["backend"] == "nccl" and g["host_hop"] is False and g["packed_on_device"] is True
+    assert g["pairs_gathered"] == 7 and g["permutation_of_all_pair_ids"] is True and g["own_records_bit_identical_on_every_rank"] is True
+    assert d["n_gpus"] == 1 and d["config"]["converged"] == 7
+
+
 def test_default_workload_parity_leg_covers_the_whole_batch():
     """BASELINE config 3 as bench.py runs it by default (271 pairs x 65,536 pts, ndt_omp, 1 m, DIRECT7): the line's parity leg
     checks every pair of the batch against the oracle -- same iteration counts, SE(3) inside the north-star tolerance -- and the
