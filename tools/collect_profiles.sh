@@ -7,10 +7,10 @@ O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # per-kernel times (trace only, no counters)
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py --cpu-seconds 0 > $O/kt_bench.json 2> $O/kt.log
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py --cpu-seconds 0 --no-host-clouds > $O/kt_bench.json 2> $O/kt.log
 # HBM-side traffic of the sweep: FETCH_SIZE and WRITE_SIZE in separate passes, no trace domains
-timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex k_sweep --output-format csv -d $O/fetch -- python $R/bench.py --cpu-seconds 0 --steps 4 --warmup 1 > /dev/null 2> $O/fetch.log
-timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex k_sweep --output-format csv -d $O/write -- python $R/bench.py --cpu-seconds 0 --steps 4 --warmup 1 > /dev/null 2> $O/write.log
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex k_sweep --output-format csv -d $O/fetch -- python $R/bench.py --cpu-seconds 0 --no-host-clouds --steps 4 --warmup 1 > /dev/null 2> $O/fetch.log
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex k_sweep --output-format csv -d $O/write -- python $R/bench.py --cpu-seconds 0 --no-host-clouds --steps 4 --warmup 1 > /dev/null 2> $O/write.log
 rm -rf $O/kt/*/*.db $O/fetch/*/*.db $O/write/*/*.db
 cd $R
 # SQ / TCP / TCC counters of the sweep: the headline workload and the live nodelet's configuration
