@@ -11,7 +11,7 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 def one(pattern):
     f = glob.glob(os.path.join(SRC, pattern), recursive=True)
     assert f, pattern
-    return f[0]
+    return max(f, key=os.path.getmtime)       # merged scratch directories may still hold an older run's files
 
 
 # ---- kernel stats (engine kernels only; torch kernels of the synthetic data generator are summed into one line)
