@@ -735,11 +735,12 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
   if (want_kdw) HIPCHK(h, grow(h->d_kdw, h->kdw_cap, h->recs_cap));
   {
     unsigned *ka = h->d_keys_a, *kb = h->d_keys_b;
-    // stable sort by cell inside every target's segment (ndt_segsort.hpp): ceil(cb / 8) passes, result in kb / d_vals_b
-    const int npass = (cb + RS_BITS - 1) / RS_BITS;
+    // stable sort by cell inside every target's segment (ndt_segsort.hpp): rs_plan(cb) passes, result in kb / d_vals_b
+    const RsPlan plan = rs_plan(cb);
+    const int npass = plan.passes;
     const int tiles = (int)((pitch + RS_TILE - 1) / RS_TILE);
     {
-      const size_t need = (size_t)B * tiles * RS_NB;
+      const size_t need = ((size_t)B * tiles) << RS_MAX_BITS;
       if (need > h->rs_cap) {
         size_t c1 = 0, c2 = 0;
         if (h->d_rs_hist) { HIPCHK(h, hipFree(h->d_rs_hist)); h->d_rs_hist = nullptr; }
@@ -752,10 +753,7 @@ int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
     unsigned *vin = (npass & 1) ? h->d_vals_a : h->d_vals_b, *vout = (npass & 1) ? h->d_vals_b : h->d_vals_a;
     k_keys<unsigned><<<dim3(gx, B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_grid, kin, nullptr, cb);
     for (int p = 0; p < npass; p++) {
-      k_rs_hist<<<xcd_grid(tiles, B), RS_THREADS, 0, s>>>(kin, pitch, p * RS_BITS, h->d_rs_hist, tiles, B);
-      k_rs_scan<<<B, RS_NB, 0, s>>>(h->d_rs_hist, h->d_rs_offs, tiles);
-      if (p == 0) k_rs_scatter<true><<<xcd_grid(tiles, B), RS_THREADS, 0, s>>>(kin, vin, kout, vout, pitch, p * RS_BITS, h->d_rs_offs, tiles, B);
-      else k_rs_scatter<false><<<xcd_grid(tiles, B), RS_THREADS, 0, s>>>(kin, vin, kout, vout, pitch, p * RS_BITS, h->d_rs_offs, tiles, B);
+      rs_pass(s, plan.bits, kin, vin, kout, vout, pitch, p * plan.bits, h->d_rs_hist, h->d_rs_offs, tiles, B, p == 0);
       std::swap(kin, kout); std::swap(vin, vout);
     }
     k_mark<unsigned><<<dim3(gx4, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, minpts, cb);
@@ -1279,7 +1277,7 @@ int mi355ndt_prefilter(mi355ndt_handle* h, const void* pts, size_t n, size_t str
   const int pf_tiles = (int)((pitch + RS_TILE - 1) / RS_TILE);
   const int pf_chunks = (int)((pitch + PF_SCAN_CHUNK - 1) / PF_SCAN_CHUNK);
   {
-    const size_t need = (size_t)pf_tiles * RS_NB;
+    const size_t need = (size_t)pf_tiles << RS_MAX_BITS;
     if (need > h->rs_cap) {
       size_t c1 = 0, c2 = 0;
       if (h->d_rs_hist) { HIPCHK(h, hipFree(h->d_rs_hist)); h->d_rs_hist = nullptr; }
@@ -1310,14 +1308,13 @@ int mi355ndt_prefilter(mi355ndt_handle* h, const void* pts, size_t n, size_t str
     } else {
       k_pf_keys<<<gx, 256, 0, s>>>(h->d_pf_in, pitch, (int)n, h->d_pf_keep, h->d_pf_grid, ka, va);
       // stable sort by voxel index: the target build's segment sort with the whole cloud as its one segment, 31 key bits
+      const RsPlan plan = rs_plan(31);
       unsigned *kin = ka, *kout = kb, *vin = va, *vout = vb;
-      for (int p = 0; p < 4; p++) {
-        k_rs_hist<<<xcd_grid(pf_tiles, 1), RS_THREADS, 0, s>>>(kin, pitch, p * RS_BITS, h->d_rs_hist, pf_tiles, 1);
-        k_rs_scan<<<1, RS_NB, 0, s>>>(h->d_rs_hist, h->d_rs_offs, pf_tiles);
-        k_rs_scatter<false><<<xcd_grid(pf_tiles, 1), RS_THREADS, 0, s>>>(kin, vin, kout, vout, pitch, p * RS_BITS, h->d_rs_offs, pf_tiles, 1);
+      for (int p = 0; p < plan.passes; p++) {
+        rs_pass(s, plan.bits, kin, vin, kout, vout, pitch, p * plan.bits, h->d_rs_hist, h->d_rs_offs, pf_tiles, 1, false);
         std::swap(kin, kout); std::swap(vin, vout);
       }
-      keys_sorted = kin; vals_sorted = vin;      // four hops: back in ka / va
+      keys_sorted = kin; vals_sorted = vin;      // (an odd number of hops ends in kb / vb)
     }
   }
   k_pf_heads<<<gx, 256, 0, s>>>(keys_sorted, h->d_pf_keep, (int)n, pitch, downsample, h->d_pf_flag);

@@ -4,25 +4,38 @@
 // stay bit-identical to the reference's sequential accumulation, voxel_grid_covariance_omp_impl.hpp:226-262).  A device-wide
 // radix sort of pair << cb | cell does that, but sorts bits it does not have to (the pair field is already in order) and
 // scatters every pass across the whole batch.  Here each pass moves a point only within its own target's segment
-// (65,536 points = 512 KB of keys + ids: the scatter stays in one XCD's L2), 8 bits per pass over the cell field only:
-// 3 passes for a 1 m KITTI-size grid instead of 4 device-wide ones.
+// (65,536 points = 512 KB of keys + ids: the scatter stays in one XCD's L2), over the cell field only, with the digit width
+// chosen per build from the field's width (rs_plan): 2 passes of 10 bits for a 1 m KITTI-size grid (19-20 bits; measured
+// 220 us against 259 us for 3 passes of 8 bits), 2 of 11 bits at 0.5 m, 3 of 11 for the prefilter's 31-bit voxel keys.
 //   per pass:  k_rs_hist  (tile digit histograms)  ->  k_rs_scan (per segment, digit-major exclusive scan)  ->  k_rs_scatter
-// A tile is 2048 consecutive positions handled by 4 waves, each owning 512 consecutive positions in 8 rounds of 64, so the
+// A tile is 4096 consecutive positions handled by 4 waves, each owning 1024 consecutive positions in 16 rounds of 64, so the
 // order inside a tile is (wave, round, lane) = position order, which is what makes the pass stable.
 #pragma once
 #include "ndt_types.hpp"
 
-#define RS_BITS    8
-#define RS_NB      (1 << RS_BITS)
+#define RS_MAX_BITS 11
 #define RS_THREADS 256
-#define RS_ROUNDS  8
+#define RS_ROUNDS  16
 #define RS_TILE    (RS_THREADS * RS_ROUNDS)
 
-// lanes of the wave holding the same digit as this lane (valid lanes only); RS_BITS ballots
+// digit width and pass count for a key field of `bits` bits: as few passes as 11-bit digits allow, then the narrowest of the
+// instantiated widths (8, 10, 11) that still covers the field in that many passes
+struct RsPlan { int bits, passes; };
+static inline RsPlan rs_plan(int field_bits) {
+  RsPlan p;
+  p.passes = (field_bits + RS_MAX_BITS - 1) / RS_MAX_BITS;
+  if (p.passes < 1) p.passes = 1;
+  const int need = (field_bits + p.passes - 1) / p.passes;
+  p.bits = need <= 8 ? 8 : (need <= 10 ? 10 : 11);
+  return p;
+}
+
+// lanes of the wave holding the same digit as this lane (valid lanes only); BITS ballots
+template <int BITS>
 __device__ __forceinline__ unsigned long long rs_match(unsigned d, bool valid) {
   unsigned long long m = __ballot(valid);
 #pragma unroll
-  for (int bit = 0; bit < RS_BITS; bit++) {
+  for (int bit = 0; bit < BITS; bit++) {
     const bool one = (d >> bit) & 1u;
     const unsigned long long bb = __ballot(one);
     m &= one ? bb : ~bb;
@@ -31,8 +44,10 @@ __device__ __forceinline__ unsigned long long rs_match(unsigned d, bool valid) {
 }
 
 // digit histogram of every tile: hist[(b * tiles + tile) * RS_NB + d]
+template <int BITS>
 __global__ void __launch_bounds__(RS_THREADS) k_rs_hist(const unsigned* __restrict__ kin, size_t pitch, int shift, unsigned* hist, int tiles,
                                                         int n_targets) {
+  constexpr int RS_NB = 1 << BITS;
   __shared__ unsigned cnt[RS_THREADS / 64][RS_NB];
   int b, tile;
   if (!xcd_map(tiles, n_targets, tile, b)) return;
@@ -49,7 +64,7 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_hist(const unsigned* __restri
   }
   // Counting needs no ranks, only totals: equal digits mostly come in runs (neighbouring points of a scan fall into the same
   // cell), so the head of each run adds the run's length with one LDS atomic -- a dozen instructions per round instead of the
-  // eight ballots of a full digit match.
+  // ballots of a full digit match.
 #pragma unroll
   for (int r = 0; r < RS_ROUNDS; r++) {
     const size_t i = wbase + r * 64 + lane;
@@ -71,26 +86,41 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_hist(const unsigned* __restri
 }
 
 // per segment: where does digit d of tile t start?  (digit-major, tile-minor exclusive scan; one block per segment)
-__global__ void __launch_bounds__(RS_NB) k_rs_scan(const unsigned* __restrict__ hist, unsigned* offs, int tiles) {
-  __shared__ unsigned sm[RS_NB / 64 + 1];
-  const int b = blockIdx.x, d = threadIdx.x;
+template <int BITS>
+__global__ void __launch_bounds__((1 << BITS) > 1024 ? 1024 : (1 << BITS)) k_rs_scan(const unsigned* __restrict__ hist, unsigned* offs, int tiles) {
+  constexpr int RS_NB = 1 << BITS, NT = RS_NB > 1024 ? 1024 : RS_NB, PER = RS_NB / NT;   // PER consecutive digits per thread
+  __shared__ unsigned sm[NT / 64 + 1];
+  const int b = blockIdx.x;
   const unsigned* H = hist + (size_t)b * tiles * RS_NB;
   unsigned* O = offs + (size_t)b * tiles * RS_NB;
-  unsigned tot = 0;
-  for (int t = 0; t < tiles; t++) tot += H[(size_t)t * RS_NB + d];
+  unsigned tot[PER], sum = 0;
+#pragma unroll
+  for (int u = 0; u < PER; u++) {
+    const int d = threadIdx.x * PER + u;
+    tot[u] = 0;
+    for (int t = 0; t < tiles; t++) tot[u] += H[(size_t)t * RS_NB + d];
+    sum += tot[u];
+  }
   unsigned all;
-  unsigned base = block_exscan<RS_NB>(tot, &all, sm);
-  for (int t = 0; t < tiles; t++) {
-    O[(size_t)t * RS_NB + d] = base;
-    base += H[(size_t)t * RS_NB + d];
+  unsigned base = block_exscan<NT>(sum, &all, sm);
+#pragma unroll
+  for (int u = 0; u < PER; u++) {
+    const int d = threadIdx.x * PER + u;
+    unsigned o = base;
+    for (int t = 0; t < tiles; t++) {
+      O[(size_t)t * RS_NB + d] = o;
+      o += H[(size_t)t * RS_NB + d];
+    }
+    base += tot[u];
   }
 }
 
 // stable scatter of one tile.  FIRST: the point id of position i is i itself (no id array to read yet).
-template <bool FIRST>
+template <int BITS, bool FIRST>
 __global__ void __launch_bounds__(RS_THREADS) k_rs_scatter(const unsigned* __restrict__ kin, const unsigned* __restrict__ vin,
                                                             unsigned* kout, unsigned* vout, size_t pitch, int shift,
                                                             const unsigned* __restrict__ offs, int tiles, int n_targets) {
+  constexpr int RS_NB = 1 << BITS;
   __shared__ unsigned run[RS_THREADS / 64][RS_NB];
   int b, tile;
   if (!xcd_map(tiles, n_targets, tile, b)) return;   // a target's tiles on one XCD: its scattered writes combine in that L2
@@ -114,7 +144,7 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_scatter(const unsigned* __res
     const size_t i = wbase + r * 64 + lane;
     const bool valid = i < pitch;
     const unsigned d = (key[r] >> shift) & (RS_NB - 1);
-    const unsigned long long m = rs_match(d, valid);
+    const unsigned long long m = rs_match<BITS>(d, valid);
     const unsigned rank = (unsigned)__popcll(m & lt), c = (unsigned)__popcll(m);
     const unsigned leader = valid ? (unsigned)__ffsll((long long)m) - 1u : (unsigned)lane;
     if (valid && rank == 0) run[w][d] += c;
@@ -143,4 +173,21 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_scatter(const unsigned* __res
     if (valid) { KO[prev + rank] = key[r]; VO[prev + rank] = val[r]; }
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+// One stable pass over `field` bits starting at bit `shift` of the keys of every segment: histogram, scan, scatter.
+template <int BITS>
+static inline void rs_pass_bits(hipStream_t s, const unsigned* kin, const unsigned* vin, unsigned* kout, unsigned* vout, size_t pitch, int shift,
+                                unsigned* hist, unsigned* offs, int tiles, int n_segments, bool first) {
+  k_rs_hist<BITS><<<xcd_grid(tiles, n_segments), RS_THREADS, 0, s>>>(kin, pitch, shift, hist, tiles, n_segments);
+  k_rs_scan<BITS><<<n_segments, (1 << BITS) > 1024 ? 1024 : (1 << BITS), 0, s>>>(hist, offs, tiles);
+  if (first) k_rs_scatter<BITS, true><<<xcd_grid(tiles, n_segments), RS_THREADS, 0, s>>>(kin, vin, kout, vout, pitch, shift, offs, tiles, n_segments);
+  else k_rs_scatter<BITS, false><<<xcd_grid(tiles, n_segments), RS_THREADS, 0, s>>>(kin, vin, kout, vout, pitch, shift, offs, tiles, n_segments);
+}
+// `first`: the point id of position i is i itself (no id array to read yet)
+static inline void rs_pass(hipStream_t s, int bits, const unsigned* kin, const unsigned* vin, unsigned* kout, unsigned* vout, size_t pitch, int shift,
+                           unsigned* hist, unsigned* offs, int tiles, int n_segments, bool first) {
+  if (bits == 8) rs_pass_bits<8>(s, kin, vin, kout, vout, pitch, shift, hist, offs, tiles, n_segments, first);
+  else if (bits == 10) rs_pass_bits<10>(s, kin, vin, kout, vout, pitch, shift, hist, offs, tiles, n_segments, first);
+  else rs_pass_bits<11>(s, kin, vin, kout, vout, pitch, shift, hist, offs, tiles, n_segments, first);
 }
