@@ -1,0 +1,40 @@
+"""CPU: bench.py's host-side helpers (argument contract, CPU-set handling) -- no GPU, no timing."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_defaults_follow_the_driver_contract(monkeypatch):
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert a.gpus == 1 and a.steps > 0 and a.warmup >= 0 and a.pairs == 271 and a.azimuth * 64 == 65536
+    assert a.mode == "direct7" and a.variant == "omp" and a.resolution == 1.0 and a.total_pairs == 0
+    assert a.host_clouds is False and a.no_host_clouds is False          # the leg is on by default at N = 1 (main decides)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2", "--total-pairs", "4541"])
+    a = bench.parse()
+    assert (a.gpus, a.steps, a.warmup, a.total_pairs) == (8, 5, 2, 4541)
+
+
+def test_allowed_cpu_set_is_captured_and_reapplied():
+    """bench.py remembers the CPUs the process may use before numpy / torch (and their OpenMP runtimes) are imported and gives
+    them back to the threads it starts itself: a runtime started with OMP_PROC_BIND narrows the loading thread's affinity."""
+    import bench
+    assert bench.ALLOWED_CPUS and bench.ALLOWED_CPUS <= set(range(os.cpu_count() or 4096))
+    before = os.sched_getaffinity(0)
+    try:
+        one = {sorted(bench.ALLOWED_CPUS)[0]}
+        os.sched_setaffinity(0, one)                                     # what an OpenMP runtime may have done to this thread
+        n = bench.apply_affinity()
+        assert n == len(bench.PIN_CPUS or bench.ALLOWED_CPUS) and n >= 1
+        assert os.sched_getaffinity(0) == (bench.PIN_CPUS or bench.ALLOWED_CPUS)
+    finally:
+        os.sched_setaffinity(0, before)
+
+
+def test_cpu_quota_is_a_positive_count_or_unknown():
+    import bench
+    q = bench.cpu_quota()
+    assert q is None or q >= 1
