@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cmath>
 #include <mutex>
+#include <atomic>
 #include <thread>
 #include <sched.h>
 #include <fstream>
@@ -552,10 +553,11 @@ int mi355ndt_batch_set_clouds(mi355ndt_handle* h, int first_pair, int n, const v
   std::vector<int> rcs((size_t)nt, MI355NDT_OK);
   cpu_set_t near;
   const bool pin = numa_cpus(mi355ndt_host_numa_node(h->device), &near);
-  auto work = [&](int t) {
+  std::atomic<int> next_pair{0};                 // pairs are taken one by one: a thread that runs slowly (the caller's, t = 0, may
+  auto work = [&](int t) {                       // sit on a narrowed CPU set) simply takes fewer of them
     (void)hipSetDevice(h->device);
     if (pin && t > 0) (void)sched_setaffinity(0, sizeof near, &near);   // the engine's own threads stage next to the GPU (t = 0 is the caller's thread)
-    for (int k = t; k < n; k += nt) {
+    for (int k = next_pair.fetch_add(1); k < n; k = next_pair.fetch_add(1)) {
       int rc = MI355NDT_OK;
       if (targets) rc = mi355ndt_batch_set_target(h, first_pair + k, targets[k], target_counts[k], stride);
       if (rc == MI355NDT_OK && sources) rc = mi355ndt_batch_set_source(h, first_pair + k, sources[k], source_counts[k], stride);

@@ -48,6 +48,8 @@ if os.environ.get("PRE", "0") != "0":
 bar = threading.Barrier(NENG+1)
 stats = {}
 def drive(idx):
+    if os.environ.get("NARROW"):                  # both driving threads confined to ONE cpu (what an OpenMP runtime did to bench.py)
+        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
     eng = ndt.Engine(prm, device=0); eng.batch_reserve(B,N,N)
     res = (ndt.Result*B)()
     tptr = tgp + np.arange(B, dtype=np.uint64)*np.uint64(N*stride); sptr = srp + np.arange(B, dtype=np.uint64)*np.uint64(N*stride)
