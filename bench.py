@@ -46,11 +46,13 @@ MODES = {"direct1": 3, "direct7": 2, "direct26": 1, "kdtree": 0}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: as many as make the timed region >= 0.5 s, at least 20)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=271, help="pairs per GPU per step (BASELINE config 3: 271); weak scaling")
     ap.add_argument("--total-pairs", type=int, default=0,
                     help="fixed job of this many pairs over all ranks (BASELINE config 4: 4541); strong scaling; overrides --pairs")
+    ap.add_argument("--config4-pairs", type=int, default=4541,
+                    help="size of the BASELINE config 4 job timed beside the default weak-scaling line (strong scaling over the same ranks; 0 = skip)")
     ap.add_argument("--azimuth", type=int, default=1024, help="firings per revolution; x64 beams = points per cloud")
     ap.add_argument("--mode", default="direct7", choices=sorted(MODES))
     ap.add_argument("--variant", default="omp", choices=["omp", "pca"])
@@ -200,36 +202,24 @@ def cpu_leg(a, T, S, G, res_np, B):
         port[str(th)] = protocol(lambda: O.Grid(tg0, op), lambda g: O.align(g, sr0, G), th, reps=10, warm=2)
     best_port = max(port, key=lambda k: port[k]["registrations_per_s"])
     best_shaped = max(shaped, key=lambda k: shaped[k]["registrations_per_s"]) if shaped else None
-    # (3) batch sample with the port at its best thread count; pose-by-pose parity of the GPU results
-    O.lib().ora_set_threads(int(best_port))
-    done, t_cpu, worst, it_match = 0, 0.0, (0.0, 0.0), 0
-    while done < B and (done < 3 or t_cpu < a.cpu_seconds):
-        tg = T[done].T.contiguous().cpu().numpy()
-        sr = S[done].T.contiguous().cpu().numpy()
-        c0 = time.perf_counter()
-        ro = O.align(O.Grid(tg, op), sr, G)
-        t_cpu += time.perf_counter() - c0
-        e = se3_err(ro["final"], res_np["final"][done].reshape(4, 4).T)
-        worst = (max(worst[0], e[0]), max(worst[1], e[1]))
-        it_match += int(ro["iterations"] == int(res_np["it"][done]))
-        done += 1
-    O.lib().ora_set_threads(0)
+    # (3) batch sample with the port at its best thread count; pose-by-pose parity of the GPU results (sample spread over the index range)
+    parity, port_batch = parity_leg(a, T, S, G, res_np, B, seconds=a.cpu_seconds, threads=int(best_port))
     label = "CPU restatement of ndt_omp (reference not buildable in this environment)"
-    if best_shaped is not None:
-        value, cores, what = shaped[best_shaped]["registrations_per_s"], int(best_shaped), "reference-shaped arrangement (oracle/ndt_oracle_refshape.inc)"
-    else:
-        value, cores, what = port[best_port]["registrations_per_s"], int(best_port), "optimised port (the reference-shaped arrangement does not cover KDTREE)"
+    # `value` = the FASTEST CPU arrangement measured (the optimised port at its best thread count), so that any GPU/CPU ratio taken
+    # from it is the conservative one; the reference-shaped arrangement SURVEY 8(d) asks for stands next to it under its own name
+    value, cores = port[best_port]["registrations_per_s"], int(best_port)
     cpu = {"value": value, "unit": "registrations/s", "cores": cores, "kind": "port",
-           "sample": f"pair 0 of this workload, one registration = target build + align, {what}: 3 warm-ups then the median of 20 repeats at "
-                     f"{settings} threads (OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}); value = the fastest setting; {label}",
+           "arrangement_of_value": "optimised port of the oracle (dense cell table, fused transform, OpenMP over 256-point chunks)",
+           "value_reference_shaped": shaped[best_shaped]["registrations_per_s"] if best_shaped is not None else None,
+           "cores_reference_shaped": int(best_shaped) if best_shaped is not None else None,
+           "arrangement_reference_shaped": "oracle/ndt_oracle_refshape.inc: ordered-map grid, serial build, per-point heap neighbour lists, exp(p) + dense 4x6 / 24x6 "
+                                           "matrices per evaluation, cloud rewrite per sweep, schedule(guided, 8) -- SURVEY.md 8(d)" if best_shaped is not None else
+                                           "not available (the reference-shaped arrangement does not cover KDTREE)",
+           "sample": f"pair 0 of this workload, one registration = target build + align: 3 warm-ups then the median of 20 repeats (reference-shaped) / "
+                     f"2 warm-ups then the median of 10 (port) at {settings} threads (OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}); each value = the fastest setting; {label}",
            "host": f"{model}; {phys} physical cores, {logical} logical CPUs" + (f", cgroup CPU quota {quota} CPUs (the 'all cores' setting is {usable} threads)" if quota else ""),
            "reference_shaped_by_threads": shaped, "optimised_port_by_threads": port,
-           "optimised_port_batch": {"registrations_per_s": round(done / t_cpu, 3), "threads": int(best_port),
-                                    "sample": f"first {done} of the {B} pairs, total wall / count"}}
-    parity = {"pairs_checked": done, "max_dtrans_m": worst[0], "max_drot_rad": worst[1], "iterations_equal": it_match,
-              "tolerance": "trans<1e-4 m, rot<1e-5 rad", "oracle": "parity unpinned (no reference-originated vectors exist, DESIGN.md 2)",
-              "note": "pairs that never converge (iterations = max_iterations + 2, e.g. ndt_pca with DIRECT26 where the compounding "
-                      "weights make the iteration oscillate) amplify rounding-order differences and are not comparable pose by pose"}
+           "optimised_port_batch": port_batch}
     return cpu, parity
 
 
@@ -305,6 +295,51 @@ def host_clouds_leg(a, ndt, prm, dev_index, T, S, guesses, B, N, steps, uploader
             "what": "host pcl::PointXYZI clouds (pageable memory) -> batch_set_target/_set_source -> build -> align -> results on the host"}, results
 
 
+RES_DT = np.dtype([("final", "<f4", 16), ("tp", "<f8"), ("score", "<f8"), ("it", "<i4"), ("conv", "<i4"), ("sweeps", "<i4"), ("status", "<i4"), ("hits", "<i8")])
+
+
+def spread_order(n):
+    """Indices 0..n-1 in an order whose every prefix covers the whole range evenly (bit-reversal / van der Corput), with the last
+    index moved to second place: a time-bounded parity sample then spans the job's index range instead of its first pairs."""
+    bits = max(1, (n - 1).bit_length())
+    order = sorted(range(n), key=lambda i: int(format(i, f"0{bits}b")[::-1], 2))
+    if n > 2:
+        order.remove(n - 1)
+        order.insert(1, n - 1)
+    return order
+
+
+def parity_leg(a, T, S, G, res_np, B, seconds, threads):
+    """Pose-by-pose check of the GPU results of one job against the oracle on a time-bounded sample that is spread over the whole
+    index range of the job (spread_order); doubles as the batch rate of the optimised port."""
+    from oracle import oracle_py as O
+    kw = dict(resolution=a.resolution, trans_epsilon=0.01, max_iterations=64, neighbor_mode=MODES[a.mode], variant=1 if a.variant == "pca" else 0)
+    op = O.default_params(**kw)
+    O.lib().ora_set_threads(int(threads))
+    done, t_cpu, worst, it_match, conv_match, idx_seen = 0, 0.0, (0.0, 0.0), 0, 0, []
+    for k in spread_order(B):
+        if done >= 3 and t_cpu >= seconds:
+            break
+        tg = T[k].T.contiguous().cpu().numpy()
+        sr = S[k].T.contiguous().cpu().numpy()
+        c0 = time.perf_counter()
+        ro = O.align(O.Grid(tg, op), sr, G)
+        t_cpu += time.perf_counter() - c0
+        e = se3_err(ro["final"], res_np["final"][k].reshape(4, 4).T)
+        worst = (max(worst[0], e[0]), max(worst[1], e[1]))
+        it_match += int(ro["iterations"] == int(res_np["it"][k]))
+        conv_match += int(bool(ro["converged"]) == bool(res_np["conv"][k]))
+        idx_seen.append(k)
+        done += 1
+    O.lib().ora_set_threads(0)
+    parity = {"pairs_checked": done, "max_dtrans_m": worst[0], "max_drot_rad": worst[1], "iterations_equal": it_match, "converged_flags_equal": conv_match,
+              "sample": f"{done} of the {B} pairs of rank 0, spread over the whole index range (bit-reversal order; slots {min(idx_seen)}..{max(idx_seen)} touched)",
+              "tolerance": "trans<1e-4 m, rot<1e-5 rad", "oracle": "parity unpinned (no reference-originated vectors exist, DESIGN.md 2; error bar: BASELINE.md 5)",
+              "note": "pairs that never converge (iterations = max_iterations + 2, e.g. ndt_pca with DIRECT26 where the compounding "
+                      "weights make the iteration oscillate) amplify rounding-order differences and are not comparable pose by pose"}
+    return parity, {"registrations_per_s": round(done / max(t_cpu, 1e-9), 3), "threads": int(threads), "sample": f"{done} of the {B} pairs, total wall / count"}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -346,104 +381,185 @@ def main():
     total = a.total_pairs if strong else a.pairs * world
     if total < world:
         raise SystemExit("fewer pairs than ranks")
+    # The config-4 block (BASELINE config 4 as worded: ONE fixed job of 4,541 pairs sharded round-robin over the N ranks, strong
+    # scaling) rides along with the default weak-scaling line, so that a driver that only ever passes --gpus N still measures it.
+    # Both jobs give pair i to rank i mod N, so a rank's pairs of either job are a prefix of the same sequence rank, rank + N, ...:
+    # the clouds are generated once, for the longer of the two prefixes.
+    c4_total = 0 if (strong or a.config4_pairs <= 0 or a.config4_pairs < world) else a.config4_pairs
     pair_ids = shard.shard_pairs(total, rank, world)           # round-robin shard of the global pair index space
+    c4_ids = shard.shard_pairs(c4_total, rank, world) if c4_total else []
+    all_ids = pair_ids if len(pair_ids) >= len(c4_ids) else c4_ids
+    assert all_ids[:len(pair_ids)] == pair_ids and all_ids[:len(c4_ids)] == c4_ids
     B, N = len(pair_ids), a.azimuth * 64
-    cap = shard.shard_capacity(total, world)
     # ---- synthetic inputs, generated on the GPU and left resident in HBM: [pair][3][N] SoA
-    T = torch.empty(B, 3, N, device=dev, dtype=torch.float32)
-    S = torch.empty(B, 3, N, device=dev, dtype=torch.float32)
-    for k, pid in enumerate(pair_ids):
+    t_gen = time.perf_counter()
+    T = torch.empty(len(all_ids), 3, N, device=dev, dtype=torch.float32)
+    S = torch.empty(len(all_ids), 3, N, device=dev, dtype=torch.float32)
+    for k, pid in enumerate(all_ids):
         t, s, dT = synth.make_pair(pid, a.azimuth, device=dev)
         T[k] = t.T
         S[k] = s.T
     torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
 
     prm = ndt.default_params(resolution=a.resolution, trans_epsilon=0.01, max_iterations=64, neighbor_mode=MODES[a.mode],
                              variant=1 if a.variant == "pca" else 0)
     eng = ndt.Engine(prm, device=local)
-    eng.batch_bind_device(T.data_ptr(), [N] * B, N, S.data_ptr(), [N] * B, N)
     G = synth.default_guess()
-    guesses = np.ascontiguousarray(np.broadcast_to(G.T.reshape(1, 16), (B, 16)), dtype=np.float32)
-    res = (ndt.Result * B)()
-    res_np = np.frombuffer(res, dtype=np.dtype([("final", "<f4", 16), ("tp", "<f8"), ("score", "<f8"), ("it", "<i4"), ("conv", "<i4"),
-                                                 ("sweeps", "<i4"), ("status", "<i4"), ("hits", "<i8")]))
-    # pose records: packed by the engine on the device into this tensor, which goes straight into the all-gather
-    rec_dev = torch.empty(cap, shard.REC_WORDS, device=dev, dtype=torch.int32)
     on_dev = backend == "nccl"
-    rec_host = None if on_dev else torch.empty(cap, shard.REC_WORDS, dtype=torch.int32).pin_memory()   # gloo functional check only
-    gathered = torch.empty(world * cap, shard.REC_WORDS, device=dev if on_dev else "cpu", dtype=torch.int32) if use_dist else None
 
-    def step():
-        eng.batch_build_targets()                 # setInputTarget for every pair: voxelise
-        eng.batch_align_raw(guesses, res)         # align every pair (synchronous: results on the host)
-        if use_dist:                              # pose gather: 96 B per pair, no host hop on the RCCL path
-            eng.batch_pose_records(rank, world, rec_dev.data_ptr(), cap)
-            if on_dev:
-                shard.gather_records(rec_dev, gathered)
-            else:
-                rec_host.copy_(rec_dev)
-                shard.gather_records(rec_host, gathered)
+    def timed_job(ids, job_total, steps, warmup):
+        """`warmup` untimed + `steps` timed passes over this rank's pairs `ids` of a job of `job_total` pairs: voxelise every target,
+        align every pair, and -- when a process group exists -- pack the pose records on the device and all-gather them.
+        Barrier + synchronize on both sides of the timed steps, MAX over ranks.  Returns timings, results, profile, gather check."""
+        nb = len(ids)
+        cap = shard.shard_capacity(job_total, world)
+        eng.batch_bind_device(T.data_ptr(), [N] * nb, N, S.data_ptr(), [N] * nb, N)
+        guesses = np.ascontiguousarray(np.broadcast_to(G.T.reshape(1, 16), (nb, 16)), dtype=np.float32)
+        res = (ndt.Result * nb)()
+        res_np = np.frombuffer(res, dtype=RES_DT)
+        # pose records: packed by the engine on the device into this tensor, which goes straight into the all-gather
+        rec_dev = torch.empty(cap, shard.REC_WORDS, device=dev, dtype=torch.int32)
+        rec_host = None if on_dev else torch.empty(cap, shard.REC_WORDS, dtype=torch.int32).pin_memory()   # gloo functional check only
+        gathered = torch.empty(world * cap, shard.REC_WORDS, device=dev if on_dev else "cpu", dtype=torch.int32) if use_dist else None
+        gather_ev, gather_host_s = [], [0.0]
 
-    eng.profile_enable(True)                      # the warm-up runs exactly what the timed steps run (event pool touched, too)
-    gc.collect()
-    gc.disable()                                  # a generation-2 collection (torch + numpy object graphs) costs ~15 ms: keep it out of
-    for _ in range(a.warmup):                     # the timed loop -- and out of the gap before it, where an idle GPU drops its clocks
-        step()
-    eng.profile_reset()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    step_ms, tp = [], t0
-    for _ in range(a.steps):
-        step()                                    # synchronous: batch_align returns with the results on the host
-        tn = time.perf_counter()
-        step_ms.append(1e3 * (tn - tp))
-        tp = tn
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    gc.enable()
-    prof = eng.profile_get()
-    eng.profile_enable(False)
+        def step(timed=False):
+            eng.batch_build_targets()                 # setInputTarget for every pair: voxelise
+            eng.batch_align_raw(guesses, res)         # align every pair (synchronous: results on the host)
+            if use_dist:                              # pose gather: 96 B per pair, no host hop on the RCCL path
+                if gather_ev:
+                    gather_ev[-1][1].synchronize()    # the previous gather has read rec_dev before it is packed again
+                eng.batch_pose_records(rank, world, rec_dev.data_ptr(), cap)
+                h0 = time.perf_counter()
+                if on_dev:                            # HIP events on torch's current stream, which the collective is ordered on
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    shard.gather_records(rec_dev, gathered)
+                    e1.record()
+                    if timed:
+                        gather_ev.append((e0, e1))
+                else:
+                    rec_host.copy_(rec_dev)
+                    shard.gather_records(rec_host, gathered)
+                    if timed:
+                        gather_host_s[0] += time.perf_counter() - h0
+
+        eng.profile_enable(True)                      # the warm-up runs exactly what the timed steps run (event pool touched, too)
+        gc.collect()
+        gc.disable()                                  # a generation-2 collection (torch + numpy object graphs) costs ~15 ms: keep it out of
+        for _ in range(warmup):                       # the timed loop -- and out of the gap before it, where an idle GPU drops its clocks
+            step()
+        if steps is None:                             # no --steps: size the timed region to >= 0.5 s (the driver passes --steps and is obeyed)
+            torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            one = max(time.perf_counter() - c0, 1e-4)
+            st = torch.tensor([float(max(20, int(np.ceil(0.5 / one))))], dtype=torch.float64, device=dev if on_dev else "cpu")
+            if dist is not None:
+                dist.all_reduce(st, op=dist.ReduceOp.MAX)
+            steps = int(st.item())
+        eng.profile_reset()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step_ms, tp = [], t0
+        for _ in range(steps):
+            step(True)                                # synchronous: batch_align returns with the results on the host
+            tn = time.perf_counter()
+            step_ms.append(1e3 * (tn - tp))
+            tp = tn
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        gc.enable()
+        prof = eng.profile_get()
+        eng.profile_enable(False)
+        gather_ms = None
+        if use_dist:
+            gather_ms = (sum(e0.elapsed_time(e1) for e0, e1 in gather_ev) if on_dev else 1e3 * gather_host_s[0]) / max(1, steps)
+        gather_check = None
+        if dist is not None:
+            tt = torch.tensor([dt, gather_ms], device=dev if on_dev else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt, gather_ms = float(tt[0].item()), float(tt[1].item())
+            # gather check: pair ids form a permutation of the global index space, and my own records came back bit-identical
+            got = shard.unpack_records(gathered)
+            perm = sorted(got) == list(range(job_total))
+            same = all(np.array_equal(got[pid]["final"], res_np["final"][k].reshape(4, 4).T) and got[pid]["iterations"] == int(res_np["it"][k])
+                       and got[pid]["converged"] == bool(res_np["conv"][k]) and np.float32(res_np["score"][k]) == np.float32(got[pid]["score"])
+                       for k, pid in enumerate(ids))
+            assert perm, "pose gather lost or duplicated pairs"
+            assert same, "gathered records differ from this rank's results"
+            ok = torch.tensor([int(perm and same)], dtype=torch.int32, device=dev if on_dev else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            gather_check = {"pairs_gathered": len(got), "permutation_of_all_pair_ids": bool(perm), "own_records_bit_identical_on_every_rank": bool(ok.item()),
+                            "record_bytes": 96, "records_per_rank": cap, "backend": backend, "packed_on_device": True, "host_hop": not on_dev,
+                            "timed_with": "HIP events around all_gather_into_tensor on the stream the collective is ordered on, max over ranks" if on_dev else
+                                          "host clock around the device-to-host copy + gloo all_gather (functional check only), max over ranks"}
+        return {"dt": dt, "steps": steps, "step_ms": step_ms, "prof": prof, "res": res, "res_np": res_np, "guesses": guesses,
+                "gather_ms_per_step": None if gather_ms is None else round(gather_ms, 4), "gather_check": gather_check, "B": nb}
+
+    def sweep_roofline(J, nb):
+        prof, dt, steps = J["prof"], J["dt"], J["steps"]
+        sw_s = prof["sweep_ms"] * 1e-3
+        ach = (prof["sweep_alg_bytes"] / sw_s / 1e9) if sw_s > 0 else 0.0
+        return {"bound": "hbm", "kernel": "k_sweep", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4),
+                "frac_of_achievable_6290": round(ach / 6290.0, 4),     # MI355X_MICROARCH.md: measured-achievable HBM rate
+                "launches": prof["sweep_launches"], "avg_launch_us": round(1e3 * prof["sweep_ms"] / max(1, prof["sweep_launches"]), 2),
+                "alg_bytes_per_launch": round(prof["sweep_alg_bytes"] / max(1, prof["sweep_launches"])),
+                "hits_per_point": round(prof["sweep_hits"] / max(1, prof["sweep_points"]), 3),
+                "sweep_share_of_step": round(sw_s / dt, 3),
+                "build_ms_per_step": round(prof["build_ms"] / max(1, steps), 3),
+                "update_ms_per_step": round(prof["update_ms"] / max(1, steps), 3),
+                "sweep_ms_per_step": round(prof["sweep_ms"] / max(1, steps), 3),
+                "step_ms_min_median_max": [round(min(J["step_ms"]), 3), round(float(np.median(J["step_ms"])), 3), round(max(J["step_ms"]), 3)],
+                "build_achieved_gbs": round(prof["build_alg_bytes"] / max(1e-9, prof["build_ms"] * 1e-3) / 1e9, 1),
+                "build_frac": round(prof["build_alg_bytes"] / max(1e-9, prof["build_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # ---- the headline job
+    J = timed_job(pair_ids, total, a.steps, a.warmup)
+    res, res_np, guesses, dt, steps = J["res"], J["res_np"], J["guesses"], J["dt"], J["steps"]
     # SURVEY 8(d) asks for the rate with and without setInputTarget: the same pairs again against the now-resident grids
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         eng.batch_align_raw(guesses, res)
     torch.cuda.synchronize()
     dt_resident = time.perf_counter() - t1
-    gather_check = None
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev if on_dev else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        # gather check: pair ids form a permutation of the global index space, and my own records came back bit-identical
-        got = shard.unpack_records(gathered)
-        perm = sorted(got) == list(range(total))
-        same = all(np.array_equal(got[pid]["final"], res_np["final"][k].reshape(4, 4).T) and got[pid]["iterations"] == int(res_np["it"][k])
-                   and got[pid]["converged"] == bool(res_np["conv"][k]) and np.float32(res_np["score"][k]) == np.float32(got[pid]["score"])
-                   for k, pid in enumerate(pair_ids))
-        assert perm, "pose gather lost or duplicated pairs"
-        assert same, "gathered records differ from this rank's results"
-        ok = torch.tensor([int(perm and same)], dtype=torch.int32, device=dev if on_dev else "cpu")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        gather_check = {"pairs_gathered": len(got), "permutation_of_all_pair_ids": bool(perm), "own_records_bit_identical_on_every_rank": bool(ok.item()),
-                        "record_bytes": 96, "records_per_rank": cap, "backend": backend, "packed_on_device": True, "host_hop": not on_dev}
+    head_res = np.frombuffer(res, dtype=np.uint8).copy()       # (the config-4 block below re-binds the engine)
+    res_np = np.frombuffer(head_res, dtype=RES_DT)
 
-    # ---- the drop-in path: host AoS clouds (pcl::PointXYZI records) in, PCIe inclusive -- rank 0's pairs, same engine
+    # ---- the drop-in path: host AoS clouds (pcl::PointXYZI records) in, PCIe inclusive -- rank 0's pairs
     host_path = None
     if rank == 0 and not a.no_host_clouds and (a.host_clouds or world == 1):
-        host_path, hres = host_clouds_leg(a, ndt, prm, local, T, S, guesses, B, N, steps=max(2, a.steps // 2), uploaders=a.uploaders or None)
+        host_path, hres = host_clouds_leg(a, ndt, prm, local, T[:B], S[:B], guesses, B, N, steps=max(2, min(steps, 40) // 2), uploaders=a.uploaders or None)
         # same bits as the device-resident run of the same pairs
-        ref = np.frombuffer(res, dtype=np.uint8)
-        fin = np.dtype([("final", "<f4", 16), ("tp", "<f8"), ("score", "<f8"), ("it", "<i4"), ("conv", "<i4"), ("sweeps", "<i4"), ("status", "<i4"), ("hits", "<i8")])
-        nh = len(np.frombuffer(hres[0], dtype=fin))      # the leg's pairs: the first min(B, 271) of the batch
+        nh = len(np.frombuffer(hres[0], dtype=RES_DT))      # the leg's pairs: the first min(B, 271) of the batch
         host_path["pairs_per_batch"] = nh
         host_path["bit_identical_to_device_resident_run"] = bool(all(
-            np.array_equal(np.frombuffer(hres[i], dtype=fin)["final"], res_np["final"][:nh]) and np.array_equal(np.frombuffer(hres[i], dtype=fin)["score"], res_np["score"][:nh])
+            np.array_equal(np.frombuffer(hres[i], dtype=RES_DT)["final"], res_np["final"][:nh]) and np.array_equal(np.frombuffer(hres[i], dtype=RES_DT)["score"], res_np["score"][:nh])
             for i in range(2)))
+
+    # ---- BASELINE config 4 beside it: the fixed 4,541-pair job, strong-scaled over the same ranks
+    cfg4 = None
+    if c4_total:
+        J4 = timed_job(c4_ids, c4_total, max(3, steps // 4) if a.steps is not None else None, min(a.warmup, 2))
+        r4 = sweep_roofline(J4, len(c4_ids))
+        cfg4 = {"workload": f"BASELINE config 4: ONE job of {c4_total} synthetic HDL-64E scan pairs ({N} pts per cloud) sharded round-robin over {world} GPU(s), "
+                            f"ndt_{a.variant}, {a.resolution} m voxels, {a.mode.upper()}; one step = voxelise + align this rank's shard + the pose all-gather of all {c4_total} records",
+                "scaling": "strong", "pairs_total": c4_total, "pairs_rank0": len(c4_ids), "n_gpus": world, "steps": J4["steps"],
+                "value": round(c4_total * J4["steps"] / J4["dt"], 2), "unit": "registrations/s", "ms_per_step": round(1e3 * J4["dt"] / J4["steps"], 3),
+                "gather_ms_per_step": J4["gather_ms_per_step"], "gather_check": J4["gather_check"],
+                "roofline_frac": r4["frac"], "avg_sweep_launch_us": r4["avg_launch_us"], "build_ms_per_step": r4["build_ms_per_step"],
+                "update_ms_per_step": r4["update_ms_per_step"], "sweep_ms_per_step": r4["sweep_ms_per_step"],
+                "mean_iterations": round(float(J4["res_np"]["it"].mean()), 2), "converged": int(J4["res_np"]["conv"].sum()), "parity": None}
+        if rank == 0 and a.cpu_seconds > 0 and world == 1:
+            cfg4["parity"], _ = parity_leg(a, T, S, G, J4["res_np"], len(c4_ids), seconds=a.cpu_seconds / 2.0, threads=cpu_quota() or os.cpu_count() or 8)
 
     if rank != 0:
         eng.close()
@@ -451,37 +567,30 @@ def main():
             dist.destroy_process_group()
         return
 
-    value = total * a.steps / dt
+    value = total * steps / dt
     its = res_np["it"].astype(np.float64)
     sweeps = res_np["sweeps"].astype(np.float64)
     # ---- roofline of the dominant kernel (derivative sweep): algorithmic bytes / HIP-event time
     wkey = f"{a.pairs if not strong else B}x{N}:{a.variant}:{a.mode}:{a.resolution}"
-    sw_s = prof["sweep_ms"] * 1e-3
-    ach = (prof["sweep_alg_bytes"] / sw_s / 1e9) if sw_s > 0 else 0.0
+    roof = sweep_roofline(J, B)
     traffic, traffic_source = a.traffic, "command line" if a.traffic is not None else None
     if traffic is None:       # PMC counters cannot be read from inside the timed run: the committed separate-pass measurement of this workload
-        tp_, traffic_source = static_profile("r02_traffic.json", wkey)
+        for name in ("r03_traffic.json", "r02_traffic.json"):
+            tp_, traffic_source = static_profile(name, wkey)
+            if tp_:
+                break
         traffic = tp_["traffic_bytes_per_launch"] if tp_ else None
-    roof = {"bound": "hbm", "kernel": "k_sweep", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-            "frac_of_achievable_6290": round(ach / 6290.0, 4),     # MI355X_MICROARCH.md: measured-achievable HBM rate
-            "launches": prof["sweep_launches"], "avg_launch_us": round(1e3 * prof["sweep_ms"] / max(1, prof["sweep_launches"]), 2),
-            "alg_bytes_per_launch": round(prof["sweep_alg_bytes"] / max(1, prof["sweep_launches"])),
-            "hits_per_point": round(prof["sweep_hits"] / max(1, prof["sweep_points"]), 3),
-            "sweep_share_of_step": round(sw_s / dt, 3),
-            "build_ms_per_step": round(prof["build_ms"] / max(1, a.steps), 3),
-            "update_ms_per_step": round(prof["update_ms"] / max(1, a.steps), 3),
-            "sweep_ms_per_step": round(prof["sweep_ms"] / max(1, a.steps), 3),
-            "step_ms_min_median_max": [round(min(step_ms), 3), round(float(np.median(step_ms)), 3), round(max(step_ms), 3)],
-            "build_achieved_gbs": round(prof["build_alg_bytes"] / max(1e-9, prof["build_ms"] * 1e-3) / 1e9, 1),
-            "build_frac": round(prof["build_alg_bytes"] / max(1e-9, prof["build_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    roof["traffic"], roof["traffic_source"] = traffic, traffic_source
     # what really bounds the sweep: vector-ALU issue (SQ counters of separate rocprofv3 --pmc passes, committed under profiles/)
-    valu, valu_source = static_profile("r02_valu.json", wkey)
     roof_valu = None
-    if valu:
-        roof_valu = {"bound": "valu issue", "kernel": "k_sweep", "active_frac": valu["valu_active_frac"], "insts_per_hit": valu["valu_insts_per_hit"],
-                     "wave_insts_per_64_hits": valu["valu_wave_insts_per_64_hits"], "physical_hbm_frac_of_peak": valu.get("physical_hbm_frac_of_peak"),
-                     "source": valu_source}
+    for name in ("r03_valu.json", "r02_valu.json"):
+        valu, valu_source = static_profile(name, wkey)
+        if valu:
+            roof_valu = {"bound": "valu issue", "kernel": "k_sweep", "active_frac": valu["valu_active_frac"],
+                         "wave_insts_per_64_hits": valu["valu_wave_insts_per_64_hits"],       # one wave-instruction serves 64 (point, voxel) evaluations
+                         "lane_insts_per_hit": round(valu["valu_wave_insts_per_64_hits"] / 64.0, 2),
+                         "physical_hbm_frac_of_peak": valu.get("physical_hbm_frac_of_peak"), "source": valu_source}
+            break
 
     cpu, parity = (None, None)
     if a.cpu_seconds > 0 and world == 1:          # the CPU leg runs on rank 0 of the single-GPU run only
@@ -489,7 +598,7 @@ def main():
 
     out = {
         "metric": "NDT registrations/sec (64k-pt Velodyne pairs)", "value": round(value, 2), "unit": "registrations/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+        "n_gpus": world, "steps": steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / steps, 3),
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32 terms, f64 accumulation",
         "data": "synthetic",
         "config": {"workload": (f"BASELINE config 4: {total} synthetic HDL-64E scan pairs sharded round-robin over {world} GPU(s) " if strong else
@@ -501,8 +610,12 @@ def main():
                    "mean_iterations": round(float(its.mean()), 2), "max_iterations_seen": int(its.max()),
                    "mean_sweeps_per_align": round(float(sweeps.mean()), 2),
                    "converged": int(res_np["conv"].sum()),
-                   "rank0_registrations_per_s_resident_targets": round(B * a.steps / dt_resident, 1)},
-        "roofline": roof, "roofline_valu": roof_valu, "cpu_baseline": cpu, "parity": parity, "gather_check": gather_check,
+                   "rank0_registrations_per_s_resident_targets": round(B * steps / dt_resident, 1),
+                   "steps_chosen_by": "--steps" if a.steps is not None else "timed region sized to >= 0.5 s",
+                   "input_generation_s": round(t_gen, 2)},
+        "gather_ms_per_step": J["gather_ms_per_step"],
+        "roofline": roof, "roofline_valu": roof_valu, "cpu_baseline": cpu, "parity": parity, "gather_check": J["gather_check"],
+        "config4": cfg4,
     }
     if host_path is not None:
         host_path["process_pinned_to"] = pinned_to

@@ -57,6 +57,7 @@ struct mi355ndt_handle {
   std::vector<int> h_tgt_cnt, h_src_cnt;
   std::vector<int> up_tgt_cnt, up_src_cnt;        // what d_tgt_cnt / d_src_cnt currently hold (uploads are skipped when unchanged)
   bool targets_built = false, have_target = false, have_source = false;
+  bool aligned_once = false;                      // d_state / d_results hold the outcome of an align of the CURRENT batch
   bool icov64_built = false;                      // ... and the f64 inverse covariances computeHessian reads (live More-Thuente)
   bool cent_built = false;                        // last target build also produced the f32 leaf centroids (KDTREE mode)
 
@@ -108,7 +109,8 @@ struct mi355ndt_handle {
   static constexpr int UP_SLOTS = 16;
   UpSlot up[UP_SLOTS];
   int up_next = 0;
-  static constexpr int UP_STREAMS = 4;            // slot i rides copy stream i % UP_STREAMS: the per-transfer latencies of the SDMA queues overlap
+  static constexpr int UP_STREAMS = 4;            // an upload rides copy stream (2 * pair + side) % UP_STREAMS: per-transfer latencies of the SDMA queues
+                                                  // overlap across pairs, uploads into the same rows stay ordered
   hipStream_t copy_stream[UP_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_uploads[UP_STREAMS] = {nullptr, nullptr, nullptr, nullptr}, ev_compute = nullptr;   // copy streams -> compute stream, compute stream -> copy streams
   bool uploads_pending = false;
@@ -360,6 +362,9 @@ const char* mi355ndt_last_error(const mi355ndt_handle* h) { return h ? h->err.c_
 int mi355ndt_synchronize(mi355ndt_handle* h) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   HIPCHK(h, hipSetDevice(h->device));
+  // uploads are asynchronous on the copy streams: "everything issued so far is done" includes them (and a failed transfer
+  // surfaces here, not in an unrelated later call)
+  for (hipStream_t cs : h->copy_stream) if (cs) HIPCHK(h, hipStreamSynchronize(cs));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MI355NDT_OK;
 }
@@ -374,7 +379,7 @@ static int ensure_pair_arrays(mi355ndt_handle* h, int n_pairs) {
   // the arrays are released and re-created one by one: until all of them exist again the engine holds no batch at all
   // (a failure half way must not leave cap_pairs vouching for freed or undersized buffers)
   h->cap_pairs = 0; h->n_pairs = 0;
-  h->targets_built = false; h->have_target = false; h->have_source = false;
+  h->targets_built = false; h->have_target = false; h->have_source = false; h->aligned_once = false;
   auto re = [&](void** p, size_t bytes) -> hipError_t {
     if (*p) { hipError_t e = hipFree(*p); *p = nullptr; if (e != hipSuccess) return e; }
     return hipMalloc(p, bytes);
@@ -428,7 +433,7 @@ int mi355ndt_batch_reserve(mi355ndt_handle* h, int n_pairs, size_t max_tgt, size
   if (n_pairs != h->n_pairs || h->d_tgt != h->d_tgt_own || h->d_src != h->d_src_own) {
     std::fill(h->h_tgt_cnt.begin(), h->h_tgt_cnt.end(), 0);
     std::fill(h->h_src_cnt.begin(), h->h_src_cnt.end(), 0);
-    h->targets_built = false; h->have_target = false; h->have_source = false;
+    h->targets_built = false; h->have_target = false; h->have_source = false; h->aligned_once = false;
   }
   rc = alloc_side(h, true, n_pairs, tp);
   if (rc) return rc;
@@ -501,7 +506,9 @@ static int upload_cloud(mi355ndt_handle* h, float* d_base, size_t pitch, int pai
   else for (size_t i = 0; i < n; i++) memcpy(u->h + 3 * i, p + i * stride, 12);
   {
     std::lock_guard<std::mutex> lk(h->up_mtx);
-    hipStream_t cs = h->copy_stream[(int)(u - h->up) % mi355ndt_handle::UP_STREAMS];
+    // the copy stream is chosen by DESTINATION (pair slot and side), not by staging slot: two uploads into the same rows -- set_source(A)
+    // then set_source(B) with no build / align in between -- ride one stream and land in call order
+    hipStream_t cs = h->copy_stream[(2 * pair + (d_base == h->d_src_own ? 1 : 0)) % mi355ndt_handle::UP_STREAMS];
     if (n) e = hipMemcpyAsync(u->d, u->h, n * 3 * sizeof(float), hipMemcpyHostToDevice, cs);
     if (e == hipSuccess) {
       k_deinterleave<<<(unsigned)((pitch + 255) / 256), 256, 0, cs>>>(u->d, (int)n, d_base + (size_t)pair * 3 * pitch, pitch);
@@ -518,7 +525,7 @@ static int upload_cloud(mi355ndt_handle* h, float* d_base, size_t pitch, int pai
 int mi355ndt_batch_set_target(mi355ndt_handle* h, int pair, const void* pts, size_t n, size_t stride) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   if (pair < 0 || pair >= h->n_pairs || h->d_tgt != h->d_tgt_own) return MI355NDT_ERR_BAD_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
+  if (hipError_t e = hipSetDevice(h->device)) { std::lock_guard<std::mutex> lk(h->up_mtx); h->err = std::string("hipSetDevice: ") + hipGetErrorString(e); return MI355NDT_ERR_HIP; }
   int rc = upload_cloud(h, h->d_tgt_own, h->tgt_pitch, pair, pts, n, stride);
   if (rc) return rc;
   std::lock_guard<std::mutex> lk(h->up_mtx);
@@ -531,7 +538,7 @@ int mi355ndt_batch_set_target(mi355ndt_handle* h, int pair, const void* pts, siz
 int mi355ndt_batch_set_source(mi355ndt_handle* h, int pair, const void* pts, size_t n, size_t stride) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   if (pair < 0 || pair >= h->n_pairs || h->d_src != h->d_src_own) return MI355NDT_ERR_BAD_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
+  if (hipError_t e = hipSetDevice(h->device)) { std::lock_guard<std::mutex> lk(h->up_mtx); h->err = std::string("hipSetDevice: ") + hipGetErrorString(e); return MI355NDT_ERR_HIP; }
   int rc = upload_cloud(h, h->d_src_own, h->src_pitch, pair, pts, n, stride);
   if (rc) return rc;
   std::lock_guard<std::mutex> lk(h->up_mtx);
@@ -551,12 +558,18 @@ int mi355ndt_batch_set_clouds(mi355ndt_handle* h, int first_pair, int n, const v
   HIPCHK(h, hipSetDevice(h->device));
   const int nt = std::max(1, std::min(n_threads > 0 ? n_threads : 8, n));
   std::vector<int> rcs((size_t)nt, MI355NDT_OK);
-  cpu_set_t near;
-  const bool pin = numa_cpus(mi355ndt_host_numa_node(h->device), &near);
+  // the engine's own threads stage next to the GPU -- but only on CPUs the CALLER may use: the NUMA node's CPUs intersected with the
+  // calling thread's affinity mask (a taskset / cgroup-restricted process keeps its restriction); an empty intersection = no pinning
+  cpu_set_t near, mine;
+  bool pin = numa_cpus(mi355ndt_host_numa_node(h->device), &near);
+  if (pin && sched_getaffinity(0, sizeof mine, &mine) == 0) {
+    CPU_AND(&near, &near, &mine);
+    pin = CPU_COUNT(&near) > 0;
+  } else pin = false;
   std::atomic<int> next_pair{0};                 // pairs are taken one by one: a thread that runs slowly (the caller's, t = 0, may
   auto work = [&](int t) {                       // sit on a narrowed CPU set) simply takes fewer of them
     (void)hipSetDevice(h->device);
-    if (pin && t > 0) (void)sched_setaffinity(0, sizeof near, &near);   // the engine's own threads stage next to the GPU (t = 0 is the caller's thread)
+    if (pin && t > 0) (void)sched_setaffinity(0, sizeof near, &near);   // (t = 0 is the caller's thread: left alone)
     for (int k = next_pair.fetch_add(1); k < n; k = next_pair.fetch_add(1)) {
       int rc = MI355NDT_OK;
       if (targets) rc = mi355ndt_batch_set_target(h, first_pair + k, targets[k], target_counts[k], stride);
@@ -565,7 +578,10 @@ int mi355ndt_batch_set_clouds(mi355ndt_handle* h, int first_pair, int n, const v
     }
   };
   std::vector<std::thread> th;
-  for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+  try {                                          // nothing may be thrown across the C boundary: a thread that cannot be created
+    th.reserve((size_t)nt);                      // (std::system_error) just means the others -- at least the caller's -- do its share
+    for (int t = 1; t < nt; t++) th.emplace_back(work, t);
+  } catch (...) {}
   work(0);
   for (auto& x : th) x.join();
   for (int rc : rcs) if (rc != MI355NDT_OK) return rc;
@@ -587,6 +603,7 @@ int mi355ndt_batch_bind_device(mi355ndt_handle* h, int n_pairs, const float* d_t
   for (int b = 0; b < n_pairs; b++) { h->h_tgt_cnt[b] = tc[b]; h->h_src_cnt[b] = scnt[b]; }
   h->targets_built = false;
   h->have_target = h->have_source = true;
+  h->aligned_once = false;
   return MI355NDT_OK;
 }
 
@@ -668,8 +685,15 @@ int mi355ndt_profile_get(mi355ndt_handle* h, mi355ndt_profile* out) {
 }
 
 // ---- target build -----------------------------------------------------------------------------
+static int build_targets_impl(mi355ndt_handle* h);
 int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  const int rc = build_targets_impl(h);
+  // an error exit may leave kernels queued that still read the cloud rows: later uploads have to wait for them all the same
+  if (rc != MI355NDT_OK && h->ev_compute) (void)compute_enqueued(h);
+  return rc;
+}
+static int build_targets_impl(mi355ndt_handle* h) {
   if (h->n_pairs <= 0 || !h->d_tgt) return MI355NDT_ERR_STATE;
   HIPCHK(h, hipSetDevice(h->device));
   { int rcu = uploads_before_compute(h); if (rcu) return rcu; }
@@ -838,8 +862,14 @@ static void launch_hessian(mi355ndt_handle* h, const SweepConst& sc) {
       gc[0], gc[1], sc.kd_r2, sc.leaf_pow2, sc.inv_leaf);
 }
 
+static int batch_align_impl(mi355ndt_handle* h, const float* guesses, mi355ndt_result* out);
 int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_result* out) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  const int rc = batch_align_impl(h, guesses, out);
+  if (rc != MI355NDT_OK && h->ev_compute) (void)compute_enqueued(h);      // see mi355ndt_batch_build_targets
+  return rc;
+}
+static int batch_align_impl(mi355ndt_handle* h, const float* guesses, mi355ndt_result* out) {
   if (!guesses || !out) return MI355NDT_ERR_BAD_ARG;
   if (h->n_pairs <= 0 || !h->d_tgt || !h->d_src) return MI355NDT_ERR_STATE;
   HIPCHK(h, hipSetDevice(h->device));
@@ -926,13 +956,14 @@ int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_resu
   HIPCHK(h, hipMemcpyAsync(out, h->d_results, (size_t)B * sizeof(mi355ndt_result), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
   HIPCHK(h, hipGetLastError());
+  h->aligned_once = true;
   return MI355NDT_OK;
 }
 
 int mi355ndt_batch_pose_records(mi355ndt_handle* h, int id_base, int id_stride, void* d_records, size_t capacity) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   if (!d_records || capacity == 0 || capacity > (size_t)MAX_PAIRS || (size_t)h->n_pairs > capacity) return MI355NDT_ERR_BAD_ARG;
-  if (h->n_pairs <= 0 || !h->d_results) return MI355NDT_ERR_STATE;
+  if (h->n_pairs <= 0 || !h->d_results || !h->aligned_once) return MI355NDT_ERR_STATE;   // no align of this batch yet: nothing to pack
   HIPCHK(h, hipSetDevice(h->device));
   static_assert(sizeof(PoseRecord) == 96, "pose record is 96 bytes");
   k_pose_records<<<(unsigned)((capacity + 255) / 256), 256, 0, h->stream>>>(h->d_results, h->n_pairs, id_base, id_stride, (PoseRecord*)d_records, (int)capacity);
@@ -1045,6 +1076,10 @@ int mi355ndt_get_incremental(mi355ndt_handle* h, int pair, float last[16], float
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   if (pair < 0 || pair >= h->n_pairs) return MI355NDT_ERR_BAD_ARG;
   if (!h->d_state) return MI355NDT_ERR_STATE;
+  if (!h->aligned_once) {                         // before any align(): transformation_ = previous_transformation_ = Identity
+    for (int a = 0; a < 16; a++) { const float v = (a % 5 == 0) ? 1.f : 0.f; if (last) last[a] = v; if (prev) prev[a] = v; }
+    return MI355NDT_OK;
+  }
   HIPCHK(h, hipSetDevice(h->device));
   float buf[32];
   HIPCHK(h, hipMemcpyAsync(buf, (const char*)(h->d_state + pair) + offsetof(PairState, inc_cm), sizeof buf, hipMemcpyDeviceToHost, h->stream));

@@ -34,6 +34,15 @@
 static int g_threads = 0;
 void ora_set_threads(int n) { g_threads = n; }
 
+/* ---- order-sensitivity variants (tools/order_sensitivity.py) ------------------------------------------
+ * The reference leaves several evaluation orders to Eigen 3.3 / libm / the OpenMP schedule, none of which can be observed
+ * here (parity unpinned).  Each flag below switches ONE such choice to another equally legitimate one; 0 = the canonical
+ * choices that every parity test, fixture and the HIP path use.  Process-wide and not thread-safe: study use only. */
+static unsigned g_var = 0;
+static int g_acc_chunk = 256;                       /* points per f64 partial sum of ora_derivatives (impl2:293-302) */
+void ora_set_variant(unsigned flags, int acc_chunk) { g_var = flags; g_acc_chunk = acc_chunk > 0 ? acc_chunk : 256; }
+unsigned ora_get_variant(void) { return g_var; }
+
 /* the exp of updateDerivatives as this oracle evaluates it (impl2:581; canonical choice): glibc's double exp of
  * the f32 argument, rounded to f32.  Exposed so a test can hold the device's table-driven exp against it argument by argument. */
 void ora_exp_f32arg(const float* a, float* out, size_t n) {
@@ -95,7 +104,9 @@ void ora_eigen_sym3(const double Ain[9], double evals[3], double evecs[9]) {
   a[0][0] = Ain[0]; a[1][1] = Ain[4]; a[2][2] = Ain[8];
   a[0][1] = a[1][0] = Ain[3]; a[0][2] = a[2][0] = Ain[6]; a[1][2] = a[2][1] = Ain[7];
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) v[i][j] = (i == j) ? 1.0 : 0.0;
-  static const int P[3] = {0, 0, 1}, Q[3] = {1, 2, 2};
+  static const int P0[3] = {0, 0, 1}, Q0[3] = {1, 2, 2}, P1[3] = {1, 0, 0}, Q1[3] = {2, 2, 1};
+  const int* P = (g_var & ORA_VAR_EIG_ORDER) ? P1 : P0;     /* study variant: the other cyclic order of the three rotations */
+  const int* Q = (g_var & ORA_VAR_EIG_ORDER) ? Q1 : Q0;
   for (int sweep = 0; sweep < 64; sweep++) {
     double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
     if (off == 0.0) break;
@@ -203,6 +214,100 @@ void ora_svd_solve6(const double H[36], const double b[6], double x[6]) {
     double w = ub / sig[j];
     for (int i = 0; i < 6; i++) x[i] += V[i][j] * w;
   }
+}
+
+/* ---- study variants of the Newton solve (impl2:138-140), see ora_set_variant ----------------------------------------- */
+/* LU with partial pivoting (what the HIP path uses when H is well conditioned); 0 = singular to working precision */
+static int lu_solve6_var(const double H[36], const double b[6], double x[6]) {
+  double A[6][7];
+  for (int i = 0; i < 6; i++) { for (int j = 0; j < 6; j++) A[i][j] = H[i * 6 + j]; A[i][6] = b[i]; }
+  for (int k = 0; k < 6; k++) {
+    int piv = k;
+    for (int i = k + 1; i < 6; i++) if (fabs(A[i][k]) > fabs(A[piv][k])) piv = i;
+    if (!(fabs(A[piv][k]) > 0)) return 0;
+    if (piv != k) for (int j = 0; j < 7; j++) { double t = A[k][j]; A[k][j] = A[piv][j]; A[piv][j] = t; }
+    for (int i = k + 1; i < 6; i++) {
+      const double f = A[i][k] / A[k][k];
+      for (int j = k; j < 7; j++) A[i][j] -= f * A[k][j];
+    }
+  }
+  for (int i = 5; i >= 0; i--) {
+    double v = A[i][6];
+    for (int j = i + 1; j < 6; j++) v -= A[i][j] * x[j];
+    x[i] = v / A[i][i];
+  }
+  return 1;
+}
+/* Two-sided Jacobi SVD arranged as Eigen 3.3's JacobiSVD<Matrix6d> is (scaling by the largest entry, sweeps over p > q with the
+ * 2x2 real SVD of real_2x2_jacobi_svd / makeJacobi, singular values sorted descending), then the same thresholded solve. */
+static void rot_rows(double W[6][6], int p, int q, double c, double s) {      /* applyOnTheLeft(p, q, {c, s}) */
+  for (int j = 0; j < 6; j++) { double x = W[p][j], y = W[q][j]; W[p][j] = c * x + s * y; W[q][j] = -s * x + c * y; }
+}
+static void rot_cols(double W[6][6], int p, int q, double c, double s) {      /* applyOnTheRight(p, q, {c, s}) */
+  for (int i = 0; i < 6; i++) { double x = W[i][p], y = W[i][q]; W[i][p] = c * x - s * y; W[i][q] = s * x + c * y; }
+}
+static void svd2_solve6_var(const double H[36], const double b[6], double x[6]) {
+  double W[6][6], U[6][6], V[6][6], scale = 0;
+  for (int i = 0; i < 36; i++) { if (!isfinite(H[i])) { for (int k = 0; k < 6; k++) x[k] = NAN; return; } if (fabs(H[i]) > scale) scale = fabs(H[i]); }
+  for (int i = 0; i < 6; i++) if (!isfinite(b[i])) { for (int k = 0; k < 6; k++) x[k] = NAN; return; }
+  if (scale == 0) scale = 1;
+  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { W[i][j] = H[i * 6 + j] / scale; U[i][j] = V[i][j] = (i == j); }
+  const double precision = 2 * DBL_EPSILON, tiny = 2 * DBL_MIN;
+  double maxdiag = 0;
+  for (int i = 0; i < 6; i++) if (fabs(W[i][i]) > maxdiag) maxdiag = fabs(W[i][i]);
+  for (int sweep = 0, done = 0; !done && sweep < 100; sweep++) {
+    done = 1;
+    for (int p = 1; p < 6; p++) for (int q = 0; q < p; q++) {
+      double thr = precision * maxdiag; if (thr < tiny) thr = tiny;
+      if (!(fabs(W[p][q]) > thr || fabs(W[q][p]) > thr)) continue;
+      done = 0;
+      /* real_2x2_jacobi_svd on [[W(p,p), W(p,q)], [W(q,p), W(q,q)]] */
+      double m00 = W[p][p], m01 = W[p][q], m10 = W[q][p], m11 = W[q][q];
+      double t = m00 + m11, d = m10 - m01, c1 = 1, s1 = 0;
+      if (!(fabs(d) < DBL_MIN)) { double u = t / d, tmp = sqrt(1 + u * u); s1 = 1 / tmp; c1 = u / tmp; }
+      /* m.applyOnTheLeft(0, 1, rot1) */
+      double n00 = c1 * m00 + s1 * m10, n01 = c1 * m01 + s1 * m11, n11 = -s1 * m01 + c1 * m11;
+      /* j_right.makeJacobi(n00, n01, n11) */
+      double cr = 1, sr = 0, deno = 2 * fabs(n01);
+      if (!(deno < DBL_MIN)) {
+        double tau = (n00 - n11) / deno, w = sqrt(tau * tau + 1);
+        double tt = tau > 0 ? 1 / (tau + w) : 1 / (tau - w);
+        double sign_t = tt > 0 ? 1 : -1, nn = 1 / sqrt(tt * tt + 1);
+        sr = -sign_t * (n01 / fabs(n01)) * fabs(tt) * nn; cr = nn;
+      }
+      /* j_left = rot1 * j_right.transpose() */
+      double cl = c1 * cr + s1 * sr, sl = -c1 * sr + s1 * cr;
+      rot_rows(W, p, q, cl, sl);
+      rot_cols(U, p, q, cl, -sl);                 /* U.applyOnTheRight(p, q, j_left.transpose()) */
+      rot_cols(W, p, q, cr, sr);
+      rot_cols(V, p, q, cr, sr);
+      if (fabs(W[p][p]) > maxdiag) maxdiag = fabs(W[p][p]);
+      if (fabs(W[q][q]) > maxdiag) maxdiag = fabs(W[q][q]);
+    }
+  }
+  double sig[6]; int ord[6];
+  for (int i = 0; i < 6; i++) { sig[i] = fabs(W[i][i]); if (W[i][i] < 0) for (int r = 0; r < 6; r++) U[r][i] = -U[r][i]; sig[i] *= scale; ord[i] = i; }
+  for (int i = 0; i < 6; i++) { int m = i; for (int j = i + 1; j < 6; j++) if (sig[ord[j]] > sig[ord[m]]) m = j; int t = ord[i]; ord[i] = ord[m]; ord[m] = t; }
+  double thr = sig[ord[0]] * (6.0 * DBL_EPSILON);
+  if (thr < DBL_MIN) thr = DBL_MIN;
+  for (int i = 0; i < 6; i++) x[i] = 0;
+  for (int k = 0; k < 6; k++) {
+    const int j = ord[k];
+    if (sig[j] < thr || sig[j] == 0.0) break;
+    double ub = 0;
+    for (int i = 0; i < 6; i++) ub += U[i][j] * b[i];
+    const double w = ub / sig[j];
+    for (int i = 0; i < 6; i++) x[i] += V[i][j] * w;
+  }
+}
+static void newton_solve6(const double H[36], const double b[6], double x[6]) {
+  if ((g_var & ORA_VAR_SOLVE_LU) && lu_solve6_var(H, b, x)) return;
+  if (g_var & ORA_VAR_SOLVE_SVD2) { svd2_solve6_var(H, b, x); return; }
+  ora_svd_solve6(H, b, x);
+}
+/* exposed for the study's self-check: solve H x = b with the variant solvers */
+void ora_solve6_variant(const double H[36], const double b[6], double x[6], unsigned flags) {
+  const unsigned keep = g_var; g_var = flags; newton_solve6(H, b, x); g_var = keep;
 }
 
 /* ------------------------------------------------------------ Sophus a621ff2 */
@@ -436,7 +541,9 @@ static void finish_leaf(ora_leaf* L, const double S[3], const double C[9], const
       L->label = dmax + 1;
       double scale = 1;
       if (L->label == 2) scale = 1.25; else if (L->label == 3) scale = 1; else if (L->label == 1) scale = 0.75;
-      L->dim2d = scale * sqrt((mu[0] * mu[0] + mu[1] * mu[1]) + mu[2] * mu[2]);
+      /* mean_.norm(): canonical = left to right; study variant = Eigen's unrolled 3-term redux x0 + (x1 + x2) */
+      L->dim2d = (g_var & ORA_VAR_NORM_TREE) ? scale * sqrt(mu[0] * mu[0] + (mu[1] * mu[1] + mu[2] * mu[2]))
+                                             : scale * sqrt((mu[0] * mu[0] + mu[1] * mu[1]) + mu[2] * mu[2]);
       L->weight = (int)L->dim2d;                                     /* pca.h:222-226 returns int */
     }
     mat3_inverse(cov, L->icov);                                      /* impl:359 */
@@ -567,14 +674,24 @@ static int build_offsets(int mode, int off[26][3]) {
 /* updateDerivatives (ndt_omp_impl2.hpp:566-619) with J/Hp of
  * computePointDerivatives_AngleAxisd (impl2:503-532) folded in.  All f32 ops are
  * single, left-to-right, uncontracted.  Returns score_inc (0 if the validity gate fires). */
-static double eval_hit(const float u[3], const float r[3], const float C[9], double d1, float d2f,
-                       double g[6], double H[36]) {
+/* The three-term f32 sums of the 4-wide inner products whose fourth term is a structural zero (x_trans4, c_inv4 and
+ * point_gradient4 all carry a zero fourth row / entry).  Canonical: left to right = Eigen's unrolled scalar redux
+ * (t0 + t1) + (t2 + 0).  Study variants: (t0 + t2) + (t1 + 0), the lane pairing of Eigen 3.3's SSE predux<Packet4f>;
+ * t0 + (t1 + t2), Eigen's unrolled redux of a genuine 3-vector. */
+static inline __attribute__((always_inline)) float sum3v(float a, float b, float c, const unsigned var) {
+  if (var & ORA_VAR_SUM3_02_1) return (a + c) + b;
+  if (var & ORA_VAR_SUM3_0_12) return a + (b + c);
+  return (a + b) + c;
+}
+static inline __attribute__((always_inline)) double eval_hit_v(const float u[3], const float r[3], const float C[9], double d1, float d2f,
+                                                               double g[6], double H[36], const unsigned var) {
   /* y = x_trans4 * c_inv4 (impl2:600) */
   float y[3];
-  for (int j = 0; j < 3; j++) y[j] = (u[0] * C[0 * 3 + j] + u[1] * C[1 * 3 + j]) + u[2] * C[2 * 3 + j];
-  float qf = (u[0] * y[0] + u[1] * y[1]) + u[2] * y[2];
-  /* impl2:581 -- exp evaluated in double on the f32 argument, rounded to f32 (canonical choice) */
-  float e0 = (float)exp((double)((-d2f * qf) * 0.5f));
+  for (int j = 0; j < 3; j++) y[j] = sum3v(u[0] * C[0 * 3 + j], u[1] * C[1 * 3 + j], u[2] * C[2 * 3 + j], var);
+  float qf = sum3v(u[0] * y[0], u[1] * y[1], u[2] * y[2], var);
+  /* impl2:581 -- exp evaluated in double on the f32 argument, rounded to f32 (canonical choice);
+   * study variant: the float overload (glibc expf) */
+  float e0 = (var & ORA_VAR_EXPF) ? expf((-d2f * qf) * 0.5f) : (float)exp((double)((-d2f * qf) * 0.5f));
   float s_inc = (float)(-d1 * (double)e0);                       /* impl2:583 */
   float e1 = d2f * e0;                                           /* impl2:585 */
   if (e1 > 1 || e1 < 0 || e1 != e1) return 0;                    /* impl2:588-589 */
@@ -588,7 +705,7 @@ static double eval_hit(const float u[3], const float r[3], const float C[9], dou
     CJ[a][5] = C[a * 3 + 0] * (-r[1]) + C[a * 3 + 1] * r[0];
   }
   float v[6];
-  for (int k = 0; k < 6; k++) v[k] = (u[0] * CJ[0][k] + u[1] * CJ[1][k]) + u[2] * CJ[2][k];   /* impl2:595 */
+  for (int k = 0; k < 6; k++) v[k] = sum3v(u[0] * CJ[0][k], u[1] * CJ[1][k], u[2] * CJ[2][k], var);   /* impl2:595 */
   for (int k = 0; k < 6; k++) g[k] += (double)(e * v[k]);                                     /* impl2:597 */
   /* JCJ = J^T * CJ (impl2:601) */
   float JCJ[6][6];
@@ -614,6 +731,11 @@ static double eval_hit(const float u[3], const float r[3], const float C[9], dou
     for (int j = 0; j < 6; j++)
       H[i * 6 + j] += (double)(e * ((((-d2f) * v[i]) * v[j] + Z[i][j]) + JCJ[j][i]));          /* impl2:611-613 */
   return (double)s_inc;
+}
+/* the canonical instance is compiled with the variant tests folded away */
+static double eval_hit(const float u[3], const float r[3], const float C[9], double d1, float d2f, double g[6], double H[36]) {
+  if (__builtin_expect(g_var & (ORA_VAR_SUM3_02_1 | ORA_VAR_SUM3_0_12 | ORA_VAR_EXPF), 0)) return eval_hit_v(u, r, C, d1, d2f, g, H, g_var);
+  return eval_hit_v(u, r, C, d1, d2f, g, H, 0u);
 }
 
 #define CHUNK 256
@@ -644,8 +766,8 @@ static int radius_search(const ora_grid* g, const float q[3], double radius, kd_
 
 /* reference-shaped mode (ndt_oracle_refshape.inc): set by ora_ref_align for the duration of one align */
 typedef struct ora_refgrid ora_refgrid;
-static ora_refgrid* g_ref = NULL;
-static double g_ref_p[6];
+static _Thread_local ora_refgrid* g_ref = NULL;     /* per calling thread: concurrent aligns on other threads are not redirected */
+static _Thread_local double g_ref_p[6];
 static long ref_derivatives(ora_refgrid* R, const ora_params* prm, const float* x, const float* y, const float* z, size_t n,
                             const float T[16], const double p[6], double* score, double grad[6], double hess[36]);
 
@@ -661,7 +783,10 @@ long ora_derivatives(const ora_grid* g, const ora_params* prm,
   int off[26][3];
   const int K = build_offsets(prm->neighbor_mode, off);
   const int pca = prm->variant == ORA_VARIANT_PCA;
-  size_t nchunks = (n + CHUNK - 1) / CHUNK;
+  /* the reference adds per-thread partial sums of a guided schedule (impl2:223, 293-302): its own f64 order changes from run
+   * to run.  Canonical here: 256-point partial sums added in order; g_acc_chunk is the study's knob for another order. */
+  const size_t CH = (size_t)g_acc_chunk;
+  size_t nchunks = (n + CH - 1) / CH;
   double* part = (double*)calloc(nchunks ? nchunks : 1, 44 * sizeof(double));
 #ifdef _OPENMP
   int nt = g_threads > 0 ? g_threads : omp_get_max_threads();
@@ -669,7 +794,7 @@ long ora_derivatives(const ora_grid* g, const ora_params* prm,
 #endif
   for (long c = 0; c < (long)nchunks; c++) {
     double* acc = part + (size_t)c * 44; /* [0]=score [1..6]=g [7..42]=H [43]=hits */
-    size_t i0 = (size_t)c * CHUNK, i1 = i0 + CHUNK < n ? i0 + CHUNK : n;
+    size_t i0 = (size_t)c * CH, i1 = i0 + CH < n ? i0 + CH : n;
     for (size_t i = i0; i < i1; i++) {
       float px = x[i], py = y[i], pz = z[i];
       if (!finite3(px, py, pz)) continue;
@@ -945,7 +1070,7 @@ int ora_align(const ora_grid* g, const ora_params* prm,
     memcpy(out->prev_inc_colmajor, out->inc_colmajor, sizeof out->inc_colmajor);   /* impl2:134 */
     double neg[6], dp[6];
     for (int a = 0; a < 6; a++) neg[a] = -grad[a];
-    ora_svd_solve6(H, neg, dp);                                    /* impl2:138-140 */
+    newton_solve6(H, neg, dp);                                     /* impl2:138-140 (canonical: ora_svd_solve6) */
     double nrm = 0;
     for (int a = 0; a < 6; a++) nrm += dp[a] * dp[a];
     nrm = sqrt(nrm);

@@ -144,6 +144,23 @@ int    ora_ref_align(ora_refgrid* g, const ora_params* prm, const float* x, cons
                      const float guess_colmajor[16], ora_result* out);   /* -2: configuration only the port serves */
 
 void ora_set_threads(int n);
+
+/* ---- order-sensitivity study (tools/order_sensitivity.py).  The reference leaves these evaluation orders to
+ * Eigen 3.3 / libm / the OpenMP schedule and none can be observed here; each flag switches ONE of them to another equally
+ * legitimate choice so that the effect on align() can be measured.  flags = 0, acc_chunk = 256: the canonical choices every
+ * parity test and fixture uses.  Process-wide, not thread-safe. */
+enum {
+  ORA_VAR_SUM3_02_1  = 1,   /* 3-term f32 sums of eval_hit as (t0 + t2) + t1: lane pairing of Eigen 3.3's SSE predux<Packet4f> */
+  ORA_VAR_SUM3_0_12  = 2,   /* ... as t0 + (t1 + t2): Eigen's unrolled redux of a 3-vector */
+  ORA_VAR_EXPF       = 4,   /* impl2:581 through the float overload (expf) instead of float(exp(double)) */
+  ORA_VAR_NORM_TREE  = 8,   /* mean_.norm() of the ndt_pca weight as sqrt(x0^2 + (x1^2 + x2^2)) */
+  ORA_VAR_SOLVE_LU   = 16,  /* Newton step by LU with partial pivoting instead of the one-sided-Jacobi SVD */
+  ORA_VAR_SOLVE_SVD2 = 32,  /* ... by a two-sided Jacobi SVD arranged like Eigen's JacobiSVD */
+  ORA_VAR_EIG_ORDER  = 64   /* 3x3 symmetric eigen-solver with the other cyclic rotation order */
+};
+void ora_set_variant(unsigned flags, int acc_chunk);
+unsigned ora_get_variant(void);
+void ora_solve6_variant(const double H[36], const double b[6], double x[6], unsigned flags);
 /* (float)exp((double)a[i]) -- the exp of impl2:581 as eval_hit evaluates it */
 void ora_exp_f32arg(const float* a, float* out, size_t n);
 

@@ -10,7 +10,8 @@ def test_defaults_follow_the_driver_contract(monkeypatch):
     import bench
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
-    assert a.gpus == 1 and a.steps > 0 and a.warmup >= 0 and a.pairs == 271 and a.azimuth * 64 == 65536
+    assert a.gpus == 1 and a.steps is None and a.warmup >= 0 and a.pairs == 271 and a.azimuth * 64 == 65536   # no --steps: timed region sized to >= 0.5 s
+    assert a.config4_pairs == 4541                                       # BASELINE config 4 rides along with the default line
     assert a.mode == "direct7" and a.variant == "omp" and a.resolution == 1.0 and a.total_pairs == 0
     assert a.host_clouds is False and a.no_host_clouds is False          # the leg is on by default at N = 1 (main decides)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2", "--total-pairs", "4541"])
@@ -38,3 +39,17 @@ def test_cpu_quota_is_a_positive_count_or_unknown():
     import bench
     q = bench.cpu_quota()
     assert q is None or q >= 1
+
+
+def test_parity_sample_order_spans_the_index_range():
+    """A time-bounded parity sample has to cover the job's whole index range (config 4: pairs 271..4540 too), not its first pairs."""
+    import bench
+    for n in (1, 2, 3, 7, 271, 4541):
+        o = bench.spread_order(n)
+        assert sorted(o) == list(range(n))
+        if n > 2:
+            assert o[0] == 0 and o[1] == n - 1
+    o = bench.spread_order(4541)
+    first = sorted(o[:285])
+    gaps = [b - a for a, b in zip(first, first[1:])]
+    assert max(gaps) <= 32 and first[-1] == 4540                         # ~every 16th pair, no hole wider than 32

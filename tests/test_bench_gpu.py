@@ -39,27 +39,33 @@ def run_bench(args, nproc=1, env_extra=None):
 
 
 def test_single_gpu_line_contract():
-    d = run_bench(["--pairs", "6", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.5"])
+    d = run_bench(["--pairs", "6", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.5", "--config4-pairs", "9"])
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
     assert d["unit"] == "registrations/s" and d["value"] > 0 and d["vs_baseline"] is None and d["data"] == "synthetic"
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "reference_shaped_by_threads" in c
+    assert c["value"] >= c["value_reference_shaped"] > 0 and "optimised port" in c["arrangement_of_value"]     # `value` = the fastest CPU arrangement
     p = d["parity"]
     assert p["pairs_checked"] >= 3 and p["iterations_equal"] == p["pairs_checked"] and p["max_dtrans_m"] < 1e-4 and p["max_drot_rad"] < 1e-5
     # the drop-in path's leg (host AoS clouds in, PCIe inclusive) is part of the default single-GPU line, and never `value`
     h = d["host_clouds"]
     assert d["value_host_clouds"] == h["registrations_per_s"] > 0 and h["bit_identical_to_device_resident_run"] is True
     assert h["pairs_per_batch"] == 6 and h["record_bytes"] == 32
-    assert "value_host_clouds" not in run_bench(["--pairs", "4", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0",
-                                                 "--no-host-clouds"])
+    # BASELINE config 4 rides along (here shrunk to 9 pairs): a strong-scaling block with its own parity sample
+    c4 = d["config4"]
+    assert c4["pairs_total"] == 9 and c4["scaling"] == "strong" and c4["value"] > 0 and c4["converged"] == 9
+    assert c4["parity"]["pairs_checked"] >= 3 and c4["parity"]["iterations_equal"] == c4["parity"]["pairs_checked"]
+    assert d["gather_ms_per_step"] is None and c4["gather_ms_per_step"] is None        # no process group in the plain N = 1 run
+    d2 = run_bench(["--pairs", "4", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-host-clouds", "--config4-pairs", "0"])
+    assert "value_host_clouds" not in d2 and d2["config4"] is None
 
 
 @pytest.mark.parametrize("extra,total", [(["--pairs", "5"], 10), (["--total-pairs", "11"], 11)])
 def test_two_ranks_on_one_gpu_gather(extra, total):
     """weak scaling (5 pairs per rank) and the config-4-literal mode with uneven shards (11 pairs: 6 + 5)."""
-    d = run_bench(["--gpus", "2", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0"] + extra, nproc=2,
+    d = run_bench(["--gpus", "2", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--config4-pairs", "13"] + extra, nproc=2,
                   env_extra={"LV_SLAM_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     assert d["n_gpus"] == 2 and d["config"]["pairs_total"] == total
     assert d["scaling"] == ("strong" if "--total-pairs" in extra else "weak")
@@ -67,6 +73,15 @@ def test_two_ranks_on_one_gpu_gather(extra, total):
     assert g["pairs_gathered"] == total and g["permutation_of_all_pair_ids"] is True and g["own_records_bit_identical_on_every_rank"] is True
     assert g["record_bytes"] == 96 and g["packed_on_device"] is True
     assert d["config"]["converged"] == d["config"]["pairs_rank0"]
+    assert d["gather_ms_per_step"] is not None and d["gather_ms_per_step"] >= 0       # the gather time listed separately
+    c4 = d["config4"]
+    if "--total-pairs" in extra:
+        assert c4 is None                              # the line itself is the fixed job
+    else:                                              # the one line a driver that only passes --gpus N gets: weak value + config-4 block
+        assert c4["pairs_total"] == 13 and c4["pairs_rank0"] == 7 and c4["scaling"] == "strong" and c4["n_gpus"] == 2 and c4["value"] > 0
+        g4 = c4["gather_check"]
+        assert g4["pairs_gathered"] == 13 and g4["permutation_of_all_pair_ids"] is True and g4["own_records_bit_identical_on_every_rank"] is True
+        assert c4["gather_ms_per_step"] is not None and c4["gather_ms_per_step"] >= 0 and c4["converged"] == 7
 
 
 def test_single_rank_through_rccl():
@@ -78,13 +93,30 @@ def test_single_rank_through_rccl():
     assert g["backend"] == "nccl" and g["host_hop"] is False and g["packed_on_device"] is True
     assert g["pairs_gathered"] == 7 and g["permutation_of_all_pair_ids"] is True and g["own_records_bit_identical_on_every_rank"] is True
     assert d["n_gpus"] == 1 and d["config"]["converged"] == 7
+    assert d["gather_ms_per_step"] is not None and d["gather_ms_per_step"] > 0 and "HIP events" in g["timed_with"]
+
+
+def test_config4_job_on_one_gpu_parity_over_the_index_range_and_rccl_gather():
+    """BASELINE config 4's job -- 4,541 pairs of 65,536 points, ndt_omp, 1 m, DIRECT7 -- as ONE batch on one GPU: the parity leg samples the
+    WHOLE index range (every ~16th pair incl. 4540, not the first 271), and the single rank is made to go through RCCL so that the
+    gather of 4,541 device-packed 96-byte records is checked too.  Independence of the pairs: scan_matching_odom_nodelet.cpp:240-250."""
+    d = run_bench(["--total-pairs", "4541", "--steps", "3", "--warmup", "1", "--cpu-seconds", "10", "--no-host-clouds"],
+                  env_extra={"LV_SLAM_BENCH_FORCE_DIST": "1", "MASTER_PORT": str(free_port()), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert d["scaling"] == "strong" and d["config"]["pairs_total"] == 4541 and d["config"]["pairs_rank0"] == 4541 and d["config"]["converged"] == 4541
+    p = d["parity"]
+    assert p["pairs_checked"] >= 285 and p["iterations_equal"] == p["pairs_checked"] and p["converged_flags_equal"] == p["pairs_checked"]
+    assert p["max_dtrans_m"] < 1e-4 and p["max_drot_rad"] < 1e-5 and "..4540" in p["sample"]
+    g = d["gather_check"]
+    assert g["backend"] == "nccl" and g["pairs_gathered"] == 4541 and g["permutation_of_all_pair_ids"] is True
+    assert g["own_records_bit_identical_on_every_rank"] is True and g["records_per_rank"] == 4541 and g["host_hop"] is False
+    assert d["gather_ms_per_step"] > 0
 
 
 def test_default_workload_parity_leg_covers_the_whole_batch():
     """BASELINE config 3 as bench.py runs it by default (271 pairs x 65,536 pts, ndt_omp, 1 m, DIRECT7): the line's parity leg
     checks every pair of the batch against the oracle -- same iteration counts, SE(3) inside the north-star tolerance -- and the
     roofline block is internally consistent."""
-    d = run_bench(["--steps", "5", "--warmup", "2", "--cpu-seconds", "20"])
+    d = run_bench(["--steps", "5", "--warmup", "2", "--cpu-seconds", "20", "--config4-pairs", "0"])
     p = d["parity"]
     assert p["pairs_checked"] == 271 and p["iterations_equal"] == 271 and p["max_dtrans_m"] < 1e-4 and p["max_drot_rad"] < 1e-5
     assert d["config"]["converged"] == 271 and d["config"]["pairs_total"] == 271

@@ -507,9 +507,10 @@ def test_batch_matches_single_and_oracle():
         assert np.array_equal(a["final"], b["final"]) and a["score"] == b["score"]
 
 
-def test_wide_keys_fall_back_to_device_wide_sort():
-    """pair field + cell field > 32 bits (many pairs AND one very large grid): the build takes its 64-bit-key path (device-wide
-    radix sort instead of the segment-local one).  Same voxels as the oracle, same alignment as a single-pair engine."""
+def test_many_pairs_with_one_very_large_grid():
+    """Many pairs AND one very large grid (25 cell bits next to 9 bits' worth of pairs).  The sort key is the cell index alone and no
+    pass leaves a target's segment, so the batch's widest grid only sets the digit plan (three 9-bit passes here instead of two
+    10-bit ones) for every segment.  Same voxels as the oracle, same alignment as a single-pair engine."""
     rng = np.random.default_rng(11)
     t0, s0, _ = synth.make_pair(30, 64, n_beams=32)
     t0, s0 = t0.numpy(), s0.numpy()
