@@ -199,6 +199,54 @@ int mi355ndt_batch_size(const mi355ndt_handle* h);
  * an RCCL all-gather: no host hop.  Returns after the records are complete (the engine's stream is synchronised). */
 int mi355ndt_batch_pose_records(mi355ndt_handle* h, int id_base, int id_stride, void* d_records, size_t capacity);
 
+/* ---- latency mode: one frame at a time, as the live nodelet runs ---------------------------------------- */
+/* Opt-in fine-grained derivative sweep for SMALL batches (a single registration above all): work items of 128 points dealt over
+ * every wave of the GPU instead of 512-point items (a 65,536-point pair then offers 512 items to the 2,048 resident waves instead
+ * of 128) and no work-queue atomics.  The per-pair f64 summation tree is this mode's own (fixed, deterministic, independent of
+ * the batch a pair is in), NOT the batch mode's: a sweep agrees with the batch mode's to the rounding of the f64 sums (~1e-16
+ * relative, inside the 1e-11 sweep bar); poses are normally bit-identical, but that is not promised across the two modes.
+ * Applies to DIRECT1 / DIRECT7 with step_size > transformation_epsilon / 2 (everything lv_slam ships); other configurations
+ * keep the batch kernels.  Default: off. */
+int mi355ndt_set_latency_mode(mi355ndt_handle* h, int on);
+
+/* keyframe policy of ScanMatchingOdomNodelet (scan_matching_odom_nodelet.cpp:67-76; launch/dlo_kitti.launch:51-53) */
+typedef struct mi355ndt_seq_params {
+  double keyframe_delta_trans;   /* [m]   default 5.0 in code, 10 in the KITTI launch file */
+  double keyframe_delta_angle;   /* [rad] default 0.17 */
+  double keyframe_delta_time;    /* [s]   default 1.0  */
+} mi355ndt_seq_params;
+
+typedef struct mi355ndt_seq_frame {
+  double odom_colmajor[16];      /* odom_velo = key_pose * tf_s2k (:234): pose of the scan in the first keyframe's frame, 4x4 f64 column-major */
+  float  tf_s2k_colmajor[16];    /* getFinalTransformation() of the scan-to-keyframe align (:222, :226) */
+  double trans_probability;      /* getTransformationProbability() of that align */
+  double dx, da, dt;             /* the three keyframe-test quantities (:237-239) */
+  int    key_id;                 /* the keyframe this scan was matched against */
+  int    new_keyframe;           /* 1: the test fired and this scan became the keyframe (:240-247) */
+  int    iterations, converged;  /* of the (last) align of this scan */
+  int    aligns;                 /* 2 for frame 1 (:223-227), 1 otherwise, 0 for frame 0 */
+  int    pad;
+} mi355ndt_seq_frame;
+
+typedef struct mi355ndt_seq_stats {
+  double    upload_ms;           /* host clouds -> HBM (staging + PCIe + AoS->SoA), host clock */
+  double    build_ms;            /* voxel grids of all frames (one batched build), HIP events */
+  double    track_ms;            /* frame 1 .. n-1: every align + the policy, HIP events; no host round trip inside */
+  long long aligns;              /* n_frames (frame 1 twice, frame 0 never) */
+  long long update_launches;     /* k_seq_update launches executed, incl. the pump's overshoot at the end */
+} mi355ndt_seq_stats;
+
+/* replaces n_frames calls of the nodelet's cloud_callback -> matching_s2k (scan_matching_odom_nodelet.cpp:144-183, 192-261):
+ * the frames are uploaded, every frame's voxel grid is built (one batched build: every frame is a potential keyframe), and then
+ * frame after frame is aligned against its keyframe with the guess, the keyframe test and the target switch decided ON THE DEVICE
+ * at the tail of the Newton-update kernel -- the host pumps (update, sweep) launches without waiting for any result.  Uses the
+ * handle's registration parameters (the nodelet's: resolution 1.0, DIRECT1, eps 0.01, 64 iterations, :109-119) and the
+ * fine-grained sweep of mi355ndt_set_latency_mode.  `stamps` = header.stamp of every frame in seconds.  out_frames: n_frames
+ * records; out_results (may be NULL): the engine-level result of every frame's last align; stats (may be NULL). */
+int mi355ndt_sequence_run(mi355ndt_handle* h, int n_frames, const void* const* clouds, const size_t* counts, size_t stride_bytes,
+                          const double* stamps, const mi355ndt_seq_params* policy,
+                          mi355ndt_seq_frame* out_frames, mi355ndt_result* out_results, mi355ndt_seq_stats* stats);
+
 /* ---- prefilter: the step immediately upstream of the path ------------------------------------------- */
 /* replaces PrefilteringNodelet::distance_filter + downsample (src/lidar_odometry/prefiltering_nodelet.cpp:137-181,
  * launch/dlo_kitti.launch:30-36): keep near < |p| < far, then pcl::VoxelGrid centroid down-sampling with leaf

@@ -25,6 +25,7 @@
 #include <thread>
 #include <sched.h>
 #include <fstream>
+#include <chrono>
 
 #include "mi355_ndt.h"
 #include "ndt_math.hpp"
@@ -37,6 +38,7 @@
 #include "ndt_sweep_kd.hpp"
 #include "ndt_fitness.hpp"
 #include "ndt_prefilter.hpp"
+#include "ndt_sequence.hpp"
 
 
 // ------------------------------------------------------------------------------------ host side
@@ -87,6 +89,14 @@ struct mi355ndt_handle {
   PairState* d_state = nullptr;
   double* d_partials = nullptr; size_t partials_cap = 0;
   int chunks_per_pair = 0;
+  int rows_per_pair = 0, pts_per_chunk = CHUNK_PTS;   // partial rows per pair / points covered by four consecutive rows (k_update's chunk)
+  bool latency_mode = false;                      // mi355ndt_set_latency_mode
+  int fine_it = 0;                                // 0: batch-mode sweep items (512 points); 1 / 2: fine items of fine_it * 64 points (latency mode)
+  int fine_tiles = 2;                             // MI355NDT_FINE_TILES overrides (tuning runs)
+  int* d_grid_of = nullptr; size_t grid_of_cap = 0;   // sequence mode: grid index per pair
+  const int* d_grid_of_use = nullptr;             // what the sweeps are given: d_grid_of inside mi355ndt_sequence_run, else null (pair b -> grid b)
+  SeqState* d_seq = nullptr; mi355ndt_seq_frame* d_seq_out = nullptr; double* d_stamps = nullptr; size_t seq_cap = 0;
+  volatile int* h_seq_flags = nullptr; int* d_seq_flags = nullptr;   // mapped pinned: [0] = run finished, [1] = update launches executed
   float* d_guess = nullptr;
   float* h_pin_guess = nullptr;                   // pinned staging copy of the caller's guesses (no sync needed after the upload)
   mi355ndt_result* d_results = nullptr;
@@ -283,6 +293,7 @@ int mi355ndt_create(const mi355ndt_params* params, int device, mi355ndt_handle**
   h->device = device;
   h->prm = p;
   { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
+  if (const char* e = std::getenv("MI355NDT_FINE_TILES")) { const int v = std::atoi(e); if (v == 1 || v == 2) h->fine_tiles = v; }
   if (const char* e = std::getenv("MI355NDT_SWEEP_DYN_SHIFT")) { const int v = std::atoi(e); if (v >= 0 && v <= 30) h->dyn_shift = v; }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
@@ -317,6 +328,8 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
                   h->d_cent, h->d_icov64, h->d_kdw, h->d_rs_hist, h->d_rs_offs, h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit, h->d_pf_in, h->d_pf_out, h->d_pf_keep, h->d_pf_keys,
                   h->d_pf_vals, h->d_pf_flag, h->d_pf_pos, h->d_pf_mm, h->d_pf_grid, h->d_pf_tmp};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (void* p : {(void*)h->d_grid_of, (void*)h->d_seq, (void*)h->d_seq_out, (void*)h->d_stamps}) if (p) (void)hipFree(p);
+  if (h->h_seq_flags) (void)hipHostFree((void*)h->h_seq_flags);
   for (hipStream_t cs : h->copy_stream) if (cs) (void)hipStreamSynchronize(cs);
   for (auto& u : h->up) { if (u.h) (void)hipHostFree(u.h); if (u.d) (void)hipFree(u.d); if (u.ev) (void)hipEventDestroy(u.ev); }
   if (h->h_pin_aligned) (void)hipHostFree(h->h_pin_aligned);
@@ -813,7 +826,22 @@ static int prep_align_ws(mi355ndt_handle* h) {
   int maxn = 0;
   for (int b = 0; b < B; b++) maxn = std::max(maxn, h->h_src_cnt[b]);
   h->chunks_per_pair = std::max(1, (maxn + CHUNK_PTS - 1) / CHUNK_PTS);
-  size_t need = (size_t)B * h->chunks_per_pair * QUARTERS * NACC;
+  // latency mode (mi355ndt_set_latency_mode): fine work items for small batches, where the 512-point items of the batch mode leave
+  // most of the GPU idle.  Served by the DIRECT1 / DIRECT7 instantiations; the live More-Thuente case keeps the batch kernels.
+  {
+    const int K = h->prm.neighbor_mode == MI355NDT_DIRECT1 ? 1 : (h->prm.neighbor_mode == MI355NDT_DIRECT7 ? 7 : 0);
+    const bool small = (long long)B * h->chunks_per_pair * QUARTERS < 4LL * h->n_cu * WAVES;     // fewer batch items than ~4 per resident wave slot pair
+    h->fine_it = (h->latency_mode && K && !mt_is_live(h->prm) && small) ? h->fine_tiles : 0;
+  }
+  if (h->fine_it) {
+    const int item_pts = h->fine_it * 64;
+    h->rows_per_pair = ((std::max(1, (maxn + item_pts - 1) / item_pts) + 3) / 4) * 4;       // whole 4-row chunks
+    h->pts_per_chunk = 4 * item_pts;
+  } else {
+    h->rows_per_pair = h->chunks_per_pair * QUARTERS;
+    h->pts_per_chunk = CHUNK_PTS;
+  }
+  size_t need = (size_t)B * h->rows_per_pair * NACC;
   HIPCHK(h, grow(h->d_partials, h->partials_cap, need));
   if (h->up_src_cnt.size() != (size_t)B || !std::equal(h->up_src_cnt.begin(), h->up_src_cnt.end(), h->h_src_cnt.begin())) {
     HIPCHK(h, hipMemcpyAsync(h->d_src_cnt, h->h_src_cnt.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -835,13 +863,21 @@ static void make_sweep_const(const mi355ndt_handle* h, SweepConst& sc) {
   sc.dyn_shift = h->dyn_shift >= 0 ? h->dyn_shift : (sc.K == 1 ? 3 : 2);
 }
 
-static int launch_sweep(mi355ndt_handle* h, const SweepConst& sc) {
+static int launch_sweep(mi355ndt_handle* h, const SweepConst& sc, int max_pairs = -1) {
   // persistent waves: SWEEP_WPE workgroups per CU pull (pair, chunk, quarter) items until the per-XCD queues are dry
-  const dim3 grid((unsigned)(h->n_cu * sweep_wpe(sc.pca != 0, sc.K)));
+  dim3 grid((unsigned)(h->n_cu * sweep_wpe(sc.pca != 0, sc.K)));
   if (h->prof) HIPCHK(h, ev_begin(h, h->ev_sweep));
-#define NDT_LAUNCH_SWEEP(P, KK) k_sweep<P, KK><<<grid, SWEEP_THREADS, 0, h->stream>>>(h->d_src, h->src_pitch, h->d_state, h->d_grid, \
-      h->d_words, h->d_recs, h->d_partials, h->chunks_per_pair, h->d_active_list, h->d_ctl + h->ctl_idx, h->d_ctl + (h->ctl_idx ^ 1), sc, h->d_cent)
-  if (sc.pca && sc.K == 27) {                    // ndt_pca + KDTREE: order-dependent weights, the literal kernel (ndt_sweep_kd.hpp)
+#define NDT_SWEEP_ARGS h->d_src, h->src_pitch, h->d_state, h->d_grid, h->d_words, h->d_recs, h->d_partials, h->rows_per_pair, h->d_active_list, \
+      h->d_ctl + h->ctl_idx, h->d_ctl + (h->ctl_idx ^ 1), sc, h->d_cent, h->d_grid_of_use
+#define NDT_LAUNCH_SWEEP(P, KK) k_sweep<P, KK><<<grid, SWEEP_THREADS, 0, h->stream>>>(NDT_SWEEP_ARGS)
+#define NDT_LAUNCH_FINE(P, KK) do { if (h->fine_it == 1) k_sweep<P, KK, 1, true><<<grid, SWEEP_THREADS, 0, h->stream>>>(NDT_SWEEP_ARGS); \
+                                    else k_sweep<P, KK, 2, true><<<grid, SWEEP_THREADS, 0, h->stream>>>(NDT_SWEEP_ARGS); } while (0)
+  if (h->fine_it) {                              // latency mode: items dealt statically over the whole grid, sized to the work there can be
+    const long long items = (long long)(max_pairs > 0 ? max_pairs : h->n_pairs) * h->rows_per_pair;
+    grid.x = (unsigned)std::max(1LL, std::min((long long)grid.x, (items + WAVES - 1) / WAVES));
+    if (sc.pca) { if (sc.K == 1) NDT_LAUNCH_FINE(true, 1); else NDT_LAUNCH_FINE(true, 7); }
+    else        { if (sc.K == 1) NDT_LAUNCH_FINE(false, 1); else NDT_LAUNCH_FINE(false, 7); }
+  } else if (sc.pca && sc.K == 27) {             // ndt_pca + KDTREE: order-dependent weights, the literal kernel (ndt_sweep_kd.hpp)
     k_sweep_pca_kd<<<dim3((unsigned)h->chunks_per_pair, (unsigned)h->n_pairs), SWEEP_THREADS, 0, h->stream>>>(
         h->d_src, h->src_pitch, h->d_state, h->d_grid, h->d_words, h->d_recs, h->d_cent, h->d_kdw, h->d_partials, h->chunks_per_pair,
         h->d_active_list, h->d_ctl + h->ctl_idx, h->d_ctl + (h->ctl_idx ^ 1), sc);
@@ -849,6 +885,8 @@ static int launch_sweep(mi355ndt_handle* h, const SweepConst& sc) {
   else        { if (sc.K == 1) NDT_LAUNCH_SWEEP(false, 1); else if (sc.K == 7) NDT_LAUNCH_SWEEP(false, 7); else if (sc.K == 26) NDT_LAUNCH_SWEEP(false, 26);
                 else NDT_LAUNCH_SWEEP(false, 27); }
 #undef NDT_LAUNCH_SWEEP
+#undef NDT_LAUNCH_FINE
+#undef NDT_SWEEP_ARGS
   h->ctl_idx ^= 1;                                // the block this sweep zeroed is the one the next update fills
   if (h->prof) HIPCHK(h, ev_end(h, h->ev_sweep));
   return MI355NDT_OK;
@@ -915,12 +953,12 @@ static int batch_align_impl(mi355ndt_handle* h, const float* guesses, mi355ndt_r
     int k = 0;
     for (; k < burst && round < max_rounds; k++, round++) {
       if (h->prof) HIPCHK(h, ev_begin(h, h->ev_update));
-      k_update<<<B, 64, 0, s>>>(h->d_state, h->d_partials, h->chunks_per_pair, h->d_results, dact + k,
+      k_update<<<B, UPD_THREADS, 0, s>>>(h->d_state, h->d_partials, h->rows_per_pair, h->pts_per_chunk, h->d_results, dact + k,
                                 h->d_active_list, h->d_ctl + h->ctl_idx, h->prof ? h->d_hits : nullptr,
                                 h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations, 0, mt_live ? 1 : 0);
       if (mt_live) {      // pairs whose More-Thuente loop iterated get their Hessian from computeHessian (impl2:999-1000)
         launch_hessian(h, sc);
-        k_update<<<B, 64, 0, s>>>(h->d_state, h->d_partials, h->chunks_per_pair, h->d_results, dact + k,
+        k_update<<<B, UPD_THREADS, 0, s>>>(h->d_state, h->d_partials, h->rows_per_pair, h->pts_per_chunk, h->d_results, dact + k,
                                   h->d_active_list, h->d_ctl + h->ctl_idx, nullptr,
                                   h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations, 0, 2);
       }
@@ -1094,7 +1132,7 @@ static int run_hook_sweep(mi355ndt_handle* h, double* score, double g[6], double
   make_sweep_const(h, sc);
   int rc = launch_sweep(h, sc);
   if (rc) return rc;
-  k_update<<<1, 64, 0, h->stream>>>(h->d_state, h->d_partials, h->chunks_per_pair, h->d_results, h->d_active, h->d_active_list, h->d_ctl,
+  k_update<<<1, UPD_THREADS, 0, h->stream>>>(h->d_state, h->d_partials, h->rows_per_pair, h->pts_per_chunk, h->d_results, h->d_active, h->d_active_list, h->d_ctl,
                                     nullptr, 0, 0, 0, 1, 0);
   PairState S;
   HIPCHK(h, hipMemcpyAsync(&S, h->d_state, sizeof(PairState), hipMemcpyDeviceToHost, h->stream));
@@ -1143,6 +1181,7 @@ int mi355ndt_compute_hessian(mi355ndt_handle* h, const double p[6], double H[36]
     h->prm = keep;
     if (rc) return rc;
   }
+  h->fine_it = 0; h->rows_per_pair = h->chunks_per_pair * QUARTERS; h->pts_per_chunk = CHUNK_PTS;   // k_hessian writes batch-mode rows
   double* dp = (double*)h->d_hook;
   HIPCHK(h, hipMemcpyAsync(dp, p, 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1152,7 +1191,7 @@ int mi355ndt_compute_hessian(mi355ndt_handle* h, const double p[6], double H[36]
   SweepConst sc;
   make_sweep_const(h, sc);
   launch_hessian(h, sc);
-  k_update<<<1, 64, 0, h->stream>>>(h->d_state, h->d_partials, h->chunks_per_pair, h->d_results, h->d_active, h->d_active_list, h->d_ctl,
+  k_update<<<1, UPD_THREADS, 0, h->stream>>>(h->d_state, h->d_partials, h->rows_per_pair, h->pts_per_chunk, h->d_results, h->d_active, h->d_active_list, h->d_ctl,
                                     nullptr, 0, 0, 0, 1, 2);
   PairState S;
   HIPCHK(h, hipMemcpyAsync(&S, h->d_state, sizeof(PairState), hipMemcpyDeviceToHost, h->stream));
@@ -1401,6 +1440,123 @@ int mi355ndt_use_prefiltered(mi355ndt_handle* h, int role) {
     return mi355ndt_batch_build_targets(h);
   }
   h->h_src_cnt[0] = (int)m; h->have_source = true;
+  return compute_enqueued(h);
+}
+
+// ---- latency mode ---------------------------------------------------------------------------------------------------------
+int mi355ndt_set_latency_mode(mi355ndt_handle* h, int on) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  h->latency_mode = on != 0;
+  return MI355NDT_OK;
+}
+
+int mi355ndt_sequence_run(mi355ndt_handle* h, int n_frames, const void* const* clouds, const size_t* counts, size_t stride,
+                          const double* stamps, const mi355ndt_seq_params* policy,
+                          mi355ndt_seq_frame* out_frames, mi355ndt_result* out_results, mi355ndt_seq_stats* stats) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (n_frames < 1 || n_frames > MAX_PAIRS || !clouds || !counts || !stamps || !out_frames || stride < 12) return MI355NDT_ERR_BAD_ARG;
+  if (mt_is_live(h->prm) || (h->prm.neighbor_mode != MI355NDT_DIRECT1 && h->prm.neighbor_mode != MI355NDT_DIRECT7)) {
+    h->err = "sequence mode serves DIRECT1 / DIRECT7 with step_size > transformation_epsilon / 2 (every configuration lv_slam ships)";
+    return MI355NDT_ERR_UNSUPPORTED;
+  }
+  size_t maxn = 0;
+  for (int k = 0; k < n_frames; k++) { if (counts[k] == 0 || counts[k] >= (1u << 31) || !clouds[k]) return MI355NDT_ERR_BAD_ARG; maxn = std::max(maxn, counts[k]); }
+  HIPCHK(h, hipSetDevice(h->device));
+  const auto t_up0 = std::chrono::steady_clock::now();
+  // every frame is a TARGET slot (its voxel grid is built: it may become a keyframe) and, through the same rows, the SOURCE of its own
+  // align: one cloud buffer serves both sides
+  int rc = mi355ndt_batch_reserve(h, n_frames, maxn, 64);
+  if (rc) return rc;
+  rc = mi355ndt_batch_set_clouds(h, 0, n_frames, clouds, counts, nullptr, nullptr, stride, 0);
+  if (rc) return rc;
+  h->d_src = h->d_tgt_own; h->src_pitch = h->tgt_pitch;
+  for (int k = 0; k < n_frames; k++) h->h_src_cnt[k] = h->h_tgt_cnt[k];
+  h->have_source = true;
+  struct Unalias { mi355ndt_handle* h; ~Unalias() { h->d_src = h->d_src_own; h->src_pitch = h->own_src_pitch; std::fill(h->h_src_cnt.begin(), h->h_src_cnt.end(), 0);
+                                                     h->have_source = false; h->d_grid_of_use = nullptr; h->aligned_once = false; } } unalias{h};
+  for (hipStream_t cs : h->copy_stream) HIPCHK(h, hipStreamSynchronize(cs));     // (upload time is reported on its own)
+  const auto t_up1 = std::chrono::steady_clock::now();
+  const bool keep_prof = h->prof;
+  h->prof = false;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  for (auto& e : ev) HIPCHK(h, hipEventCreate(&e));
+  struct EvFree { hipEvent_t* e; ~EvFree() { for (int i = 0; i < 3; i++) if (e[i]) (void)hipEventDestroy(e[i]); } } evfree{ev};
+  hipStream_t s = h->stream;
+  HIPCHK(h, hipEventRecord(ev[0], s));
+  rc = mi355ndt_batch_build_targets(h);
+  if (rc) { h->prof = keep_prof; return rc; }
+  HIPCHK(h, hipEventRecord(ev[1], s));
+  const bool lat = h->latency_mode;
+  h->latency_mode = true;
+  rc = prep_align_ws(h);
+  h->latency_mode = lat;
+  if (rc) { h->prof = keep_prof; return rc; }
+  // one pair is in flight at a time: the fine grid is sized for one pair
+  if ((size_t)n_frames > h->seq_cap) {
+    for (void** p : {(void**)&h->d_grid_of, (void**)&h->d_seq_out, (void**)&h->d_stamps}) if (*p) { HIPCHK(h, hipFree(*p)); *p = nullptr; }
+    h->seq_cap = 0;
+    HIPCHK(h, hipMalloc((void**)&h->d_grid_of, (size_t)n_frames * sizeof(int)));
+    HIPCHK(h, hipMalloc((void**)&h->d_seq_out, (size_t)n_frames * sizeof(mi355ndt_seq_frame)));
+    HIPCHK(h, hipMalloc((void**)&h->d_stamps, (size_t)n_frames * sizeof(double)));
+    h->seq_cap = (size_t)n_frames;
+  }
+  if (!h->d_seq) HIPCHK(h, hipMalloc((void**)&h->d_seq, sizeof(SeqState)));
+  if (!h->h_seq_flags) {
+    HIPCHK(h, hipHostMalloc((void**)&h->h_seq_flags, 64, hipHostMallocMapped));
+    HIPCHK(h, hipHostGetDevicePointer((void**)&h->d_seq_flags, (void*)h->h_seq_flags, 0));
+  }
+  h->h_seq_flags[0] = 0; h->h_seq_flags[1] = 0;
+  SeqState q0;
+  memset(&q0, 0, sizeof q0);
+  q0.n_frames = n_frames;
+  q0.d_trans = policy ? policy->keyframe_delta_trans : 5.0;                       // scan_matching_odom_nodelet.cpp:67-76
+  q0.d_angle = policy ? policy->keyframe_delta_angle : 0.17;
+  q0.d_time = policy ? policy->keyframe_delta_time : 1.0;
+  HIPCHK(h, hipMemcpyAsync(h->d_seq, &q0, sizeof q0, hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(h->d_stamps, stamps, (size_t)n_frames * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemsetAsync(h->d_grid_of, 0, (size_t)n_frames * sizeof(int), s));
+  HIPCHK(h, hipMemsetAsync(h->d_results, 0, (size_t)n_frames * sizeof(mi355ndt_result), s));
+  HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, 2 * sizeof(SweepCtl), s));
+  HIPCHK(h, hipStreamSynchronize(s));            // q0 / stamps are pageable: they must be out of the caller's memory before the pump starts
+  h->ctl_idx = 0;
+  h->d_grid_of_use = h->d_grid_of;
+  SweepConst sc;
+  make_sweep_const(h, sc);
+  k_seq_begin<<<1, 64, 0, s>>>(h->d_seq, h->d_state, h->d_grid, h->d_src_cnt, h->d_stamps, h->d_seq_out, h->d_active_list, h->d_ctl, h->d_grid_of, h->d_seq_flags);
+  rc = launch_sweep(h, sc, 1);
+  // The pump: (update, sweep), (update, sweep), ... enqueued blindly, at most `depth` rounds ahead of what the device has executed;
+  // whether a launch continues a frame's Newton loop, closes the frame and opens the next, or has nothing left to do is decided
+  // on the device.  The host never waits for a result -- it only reads two words the device writes into mapped memory.
+  const int depth = 12;
+  long long enq = 0;
+  const long long max_launches = (long long)n_frames * (h->prm.max_iterations + 6) + 64;
+  while (rc == MI355NDT_OK && !h->h_seq_flags[0] && enq < max_launches) {
+    if (enq - (long long)h->h_seq_flags[1] >= depth) { std::this_thread::yield(); continue; }
+    k_seq_update<<<1, UPD_THREADS, 0, s>>>(h->d_seq, h->d_state, h->d_partials, h->rows_per_pair, h->pts_per_chunk, h->d_results, h->d_grid, h->d_src_cnt,
+                                           h->d_stamps, h->d_seq_out, h->d_active_list, h->d_ctl + h->ctl_idx, h->d_grid_of, h->d_seq_flags,
+                                           h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations);
+    rc = launch_sweep(h, sc, 1);
+    enq++;
+  }
+  hipError_t e = hipEventRecord(ev[2], s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  h->prof = keep_prof;
+  if (e != hipSuccess) { h->err = std::string("sequence run: ") + hipGetErrorString(e); return MI355NDT_ERR_HIP; }
+  if (rc) return rc;
+  HIPCHK(h, hipGetLastError());
+  if (!h->h_seq_flags[0]) { h->err = "sequence run did not finish within its launch budget"; return MI355NDT_ERR_STATE; }
+  HIPCHK(h, hipMemcpy(out_frames, h->d_seq_out, (size_t)n_frames * sizeof(mi355ndt_seq_frame), hipMemcpyDeviceToHost));
+  if (out_results) HIPCHK(h, hipMemcpy(out_results, h->d_results, (size_t)n_frames * sizeof(mi355ndt_result), hipMemcpyDeviceToHost));
+  if (stats) {
+    float b_ms = 0, t_ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&b_ms, ev[0], ev[1]));
+    HIPCHK(h, hipEventElapsedTime(&t_ms, ev[1], ev[2]));
+    stats->upload_ms = std::chrono::duration<double, std::milli>(t_up1 - t_up0).count();
+    stats->build_ms = b_ms;
+    stats->track_ms = t_ms;
+    stats->aligns = n_frames > 1 ? n_frames : 0;
+    stats->update_launches = h->h_seq_flags[1];
+  }
   return compute_enqueued(h);
 }
 

@@ -1,0 +1,163 @@
+// ndt_sequence.hpp -- latency mode: a whole run of frames tracked on the device.
+//
+// Restates the per-frame body of ScanMatchingOdomNodelet::matching_s2k
+// (src/lidar_odometry/scan_matching_odom_nodelet.cpp:192-261): scan-to-keyframe align, the frame-1 double align (:223-227),
+// tf_s2s / odom_velo (:231-234), the keyframe test (:237-240: |t|, 2 acos(q.w) in f32, stamp difference), target switch (:241-247)
+// and the constant-velocity guess (:249-250) -- as the tail of the Newton-update kernel, so that no host round trip separates
+// one frame's last Newton step from the next frame's first sweep.  The host only pumps an alternating stream of
+// (k_seq_update, k_sweep<FINE>) launches and stops when the device says the last frame is done (mi355_ndt.hip:
+// mi355ndt_sequence_run); how many rounds a frame needs is decided here, on the device.
+//
+// The frames' voxel grids are built beforehand, all at once, by the batched target build (every frame is a potential keyframe:
+// 2.6 us per grid in a 271-frame batch); `grid_of[k]` names the grid frame k is matched against (its keyframe's).
+#pragma once
+#include "ndt_types.hpp"
+#include "ndt_math.hpp"
+#include "ndt_update.hpp"
+
+struct SeqState {
+  int    n_frames, cur, key_id, second_done, done, aligns, launches, pad1;
+  double pre_tf_s2k[16], key_pose[16];          // 4x4 f64 row-major
+  double keyframe_stamp;
+  double d_trans, d_angle, d_time;              // keyframe_delta_trans / _angle / _time (:67-76)
+};
+
+// ---- 4x4 f64 helpers, explicit operation order (canonical choices; Eigen's own order is not observable here) ---------------
+namespace seqm {
+__device__ __host__ inline void mul4(const double A[16], const double B[16], double C[16]) {
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++)
+      C[i * 4 + j] = ((A[i * 4 + 0] * B[0 * 4 + j] + A[i * 4 + 1] * B[1 * 4 + j]) + A[i * 4 + 2] * B[2 * 4 + j]) + A[i * 4 + 3] * B[3 * 4 + j];
+}
+// general 4x4 inverse by cofactors (the shape of Eigen 3.3's compute_inverse_size4: cofactor matrix, then one division by
+// col(0) . cofactor row)
+__device__ __host__ inline double det3h(const double* m, int i1, int i2, int i3, int j1, int j2, int j3) {
+  return m[i1 * 4 + j1] * (m[i2 * 4 + j2] * m[i3 * 4 + j3] - m[i2 * 4 + j3] * m[i3 * 4 + j2]);
+}
+__device__ __host__ inline double cof4(const double* m, int i, int j) {
+  const int i1 = (i + 1) % 4, i2 = (i + 2) % 4, i3 = (i + 3) % 4, j1 = (j + 1) % 4, j2 = (j + 2) % 4, j3 = (j + 3) % 4;
+  return (det3h(m, i1, i2, i3, j1, j2, j3) + det3h(m, i2, i3, i1, j1, j2, j3)) + det3h(m, i3, i1, i2, j1, j2, j3);
+}
+__device__ __host__ inline void inv4(const double M[16], double R[16]) {
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      const double c = cof4(M, i, j);
+      R[j * 4 + i] = ((i + j) & 1) ? -c : c;
+    }
+  const double det = ((M[0 * 4 + 0] * R[0 * 4 + 0] + M[1 * 4 + 0] * R[0 * 4 + 1]) + M[2 * 4 + 0] * R[0 * 4 + 2]) + M[3 * 4 + 0] * R[0 * 4 + 3];
+  for (int a = 0; a < 16; a++) R[a] = R[a] / det;
+}
+// w of Eigen::Quaternionf(R.cast<float>()) (quaternionbase_assign_impl<Matrix3f>), f32 arithmetic
+__device__ __host__ inline float quat_w_f32(const float m[9]) {
+  float t = (m[0] + m[4]) + m[8];
+  if (t > 0.f) return 0.5f * sqrtf(t + 1.0f);
+  int i = 0;
+  if (m[4] > m[0]) i = 1;
+  if (m[8] > m[i * 3 + i]) i = 2;
+  const int j = (i + 1) % 3, k = (j + 1) % 3;
+  t = sqrtf(((m[i * 3 + i] - m[j * 3 + j]) - m[k * 3 + k]) + 1.0f);
+  return (m[k * 3 + j] - m[j * 3 + k]) * (0.5f / t);
+}
+}  // namespace seqm
+
+// frame 0 (:194-208): it becomes the first keyframe; frame 1's first align starts from Identity + 1.5 m along x
+__global__ void k_seq_begin(SeqState* seq, PairState* st, const GridDesc* __restrict__ gd, const int* __restrict__ cnt,
+                            const double* __restrict__ stamps, mi355ndt_seq_frame* out, int* active_list, SweepCtl* ctl, int* grid_of,
+                            volatile int* host_flags) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  SeqState& Q = *seq;
+  Q.cur = 1; Q.key_id = 0; Q.second_done = 0; Q.aligns = 0; Q.done = 0; Q.launches = 0;
+  for (int a = 0; a < 16; a++) Q.pre_tf_s2k[a] = Q.key_pose[a] = (a % 5 == 0) ? 1.0 : 0.0;
+  Q.keyframe_stamp = stamps[0];
+  mi355ndt_seq_frame f;
+  memset(&f, 0, sizeof f);
+  for (int a = 0; a < 16; a++) { f.odom_colmajor[a] = (a % 5 == 0) ? 1.0 : 0.0; f.tf_s2k_colmajor[a] = (a % 5 == 0) ? 1.f : 0.f; }
+  f.key_id = 0; f.new_keyframe = 1; f.converged = 1;
+  out[0] = f;
+  grid_of[0] = 0;
+  if (Q.n_frames < 2) { Q.done = 1; host_flags[0] = 1; return; }
+  float G[16];
+  for (int a = 0; a < 16; a++) G[a] = (a % 5 == 0) ? 1.f : 0.f;
+  G[12] = 1.5f;                                                                  // guess_trans(0,3) = 1.5 (:199-200)
+  grid_of[1] = 0;
+  init_pair_state(st[1], G, cnt[1], gd[0].status);
+  active_list[0] = 1;
+  ctl->n_active = 1;
+}
+
+// One launch = "the next thing the run needs after a sweep": reduce the current frame's rows, take its Newton step; when its align
+// is over, run the call-site policy and set the next frame up.  One block; the host launches it blindly between sweeps.
+__global__ void __launch_bounds__(UPD_THREADS)
+k_seq_update(SeqState* seq, PairState* st, const double* __restrict__ partials, int rows_per_pair, int pts_per_chunk, mi355ndt_result* results,
+             const GridDesc* __restrict__ gd, const int* __restrict__ cnt, const double* __restrict__ stamps, mi355ndt_seq_frame* out,
+             int* active_list, SweepCtl* ctl, int* grid_of, volatile int* host_flags,
+             double step_max, double eps, int max_iterations) {
+  __shared__ double sm[UPD_WAVES][NACC];
+  SeqState& Q = *seq;
+  if (threadIdx.x == 0) { Q.launches++; host_flags[1] = Q.launches; }            // launches executed (the host bounds its queue depth with it)
+  if (Q.done) return;                                                            // (block-uniform; the pump's overshoot)
+  const int cur = Q.cur;
+  PairState& S = st[cur];
+  const int lane = threadIdx.x & 63;
+  const int nchunks = (S.n_src + pts_per_chunk - 1) / pts_per_chunk;
+  const double v = reduce_pair_rows(partials + (size_t)cur * rows_per_pair * NACC, nchunks, true, sm);
+  if (threadIdx.x < NACC) {
+    if (lane == 0) S.score = v;
+    else if (lane < 7) S.g[lane - 1] = v;
+    else if (lane < 43) S.H[lane - 7] = v;
+    else S.hits = (long long)v;
+  }
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  const int rc = newton_update(S, &results[cur], step_max, eps, max_iterations, 0);
+  if (lane != 0) return;
+  if (rc == NEWTON_SWEEP) { active_list[0] = cur; ctl->n_active = 1; return; }
+  // ---- the align of frame `cur` is over: scan_matching_odom_nodelet.cpp:221-250
+  Q.aligns++;
+  const float* F = S.final_cm;                                                   // getFinalTransformation(), column-major f32
+  if (cur == 1 && !Q.second_done) {                                              // :223-227: frame 1 is aligned twice, the second time from the first result
+    Q.second_done = 1;
+    float G[16];
+    for (int a = 0; a < 16; a++) G[a] = F[a];                                    // tf_s2k.cast<float>() of a float matrix cast to double: the same floats
+    init_pair_state(S, G, cnt[cur], gd[grid_of[cur]].status);
+    active_list[0] = cur; ctl->n_active = 1;
+    return;
+  }
+  double tf[16], inv[16], s2s[16], odom[16];
+  for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) tf[r * 4 + c] = (double)F[c * 4 + r];
+  seqm::inv4(Q.pre_tf_s2k, inv);
+  seqm::mul4(inv, tf, s2s);                                                      // tf_s2s = pre_tf_s2k.inverse() * tf_s2k (:231)
+  seqm::mul4(Q.key_pose, tf, odom);                                              // odom_velo = key_pose * tf_s2k (:234)
+  const double dx = sqrt((tf[3] * tf[3] + tf[7] * tf[7]) + tf[11] * tf[11]);      // :237
+  float Rf[9];
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Rf[r * 3 + c] = F[c * 4 + r];
+  const double da = (double)(2.f * acosf(seqm::quat_w_f32(Rf)));                 // :238: std::acos(float) -> float, times int
+  const double dt = stamps[cur] - Q.keyframe_stamp;                              // :239
+  mi355ndt_seq_frame f;
+  memset(&f, 0, sizeof f);
+  for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) f.odom_colmajor[c * 4 + r] = odom[r * 4 + c];
+  for (int a = 0; a < 16; a++) f.tf_s2k_colmajor[a] = F[a];
+  f.key_id = Q.key_id;
+  f.iterations = S.it; f.converged = S.converged; f.trans_probability = S.trans_probability;
+  f.dx = dx; f.da = da; f.dt = dt;
+  f.aligns = (cur == 1) ? 2 : 1;
+  if (dx > Q.d_trans || da > Q.d_angle || dt > Q.d_time) {                       // :240-247: this scan becomes the keyframe
+    Q.key_id = cur;
+    for (int a = 0; a < 16; a++) { tf[a] = (a % 5 == 0) ? 1.0 : 0.0; Q.key_pose[a] = odom[a]; }
+    Q.keyframe_stamp = stamps[cur];
+    f.new_keyframe = 1;
+  }
+  out[cur] = f;
+  double guess[16];
+  for (int a = 0; a < 16; a++) Q.pre_tf_s2k[a] = tf[a];                          // :249
+  seqm::mul4(tf, s2s, guess);                                                    // guess_trans = pre_tf_s2k * tf_s2s (:250)
+  const int nxt = cur + 1;
+  if (nxt >= Q.n_frames) { Q.done = 1; Q.cur = nxt; __threadfence_system(); host_flags[0] = 1; return; }
+  float G[16];
+  for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) G[c * 4 + r] = (float)guess[r * 4 + c];   // guess_trans.cast<float>() (:221)
+  grid_of[nxt] = Q.key_id;
+  init_pair_state(st[nxt], G, cnt[nxt], gd[Q.key_id].status);
+  Q.cur = nxt;
+  active_list[0] = nxt;
+  ctl->n_active = 1;
+}

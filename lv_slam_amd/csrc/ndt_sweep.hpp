@@ -147,12 +147,19 @@ struct SweepTune {
 };
 static inline int sweep_wpe(bool pca, int K) { (void)pca; (void)K; return SWEEP_WPE; }
 
-template <bool PCA, int K>
+// IT = tiles of 64 points per work item.  8 is the batch mode described above (a wave-quarter of a 2048-point chunk).
+// FINE (latency mode): small items (IT = 1 or 2) dealt statically over ALL waves of the grid, for a sweep over one or a
+// few pairs -- a single 65,536-point pair then offers 512-1024 items to the 2,048 resident waves instead of 128, and no wave
+// claims anything with an atomic.  A pair's rows are then summed by k_update with the same rule over 4-row chunks of 4 * IT * 64
+// points: its own fixed tree, not the batch mode's (results agree to the f64 rounding of the sums, ~1e-16 relative).
+// `grid_of` (may be null): pair b is aligned against the target grid gd[grid_of[b]] instead of gd[b] (sequence mode: the frames'
+// grids are built once, the keyframe policy picks which one a frame is matched against).
+template <bool PCA, int K, int IT = 8, bool FINE = false>
 __global__ void __launch_bounds__(SWEEP_THREADS, (SweepTune<PCA, K>::WPE))
 k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict__ st,
         const GridDesc* __restrict__ gd, const BitWord* __restrict__ words, const VoxelRec* __restrict__ recs,
-        double* partials, int chunks_per_pair, const int* __restrict__ active_list, SweepCtl* ctl, SweepCtl* ctl_next, SweepConst sc,
-        const float* __restrict__ cent) {
+        double* partials, int rows_per_pair, const int* __restrict__ active_list, SweepCtl* ctl, SweepCtl* ctl_next, SweepConst sc,
+        const float* __restrict__ cent, const int* __restrict__ grid_of) {
   // K == 27 is the KDTREE mode (ndt_omp_impl2.hpp:251-253): radiusSearch(point, resolution) over the f32 centroids of the
   // searchable leaves (voxel_grid_covariance_omp.h:505-534).  A centroid lies inside its own cell, so every centroid closer
   // than one leaf sits in the 3x3x3 block around the point's cell: probe those 27 cells and keep d^2 < float(r*r).  The
@@ -167,7 +174,7 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const int n_active = ctl->n_active;
-  const int items_per_pair = chunks_per_pair * QUARTERS;
+  const int items_per_pair = rows_per_pair;         // one partial row per work item
 
   // ndt_pca's per-hit multiplier is the product of the hit's own weight and those of the point's LATER hits, known only in phase A.
   // With one probe per point (DIRECT1) it is just the leaf's own weight, which phase B reads with the record anyway: no weight
@@ -183,8 +190,8 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
   // their ballots -- the probe stage costs a few L2 round trips per super-tile, not per tile.  DIRECT1 has one probe per point
   // and ~0.9 hits, so it is probe-stage bound: 4 tiles at a time; DIRECT7: 2 (14 bitmap words in flight); the 26/27-cell
   // searches already have 7-probe groups inside one tile.
-  constexpr int TP = SweepTune<PCA, K>::TP;
-  constexpr int NBUF = (CHUNK_PTS / WAVES / 64 / TP > 1) ? 2 : 1;   // a super-tile that is the whole item needs no second buffer
+  constexpr int TP = SweepTune<PCA, K>::TP < IT ? SweepTune<PCA, K>::TP : IT;
+  constexpr int NBUF = (IT / TP > 1) ? 2 : 1;   // a super-tile that is the whole item needs no second buffer
   __shared__ float stage[WAVES][NBUF * 64 * TP][6];   // (two) super-tiles of staged points: x'(3), R x (3)
 
   __shared__ double exp_tab[64];                   // 2^(j/64) for ndtm::exp_f32arg
@@ -199,23 +206,28 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
   // order (vmcnt), so every load issued after a returning atomic -- an agent-scope atomic takes ~4 us here -- waits for it;
   // with one claim per item the point loads of every item sat behind one (measured with -DNDT_TIMELINE: 10 k cycles per item).
   // The dynamic tail (1 / 2^sc.dyn_shift of the queue, more when that is no whole round) absorbs the imbalance.
-  const int xw = (int)(gridDim.x >> 3) * WAVES;  // waves per XCD
-  const int wx = (int)(blockIdx.x >> 3) * WAVES + wv;
+  // FLAT dealing: one queue over all active pairs, item i to wave i of the whole grid (then i + all waves, ...), no atomics and no
+  // XCD affinity.  Always in latency mode; in batch mode whenever the launch has no more items than waves -- the last rounds of a
+  // batch, when a handful of pairs are still iterating: with fewer than eight active pairs most XCDs own no queue and their waves
+  // would do nothing but steal, one returning atomic (~4 us) per item.  Which wave runs an item is no part of its result.
+  const bool flat = FINE || (n_active * items_per_pair <= (int)gridDim.x * WAVES);
+  const int xw = flat ? (int)gridDim.x * WAVES : (int)(gridDim.x >> 3) * WAVES;          // waves per XCD (flat: of the whole grid)
+  const int wx = flat ? (int)blockIdx.x * WAVES + wv : (int)(blockIdx.x >> 3) * WAVES + wv;
 #ifdef NDT_TIMELINE
   unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tl_last = __builtin_readcyclecounter();
 #endif
 #pragma unroll 1
-  for (int probe = 0; probe < 8; probe++) {        // own XCD first, then steal
-    const int xcd = (my_xcd + probe) & 7;
-    const int pairs_here = n_active > xcd ? (n_active - xcd + 7) / 8 : 0;
+  for (int probe = 0; probe < (flat ? 1 : 8); probe++) {        // own XCD first, then steal (flat: one queue, all static)
+    const int xcd = flat ? 0 : (my_xcd + probe) & 7;
+    const int pairs_here = flat ? n_active : (n_active > xcd ? (n_active - xcd + 7) / 8 : 0);
     const int items_here = pairs_here * items_per_pair;
     if (items_here == 0) continue;
     // static rounds of this queue (the same number for every wave; none when the grid is no multiple of 8 or for a thief)
-    const int n_static = ((gridDim.x & 7) == 0) ? (items_here - (items_here >> sc.dyn_shift)) / xw : 0;
+    const int n_static = flat ? (items_here + xw - 1) / xw : (((gridDim.x & 7) == 0) ? (items_here - (items_here >> sc.dyn_shift)) / xw : 0);
     const int dyn0 = n_static * xw;               // first item of the dynamic tail
     int round = 0;
-    const bool own = (probe == 0) && n_static > 0;
+    const bool own = flat || ((probe == 0) && n_static > 0);
     int item = 0;
     if (own) item = wx;
     else {
@@ -229,15 +241,15 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
       // the next item: static while rounds are left, else claimed NOW (the atomic's round trip is hidden behind this item's work)
       const bool next_static = own && (round + 1 < n_static);
       int next_item = 0;
-      if (!next_static && lane == 0) next_item = dyn0 + atomicAdd(&ctl->next_item[xcd], 1);
-      const int b = active_list[xcd + 8 * (item / items_per_pair)];
-      const int rem = item % items_per_pair;
-      const int chunk = rem / QUARTERS, quarter = rem % QUARTERS;
+      if (flat) next_item = items_here;             // no dynamic tail
+      else if (!next_static && lane == 0) next_item = dyn0 + atomicAdd(&ctl->next_item[xcd], 1);
+      const int b = active_list[flat ? item / items_per_pair : xcd + 8 * (item / items_per_pair)];
+      const int rem = item % items_per_pair;        // the pair's work item = its partial row
       TL_STAMP(0);
 
   const PairState& S = st[b];
   const int n = S.n_src;
-  const GridDesc& g = gd[b];
+  const GridDesc& g = gd[grid_of ? grid_of[b] : b];
   const float* X = src + (size_t)b * 3 * pitch;
   const BitWord* W = words + g.word_off;
   const VoxelRec* R = recs + g.rec_off;
@@ -258,7 +270,7 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
     unsigned nhits = 0;                              // wave-uniform
     int qhead = 0, qcount = 0;                       // wave-uniform
     int q_old = 0;                                   // queued entries that reference the OTHER staging half (older tile)
-    const int wbase = chunk * CHUNK_PTS + quarter * (CHUNK_PTS / QUARTERS);
+    const int wbase = rem * (IT * 64);
 
     // One batch of queued hits (one per lane): queue entry + the voxel record it points at, in registers.
     struct Batch { unsigned slot; double m0, m1, m2; float C[9]; int weight; double w; };
@@ -316,7 +328,7 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
       }
     };
     if (wbase < n && grid_ok) {
-      constexpr int NST = CHUNK_PTS / WAVES / 64 / TP;        // super-tiles per item
+      constexpr int NST = IT / TP;                            // super-tiles per item
       const unsigned e0 = (unsigned)(xb0 - mb0), e1 = (unsigned)(xb1 - mb1), e2 = (unsigned)(xb2 - mb2);
       const unsigned empty_cell = (unsigned)(nwords - 1) << 6;
       // points of the next super-tile are fetched one super-tile ahead (HBM latency ~2 us would otherwise be exposed each time)
@@ -473,7 +485,7 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
     if ((lane & 15) == 0) {
       // row 0 (lane 0) holds values 0..10, row 1: 11..21, row 2: 22..32, row 3: 33..42 (+ the pad)
       const int row = lane >> 4, base = 11 * (row & 1) + 22 * (row >> 1);
-      double* P = partials + (((size_t)b * chunks_per_pair + chunk) * QUARTERS + quarter) * NACC;
+      double* P = partials + ((size_t)b * rows_per_pair + rem) * NACC;
 #pragma unroll
       for (int i = 0; i < 11; i++) if (base + i < 43) P[base + i] = P2[i];
       if (lane == 0) P[43] = (double)nhits;

@@ -22,26 +22,29 @@ __device__ void finalize_pair(PairState& S, mi355ndt_result* res, int converged)
   *res = o;
 }
 
-// transformation_ = (Sophus::SE3::exp(delta_p).matrix()).cast<float>() (impl2:163)
-__device__ inline void set_increment(PairState& S, const double dp[6]) {
-  float T[12], Rj[9];
-  ndtm::pose_to_f32(dp, T, Rj);
+// transformation_ = (Sophus::SE3::exp(delta_p).matrix()).cast<float>() (impl2:163); `e` = exp(delta_p)
+__device__ inline void set_increment_se3(PairState& S, const ndtm::SE3& e) {
+  double R[9];
+  ndtm::q_to_matrix(e.q, R);
   for (int r = 0; r < 3; r++) {
-    for (int c = 0; c < 4; c++) S.inc_cm[c * 4 + r] = T[r * 4 + c];
+    for (int c = 0; c < 3; c++) S.inc_cm[c * 4 + r] = (float)R[r * 3 + c];
+    S.inc_cm[12 + r] = (float)e.t[r];
     S.inc_cm[r * 4 + 3] = 0.f;
   }
   S.inc_cm[15] = 1.f;
 }
+__device__ inline void set_increment(PairState& S, const double dp[6]) { set_increment_se3(S, ndtm::se3_exp(dp)); }
 
-// p = SE3(R,t).log(); first sweep moves the cloud by the caller's f32 guess itself (impl2:102-129)
-__global__ void k_init_state(PairState* st, const float* __restrict__ guess_cm, const int* __restrict__ src_cnt,
-                             const GridDesc* __restrict__ gd, int n_pairs, int* active_list, SweepCtl* ctl) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= n_pairs) return;
-  active_list[b] = b;                            // the first sweep covers every pair
-  if (b == 0) ctl->n_active = n_pairs;
-  PairState& S = st[b];
-  const float* G = guess_cm + (size_t)b * 16;
+__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src); }
+__device__ __forceinline__ ndtm::SE3 shfl_se3(const ndtm::SE3& e, int src) {
+  ndtm::SE3 r;
+  r.q.w = shfl_d(e.q.w, src); r.q.x = shfl_d(e.q.x, src); r.q.y = shfl_d(e.q.y, src); r.q.z = shfl_d(e.q.z, src);
+  r.t[0] = shfl_d(e.t[0], src); r.t[1] = shfl_d(e.t[1], src); r.t[2] = shfl_d(e.t[2], src);
+  return r;
+}
+
+// computeTransformation's set-up for one pair (impl2:102-129): p = log(guess), first sweep moves the cloud by the f32 guess itself
+__device__ inline void init_pair_state(PairState& S, const float G[16] /* column-major */, int n_src, int grid_status) {
   double R[9], t[3];
   for (int r = 0; r < 3; r++) {
     for (int c = 0; c < 3; c++) { S.T[r * 4 + c] = G[c * 4 + r]; R[r * 3 + c] = (double)G[c * 4 + r]; }
@@ -54,8 +57,18 @@ __global__ void k_init_state(PairState* st, const float* __restrict__ guess_cm, 
   ndtm::pose_to_f32(S.p, Tdummy, S.Rj);
   S.it = 0; S.phase = PH_SWEEP0; S.converged = 0; S.sweeps = 1; S.a_t = 0; S.hits = 0; S.score = 0; S.mt_loops = 0;
   for (int a = 0; a < 16; a++) S.inc_cm[a] = S.prev_inc_cm[a] = (a % 5 == 0) ? 1.f : 0.f;    // align(): transformation_ = previous_ = I
-  S.n_src = src_cnt[b];
-  S.grid_status = gd[b].status;
+  S.n_src = n_src;
+  S.grid_status = grid_status;
+}
+
+// p = SE3(R,t).log(); first sweep moves the cloud by the caller's f32 guess itself (impl2:102-129)
+__global__ void k_init_state(PairState* st, const float* __restrict__ guess_cm, const int* __restrict__ src_cnt,
+                             const GridDesc* __restrict__ gd, int n_pairs, int* active_list, SweepCtl* ctl) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_pairs) return;
+  active_list[b] = b;                            // the first sweep covers every pair
+  if (b == 0) ctl->n_active = n_pairs;
+  init_pair_state(st[b], guess_cm + (size_t)b * 16, src_cnt[b], gd[b].status);
 }
 
 // explicit sweep pose (parity hooks)
@@ -157,48 +170,77 @@ __device__ inline int mt_loop(PairState& S, double step_max, double step_min) {
   return its;
 }
 
-// One wave per pair: fixed-order reduction of the chunk partials, then the body of the while loop of
-// computeTransformation (impl2:131-183) with computeStepLengthMT (impl2:841-1003).
-// mt = 0: step_size > eps/2, the More-Thuente loop is dead (every shipped configuration);
-// mt = 1: live case, called after a derivative sweep;  mt = 2: live case, called after the computeHessian pass.
-__global__ void __launch_bounds__(64)
-k_update(PairState* st, const double* __restrict__ partials, int chunks_per_pair, mi355ndt_result* results,
-         int* active_counter, int* active_list, SweepCtl* ctl, unsigned long long* hits_total,
-         double step_max, double eps, int max_iterations, int reduce_only, int mt) {
-  const int b = blockIdx.x;
-  PairState& S = st[b];
-  if (S.phase == PH_DONE) return;
-  if (mt == 2 && S.phase != PH_HESS) return;                                     // only pairs whose Hessian pass just ran
-  const int lane = threadIdx.x;
-  const int nchunks = (S.n_src + CHUNK_PTS - 1) / CHUNK_PTS;
-  if (lane < NACC && (mt != 2 || (lane >= 7 && lane < 43))) {
-    double v = 0.0;
-    const double* P = partials + (size_t)b * chunks_per_pair * QUARTERS * NACC + lane;
-    // impl2:298-302 (fixed order).  Eight chunks' rows are loaded together, then added in chunk order: the loop is a chain of
-    // dependent adds, but its 4 * nchunks loads do not have to wait for one another.
-    int c = 0;
-    for (; c + 8 <= nchunks; c += 8) {
-      double q[8][QUARTERS];
+// ---- fixed-order reduction of one pair's partial rows ------------------------------------------------------------------
+// A pair's sweep leaves one 44-double row per work item (score, g[6], H[36], hits).  Four consecutive rows form a CHUNK,
+// ((r0 + r1) + r2) + r3 (impl2:298-302 adds per-thread sums in a fixed order; so does this).  Eight consecutive chunks form a
+// GROUP, added in chunk order.  Group k belongs to wave k % UPD_WAVES (= 4) of the block, which adds its groups in ascending order;
+// wave 0 then adds the four wave sums in wave order.  (Four waves = one per SIMD: the Newton step below wants 300+ VGPRs.)  The tree is a function of the number of chunks alone -- never of the batch,
+// the launch geometry or which wave ran an item -- so batched and single runs of a pair stay bit-identical; up to eight chunks
+// (16,384 points) it is the plain sequential sum.  Every wave has all 32 loads of a group in flight at once: the reduction of a
+// 131,072-point pair (256 rows) is two memory round trips per wave instead of eight on one wave.
+#define UPD_WAVES   4
+#define UPD_THREADS (64 * UPD_WAVES)
+__device__ __forceinline__ double reduce_pair_rows(const double* __restrict__ rows, int nchunks, bool take, double (*sm)[NACC]) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane < NACC) {
+    double acc = 0.0;
+    if (take) {
+      const double* P = rows + lane;
+#pragma unroll 1
+      for (int c0 = w * 8; c0 < nchunks; c0 += 8 * UPD_WAVES) {
+        double gs = 0.0;
+        if (c0 + 8 <= nchunks) {
+          double q[8][4];
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const double* Q = P + (size_t)(c + u) * QUARTERS * NACC;
+          for (int u = 0; u < 8; u++) {
+            const double* Q = P + (size_t)(c0 + u) * 4 * NACC;
 #pragma unroll
-        for (int k = 0; k < QUARTERS; k++) q[u][k] = Q[k * NACC];
+            for (int k = 0; k < 4; k++) q[u][k] = Q[k * NACC];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) gs += ((q[u][0] + q[u][1]) + q[u][2]) + q[u][3];
+        } else {
+          for (int c = c0; c < nchunks; c++) {
+            const double* Q = P + (size_t)c * 4 * NACC;
+            gs += ((Q[0] + Q[NACC]) + Q[2 * NACC]) + Q[3 * NACC];
+          }
+        }
+        acc += gs;
       }
-#pragma unroll
-      for (int u = 0; u < 8; u++) v += ((q[u][0] + q[u][1]) + q[u][2]) + q[u][3];   // the chunk's four wave-quarters, in order
     }
-    for (; c < nchunks; c++) {
-      const double* Q = P + (size_t)c * QUARTERS * NACC;
-      v += ((Q[0] + Q[NACC]) + Q[2 * NACC]) + Q[3 * NACC];
-    }
-    if (lane == 0) S.score = v;
-    else if (lane < 7) S.g[lane - 1] = v;
-    else if (lane < 43) S.H[lane - 7] = v;
-    else { S.hits = (long long)v; if (hits_total) atomicAdd(hits_total, (unsigned long long)v); }
+    sm[w][lane] = acc;
   }
   __syncthreads();
-  if (lane != 0 || reduce_only) return;
+  double v = 0.0;
+  if (w == 0 && lane < NACC) {
+#pragma unroll
+    for (int k = 0; k < UPD_WAVES; k++) v += sm[k][lane];
+  }
+  return v;
+}
+
+enum { NEWTON_DONE = 0, NEWTON_SWEEP = 1, NEWTON_HESSIAN = 2 };
+
+// The body of the while loop of computeTransformation (impl2:131-183) with computeStepLengthMT (impl2:841-1003), for one pair
+// whose reduced (score, g, H) are in S.  Called by every lane of one wave; lane 0 carries the state, the others only help where
+// the same function is needed on several arguments at once (the SE(3) exponentials of the re-basing step: SIMT runs them for
+// the price of one).  Returns on lane 0: NEWTON_DONE (pair finalised), NEWTON_SWEEP (a step was scheduled: the pair takes part
+// in the next derivative sweep), NEWTON_HESSIAN (live More-Thuente case: waiting for the computeHessian pass).
+// mt = 0: step_size > eps/2, the More-Thuente loop is dead (every shipped configuration);
+// mt = 1: live case, called after a derivative sweep;  mt = 2: live case, called after the computeHessian pass.
+__device__ __forceinline__ int newton_update(PairState& S, mi355ndt_result* res, double step_max, double eps, int max_iterations, int mt) {
+  const int lane = threadIdx.x & 63;
+  // exp(delta_p) and exp(p) of impl2:163-166, side by side on two lanes (same bits as one after the other on one lane)
+  ndtm::SE3 e_dp, e_p;
+  const bool pre = (mt == 0) && (S.phase == PH_STEP);                            // wave-uniform: nothing has been written yet
+  if (pre) {
+    double in[6];
+    for (int a = 0; a < 6; a++) in[a] = (lane & 1) ? S.p[a] : S.dir[a] * S.a_t;   // impl2:156
+    const ndtm::SE3 e = ndtm::se3_exp(in);
+    e_dp = shfl_se3(e, 0);
+    e_p = shfl_se3(e, 1);
+  }
+  if (lane != 0) return NEWTON_DONE;
 
   const double step_min = eps / 2;
   if (mt == 1 && S.phase == PH_STEP) {                                           // impl2:920-1000
@@ -220,20 +262,27 @@ k_update(PairState* st, const double* __restrict__ partials, int chunks_per_pair
         for (int a = 0; a < 36; a++) S.H[a] = 0;                                 // computeHessian over a NaN cloud
       } else {
         S.phase = PH_HESS;                                                       // impl2:999-1000: H comes from computeHessian
-        return;
+        return NEWTON_HESSIAN;
       }
     }
   }
   if (S.phase == PH_HESS) S.phase = PH_STEP;
   if (S.phase == PH_STEP) {
-    double dp[6], pn[6];
-    for (int a = 0; a < 6; a++) dp[a] = S.dir[a] * S.a_t;                        // impl2:156
-    set_increment(S, dp);                                                        // impl2:163
-    ndtm::se3_log(ndtm::se3_mul(ndtm::se3_exp(dp), ndtm::se3_exp(S.p)), pn);     // impl2:166
+    double pn[6];
+    if (pre) {
+      set_increment_se3(S, e_dp);                                                // impl2:163
+      ndtm::se3_log(ndtm::se3_mul(e_dp, e_p), pn);                               // impl2:166
+    } else {
+      double dp[6];
+      for (int a = 0; a < 6; a++) dp[a] = S.dir[a] * S.a_t;                      // impl2:156
+      const ndtm::SE3 ed = ndtm::se3_exp(dp);
+      set_increment_se3(S, ed);
+      ndtm::se3_log(ndtm::se3_mul(ed, ndtm::se3_exp(S.p)), pn);
+    }
     for (int a = 0; a < 6; a++) S.p[a] = pn[a];
     const bool conv = (S.it > max_iterations) || (S.it && (fabs(S.a_t) < eps));  // impl2:175-179
     S.it++;
-    if (conv) { finalize_pair(S, &results[b], 1); return; }
+    if (conv) { finalize_pair(S, res, 1); return NEWTON_DONE; }
   }
   for (int guard = 0; guard < 4; guard++) {
     for (int a = 0; a < 16; a++) S.prev_inc_cm[a] = S.inc_cm[a];                 // impl2:134
@@ -249,7 +298,7 @@ k_update(PairState* st, const double* __restrict__ partials, int chunks_per_pair
     double nrm = 0;
     for (int a = 0; a < 6; a++) nrm += d[a] * d[a];
     nrm = sqrt(nrm);
-    if (nrm == 0 || nrm != nrm) { finalize_pair(S, &results[b], nrm == nrm); return; }   // impl2:147-152
+    if (nrm == 0 || nrm != nrm) { finalize_pair(S, res, nrm == nrm); return NEWTON_DONE; }   // impl2:147-152
     for (int a = 0; a < 6; a++) d[a] /= nrm;                                     // impl2:154
     double dphi0 = 0;
     for (int a = 0; a < 6; a++) dphi0 += S.g[a] * d[a];
@@ -262,7 +311,7 @@ k_update(PairState* st, const double* __restrict__ partials, int chunks_per_pair
       for (int a = 0; a < 6; a++) S.p[a] = pn[a];
       const bool conv = (S.it > max_iterations) || (S.it && (0.0 < eps));
       S.it++;
-      if (conv) { finalize_pair(S, &results[b], 1); return; }
+      if (conv) { finalize_pair(S, res, 1); return NEWTON_DONE; }
       continue;
     }
     if (dphi0 >= 0) { for (int a = 0; a < 6; a++) d[a] = -d[a]; }                // impl2:861-862
@@ -282,11 +331,40 @@ k_update(PairState* st, const double* __restrict__ partials, int chunks_per_pair
     S.final_cm[15] = 1.f;
     S.phase = PH_STEP;
     S.sweeps++;
+    return NEWTON_SWEEP;
+  }
+  finalize_pair(S, res, 1);
+  return NEWTON_DONE;
+}
+
+// One block (UPD_WAVES waves) per pair: fixed-order reduction of the pair's partial rows (reduce_pair_rows), then wave 0 runs the
+// Newton control (newton_update).  `pts_per_chunk` = points covered by four consecutive rows (CHUNK_PTS in batch mode).
+__global__ void __launch_bounds__(UPD_THREADS)
+k_update(PairState* st, const double* __restrict__ partials, int rows_per_pair, int pts_per_chunk, mi355ndt_result* results,
+         int* active_counter, int* active_list, SweepCtl* ctl, unsigned long long* hits_total,
+         double step_max, double eps, int max_iterations, int reduce_only, int mt) {
+  __shared__ double sm[UPD_WAVES][NACC];
+  const int b = blockIdx.x;
+  PairState& S = st[b];
+  if (S.phase == PH_DONE) return;                                                // (block-uniform)
+  if (mt == 2 && S.phase != PH_HESS) return;                                     // only pairs whose Hessian pass just ran
+  const int lane = threadIdx.x & 63;
+  const int nchunks = (S.n_src + pts_per_chunk - 1) / pts_per_chunk;
+  const bool take = (mt != 2 || (lane >= 7 && lane < 43));                       // the Hessian pass fills H only
+  const double v = reduce_pair_rows(partials + (size_t)b * rows_per_pair * NACC, nchunks, take, sm);
+  if (threadIdx.x < NACC && take) {
+    if (lane == 0) S.score = v;
+    else if (lane < 7) S.g[lane - 1] = v;
+    else if (lane < 43) S.H[lane - 7] = v;
+    else { S.hits = (long long)v; if (hits_total) atomicAdd(hits_total, (unsigned long long)v); }
+  }
+  __syncthreads();                                                               // lane 0 reads what lanes 0..43 just stored
+  if (threadIdx.x >= 64 || reduce_only) return;
+  const int rc = newton_update(S, &results[b], step_max, eps, max_iterations, mt);
+  if (lane == 0 && rc == NEWTON_SWEEP) {
     atomicAdd(active_counter, 1);
     active_list[atomicAdd(&ctl->n_active, 1)] = b;                               // this pair takes part in the next sweep
-    return;
   }
-  finalize_pair(S, &results[b], 1);
 }
 
 // output cloud of align(): source moved by final_transformation_ (f32), written as packed x,y,z triples (what goes back over PCIe)

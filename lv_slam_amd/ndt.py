@@ -57,6 +57,21 @@ class Profile(C.Structure):
                 ("update_launches", C.c_longlong)]
 
 
+class SeqParams(C.Structure):
+    _fields_ = [("keyframe_delta_trans", C.c_double), ("keyframe_delta_angle", C.c_double), ("keyframe_delta_time", C.c_double)]
+
+
+class SeqFrame(C.Structure):
+    _fields_ = [("odom_colmajor", C.c_double * 16), ("tf_s2k_colmajor", C.c_float * 16), ("trans_probability", C.c_double),
+                ("dx", C.c_double), ("da", C.c_double), ("dt", C.c_double), ("key_id", C.c_int), ("new_keyframe", C.c_int),
+                ("iterations", C.c_int), ("converged", C.c_int), ("aligns", C.c_int), ("pad", C.c_int)]
+
+
+class SeqStats(C.Structure):
+    _fields_ = [("upload_ms", C.c_double), ("build_ms", C.c_double), ("track_ms", C.c_double), ("aligns", C.c_longlong),
+                ("update_launches", C.c_longlong)]
+
+
 # every symbol include/mi355_ndt.h declares
 SYMBOLS = [
     "mi355ndt_version", "mi355ndt_device_count", "mi355ndt_host_numa_node", "mi355ndt_default_params", "mi355ndt_create", "mi355ndt_destroy",
@@ -66,6 +81,7 @@ SYMBOLS = [
     "mi355ndt_batch_reserve", "mi355ndt_batch_set_target", "mi355ndt_batch_set_source", "mi355ndt_batch_set_clouds", "mi355ndt_batch_bind_device",
     "mi355ndt_batch_build_targets", "mi355ndt_batch_align", "mi355ndt_batch_size", "mi355ndt_batch_pose_records",
     "mi355ndt_profile_enable", "mi355ndt_profile_reset", "mi355ndt_profile_get", "mi355ndt_synchronize",
+    "mi355ndt_set_latency_mode", "mi355ndt_sequence_run",
 ]
 
 _LIB = None
@@ -118,6 +134,8 @@ def load_library(path: str = LIB_PATH):
     L.mi355ndt_profile_reset.argtypes = [vp]
     L.mi355ndt_profile_get.argtypes = [vp, C.POINTER(Profile)]
     L.mi355ndt_synchronize.argtypes = [vp]
+    L.mi355ndt_set_latency_mode.argtypes = [vp, i]
+    L.mi355ndt_sequence_run.argtypes = [vp, i, vp, vp, sz, vp, C.POINTER(SeqParams), vp, vp, C.POINTER(SeqStats)]
     _LIB = L
     return L
 
@@ -344,6 +362,35 @@ class Engine:
 
     def synchronize(self):
         self._chk(self.lib.mi355ndt_synchronize(self.h), "synchronize")
+
+    # -- latency mode
+    def set_latency_mode(self, on: bool = True):
+        """Opt-in fine-grained sweep for small batches (a single registration above all); see mi355ndt_set_latency_mode."""
+        self._chk(self.lib.mi355ndt_set_latency_mode(self.h, int(on)), "set_latency_mode")
+
+    def sequence_run(self, frames, stamps, keyframe_delta_trans=5.0, keyframe_delta_angle=0.17, keyframe_delta_time=1.0):
+        """mi355ndt_sequence_run: a run of frames tracked on the device the way ScanMatchingOdomNodelet::matching_s2k tracks them
+        (scan_matching_odom_nodelet.cpp:192-261).  frames: list of [N,>=3] float arrays (x,y,z first); stamps: seconds.
+        Returns (list of per-frame dicts, stats dict)."""
+        clouds = [_as_points(f) for f in frames]
+        n = len(clouds)
+        strides = {c.strides[0] for c in clouds}
+        if len(strides) != 1:
+            raise ValueError("all frames must share one record stride")
+        ptrs = np.array([c.ctypes.data for c in clouds], np.uint64)
+        cnts = np.array([c.shape[0] for c in clouds], np.uint64)
+        st = np.ascontiguousarray(stamps, np.float64)
+        if len(st) != n:
+            raise ValueError("one stamp per frame")
+        sp = SeqParams(keyframe_delta_trans, keyframe_delta_angle, keyframe_delta_time)
+        out, res, stats = (SeqFrame * n)(), (Result * n)(), SeqStats()
+        self._chk(self.lib.mi355ndt_sequence_run(self.h, n, ptrs.ctypes.data_as(C.c_void_p), cnts.ctypes.data_as(C.c_void_p), strides.pop(),
+                                                 st.ctypes.data_as(C.c_void_p), C.byref(sp), C.cast(out, C.c_void_p), C.cast(res, C.c_void_p),
+                                                 C.byref(stats)), "sequence_run")
+        frames_out = [dict(odom=np.array(f.odom_colmajor, np.float64).reshape(4, 4).T.copy(), tf_s2k=np.array(f.tf_s2k_colmajor, np.float32).reshape(4, 4).T.copy(),
+                           trans_probability=f.trans_probability, test=(f.dx, f.da, f.dt), key_id=f.key_id, new_keyframe=bool(f.new_keyframe),
+                           iterations=f.iterations, converged=bool(f.converged), aligns=f.aligns, result=_result_dict(r)) for f, r in zip(out, res)]
+        return frames_out, {k: getattr(stats, k) for k, _ in SeqStats._fields_}
 
     # -- profiling
     def profile_enable(self, on=True):

@@ -1099,6 +1099,69 @@ int ora_align(const ora_grid* g, const ora_params* prm,
   return 0;
 }
 
+/* ------------------------------------------------------------------ call-site policy of the odometry node
+ * ScanMatchingOdomNodelet::matching_s2k after the align (src/lidar_odometry/scan_matching_odom_nodelet.cpp:229-250): tf_s2s,
+ * odom_velo, the keyframe test and the constant-velocity guess, in f64 with an explicit operation order (Matrix4d products with
+ * k ascending, the general 4x4 inverse by cofactors; Eigen's own order is not observable here -- canonical choices shared with
+ * the device policy in lv_slam_amd/csrc/ndt_sequence.hpp).  Matrices are 4x4 f64 ROW-major except final_cm (column-major f32). */
+static void mul4(const double A[16], const double B[16], double C[16]) {
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++)
+      C[i * 4 + j] = ((A[i * 4 + 0] * B[0 * 4 + j] + A[i * 4 + 1] * B[1 * 4 + j]) + A[i * 4 + 2] * B[2 * 4 + j]) + A[i * 4 + 3] * B[3 * 4 + j];
+}
+static double det3h(const double* m, int i1, int i2, int i3, int j1, int j2, int j3) {
+  return m[i1 * 4 + j1] * (m[i2 * 4 + j2] * m[i3 * 4 + j3] - m[i2 * 4 + j3] * m[i3 * 4 + j2]);
+}
+static double cof4(const double* m, int i, int j) {
+  const int i1 = (i + 1) % 4, i2 = (i + 2) % 4, i3 = (i + 3) % 4, j1 = (j + 1) % 4, j2 = (j + 2) % 4, j3 = (j + 3) % 4;
+  return (det3h(m, i1, i2, i3, j1, j2, j3) + det3h(m, i2, i3, i1, j1, j2, j3)) + det3h(m, i3, i1, i2, j1, j2, j3);
+}
+static void inv4(const double M[16], double R[16]) {
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      const double c = cof4(M, i, j);
+      R[j * 4 + i] = ((i + j) & 1) ? -c : c;
+    }
+  const double det = ((M[0] * R[0] + M[4] * R[1]) + M[8] * R[2]) + M[12] * R[3];
+  for (int a = 0; a < 16; a++) R[a] = R[a] / det;
+}
+/* w of Eigen::Quaternionf(R.cast<float>()) */
+static float quat_w_f32(const float m[9]) {
+  float t = (m[0] + m[4]) + m[8];
+  if (t > 0.f) return 0.5f * sqrtf(t + 1.0f);
+  int i = 0;
+  if (m[4] > m[0]) i = 1;
+  if (m[8] > m[i * 3 + i]) i = 2;
+  const int j = (i + 1) % 3, k = (j + 1) % 3;
+  t = sqrtf(((m[i * 3 + i] - m[j * 3 + j]) - m[k * 3 + k]) + 1.0f);
+  return (m[k * 3 + j] - m[j * 3 + k]) * (0.5f / t);
+}
+/* state = {pre_tf_s2k[16], key_pose[16], keyframe_stamp}; thr = {keyframe_delta_trans, _angle, _time} (:67-76).
+ * Outputs: odom_velo (:234), the next guess (:250, f64), quantities of the keyframe test; returns 1 when the scan became the keyframe. */
+int ora_policy_step(double pre_tf_s2k[16], double key_pose[16], double* keyframe_stamp, const float final_cm[16], double stamp,
+                    const double thr[3], double odom[16], double guess[16], double test[3]) {
+  double tf[16], inv[16], s2s[16];
+  for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) tf[r * 4 + c] = (double)final_cm[c * 4 + r];
+  inv4(pre_tf_s2k, inv);
+  mul4(inv, tf, s2s);                                                            /* :231 */
+  mul4(key_pose, tf, odom);                                                      /* :234 */
+  const double dx = sqrt((tf[3] * tf[3] + tf[7] * tf[7]) + tf[11] * tf[11]);      /* :237 */
+  float Rf[9];
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Rf[r * 3 + c] = final_cm[c * 4 + r];
+  const double da = (double)(2.f * acosf(quat_w_f32(Rf)));                       /* :238: std::acos(float) is the float overload */
+  const double dt = stamp - *keyframe_stamp;                                     /* :239 */
+  test[0] = dx; test[1] = da; test[2] = dt;
+  int key = 0;
+  if (dx > thr[0] || da > thr[1] || dt > thr[2]) {                               /* :240-247 */
+    key = 1;
+    for (int a = 0; a < 16; a++) { tf[a] = (a % 5 == 0) ? 1.0 : 0.0; key_pose[a] = odom[a]; }
+    *keyframe_stamp = stamp;
+  }
+  memcpy(pre_tf_s2k, tf, sizeof tf);                                             /* :249 */
+  mul4(tf, s2s, guess);                                                          /* :250 */
+  return key;
+}
+
 /* pcl::Registration::getFitnessScore(max_range) == InformationMatrixCalculator::calc_fitness_score
  * (src/global_graph/information_matrix_calculator.cpp:53-87): source moved by T (f32, PCL scalar form), exact nearest
  * target point (brute force here; FLANN's L2_Simple f32 accumulation order), squared distance compared with max_range

@@ -128,6 +128,12 @@ double ora_fitness_score(const float* tx, const float* ty, const float* tz, size
                          const float* sx, const float* sy, const float* sz, size_t ns,
                          const float T_colmajor[16], double max_range, long* n_in);
 
+/* call-site policy after one scan-to-keyframe align (scan_matching_odom_nodelet.cpp:229-250): tf_s2s, odom_velo, keyframe test,
+ * constant-velocity guess.  pre_tf_s2k / key_pose / *keyframe_stamp are updated in place; matrices 4x4 f64 row-major, final_cm the
+ * column-major f32 result of the align; thr = {keyframe_delta_trans, _angle, _time}; test = {dx, da, dt}.  Returns 1 on a keyframe switch. */
+int ora_policy_step(double pre_tf_s2k[16], double key_pose[16], double* keyframe_stamp, const float final_cm[16], double stamp,
+                    const double thr[3], double odom[16], double guess[16], double test[3]);
+
 /* distance filter + VoxelGrid centroid downsample (prefiltering_nodelet.cpp:137-181); outputs sized n */
 size_t ora_prefilter(const float* x, const float* y, const float* z, size_t n, int use_df, double dnear, double dfar, float leaf,
                      float* ox, float* oy, float* oz);

@@ -90,6 +90,8 @@ def lib():
         L.ora_exp_f32arg.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.ora_prefilter.restype = C.c_size_t
         L.ora_prefilter.argtypes = [C.c_void_p] * 3 + [C.c_size_t, C.c_int, C.c_double, C.c_double, C.c_float] + [C.c_void_p] * 3
+        L.ora_policy_step.restype = C.c_int
+        L.ora_policy_step.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ora_fitness_score.restype = C.c_double
         L.ora_fitness_score.argtypes = [C.c_void_p] * 3 + [C.c_size_t] + [C.c_void_p] * 3 + [C.c_size_t, C.c_void_p, C.c_double, C.c_void_p]
         _LIB = L
@@ -270,6 +272,36 @@ def prefilter(pts: np.ndarray, distance_near=0.5, distance_far=100.0, leaf=0.1, 
     m = lib().ora_prefilter(_p(x), _p(y), _p(z), n, int(use_distance_filter), float(distance_near), float(distance_far), float(leaf),
                             _p(ox), _p(oy), _p(oz))
     return np.stack([ox[:m], oy[:m], oz[:m]], axis=1)
+
+
+def sequence(frames, stamps, prm: Params, keyframe_delta_trans=5.0, keyframe_delta_angle=0.17, keyframe_delta_time=1.0):
+    """ScanMatchingOdomNodelet::matching_s2k over a run of frames (scan_matching_odom_nodelet.cpp:192-261) with the oracle as the
+    registration: frame 0 becomes the keyframe, frame 1 is aligned twice (:223-227), ora_policy_step does :229-250.
+    Returns a list of dicts per frame: odom[4,4] f64, tf_s2k[4,4] f32, key_id, new_keyframe, iterations, converged, test (dx, da, dt)."""
+    pre, key_pose = np.eye(4).ravel().copy(), np.eye(4).ravel().copy()
+    kstamp = C.c_double(float(stamps[0]))
+    thr = np.array([keyframe_delta_trans, keyframe_delta_angle, keyframe_delta_time], np.float64)
+    out = [dict(odom=np.eye(4), tf_s2k=np.eye(4, dtype=np.float32), key_id=0, new_keyframe=True, iterations=0, converged=True, test=(0.0, 0.0, 0.0), aligns=0)]
+    key_id, grid = 0, Grid(np.asarray(frames[0], np.float32), prm)
+    guess = np.eye(4, dtype=np.float32)
+    guess[0, 3] = 1.5                                                  # :199-200
+    for k in range(1, len(frames)):
+        cloud = np.asarray(frames[k], np.float32)
+        r = align(grid, cloud, guess)
+        n_al = 1
+        if k == 1:                                                      # :223-227
+            r = align(grid, cloud, r["final"])
+            n_al = 2
+        fin = np.asarray(r["final"], np.float32).ravel(order="F").copy()
+        odom, g64, test = np.zeros(16), np.zeros(16), np.zeros(3)
+        matched = key_id
+        newkey = lib().ora_policy_step(_p(pre), _p(key_pose), C.byref(kstamp), _p(fin), float(stamps[k]), _p(thr), _p(odom), _p(g64), _p(test))
+        if newkey:
+            key_id, grid = k, Grid(cloud, prm)                          # :243 setInputTarget(key)
+        guess = g64.reshape(4, 4).astype(np.float32)                    # guess_trans.cast<float>() (:221)
+        out.append(dict(odom=odom.reshape(4, 4).copy(), tf_s2k=np.asarray(r["final"], np.float32), key_id=matched, new_keyframe=bool(newkey),
+                        iterations=r["iterations"], converged=r["converged"], test=tuple(test), aligns=n_al, trans_probability=r["trans_probability"]))
+    return out
 
 
 class RefGrid:

@@ -39,7 +39,7 @@ def run_bench(args, nproc=1, env_extra=None):
 
 
 def test_single_gpu_line_contract():
-    d = run_bench(["--pairs", "6", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.5", "--config4-pairs", "9"])
+    d = run_bench(["--pairs", "6", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.5", "--config4-pairs", "9", "--seq-frames", "9"])
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
     assert d["unit"] == "registrations/s" and d["value"] > 0 and d["vs_baseline"] is None and d["data"] == "synthetic"
     r = d["roofline"]
@@ -58,8 +58,13 @@ def test_single_gpu_line_contract():
     assert c4["pairs_total"] == 9 and c4["scaling"] == "strong" and c4["value"] > 0 and c4["converged"] == 9
     assert c4["parity"]["pairs_checked"] >= 3 and c4["parity"]["iterations_equal"] == c4["parity"]["pairs_checked"]
     assert d["gather_ms_per_step"] is None and c4["gather_ms_per_step"] is None        # no process group in the plain N = 1 run
-    d2 = run_bench(["--pairs", "4", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-host-clouds", "--config4-pairs", "0"])
-    assert "value_host_clouds" not in d2 and d2["config4"] is None
+    # latency mode: the nodelet's per-frame loop on a drive, tracked on the device
+    q = d["sequential"]
+    assert d["value_sequential"] == q["frames_per_s"] > 0 and q["frames"] == 9 and q["aligns"] == 9 and q["converged"] == 8
+    assert q["parity"]["frames_checked"] == 8 and q["parity"]["iterations_equal"] == 8 and q["parity"]["keyframe_decisions_equal"] == 8
+    assert q["parity"]["max_dtrans_m"] < 1e-4 and q["parity"]["max_drot_rad"] < 1e-5 and q["host_round_trips_between_frames"] == 0
+    d2 = run_bench(["--pairs", "4", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-host-clouds", "--config4-pairs", "0", "--seq-frames", "0"])
+    assert "value_host_clouds" not in d2 and d2["config4"] is None and "value_sequential" not in d2
 
 
 @pytest.mark.parametrize("extra,total", [(["--pairs", "5"], 10), (["--total-pairs", "11"], 11)])
@@ -87,7 +92,7 @@ def test_two_ranks_on_one_gpu_gather(extra, total):
 def test_single_rank_through_rccl():
     """The N > 1 code path with the backend the driver's scaling runs use (nccl = RCCL), as far as one GPU can take it: a single
     rank made to go through the process group, the records packed on the device and all_gather_into_tensor on device memory."""
-    d = run_bench(["--pairs", "7", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-host-clouds"],
+    d = run_bench(["--pairs", "7", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-host-clouds", "--seq-frames", "0"],
                   env_extra={"LV_SLAM_BENCH_FORCE_DIST": "1", "MASTER_PORT": str(free_port()), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     g = d["gather_check"]
     assert g["backend"] == "nccl" and g["host_hop"] is False and g["packed_on_device"] is True
@@ -100,7 +105,7 @@ def test_config4_job_on_one_gpu_parity_over_the_index_range_and_rccl_gather():
     """BASELINE config 4's job -- 4,541 pairs of 65,536 points, ndt_omp, 1 m, DIRECT7 -- as ONE batch on one GPU: the parity leg samples the
     WHOLE index range (every ~16th pair incl. 4540, not the first 271), and the single rank is made to go through RCCL so that the
     gather of 4,541 device-packed 96-byte records is checked too.  Independence of the pairs: scan_matching_odom_nodelet.cpp:240-250."""
-    d = run_bench(["--total-pairs", "4541", "--steps", "3", "--warmup", "1", "--cpu-seconds", "10", "--no-host-clouds"],
+    d = run_bench(["--total-pairs", "4541", "--steps", "3", "--warmup", "1", "--cpu-seconds", "10", "--no-host-clouds", "--seq-frames", "0"],
                   env_extra={"LV_SLAM_BENCH_FORCE_DIST": "1", "MASTER_PORT": str(free_port()), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     assert d["scaling"] == "strong" and d["config"]["pairs_total"] == 4541 and d["config"]["pairs_rank0"] == 4541 and d["config"]["converged"] == 4541
     p = d["parity"]
@@ -116,7 +121,7 @@ def test_default_workload_parity_leg_covers_the_whole_batch():
     """BASELINE config 3 as bench.py runs it by default (271 pairs x 65,536 pts, ndt_omp, 1 m, DIRECT7): the line's parity leg
     checks every pair of the batch against the oracle -- same iteration counts, SE(3) inside the north-star tolerance -- and the
     roofline block is internally consistent."""
-    d = run_bench(["--steps", "5", "--warmup", "2", "--cpu-seconds", "20", "--config4-pairs", "0"])
+    d = run_bench(["--steps", "5", "--warmup", "2", "--cpu-seconds", "20", "--config4-pairs", "0", "--seq-frames", "0"])
     p = d["parity"]
     assert p["pairs_checked"] == 271 and p["iterations_equal"] == 271 and p["max_dtrans_m"] < 1e-4 and p["max_drot_rad"] < 1e-5
     assert d["config"]["converged"] == 271 and d["config"]["pairs_total"] == 271

@@ -759,3 +759,46 @@ def test_caller_stream_and_engine_cell_cap():
     e3.set_source(src)
     r = e3.align(G)
     assert r["status"] == -4 and r["hits_last"] == 0 and r["iterations"] == 0 and np.array_equal(r["final"], G)
+
+
+def test_repeated_uploads_into_one_slot_land_in_call_order():
+    """Uploads are asynchronous on copy streams.  Two uploads into the SAME rows with no build / align between them -- setInputSource(A)
+    then setInputSource(B), or a pair slot of a batch set twice -- must leave the second cloud there, with the second count (the
+    copy stream is chosen by destination, so they are ordered).  Also: before any align() the incremental transforms are Identity
+    (pcl::Registration::align resets them), and the pose-record packer refuses a batch that was never aligned."""
+    tgt, src, _ = synth.make_pair(12, 512)
+    tgt, src = tgt.numpy(), src.numpy()
+    decoy = (src[::3] + np.float32([40.0, -25.0, 3.0])).astype(np.float32)          # a shorter cloud somewhere else entirely
+    G = synth.default_guess()
+    ref = ndt.Engine(ndt.default_params(trans_epsilon=0.01, max_iterations=64))
+    ref.set_target(tgt)
+    a, b = ref.get_incremental()
+    assert np.array_equal(a, np.eye(4, dtype=np.float32)) and np.array_equal(b, np.eye(4, dtype=np.float32))
+    ref.set_source(src)
+    want = ref.align(G)
+    for rep in range(8):                                   # the race, if there is one, needs a few tries
+        e = ndt.Engine(ndt.default_params(trans_epsilon=0.01, max_iterations=64))
+        e.set_target(tgt)
+        for _ in range(3):
+            e.set_source(decoy)
+            e.set_source(src)
+        got = e.align(G)
+        assert np.array_equal(got["final"], want["final"]) and got["iterations"] == want["iterations"] and got["score"] == want["score"]
+        e.close()
+    # the same through the batch calls, several slots, each set twice (first with the decoy)
+    eng = ndt.Engine(ndt.default_params(trans_epsilon=0.01, max_iterations=64))
+    eng.batch_reserve(5, len(tgt), len(src))
+    with pytest.raises(ndt.NDTError):
+        import torch
+        buf = torch.empty(5, 24, dtype=torch.int32, device="cuda")
+        eng.batch_pose_records(0, 1, buf.data_ptr(), 5)    # nothing aligned yet
+    for k in range(5):
+        eng.batch_set_target(k, decoy)
+        eng.batch_set_source(k, decoy)
+    for k in range(5):
+        eng.batch_set_target(k, tgt)
+        eng.batch_set_source(k, src)
+    res = eng.batch_align(np.broadcast_to(G, (5, 4, 4)))
+    for r in res:
+        assert np.array_equal(r["final"], want["final"]) and r["iterations"] == want["iterations"]
+    eng.synchronize()

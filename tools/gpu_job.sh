@@ -1,0 +1,25 @@
+#!/bin/bash
+# One gpurun call's worth of work (GPU box).  usage: gpurun -- 'bash tools/gpu_job.sh <stage>...'; everything lands under gpurun_out/<stage>/
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+for stage in "$@"; do
+  O=$R/gpurun_out/$stage; mkdir -p $O
+  case $stage in
+    tests)      timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 > $O/pytest.txt; cat $O/pytest.txt ;;
+    tests_new)  timeout 1500 python -m pytest tests/test_bench_gpu.py tests/test_gpu_parity.py::test_repeated_uploads_into_one_slot_land_in_call_order -x -q 2>&1 | tail -25 > $O/pytest.txt; cat $O/pytest.txt ;;
+    bench)      (time timeout 900 python bench.py) > $O/bench.json 2> $O/bench.log; tail -c 3000 $O/bench.json; tail -5 $O/bench.log ;;
+    bench20)    (time timeout 900 python bench.py --steps 20 --warmup 3) > $O/bench.json 2> $O/bench.log; tail -c 3000 $O/bench.json; tail -5 $O/bench.log ;;
+    pmc_cfg5d1) timeout 900 tools/pmc_kernel.sh k_sweep run_cfg5_d1 --variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128 > $O/pmc.txt 2>&1; cat $O/pmc.txt ;;
+    pmc_build)  timeout 900 tools/pmc_kernel.sh 'k_leafsum|k_rs_scatter|k_rs_hist|k_keys|k_voxels|k_mark|k_segstart|k_minmax' run_build > $O/pmc.txt 2>&1; cat $O/pmc.txt ;;
+    pmc_update) timeout 900 tools/pmc_kernel.sh 'k_update' run_update --variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128 > $O/pmc.txt 2>&1; cat $O/pmc.txt ;;
+    kstats_cfg5d1) timeout 600 tools/kstats.sh kstats_cfg5d1_run --no-host-clouds --variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128 --steps 10 --warmup 2 > $O/out.txt 2>&1; cat $O/out.txt ;;
+    kstats)     timeout 600 tools/kstats.sh kstats_run --no-host-clouds --steps 20 --warmup 3 > $O/out.txt 2>&1; cat $O/out.txt ;;
+    tests_seq)  timeout 1500 python -m pytest tests/test_sequence.py -x -q -s 2>&1 | tail -25 > $O/pytest.txt; cat $O/pytest.txt ;;
+    latency)    (timeout 300 python tools/latency_single.py; LATENCY_MODE=1 timeout 300 python tools/latency_single.py; MI355NDT_FINE_TILES=1 LATENCY_MODE=1 timeout 300 python tools/latency_single.py) 2>&1 | grep -v amdgpu.ids > $O/latency.txt; cat $O/latency.txt ;;
+    trace_cfg5d1) cd /tmp && export TMPDIR=/tmp; timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/kt -- python $R/bench.py --cpu-seconds 0 --no-host-clouds --config4-pairs 0 --seq-frames 0 --variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128 --steps 3 --warmup 1 > $O/bench.json 2> $O/kt.log; cd $R
+                python tools/dispatch_table.py $O/kt 'k_sweep|k_update' > $O/dispatches.txt; rm -rf $O/kt; tail -80 $O/dispatches.txt ;;
+    trace_default) cd /tmp && export TMPDIR=/tmp; timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/kt -- python $R/bench.py --cpu-seconds 0 --no-host-clouds --config4-pairs 0 --seq-frames 0 --steps 3 --warmup 1 > $O/bench.json 2> $O/kt.log; cd $R
+                python tools/dispatch_table.py $O/kt 'k_' > $O/dispatches.txt; rm -rf $O/kt; tail -80 $O/dispatches.txt ;;
+    *) echo "unknown stage $stage" ;;
+  esac
+done

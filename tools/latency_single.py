@@ -7,9 +7,13 @@ tgt, src, _ = synth.make_pair(0, 1024, device="cuda")
 T = tgt.T.contiguous()[None].contiguous(); S = src.T.contiguous()[None].contiguous()
 tgt_h, src_h = tgt.cpu().numpy(), src.cpu().numpy()
 G = synth.default_guess()
+import os
+LAT = bool(os.environ.get("LATENCY_MODE"))            # LATENCY_MODE=1: the opt-in fine-grained sweep (mi355ndt_set_latency_mode)
 for variant, mode, name in ((0, ndt.DIRECT7, "ndt_omp/DIRECT7"), (1, ndt.DIRECT1, "ndt_pca/DIRECT1")):
+    name += " [latency mode]" if LAT else ""
     prm = ndt.default_params(trans_epsilon=0.01, max_iterations=64, neighbor_mode=mode, variant=variant)
     e = ndt.Engine(prm)
+    e.set_latency_mode(LAT)
     def host():
         e.set_target(tgt_h); e.set_source(src_h); return e.align(G)
     for _ in range(3): r = host()
@@ -33,6 +37,7 @@ for variant, mode, name in ((0, ndt.DIRECT7, "ndt_omp/DIRECT7"), (1, ndt.DIRECT1
     print(f"{name}: set_source+align against a resident target: 12-B records {v['xyz12']:.3f} ms, 32-B PointXYZI records {v['xyzi32']:.3f} ms, "
           f"with the output cloud fetched {v['xyzi32+output']:.3f} ms", flush=True)
     e2 = ndt.Engine(prm)
+    e2.set_latency_mode(LAT)
     n = tgt.shape[0]
     e2.batch_bind_device(T.data_ptr(), [n], n, S.data_ptr(), [n], n)
     def dev():
