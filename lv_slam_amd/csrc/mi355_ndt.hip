@@ -1530,8 +1530,18 @@ int mi355ndt_sequence_run(mi355ndt_handle* h, int n_frames, const void* const* c
   const int depth = 12;
   long long enq = 0;
   const long long max_launches = (long long)n_frames * (h->prm.max_iterations + 6) + 64;
+  auto t_progress = std::chrono::steady_clock::now();
+  long long seen_last = -1;
+  bool stuck = false;
   while (rc == MI355NDT_OK && !h->h_seq_flags[0] && enq < max_launches) {
-    if (enq - (long long)h->h_seq_flags[1] >= depth) { std::this_thread::yield(); continue; }
+    const long long seen = h->h_seq_flags[1];
+    if (seen != seen_last) { seen_last = seen; t_progress = std::chrono::steady_clock::now(); }
+    if (enq - seen >= depth) {
+      // (a device that stops answering -- a faulted kernel -- must not leave the host spinning here)
+      if (std::chrono::steady_clock::now() - t_progress > std::chrono::seconds(20)) { stuck = true; break; }
+      std::this_thread::yield();
+      continue;
+    }
     k_seq_update<<<1, UPD_THREADS, 0, s>>>(h->d_seq, h->d_state, h->d_partials, h->rows_per_pair, h->pts_per_chunk, h->d_results, h->d_grid, h->d_src_cnt,
                                            h->d_stamps, h->d_seq_out, h->d_active_list, h->d_ctl + h->ctl_idx, h->d_grid_of, h->d_seq_flags,
                                            h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations);
@@ -1544,7 +1554,7 @@ int mi355ndt_sequence_run(mi355ndt_handle* h, int n_frames, const void* const* c
   if (e != hipSuccess) { h->err = std::string("sequence run: ") + hipGetErrorString(e); return MI355NDT_ERR_HIP; }
   if (rc) return rc;
   HIPCHK(h, hipGetLastError());
-  if (!h->h_seq_flags[0]) { h->err = "sequence run did not finish within its launch budget"; return MI355NDT_ERR_STATE; }
+  if (stuck || !h->h_seq_flags[0]) { h->err = stuck ? "sequence run: the device stopped making progress" : "sequence run did not finish within its launch budget"; return MI355NDT_ERR_STATE; }
   HIPCHK(h, hipMemcpy(out_frames, h->d_seq_out, (size_t)n_frames * sizeof(mi355ndt_seq_frame), hipMemcpyDeviceToHost));
   if (out_results) HIPCHK(h, hipMemcpy(out_results, h->d_results, (size_t)n_frames * sizeof(mi355ndt_result), hipMemcpyDeviceToHost));
   if (stats) {
