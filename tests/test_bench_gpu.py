@@ -130,3 +130,16 @@ def test_default_workload_parity_leg_covers_the_whole_batch():
     assert abs(r["alg_bytes_per_launch"] * r["launches"] / (r["sweep_ms_per_step"] * 1e-3 * d["steps"]) / 1e9 - r["achieved"]) < 0.02 * r["achieved"]
     c = d["cpu_baseline"]
     assert set(c["reference_shaped_by_threads"]) == set(c["optimised_port_by_threads"]) and c["value"] > 0
+
+
+def test_prefiltered_row():
+    """bench.py --prefiltered: the reference-conditioned row (raw scans -> device prefilter as launch/dlo_kitti.launch:30-36 sets it ->
+    target / source -> align), with the oracle's prefilter + align as the checker."""
+    d = run_bench(["--prefiltered", "--azimuth", "512", "--pairs", "4", "--variant", "pca", "--mode", "direct1", "--cpu-seconds", "2"])
+    assert d["value"] > 0 and d["registrations_per_s_without_prefilter_time"] > d["value"] and d["config"]["converged"] == 4
+    c = d["config"]
+    assert c["raw_points_per_cloud"] == 32768 and 0 < c["filtered_points_per_target_mean"] < 32768 and c["searchable_leaves_per_target_mean"] > 50
+    p = d["parity"]
+    assert p["pairs_checked"] >= 2 and p["iterations_equal"] == p["pairs_checked"] and p["filtered_point_counts_equal"] == p["pairs_checked"]
+    assert p["max_dtrans_m"] < 1e-4 and p["max_drot_rad"] < 1e-5
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0

@@ -20,6 +20,8 @@ for stage in "$@"; do
                 python tools/dispatch_table.py $O/kt 'k_sweep|k_update' > $O/dispatches.txt; rm -rf $O/kt; tail -80 $O/dispatches.txt ;;
     trace_default) cd /tmp && export TMPDIR=/tmp; timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/kt -- python $R/bench.py --cpu-seconds 0 --no-host-clouds --config4-pairs 0 --seq-frames 0 --steps 3 --warmup 1 > $O/bench.json 2> $O/kt.log; cd $R
                 python tools/dispatch_table.py $O/kt 'k_' > $O/dispatches.txt; rm -rf $O/kt; tail -80 $O/dispatches.txt ;;
+    prefiltered) timeout 600 python bench.py --prefiltered --azimuth 2048 --pairs 64 --variant pca --mode direct1 --cpu-seconds 10 > $O/bench.json 2> $O/bench.log; tail -c 2500 $O/bench.json ;;
+    tests_bench) timeout 1500 python -m pytest tests/test_bench_gpu.py -x -q 2>&1 | tail -25 > $O/pytest.txt; cat $O/pytest.txt ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
