@@ -89,7 +89,8 @@ struct mi355ndt_handle {
   PairState* d_state = nullptr;
   double* d_partials = nullptr; size_t partials_cap = 0;
   int chunks_per_pair = 0;
-  int rows_per_pair = 0, pts_per_chunk = CHUNK_PTS;   // partial rows per pair / points covered by four consecutive rows (k_update's chunk)
+  int rows_per_pair = 0, pts_per_chunk = CHUNK_PTS;   // stored partial rows per pair / points covered by one chunk of k_update's tree
+  int items_per_pair = 0;                         // sweep work items per pair (= rows_per_pair in batch mode, 4 x rows_per_pair in latency mode)
   bool latency_mode = false;                      // mi355ndt_set_latency_mode
   int fine_it = 0;                                // 0: batch-mode sweep items (512 points); 1 / 2: fine items of fine_it * 64 points (latency mode)
   int fine_tiles = 2;                             // MI355NDT_FINE_TILES overrides (tuning runs)
@@ -796,7 +797,7 @@ static int build_targets_impl(mi355ndt_handle* h) {
       std::swap(kin, kout); std::swap(vin, vout);
     }
     k_mark<unsigned><<<dim3(gx4, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, minpts, cb);
-    k_rank<<<B, 256, 0, s>>>(h->d_grid, h->d_words);
+    k_rank<<<B, 1024, 0, s>>>(h->d_grid, h->d_words);
     k_segstart<unsigned><<<dim3(gx4, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, h->d_seg_start, minpts, cb);
     if (want_cent) k_leafsum<unsigned, true><<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start,
                                                                                     h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent, lb, B);
@@ -835,13 +836,15 @@ static int prep_align_ws(mi355ndt_handle* h) {
   }
   if (h->fine_it) {
     const int item_pts = h->fine_it * 64;
-    h->rows_per_pair = ((std::max(1, (maxn + item_pts - 1) / item_pts) + 3) / 4) * 4;       // whole 4-row chunks
-    h->pts_per_chunk = 4 * item_pts;
+    h->pts_per_chunk = 4 * item_pts;                                   // a block of the fine sweep = four items = one chunk, stored as ONE row
+    h->rows_per_pair = std::max(1, (maxn + h->pts_per_chunk - 1) / h->pts_per_chunk);
+    h->items_per_pair = 4 * h->rows_per_pair;
   } else {
     h->rows_per_pair = h->chunks_per_pair * QUARTERS;
+    h->items_per_pair = h->rows_per_pair;
     h->pts_per_chunk = CHUNK_PTS;
   }
-  size_t need = (size_t)B * h->rows_per_pair * NACC;
+  size_t need = (size_t)B * std::max(h->rows_per_pair, h->chunks_per_pair * QUARTERS) * NACC;   // (the parity hooks may fall back to batch-mode rows)
   HIPCHK(h, grow(h->d_partials, h->partials_cap, need));
   if (h->up_src_cnt.size() != (size_t)B || !std::equal(h->up_src_cnt.begin(), h->up_src_cnt.end(), h->h_src_cnt.begin())) {
     HIPCHK(h, hipMemcpyAsync(h->d_src_cnt, h->h_src_cnt.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -867,13 +870,13 @@ static int launch_sweep(mi355ndt_handle* h, const SweepConst& sc, int max_pairs 
   // persistent waves: SWEEP_WPE workgroups per CU pull (pair, chunk, quarter) items until the per-XCD queues are dry
   dim3 grid((unsigned)(h->n_cu * sweep_wpe(sc.pca != 0, sc.K)));
   if (h->prof) HIPCHK(h, ev_begin(h, h->ev_sweep));
-#define NDT_SWEEP_ARGS h->d_src, h->src_pitch, h->d_state, h->d_grid, h->d_words, h->d_recs, h->d_partials, h->rows_per_pair, h->d_active_list, \
+#define NDT_SWEEP_ARGS h->d_src, h->src_pitch, h->d_state, h->d_grid, h->d_words, h->d_recs, h->d_partials, h->items_per_pair, h->d_active_list, \
       h->d_ctl + h->ctl_idx, h->d_ctl + (h->ctl_idx ^ 1), sc, h->d_cent, h->d_grid_of_use
 #define NDT_LAUNCH_SWEEP(P, KK) k_sweep<P, KK><<<grid, SWEEP_THREADS, 0, h->stream>>>(NDT_SWEEP_ARGS)
 #define NDT_LAUNCH_FINE(P, KK) do { if (h->fine_it == 1) k_sweep<P, KK, 1, true><<<grid, SWEEP_THREADS, 0, h->stream>>>(NDT_SWEEP_ARGS); \
                                     else k_sweep<P, KK, 2, true><<<grid, SWEEP_THREADS, 0, h->stream>>>(NDT_SWEEP_ARGS); } while (0)
   if (h->fine_it) {                              // latency mode: items dealt statically over the whole grid, sized to the work there can be
-    const long long items = (long long)(max_pairs > 0 ? max_pairs : h->n_pairs) * h->rows_per_pair;
+    const long long items = (long long)(max_pairs > 0 ? max_pairs : h->n_pairs) * h->items_per_pair;
     grid.x = (unsigned)std::max(1LL, std::min((long long)grid.x, (items + WAVES - 1) / WAVES));
     if (sc.pca) { if (sc.K == 1) NDT_LAUNCH_FINE(true, 1); else NDT_LAUNCH_FINE(true, 7); }
     else        { if (sc.K == 1) NDT_LAUNCH_FINE(false, 1); else NDT_LAUNCH_FINE(false, 7); }
@@ -953,12 +956,12 @@ static int batch_align_impl(mi355ndt_handle* h, const float* guesses, mi355ndt_r
     int k = 0;
     for (; k < burst && round < max_rounds; k++, round++) {
       if (h->prof) HIPCHK(h, ev_begin(h, h->ev_update));
-      k_update<<<B, UPD_THREADS, 0, s>>>(h->d_state, h->d_partials, h->rows_per_pair, h->pts_per_chunk, h->d_results, dact + k,
+      k_update<<<B, UPD_THREADS, 0, s>>>(h->d_state, h->d_partials, h->rows_per_pair, h->pts_per_chunk, h->fine_it ? 1 : 0, h->d_results, dact + k,
                                 h->d_active_list, h->d_ctl + h->ctl_idx, h->prof ? h->d_hits : nullptr,
                                 h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations, 0, mt_live ? 1 : 0);
       if (mt_live) {      // pairs whose More-Thuente loop iterated get their Hessian from computeHessian (impl2:999-1000)
         launch_hessian(h, sc);
-        k_update<<<B, UPD_THREADS, 0, s>>>(h->d_state, h->d_partials, h->rows_per_pair, h->pts_per_chunk, h->d_results, dact + k,
+        k_update<<<B, UPD_THREADS, 0, s>>>(h->d_state, h->d_partials, h->rows_per_pair, h->pts_per_chunk, h->fine_it ? 1 : 0, h->d_results, dact + k,
                                   h->d_active_list, h->d_ctl + h->ctl_idx, nullptr,
                                   h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations, 0, 2);
       }
@@ -1132,7 +1135,7 @@ static int run_hook_sweep(mi355ndt_handle* h, double* score, double g[6], double
   make_sweep_const(h, sc);
   int rc = launch_sweep(h, sc);
   if (rc) return rc;
-  k_update<<<1, UPD_THREADS, 0, h->stream>>>(h->d_state, h->d_partials, h->rows_per_pair, h->pts_per_chunk, h->d_results, h->d_active, h->d_active_list, h->d_ctl,
+  k_update<<<1, UPD_THREADS, 0, h->stream>>>(h->d_state, h->d_partials, h->rows_per_pair, h->pts_per_chunk, h->fine_it ? 1 : 0, h->d_results, h->d_active, h->d_active_list, h->d_ctl,
                                     nullptr, 0, 0, 0, 1, 0);
   PairState S;
   HIPCHK(h, hipMemcpyAsync(&S, h->d_state, sizeof(PairState), hipMemcpyDeviceToHost, h->stream));
@@ -1181,7 +1184,7 @@ int mi355ndt_compute_hessian(mi355ndt_handle* h, const double p[6], double H[36]
     h->prm = keep;
     if (rc) return rc;
   }
-  h->fine_it = 0; h->rows_per_pair = h->chunks_per_pair * QUARTERS; h->pts_per_chunk = CHUNK_PTS;   // k_hessian writes batch-mode rows
+  h->fine_it = 0; h->rows_per_pair = h->items_per_pair = h->chunks_per_pair * QUARTERS; h->pts_per_chunk = CHUNK_PTS;   // k_hessian writes batch-mode rows
   double* dp = (double*)h->d_hook;
   HIPCHK(h, hipMemcpyAsync(dp, p, 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1191,7 +1194,7 @@ int mi355ndt_compute_hessian(mi355ndt_handle* h, const double p[6], double H[36]
   SweepConst sc;
   make_sweep_const(h, sc);
   launch_hessian(h, sc);
-  k_update<<<1, UPD_THREADS, 0, h->stream>>>(h->d_state, h->d_partials, h->rows_per_pair, h->pts_per_chunk, h->d_results, h->d_active, h->d_active_list, h->d_ctl,
+  k_update<<<1, UPD_THREADS, 0, h->stream>>>(h->d_state, h->d_partials, h->rows_per_pair, h->pts_per_chunk, h->fine_it ? 1 : 0, h->d_results, h->d_active, h->d_active_list, h->d_ctl,
                                     nullptr, 0, 0, 0, 1, 2);
   PairState S;
   HIPCHK(h, hipMemcpyAsync(&S, h->d_state, sizeof(PairState), hipMemcpyDeviceToHost, h->stream));

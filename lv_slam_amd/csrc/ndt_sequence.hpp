@@ -100,7 +100,7 @@ k_seq_update(SeqState* seq, PairState* st, const double* __restrict__ partials, 
   PairState& S = st[cur];
   const int lane = threadIdx.x & 63;
   const int nchunks = (S.n_src + pts_per_chunk - 1) / pts_per_chunk;
-  const double v = reduce_pair_rows(partials + (size_t)cur * rows_per_pair * NACC, nchunks, true, sm);
+  const double v = reduce_pair_rows(partials + (size_t)cur * rows_per_pair * NACC, nchunks, true, sm, true);   // latency mode: chunk rows
   if (threadIdx.x < NACC) {
     if (lane == 0) S.score = v;
     else if (lane < 7) S.g[lane - 1] = v;

@@ -194,6 +194,10 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
   constexpr int NBUF = (IT / TP > 1) ? 2 : 1;   // a super-tile that is the whole item needs no second buffer
   __shared__ float stage[WAVES][NBUF * 64 * TP][6];   // (two) super-tiles of staged points: x'(3), R x (3)
 
+  // FINE: the four waves of a block always hold the four rows of ONE chunk (items 4q .. 4q+3: static dealing, four waves per block, a
+  // multiple of four items per pair), so the chunk level of k_update's tree -- ((r0 + r1) + r2) + r3 -- is added here through LDS and
+  // one row per chunk goes to memory: a quarter of the rows for the update to fetch.
+  __shared__ double red[FINE ? WAVES : 1][FINE ? NACC : 1];
   __shared__ double exp_tab[64];                   // 2^(j/64) for ndtm::exp_f32arg
   if (threadIdx.x < 64) exp_tab[threadIdx.x] = ndtm::c_exp2_64[threadIdx.x];
   __syncthreads();                                 // (the only block barrier of the kernel, before the persistent loop)
@@ -485,10 +489,16 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
     if ((lane & 15) == 0) {
       // row 0 (lane 0) holds values 0..10, row 1: 11..21, row 2: 22..32, row 3: 33..42 (+ the pad)
       const int row = lane >> 4, base = 11 * (row & 1) + 22 * (row >> 1);
-      double* P = partials + ((size_t)b * rows_per_pair + rem) * NACC;
+      double* P = FINE ? &red[FINE ? wv : 0][0] : partials + ((size_t)b * rows_per_pair + rem) * NACC;
 #pragma unroll
       for (int i = 0; i < 11; i++) if (base + i < 43) P[base + i] = P2[i];
       if (lane == 0) P[43] = (double)nhits;
+    }
+    if (FINE) {
+      __syncthreads();                              // (uniform: the four waves of a block run the same items loop, see above)
+      if (wv == 0 && lane < NACC)
+        partials[((size_t)b * (rows_per_pair >> 2) + (rem >> 2)) * NACC + lane] = ((red[0][lane] + red[FINE ? 1 : 0][lane]) + red[FINE ? 2 : 0][lane]) + red[FINE ? 3 : 0][lane];
+      __syncthreads();
     }
     TL_STAMP(6);
 #ifdef NDT_TIMELINE

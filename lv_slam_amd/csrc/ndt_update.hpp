@@ -180,7 +180,8 @@ __device__ inline int mt_loop(PairState& S, double step_max, double step_min) {
 // 131,072-point pair (256 rows) is two memory round trips per wave instead of eight on one wave.
 #define UPD_WAVES   4
 #define UPD_THREADS (64 * UPD_WAVES)
-__device__ __forceinline__ double reduce_pair_rows(const double* __restrict__ rows, int nchunks, bool take, double (*sm)[NACC]) {
+// `chunk_rows`: the rows are chunk sums already (latency mode: the sweep's blocks add the four rows of a chunk themselves).
+__device__ __forceinline__ double reduce_pair_rows(const double* __restrict__ rows, int nchunks, bool take, double (*sm)[NACC], bool chunk_rows = false) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane < NACC) {
     double acc = 0.0;
@@ -189,7 +190,13 @@ __device__ __forceinline__ double reduce_pair_rows(const double* __restrict__ ro
 #pragma unroll 1
       for (int c0 = w * 8; c0 < nchunks; c0 += 8 * UPD_WAVES) {
         double gs = 0.0;
-        if (c0 + 8 <= nchunks) {
+        if (chunk_rows) {
+          double q[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) q[u] = (c0 + u < nchunks) ? P[(size_t)(c0 + u) * NACC] : 0.0;
+#pragma unroll
+          for (int u = 0; u < 8; u++) if (c0 + u < nchunks) gs += q[u];
+        } else if (c0 + 8 <= nchunks) {
           double q[8][4];
 #pragma unroll
           for (int u = 0; u < 8; u++) {
@@ -338,9 +345,10 @@ __device__ __forceinline__ int newton_update(PairState& S, mi355ndt_result* res,
 }
 
 // One block (UPD_WAVES waves) per pair: fixed-order reduction of the pair's partial rows (reduce_pair_rows), then wave 0 runs the
-// Newton control (newton_update).  `pts_per_chunk` = points covered by four consecutive rows (CHUNK_PTS in batch mode).
-__global__ void __launch_bounds__(UPD_THREADS)
-k_update(PairState* st, const double* __restrict__ partials, int rows_per_pair, int pts_per_chunk, mi355ndt_result* results,
+// Newton control (newton_update).  `rows_per_pair` = stored rows per pair (the row stride), `pts_per_chunk` = points covered by one
+// chunk = four consecutive rows (CHUNK_PTS in batch mode) or, with `chunk_rows`, by one stored row (latency mode).
+__global__ void __launch_bounds__(UPD_THREADS, 2)
+k_update(PairState* st, const double* __restrict__ partials, int rows_per_pair, int pts_per_chunk, int chunk_rows, mi355ndt_result* results,
          int* active_counter, int* active_list, SweepCtl* ctl, unsigned long long* hits_total,
          double step_max, double eps, int max_iterations, int reduce_only, int mt) {
   __shared__ double sm[UPD_WAVES][NACC];
@@ -351,7 +359,7 @@ k_update(PairState* st, const double* __restrict__ partials, int rows_per_pair, 
   const int lane = threadIdx.x & 63;
   const int nchunks = (S.n_src + pts_per_chunk - 1) / pts_per_chunk;
   const bool take = (mt != 2 || (lane >= 7 && lane < 43));                       // the Hessian pass fills H only
-  const double v = reduce_pair_rows(partials + (size_t)b * rows_per_pair * NACC, nchunks, take, sm);
+  const double v = reduce_pair_rows(partials + (size_t)b * rows_per_pair * NACC, nchunks, take, sm, chunk_rows != 0);
   if (threadIdx.x < NACC && take) {
     if (lane == 0) S.score = v;
     else if (lane < 7) S.g[lane - 1] = v;

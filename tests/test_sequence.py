@@ -142,9 +142,10 @@ def test_device_sequence_vs_oracle_small(mode, variant):
     prm = O.default_params(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=mode, variant=variant)
     ro = O.align(O.Grid(scans[0], prm), scans[1], G)
     assert r["iterations"] == ro["iterations"]
-    # against the drive itself (scene-noise level)
+    # against the drive itself: sparse 8,192-point scans, a dozen frames of drift -- a sanity bound, not an accuracy claim
+    # (device and oracle agree with each other to 1e-4 m above; this is how far BOTH are from the true motion)
     dt, dr = se3_err(np.linalg.inv(truth[0]) @ truth[-1], dev[-1]["odom"])
-    assert dt < 0.5 and dr < 0.05, (dt, dr)
+    assert dt < 2.5 and dr < 0.2, (dt, dr)
 
 
 @pytest.mark.gpu

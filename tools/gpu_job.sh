@@ -22,6 +22,9 @@ for stage in "$@"; do
                 python tools/dispatch_table.py $O/kt 'k_' > $O/dispatches.txt; rm -rf $O/kt; tail -80 $O/dispatches.txt ;;
     prefiltered) timeout 600 python bench.py --prefiltered --azimuth 2048 --pairs 64 --variant pca --mode direct1 --cpu-seconds 10 > $O/bench.json 2> $O/bench.log; tail -c 2500 $O/bench.json ;;
     tests_bench) timeout 1500 python -m pytest tests/test_bench_gpu.py -x -q 2>&1 | tail -25 > $O/pytest.txt; cat $O/pytest.txt ;;
+    seq)        timeout 300 python tools/seq_run.py 129 2>&1 | grep -v amdgpu.ids > $O/seq.txt; cat $O/seq.txt
+                cd /tmp && export TMPDIR=/tmp; timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt -- python $R/tools/seq_run.py 65 > $O/seq_traced.txt 2> $O/kt.log; cd $R
+                python tools/seq_kernels.py $O/kt > $O/seq_kernels.txt; rm -rf $O/kt; cat $O/seq_kernels.txt ;;
     *) echo "unknown stage $stage" ;;
   esac
 done

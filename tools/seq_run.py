@@ -1,0 +1,19 @@
+"""Latency mode on a drive: mi355ndt_sequence_run over N frames of 65,536 points (the nodelet's configuration); prints the per-frame
+track time.  Under `rocprofv3 --kernel-trace` + tools/seq_kernels.py it gives the per-kernel picture of one round."""
+import sys, time
+import numpy as np
+sys.path.insert(0, ".")
+from lv_slam_amd import ndt, synth
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65
+scans, _ = synth.make_sequence(n, 1024, device="cuda")
+scans = [s.cpu().numpy() for s in scans]
+stamps = [0.1 * k for k in range(n)]
+eng = ndt.Engine(ndt.default_params(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=ndt.DIRECT1, variant=ndt.VARIANT_PCA))
+eng.sequence_run(scans[:8], stamps[:8])
+for rep in range(3):
+    t0 = time.perf_counter()
+    out, st = eng.sequence_run(scans, stamps)
+    wall = time.perf_counter() - t0
+    its = np.mean([f["iterations"] for f in out[1:]])
+    print(f"frames {n}: wall {1e3 * wall:.2f} ms, upload {st['upload_ms']:.2f}, build {st['build_ms']:.3f}, track {st['track_ms']:.3f} ms = {st['track_ms'] / (n - 1):.4f} ms/frame, "
+          f"mean iterations {its:.2f}, update launches {st['update_launches']}, per round {1e3 * st['track_ms'] / st['update_launches']:.2f} us", flush=True)
