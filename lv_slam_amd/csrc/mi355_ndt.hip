@@ -92,6 +92,7 @@ struct mi355ndt_handle {
   int rows_per_pair = 0, pts_per_chunk = CHUNK_PTS;   // stored partial rows per pair / points covered by one chunk of k_update's tree
   int items_per_pair = 0;                         // sweep work items per pair (= rows_per_pair in batch mode, 4 x rows_per_pair in latency mode)
   bool latency_mode = false;                      // mi355ndt_set_latency_mode
+  bool seq_running = false;                       // inside mi355ndt_sequence_run
   int fine_it = 0;                                // 0: batch-mode sweep items (512 points); 1 / 2: fine items of fine_it * 64 points (latency mode)
   int fine_tiles = 2;                             // MI355NDT_FINE_TILES overrides (tuning runs)
   int* d_grid_of = nullptr; size_t grid_of_cap = 0;   // sequence mode: grid index per pair
@@ -831,7 +832,8 @@ static int prep_align_ws(mi355ndt_handle* h) {
   // most of the GPU idle.  Served by the DIRECT1 / DIRECT7 instantiations; the live More-Thuente case keeps the batch kernels.
   {
     const int K = h->prm.neighbor_mode == MI355NDT_DIRECT1 ? 1 : (h->prm.neighbor_mode == MI355NDT_DIRECT7 ? 7 : 0);
-    const bool small = (long long)B * h->chunks_per_pair * QUARTERS < 4LL * h->n_cu * WAVES;     // fewer batch items than ~4 per resident wave slot pair
+    // "small": fewer batch-mode items than two per resident wave; a sequence run sweeps ONE pair at a time whatever the number of frames
+    const bool small = h->seq_running || (long long)B * h->chunks_per_pair * QUARTERS < 4LL * h->n_cu * WAVES;
     h->fine_it = (h->latency_mode && K && !mt_is_live(h->prm) && small) ? h->fine_tiles : 0;
   }
   if (h->fine_it) {
@@ -1490,9 +1492,10 @@ int mi355ndt_sequence_run(mi355ndt_handle* h, int n_frames, const void* const* c
   if (rc) { h->prof = keep_prof; return rc; }
   HIPCHK(h, hipEventRecord(ev[1], s));
   const bool lat = h->latency_mode;
-  h->latency_mode = true;
+  h->latency_mode = true; h->seq_running = true;
   rc = prep_align_ws(h);
-  h->latency_mode = lat;
+  h->latency_mode = lat; h->seq_running = false;
+  if (rc == MI355NDT_OK && !h->fine_it) { h->err = "sequence run: the fine-grained sweep does not serve this configuration"; rc = MI355NDT_ERR_UNSUPPORTED; }
   if (rc) { h->prof = keep_prof; return rc; }
   // one pair is in flight at a time: the fine grid is sized for one pair
   if ((size_t)n_frames > h->seq_cap) {
