@@ -768,7 +768,7 @@ def main():
     roof["traffic"], roof["traffic_source"] = traffic, traffic_source
     # what really bounds the sweep: vector-ALU issue (SQ counters of separate rocprofv3 --pmc passes, committed under profiles/)
     roof_valu = None
-    for name in ("r03_valu.json", "r02_valu.json"):
+    for name in ("r03_valu.json", "r03_valu_pca_direct1.json", "r03_valu_cfg5_d1.json", "r02_valu.json", "r02_valu_pca_direct1.json"):
         valu, valu_source = static_profile(name, wkey)
         if valu:
             roof_valu = {"bound": "valu issue", "kernel": "k_sweep", "active_frac": valu["valu_active_frac"],

@@ -187,16 +187,33 @@ __device__ __forceinline__ double reduce_pair_rows(const double* __restrict__ ro
     double acc = 0.0;
     if (take) {
       const double* P = rows + lane;
+      if (chunk_rows) {
+        // one stored row per chunk: the loads of up to four of the wave's groups are in flight together (a 65,536-point pair in latency
+        // mode has 128 chunk rows = 16 groups = four per wave: one memory round trip); the adds keep the order described above
+#pragma unroll 1
+        for (int c0 = w * 8; c0 < nchunks; c0 += 4 * 8 * UPD_WAVES) {
+          double q[4][8];
+#pragma unroll
+          for (int g = 0; g < 4; g++)
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              const int c = c0 + g * 8 * UPD_WAVES + u;
+              q[g][u] = (c < nchunks) ? P[(size_t)c * NACC] : 0.0;
+            }
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            if (c0 + g * 8 * UPD_WAVES >= nchunks) break;
+            double gs = 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (c0 + g * 8 * UPD_WAVES + u < nchunks) gs += q[g][u];
+            acc += gs;
+          }
+        }
+      } else
 #pragma unroll 1
       for (int c0 = w * 8; c0 < nchunks; c0 += 8 * UPD_WAVES) {
         double gs = 0.0;
-        if (chunk_rows) {
-          double q[8];
-#pragma unroll
-          for (int u = 0; u < 8; u++) q[u] = (c0 + u < nchunks) ? P[(size_t)(c0 + u) * NACC] : 0.0;
-#pragma unroll
-          for (int u = 0; u < 8; u++) if (c0 + u < nchunks) gs += q[u];
-        } else if (c0 + 8 <= nchunks) {
+        if (c0 + 8 <= nchunks) {
           double q[8][4];
 #pragma unroll
           for (int u = 0; u < 8; u++) {

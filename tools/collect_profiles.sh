@@ -1,31 +1,60 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): rocprofv3 kernel trace + separate PMC passes over bench.py, the bench lines of the
-# BASELINE configurations (parity and CPU legs ON) and the latency / upload tools.  Everything lands under gpurun_out/final/;
-# profiles/summarize.py turns it into the committed files.   usage: tools/collect_profiles.sh
+# BASELINE configurations (parity and CPU legs ON), the latency-mode tools.  Everything lands under gpurun_out/final/;
+# profiles/summarize.py turns it into the committed files.   usage: tools/collect_profiles.sh [part ...]   (default: all parts)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/final
-rm -rf $O; mkdir -p $O
-cd /tmp && export TMPDIR=/tmp
-# per-kernel times (trace only, no counters)
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py --cpu-seconds 0 --no-host-clouds > $O/kt_bench.json 2> $O/kt.log
-# HBM-side traffic of the sweep: FETCH_SIZE and WRITE_SIZE in separate passes, no trace domains
-timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex k_sweep --output-format csv -d $O/fetch -- python $R/bench.py --cpu-seconds 0 --no-host-clouds --steps 4 --warmup 1 > /dev/null 2> $O/fetch.log
-timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex k_sweep --output-format csv -d $O/write -- python $R/bench.py --cpu-seconds 0 --no-host-clouds --steps 4 --warmup 1 > /dev/null 2> $O/write.log
-rm -rf $O/kt/*/*.db $O/fetch/*/*.db $O/write/*/*.db
-cd $R
-# SQ / TCP / TCC counters of the sweep: the headline workload and the live nodelet's configuration
-timeout 500 tools/pmc_kernel.sh k_sweep sq_direct7 > $O/pmc_sq_direct7.txt 2>&1
-timeout 500 tools/pmc_kernel.sh k_sweep sq_pca_direct1 --variant pca --mode direct1 > $O/pmc_sq_pca_direct1.txt 2>&1
-# bench lines (CPU baseline + pose-by-pose parity legs on)
-timeout 600 python bench.py 2> $O/bench.log | tail -1 > $O/bench.json
-timeout 400 python bench.py --variant pca --mode direct1 2>> $O/bench.log | tail -1 > $O/bench_pca_d1.json
-timeout 400 python bench.py --variant pca --mode direct7 --resolution 0.5 --azimuth 2048 --pairs 128 2>> $O/bench.log | tail -1 > $O/bench_cfg5.json
-timeout 400 python bench.py --variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128 2>> $O/bench.log | tail -1 > $O/bench_cfg5_d1.json
-timeout 400 python bench.py --pairs 1536 --steps 5 --warmup 1 --cpu-seconds 30 2>> $O/bench.log | tail -1 > $O/bench_1536.json
-timeout 400 python bench.py --total-pairs 4541 --steps 3 --warmup 1 --cpu-seconds 0 2>> $O/bench.log | tail -1 > $O/bench_cfg4_1gpu.json
-# the N > 1 branch as two ranks sharing this GPU (gloo): functional evidence only, not a scaling number
-LV_SLAM_BENCH_BACKEND=gloo timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29533 \
-    bench.py --gpus 2 --total-pairs 542 --steps 3 --warmup 1 --cpu-seconds 0 2>> $O/bench.log | grep '^{' | tail -1 > $O/bench_2ranks_1gpu_gloo.json
-timeout 200 python tools/latency_single.py 2>&1 | grep -v amdgpu.ids | tail -4 > $O/latency.txt
-timeout 200 python tools/upload_rate.py 2>&1 | grep -v amdgpu.ids | tail -10 > $O/upload_rate.txt
+mkdir -p $O
+PARTS=${@:-"trace pmc bench extra"}
+QUIET="--cpu-seconds 0 --no-host-clouds --config4-pairs 0 --seq-frames 0"
+for part in $PARTS; do
+case $part in
+trace)
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $O/kt $O/fetch $O/write
+  # per-kernel times (trace only, no counters)
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py $QUIET --steps 20 --warmup 3 > $O/kt_bench.json 2> $O/kt.log
+  # HBM-side traffic of the sweep: FETCH_SIZE and WRITE_SIZE in separate passes, no trace domains
+  timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex k_sweep --output-format csv -d $O/fetch -- python $R/bench.py $QUIET --steps 4 --warmup 1 > /dev/null 2> $O/fetch.log
+  timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex k_sweep --output-format csv -d $O/write -- python $R/bench.py $QUIET --steps 4 --warmup 1 > /dev/null 2> $O/write.log
+  rm -rf $O/kt/*/*.db $O/fetch/*/*.db $O/write/*/*.db
+  cd $R
+  timeout 400 tools/kstats.sh final_kd1 --no-host-clouds --variant pca --mode direct1 --steps 20 --warmup 3 > $O/kstats_pca_d1.txt 2>&1
+  timeout 400 tools/kstats.sh final_kc5 --no-host-clouds --variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128 --steps 10 --warmup 2 > $O/kstats_cfg5_d1.txt 2>&1
+  ;;
+pmc)
+  cd $R
+  # SQ / TCP / TCC counters: the sweep on the headline workload, the live nodelet's configuration and config 5 with DIRECT1; the build kernels; the update
+  timeout 500 tools/pmc_kernel.sh k_sweep sq_direct7 > $O/pmc_sq_direct7.txt 2>&1
+  timeout 500 tools/pmc_kernel.sh k_sweep sq_pca_direct1 --variant pca --mode direct1 > $O/pmc_sq_pca_direct1.txt 2>&1
+  timeout 500 tools/pmc_kernel.sh k_sweep sq_cfg5_d1 --variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128 > $O/pmc_sq_cfg5_d1.txt 2>&1
+  timeout 500 tools/pmc_kernel.sh 'k_leafsum|k_rs_|k_keys|k_voxels|k_mark|k_rank|k_segstart|k_minmax' sq_build > $O/pmc_build.txt 2>&1
+  timeout 500 tools/pmc_kernel.sh 'k_update' sq_update > $O/pmc_update.txt 2>&1
+  ;;
+bench)
+  cd $R
+  # bench lines (CPU baseline + pose-by-pose parity legs on); the default line carries the config-4 block and the latency-mode leg
+  timeout 900 python bench.py 2> $O/bench.log | tail -1 > $O/bench.json
+  timeout 400 python bench.py --variant pca --mode direct1 --config4-pairs 0 --seq-frames 0 2>> $O/bench.log | tail -1 > $O/bench_pca_d1.json
+  timeout 400 python bench.py --variant pca --mode direct7 --resolution 0.5 --azimuth 2048 --pairs 128 --config4-pairs 0 --seq-frames 0 2>> $O/bench.log | tail -1 > $O/bench_cfg5.json
+  timeout 400 python bench.py --variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128 --config4-pairs 0 --seq-frames 0 2>> $O/bench.log | tail -1 > $O/bench_cfg5_d1.json
+  timeout 400 python bench.py --pairs 1536 --steps 5 --warmup 1 --cpu-seconds 30 --config4-pairs 0 --seq-frames 0 2>> $O/bench.log | tail -1 > $O/bench_1536.json
+  # BASELINE config 4's whole job on one GPU, through the RCCL gather (one forced rank), parity sample spread over pairs 0..4540
+  LV_SLAM_BENCH_FORCE_DIST=1 MASTER_PORT=29541 timeout 600 python bench.py --total-pairs 4541 --steps 5 --warmup 1 --cpu-seconds 16 --no-host-clouds --seq-frames 0 2>> $O/bench.log | grep '^{' | tail -1 > $O/bench_cfg4_1gpu.json
+  # the N > 1 branch as two ranks sharing this GPU (gloo), DEFAULT flags = what the driver's scaling runs pass: weak line + config-4 block + gather times
+  LV_SLAM_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29533 \
+      bench.py --gpus 2 --steps 5 --warmup 2 2>> $O/bench.log | grep '^{' | tail -1 > $O/bench_2ranks_1gpu_gloo.json
+  timeout 600 python bench.py --prefiltered --azimuth 2048 --pairs 64 --variant pca --mode direct1 --cpu-seconds 10 2>> $O/bench.log | tail -1 > $O/bench_prefiltered.json
+  ;;
+extra)
+  cd $R
+  (timeout 200 python tools/latency_single.py; LATENCY_MODE=1 timeout 200 python tools/latency_single.py) 2>&1 | grep -v amdgpu.ids > $O/latency.txt
+  timeout 300 python tools/seq_run.py 271 2>&1 | grep -v amdgpu.ids > $O/sequence.txt
+  cd /tmp && export TMPDIR=/tmp; rm -rf $O/seqkt
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/seqkt -- python $R/tools/seq_run.py 65 > /dev/null 2> $O/seqkt.log; cd $R
+  python tools/seq_kernels.py $O/seqkt >> $O/sequence.txt 2>&1; rm -rf $O/seqkt
+  timeout 200 python tools/upload_rate.py 2>&1 | grep -v amdgpu.ids | tail -10 > $O/upload_rate.txt
+  ;;
+esac
+done
 ls -la $O

@@ -2,7 +2,7 @@
 track time.  Under `rocprofv3 --kernel-trace` + tools/seq_kernels.py it gives the per-kernel picture of one round."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from lv_slam_amd import ndt, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65
 scans, _ = synth.make_sequence(n, 1024, device="cuda")
