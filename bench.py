@@ -711,6 +711,11 @@ def main():
         eng.batch_align_raw(guesses, res)
     torch.cuda.synchronize()
     dt_resident = time.perf_counter() - t1
+    # leaf statistics of the workload's targets (what the derivative sweep's cost depends on besides the point count)
+    lv = [eng.get_voxels(k) for k in range(min(B, 8))]
+    leaf_stats = {"targets_sampled": len(lv), "searchable_leaves_per_target_mean": round(float(np.mean([len(v) for v in lv])), 1),
+                  "points_per_leaf_mean": round(float(np.mean([v["n"][v["n"] > 0].mean() for v in lv])), 2),
+                  "largest_leaf_points": int(max(v["n"].max() for v in lv))}
     head_res = np.frombuffer(res, dtype=np.uint8).copy()       # (the config-4 block below re-binds the engine)
     res_np = np.frombuffer(head_res, dtype=RES_DT)
 
@@ -796,6 +801,7 @@ def main():
                    "mean_sweeps_per_align": round(float(sweeps.mean()), 2),
                    "converged": int(res_np["conv"].sum()),
                    "rank0_registrations_per_s_resident_targets": round(B * steps / dt_resident, 1),
+                   "target_leaf_statistics": leaf_stats,
                    "steps_chosen_by": "--steps" if a.steps is not None else "timed region sized to >= 0.5 s",
                    "input_generation_s": round(t_gen, 2)},
         "gather_ms_per_step": J["gather_ms_per_step"],

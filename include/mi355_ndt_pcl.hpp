@@ -54,6 +54,9 @@ class NormalDistributionsTransform : public pcl::Registration<PointSource, Point
   inline double getOulierRatio() const { return prm_.outlier_ratio; }
   inline void setOulierRatio(double o) { prm_.outlier_ratio = o; }
   inline void setNeighborhoodSearchMethod(NeighborSearchMethod m) { prm_.neighbor_mode = m; }
+  // not in the reference: the engine's opt-in fine-grained sweep for one registration at a time (mi355ndt_set_latency_mode) --
+  // what a live nodelet wants; results stay inside the parity tolerance, the f64 summation tree is that mode's own
+  inline void setLatencyMode(bool on) { mi355ndt_set_latency_mode(h_, on ? 1 : 0); }
   inline double getTransformationProbability() const { return trans_probability_; }
   inline int getFinalNumIteration() const { return nr_iterations_; }
   // pclpca's getTargetCells() (ndt_pca.h:129-133) hands out the VoxelGridCovariance itself; that container lives on the GPU here,

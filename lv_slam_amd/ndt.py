@@ -466,6 +466,9 @@ class NormalDistributionsTransform:
         self._prm.max_iterations = int(n)
         self._push()
 
+    def setLatencyMode(self, on: bool = True):         # not in the reference: mi355ndt_set_latency_mode (opt-in fine-grained sweep)
+        self._eng.set_latency_mode(on)
+
     def getTransformationProbability(self) -> float:
         return self._trans_probability
 

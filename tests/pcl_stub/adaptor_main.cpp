@@ -1,6 +1,6 @@
 // TEST INFRASTRUCTURE: drives include/mi355_ndt_pcl.hpp the way lv_slam's odometry nodelet drives its registration object
 // (scan_matching_odom_nodelet.cpp:109-119, 197, 220-226), against tests/pcl_stub's stand-in for pcl::Registration.
-//   adaptor_main <target.f32> <source.f32> <n_target> <n_source> <variant> <mode> <resolution>
+//   adaptor_main <target.f32> <source.f32> <n_target> <n_source> <variant> <mode> <resolution> [latency_mode]
 // clouds are raw float32 x,y,z triples; prints one line of numbers (final 16, last-increment 16, previous 16, iterations,
 // converged, trans_probability, visualizer calls, fitness score) and the first 4 output points.
 #include <cstdio>
@@ -37,6 +37,7 @@ int main(int argc, char** argv) {
   reg.setMaximumIterations(64);
   reg.setResolution((float)atof(argv[7]));
   reg.setNeighborhoodSearchMethod((mi355ndt::NeighborSearchMethod)atoi(argv[6]));
+  if (argc > 8 && atoi(argv[8])) reg.setLatencyMode(true);      // the engine's opt-in fine-grained sweep (not in the reference)
   std::function<void(const pcl::PointCloud<PointT>&, const std::vector<int>&, const pcl::PointCloud<PointT>&, const std::vector<int>&)> cb =
       [](const pcl::PointCloud<PointT>&, const std::vector<int>&, const pcl::PointCloud<PointT>&, const std::vector<int>&) { g_vis_calls++; };
   reg.registerVisualizationCallback(cb);

@@ -27,13 +27,13 @@ def test_adaptor_compiles_and_links_against_pcl_stub():
     # the ABI symbols the adaptor needs are undefined in the binary and exported by the library
     und = subprocess.check_output(["nm", "-u", exe], text=True)
     for sym in ["mi355ndt_create", "mi355ndt_set_target", "mi355ndt_set_source", "mi355ndt_align", "mi355ndt_get_aligned",
-                "mi355ndt_get_incremental", "mi355ndt_set_params", "mi355ndt_get_fitness_score", "mi355ndt_get_voxels"]:
+                "mi355ndt_get_incremental", "mi355ndt_set_params", "mi355ndt_get_fitness_score", "mi355ndt_get_voxels", "mi355ndt_set_latency_mode"]:
         assert sym in und, sym
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant,mode,res", [(0, 2, 1.0), (1, 3, 1.0)])      # ndt_omp/DIRECT7 and the nodelet's ndt_pca/DIRECT1
-def test_adaptor_end_to_end(tmp_path, variant, mode, res):
+@pytest.mark.parametrize("variant,mode,res,lat", [(0, 2, 1.0, 0), (1, 3, 1.0, 0), (1, 3, 1.0, 1)])      # ndt_omp/DIRECT7, the nodelet's ndt_pca/DIRECT1, and the latter in latency mode
+def test_adaptor_end_to_end(tmp_path, variant, mode, res, lat):
     from conftest import se3_err
     from lv_slam_amd import ndt, synth
     from oracle import oracle_py as O
@@ -43,7 +43,7 @@ def test_adaptor_end_to_end(tmp_path, variant, mode, res):
     tgt.tofile(tmp_path / "t.f32")
     src.tofile(tmp_path / "s.f32")
     out = subprocess.check_output([exe, str(tmp_path / "t.f32"), str(tmp_path / "s.f32"), str(len(tgt)), str(len(src)),
-                                   str(variant), str(mode), str(res)], text=True, timeout=300).strip().splitlines()
+                                   str(variant), str(mode), str(res), str(lat)], text=True, timeout=300).strip().splitlines()
     v = out[0].split()
     F = np.array(v[:16], np.float32).reshape(4, 4).T
     L = np.array(v[16:32], np.float32).reshape(4, 4).T
@@ -51,6 +51,7 @@ def test_adaptor_end_to_end(tmp_path, variant, mode, res):
     kw = dict(resolution=res, trans_epsilon=0.01, max_iterations=64, neighbor_mode=mode, variant=variant)
     G = synth.default_guess()
     eng = ndt.Engine(ndt.default_params(**kw))
+    eng.set_latency_mode(bool(lat))
     eng.set_target(tgt)
     eng.set_source(src)
     r = eng.align(G)
