@@ -866,6 +866,8 @@ static void make_sweep_const(const mi355ndt_handle* h, SweepConst& sc) {
   sc.kd_r2 = (float)((double)h->prm.resolution * (double)h->prm.resolution);   // KdTreeFLANN::radiusSearch: float(radius * radius)
   build_offsets(h->prm.neighbor_mode, sc);
   sc.dyn_shift = h->dyn_shift >= 0 ? h->dyn_shift : (sc.K == 1 ? 3 : 2);
+  sc.host_flags = nullptr;
+  sc.seq_no = 0;
 }
 
 static int launch_sweep(mi355ndt_handle* h, const SweepConst& sc, int max_pairs = -1) {
@@ -912,6 +914,51 @@ int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_resu
   if (rc != MI355NDT_OK && h->ev_compute) (void)compute_enqueued(h);      // see mi355ndt_batch_build_targets
   return rc;
 }
+static int ensure_seq_flags(mi355ndt_handle* h) {
+  if (!h->h_seq_flags) {
+    HIPCHK(h, hipHostMalloc((void**)&h->h_seq_flags, 64, hipHostMallocMapped));
+    HIPCHK(h, hipHostGetDevicePointer((void**)&h->d_seq_flags, (void*)h->h_seq_flags, 0));
+  }
+  return MI355NDT_OK;
+}
+
+// Latency mode's Newton loop: (update, sweep) rounds enqueued at most `depth` ahead of the sweep the device last reported from;
+// every fine sweep writes "pairs still active" and its sequence number into mapped host memory, so the loop needs neither the
+// per-burst counter copy nor an event wait.  Ends when a sweep reports that no pair is active.
+static int align_pump(mi355ndt_handle* h, SweepConst sc, int B) {
+  int rc = ensure_seq_flags(h);
+  if (rc) return rc;
+  hipStream_t s = h->stream;
+  h->h_seq_flags[0] = 0; h->h_seq_flags[1] = -1;
+  sc.host_flags = h->d_seq_flags;
+  sc.seq_no = 1;
+  rc = launch_sweep(h, sc);                      // the sweep at the guess
+  if (rc) return rc;
+  const int depth = 2;
+  const long long max_rounds = h->prm.max_iterations + 4;
+  long long enq = 0;                             // (update, sweep) rounds enqueued; sweep of round r carries seq_no r + 1
+  auto t_progress = std::chrono::steady_clock::now();
+  long long seen_last = -1;
+  for (;;) {
+    const long long seen = h->h_seq_flags[0];    // sequence number of the last sweep that has started
+    const int active = h->h_seq_flags[1];
+    if (seen >= 1 && active == 0) break;         // that sweep found nothing to do: every pair is finalised
+    if (seen != seen_last) { seen_last = seen; t_progress = std::chrono::steady_clock::now(); }
+    if (enq >= max_rounds || enq + 1 - seen >= depth) {
+      if (std::chrono::steady_clock::now() - t_progress > std::chrono::seconds(20)) { h->err = "align: the device stopped making progress"; return MI355NDT_ERR_STATE; }
+      continue;                                  // (busy-wait: a round is ~20 us, a yield costs more than it gives)
+    }
+    k_update<<<B, UPD_THREADS, 0, s>>>(h->d_state, h->d_partials, h->rows_per_pair, h->pts_per_chunk, 1, h->d_results, h->d_active,
+                                       h->d_active_list, h->d_ctl + h->ctl_idx, h->prof ? h->d_hits : nullptr, h->prm.step_size, h->prm.trans_epsilon,
+                                       h->prm.max_iterations, 0, 0);
+    sc.seq_no = (int)(enq + 2);
+    rc = launch_sweep(h, sc);
+    if (rc) return rc;
+    enq++;
+  }
+  return MI355NDT_OK;
+}
+
 static int batch_align_impl(mi355ndt_handle* h, const float* guesses, mi355ndt_result* out) {
   if (!guesses || !out) return MI355NDT_ERR_BAD_ARG;
   if (h->n_pairs <= 0 || !h->d_tgt || !h->d_src) return MI355NDT_ERR_STATE;
@@ -933,6 +980,21 @@ static int batch_align_impl(mi355ndt_handle* h, const float* guesses, mi355ndt_r
   HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, 2 * sizeof(SweepCtl), s));
   h->ctl_idx = 0;
   k_init_state<<<(B + 63) / 64, 64, 0, s>>>(h->d_state, h->d_guess, h->d_src_cnt, h->d_grid, B, h->d_active_list, h->d_ctl);
+  if (h->fine_it) {                                // latency mode: the pump (no bursts, no counter copies, no event waits)
+    rc = align_pump(h, sc, B);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(out, h->d_results, (size_t)B * sizeof(mi355ndt_result), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    HIPCHK(h, hipGetLastError());
+    if (h->prof) {                                 // every sweep a pair took part in streamed its points + K table probes
+      for (int b = 0; b < B; b++) {
+        h->P.sweep_alg_bytes += (double)out[b].sweeps * h->h_src_cnt[b] * (12.0 + 4.0 * sc.K);
+        h->P.sweep_points += (long long)out[b].sweeps * h->h_src_cnt[b];
+      }
+    }
+    h->aligned_once = true;
+    return MI355NDT_OK;
+  }
   rc = launch_sweep(h, sc);
   if (rc) return rc;
   const int max_rounds = h->prm.max_iterations + 4;   // loop body runs for it = 0 .. max_iterations+1
@@ -1507,10 +1569,8 @@ int mi355ndt_sequence_run(mi355ndt_handle* h, int n_frames, const void* const* c
     h->seq_cap = (size_t)n_frames;
   }
   if (!h->d_seq) HIPCHK(h, hipMalloc((void**)&h->d_seq, sizeof(SeqState)));
-  if (!h->h_seq_flags) {
-    HIPCHK(h, hipHostMalloc((void**)&h->h_seq_flags, 64, hipHostMallocMapped));
-    HIPCHK(h, hipHostGetDevicePointer((void**)&h->d_seq_flags, (void*)h->h_seq_flags, 0));
-  }
+  rc = ensure_seq_flags(h);
+  if (rc) { h->prof = keep_prof; return rc; }
   h->h_seq_flags[0] = 0; h->h_seq_flags[1] = 0;
   SeqState q0;
   memset(&q0, 0, sizeof q0);

@@ -203,6 +203,11 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
   __syncthreads();                                 // (the only block barrier of the kernel, before the persistent loop)
   // the control block of the NEXT round (k_update fills it after this kernel) is cleared here, not by a host memset
   if (blockIdx.x == 0 && threadIdx.x < 9) reinterpret_cast<int*>(ctl_next)[threadIdx.x] = 0;
+  if (FINE && sc.host_flags && blockIdx.x == 0 && threadIdx.x == 0) {     // progress report of the latency-mode pump (posted writes over PCIe)
+    sc.host_flags[1] = n_active;
+    __threadfence_system();
+    sc.host_flags[0] = sc.seq_no;
+  }
   if (n_active == 0) return;                       // nothing left to sweep (the loop's last, empty round)
   const int my_xcd = blockIdx.x & 7;
   // Items of a queue are handed out in two ways.  The first `n_static` rounds are STATIC: wave `wx` of the XCD's `xw` waves takes

@@ -73,6 +73,10 @@ struct SweepConst {
   int    leaf_pow2;            // resolution is a power of two: x / leaf == x * inv_leaf bit for bit
   float  inv_leaf;
   int    dyn_shift;            // the sweep claims 1 / 2^dyn_shift of every work queue dynamically, the rest is dealt statically
+  // latency mode only (may be null): two words in mapped host memory the sweep reports to -- [1] = active pairs it found, then
+  // [0] = its sequence number -- so that the host can pump (update, sweep) launches without waiting for a copy or an event
+  volatile int* host_flags;
+  int    seq_no;
 };
 
 // Neighbour offsets in the reference's probe order.  DIRECT1: voxel_grid_covariance_omp_impl.hpp:441;

@@ -5,7 +5,9 @@ import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "final")
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
-OUT = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = sys.argv[2] if len(sys.argv) > 2 else HERE      # (on the GPU box: a directory under gpurun_out/, copied into profiles/ afterwards)
+os.makedirs(OUT, exist_ok=True)
 
 
 def one(pattern):
@@ -14,71 +16,10 @@ def one(pattern):
     return max(f, key=os.path.getmtime)       # merged scratch directories may still hold an older run's files
 
 
-# ---- kernel stats (engine kernels only; torch kernels of the synthetic data generator are summed into one line)
-rows = list(csv.DictReader(open(one("kt/**/*_kernel_stats.csv"))))
-ours, other_calls, other_ns = [], 0, 0.0
-for r in rows:
-    n = r["Name"]
-    if any(k in n for k in ("k_sweep", "k_update", "k_leafsum", "k_rs_", "k_keys", "k_mark", "k_segstart", "k_minmax", "k_voxels", "k_rank",
-                            "k_init_state", "k_griddesc", "k_seq_", "k_set_word_off", "k_word_offsets", "k_pose_records", "k_deinterleave", "k_hessian", "k_fitness", "k_cellrange", "k_transform", "rocprim",
-                            "rocclr")):
-        ours.append(r)
-    else:
-        other_calls += int(r["Calls"]); other_ns += float(r["TotalDurationNs"])
-with open(os.path.join(OUT, f"{TAG}_final_kernel_stats.csv"), "w") as f:
-    f.write("kernel,calls,total_us,avg_us,min_us,max_us\n")
-    for r in ours:
-        f.write(f"\"{r['Name'][:110]}\",{r['Calls']},{float(r['TotalDurationNs']) / 1e3:.1f},{float(r['AverageNs']) / 1e3:.3f},"
-                f"{float(r['MinNs']) / 1e3:.2f},{float(r['MaxNs']) / 1e3:.2f}\n")
-    f.write(f"\"(torch kernels: synthetic data generation, outside the path)\",{other_calls},{other_ns / 1e3:.1f},,,\n")
-
-# ---- every sweep dispatch
-tr = list(csv.DictReader(open(one("kt/**/*_kernel_trace.csv"))))
-sw = [r for r in tr if "k_sweep" in r["Kernel_Name"]]
-sw.sort(key=lambda r: int(r["Start_Timestamp"]))
-with open(os.path.join(OUT, f"{TAG}_final_sweep_dispatches.csv"), "w") as f:
-    f.write("dispatch,duration_us,grid_size,vgpr,sgpr,lds_bytes,scratch\n")
-    for k, r in enumerate(sw):
-        f.write(f"{k},{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:.2f},{r.get('Grid_Size', r.get('Grid_Size_X', ''))},"
-                f"{r.get('VGPR_Count', '')},{r.get('SGPR_Count', '')},{r.get('LDS_Block_Size', '')},{r.get('Scratch_Size', '')}\n")
-
-
-# ---- PMC passes: FETCH_SIZE / WRITE_SIZE per sweep dispatch (rocprofv3 reports them in KB)
-def counter(dirname, name):
-    rows = list(csv.DictReader(open(one(f"{dirname}/**/*_counter_collection.csv"))))
-    rows = [r for r in rows if r["Counter_Name"] == name and "k_sweep" in r["Kernel_Name"]]
-    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    return [float(r["Counter_Value"]) for r in rows]
-
-
-fe, wr = counter("fetch", "FETCH_SIZE"), counter("write", "WRITE_SIZE")
-n = min(len(fe), len(wr))
-with open(os.path.join(OUT, f"{TAG}_final_pmc_sweep.csv"), "w") as f:
-    f.write("dispatch,FETCH_SIZE_KB,WRITE_SIZE_KB\n")
-    for k in range(n):
-        f.write(f"{k},{fe[k]},{wr[k]}\n")
-fe_avg, wr_avg = sum(fe[:n]) / n, sum(wr[:n]) / n
-kmax = max(range(n), key=lambda k: fe[k])
 def load_line(path):
     return json.loads([l for l in open(path).read().splitlines() if l.startswith("{")][-1])
 
 
-bench = load_line(os.path.join(SRC, "kt_bench.json"))
-traffic = {
-    "kernel": "k_sweep", "workload": "bench.py defaults (271 pairs x 65536 pts, ndt_omp, 1.0 m, DIRECT7)", "workload_key": "271x65536:omp:direct7:1.0",
-    "launches_counted": n, "fetch_size_kb_avg_per_launch": fe_avg, "write_size_kb_avg_per_launch": wr_avg, "fetch_correction": 2.0,
-    "traffic_bytes_per_launch": (2.0 * fe_avg + wr_avg) * 1024, "traffic_bytes_per_launch_uncorrected": (fe_avg + wr_avg) * 1024,
-    "full_launch": {"fetch_kb": fe[kmax], "write_kb": wr[kmax]},
-    "algorithmic_bytes_per_launch": bench["roofline"]["alg_bytes_per_launch"],
-    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --cpu-seconds 0 --steps 4 --warmup 1`, "
-              "--kernel-include-regex k_sweep, no trace domains; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE x2 is the gfx950 "
-              "half-counting correction of MI355X_MICROARCH.md (HBM section), calibrated on the compulsory traffic of a full launch "
-              "(source points 213 MB + records ~25 MB + bitmap ~11 MB).  The average runs over every sweep launch of the run, including "
-              "the empty speculative ones that close each align.",
-}
-json.dump(traffic, open(os.path.join(OUT, f"{TAG}_traffic.json"), "w"), indent=1)
-
-# ---- SQ counters of the sweep (tools/pmc_kernel.sh summaries) -> what bounds it: VALU issue
 def pmc_summary(path):
     d = {}
     for l in open(path).read().splitlines():
@@ -91,58 +32,156 @@ def pmc_summary(path):
     return d
 
 
-for tag, key, benchfile, outname in (("sq_direct7", "271x65536:omp:direct7:1.0", "bench.json", f"{TAG}_valu.json"),
-                                     ("sq_pca_direct1", "271x65536:pca:direct1:1.0", "bench_pca_d1.json", f"{TAG}_valu_pca_direct1.json"),
-                                     ("sq_cfg5_d1", "128x131072:pca:direct1:0.5", "bench_cfg5_d1.json", f"{TAG}_valu_cfg5_d1.json")):
-    pth = os.path.join(SRC, f"pmc_{tag}.txt")
-    if not os.path.exists(pth) or not os.path.exists(os.path.join(SRC, benchfile)):
-        continue
-    open(os.path.join(OUT, f"{TAG}_pmc_{tag}.txt"), "w").write(open(pth).read())
-    c = pmc_summary(pth)
-    if "SQ_ACTIVE_INST_VALU" not in c:
-        continue
-    b = load_line(os.path.join(SRC, benchfile))
-    hits_per_launch = b["roofline"]["hits_per_point"] * (b["roofline"]["alg_bytes_per_launch"] / (12 + 4 * {"direct7": 7, "direct1": 1}[b["config"]["neighbor_mode"]] + 64 * b["roofline"]["hits_per_point"]))
-    cycles = c["GRBM_GUI_ACTIVE"] / 8.0                       # the counter sums the eight XCDs
-    valu = {
-        "workload_key": key, "kernel": "k_sweep", "source_counters": f"profiles/{TAG}_pmc_{tag}.txt (rocprofv3 --pmc passes of tools/pmc_kernel.sh, mean per dispatch)",
-        "kernel_cycles_mean_per_dispatch": cycles,
-        "valu_active_frac": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * cycles), 3),      # SQ_ACTIVE_INST_VALU counts quad-cycles; 1024 SIMDs
-        "valu_wave_insts_per_64_hits": round(64.0 * c["SQ_INSTS_VALU"] / hits_per_launch, 1),  # one wave-instruction serves 64 (point, voxel) evaluations
-        "valu_lane_insts_per_hit": round(c["SQ_INSTS_VALU"] / hits_per_launch, 2),
-        "wave_wait_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3),
-        "tcp_busy_frac": round(c.get("TCP_GATE_EN1_sum", 0.0) / (256.0 * cycles), 3),
-        "tcp_line_accesses_per_dispatch": c.get("TCP_TOTAL_CACHE_ACCESSES_sum"),
-        "l2_hit_frac": round(c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3) if "TCC_HIT_sum" in c else None,
-        "physical_hbm_frac_of_peak": round(traffic["traffic_bytes_per_launch"] / (cycles / 2.4e9) / 8.0e12, 4) if tag == "sq_direct7" else None,
-        "note": "mean over every sweep dispatch of a short bench run (full launches, the shrinking tail and the empty ones alike); cycles at 2.4 GHz",
+import traceback
+traffic = {"traffic_bytes_per_launch": 0.0}
+fe, wr, sw, kmax = [0.0], [0.0], [], 0
+
+
+def section(fn):
+    try:
+        fn()
+    except Exception:
+        print("section", fn.__name__, "skipped:", traceback.format_exc().splitlines()[-1])
+
+
+def sec1():
+    global traffic, fe, wr, sw, kmax, bench
+    # ---- kernel stats (engine kernels only; torch kernels of the synthetic data generator are summed into one line)
+    rows = list(csv.DictReader(open(one("kt/**/*_kernel_stats.csv"))))
+    ours, other_calls, other_ns = [], 0, 0.0
+    for r in rows:
+        n = r["Name"]
+        if any(k in n for k in ("k_sweep", "k_update", "k_leafsum", "k_rs_", "k_keys", "k_mark", "k_segstart", "k_minmax", "k_voxels", "k_rank",
+                                "k_init_state", "k_griddesc", "k_seq_", "k_set_word_off", "k_word_offsets", "k_pose_records", "k_deinterleave", "k_hessian", "k_fitness", "k_cellrange", "k_transform", "rocprim",
+                                "rocclr")):
+            ours.append(r)
+        else:
+            other_calls += int(r["Calls"]); other_ns += float(r["TotalDurationNs"])
+    with open(os.path.join(OUT, f"{TAG}_final_kernel_stats.csv"), "w") as f:
+        f.write("kernel,calls,total_us,avg_us,min_us,max_us\n")
+        for r in ours:
+            f.write(f"\"{r['Name'][:110]}\",{r['Calls']},{float(r['TotalDurationNs']) / 1e3:.1f},{float(r['AverageNs']) / 1e3:.3f},"
+                    f"{float(r['MinNs']) / 1e3:.2f},{float(r['MaxNs']) / 1e3:.2f}\n")
+        f.write(f"\"(torch kernels: synthetic data generation, outside the path)\",{other_calls},{other_ns / 1e3:.1f},,,\n")
+
+
+section(sec1)
+
+def sec2():
+    global traffic, fe, wr, sw, kmax, bench
+    # ---- every sweep dispatch
+    tr = list(csv.DictReader(open(one("kt/**/*_kernel_trace.csv"))))
+    sw = [r for r in tr if "k_sweep" in r["Kernel_Name"]]
+    sw.sort(key=lambda r: int(r["Start_Timestamp"]))
+    with open(os.path.join(OUT, f"{TAG}_final_sweep_dispatches.csv"), "w") as f:
+        f.write("dispatch,duration_us,grid_size,vgpr,sgpr,lds_bytes,scratch\n")
+        for k, r in enumerate(sw):
+            f.write(f"{k},{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:.2f},{r.get('Grid_Size', r.get('Grid_Size_X', ''))},"
+                    f"{r.get('VGPR_Count', '')},{r.get('SGPR_Count', '')},{r.get('LDS_Block_Size', '')},{r.get('Scratch_Size', '')}\n")
+
+
+section(sec2)
+
+def sec3():
+    global traffic, fe, wr, sw, kmax, bench
+    # ---- PMC passes: FETCH_SIZE / WRITE_SIZE per sweep dispatch (rocprofv3 reports them in KB)
+    def counter(dirname, name):
+        rows = list(csv.DictReader(open(one(f"{dirname}/**/*_counter_collection.csv"))))
+        rows = [r for r in rows if r["Counter_Name"] == name and "k_sweep" in r["Kernel_Name"]]
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        return [float(r["Counter_Value"]) for r in rows]
+
+
+    fe, wr = counter("fetch", "FETCH_SIZE"), counter("write", "WRITE_SIZE")
+    n = min(len(fe), len(wr))
+    with open(os.path.join(OUT, f"{TAG}_final_pmc_sweep.csv"), "w") as f:
+        f.write("dispatch,FETCH_SIZE_KB,WRITE_SIZE_KB\n")
+        for k in range(n):
+            f.write(f"{k},{fe[k]},{wr[k]}\n")
+    fe_avg, wr_avg = sum(fe[:n]) / n, sum(wr[:n]) / n
+    kmax = max(range(n), key=lambda k: fe[k])
+    bench = load_line(os.path.join(SRC, "kt_bench.json"))
+    traffic = {
+        "kernel": "k_sweep", "workload": "bench.py defaults (271 pairs x 65536 pts, ndt_omp, 1.0 m, DIRECT7)", "workload_key": "271x65536:omp:direct7:1.0",
+        "launches_counted": n, "fetch_size_kb_avg_per_launch": fe_avg, "write_size_kb_avg_per_launch": wr_avg, "fetch_correction": 2.0,
+        "traffic_bytes_per_launch": (2.0 * fe_avg + wr_avg) * 1024, "traffic_bytes_per_launch_uncorrected": (fe_avg + wr_avg) * 1024,
+        "full_launch": {"fetch_kb": fe[kmax], "write_kb": wr[kmax]},
+        "algorithmic_bytes_per_launch": bench["roofline"]["alg_bytes_per_launch"],
+        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --cpu-seconds 0 --steps 4 --warmup 1`, "
+                  "--kernel-include-regex k_sweep, no trace domains; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE x2 is the gfx950 "
+                  "half-counting correction of MI355X_MICROARCH.md (HBM section), calibrated on the compulsory traffic of a full launch "
+                  "(source points 213 MB + records ~25 MB + bitmap ~11 MB).  The average runs over every sweep launch of the run, including "
+                  "the empty speculative ones that close each align.",
     }
-    json.dump(valu, open(os.path.join(OUT, outname), "w"), indent=1)
+    json.dump(traffic, open(os.path.join(OUT, f"{TAG}_traffic.json"), "w"), indent=1)
 
-# ---- build / update kernels: counter summaries + reduced ratios (profiles/reduce_pmc.py)
-import subprocess
-for name in ("build", "update"):
-    pth = os.path.join(SRC, f"pmc_{name}.txt")
-    if os.path.exists(pth) and os.path.getsize(pth) > 100:
-        open(os.path.join(OUT, f"{TAG}_pmc_{name}.txt"), "w").write(open(pth).read())
-        red = subprocess.run([sys.executable, os.path.join(OUT, "reduce_pmc.py"), pth], capture_output=True, text=True).stdout
-        open(os.path.join(OUT, f"{TAG}_{name}_counters.json"), "w").write(red)
 
-for name in ("kstats_pca_d1.txt", "kstats_cfg5_d1.txt"):
-    pth = os.path.join(SRC, name)
-    if os.path.exists(pth):
-        txt = [l for l in open(pth).read().splitlines() if l.startswith("kernel ") or l.startswith("k_") or l.startswith("void k_")]
-        open(os.path.join(OUT, f"{TAG}_{name}"), "w").write("\n".join(txt) + "\n")
+section(sec3)
 
-for src, dst in (("bench_cfg5_d1.json", f"{TAG}_bench_cfg5_d1.json"), ("bench_cfg4_1gpu.json", f"{TAG}_bench_cfg4_1gpu.json"),
-                 ("bench_2ranks_1gpu_gloo.json", f"{TAG}_bench_2ranks_1gpu_gloo.json"), ("bench.json", f"{TAG}_bench.json"), ("bench_pca_d1.json", f"{TAG}_bench_pca_d1.json"),
-                 ("bench_cfg5.json", f"{TAG}_bench_cfg5.json"), ("bench_1536.json", f"{TAG}_bench_1536pairs.json"), ("bench_prefiltered.json", f"{TAG}_bench_prefiltered.json"),
-                 ("kt_bench.json", f"{TAG}_bench_under_rocprof.json")):
-    p = os.path.join(SRC, src)
-    if os.path.exists(p) and os.path.getsize(p) > 10:
-        json.dump(load_line(p), open(os.path.join(OUT, dst), "w"), indent=1)
-for src, dst in (("upload_rate.txt", f"{TAG}_upload_rate.txt"), ("latency.txt", f"{TAG}_latency.txt"), ("sequence.txt", f"{TAG}_sequence.txt")):
-    if os.path.exists(os.path.join(SRC, src)):
-        open(os.path.join(OUT, dst), "w").write(open(os.path.join(SRC, src)).read())
-print("sweep launches", len(sw), "avg us", sum((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) for r in sw) / 1e3 / max(1, len(sw)))
-print("traffic per launch MB", traffic["traffic_bytes_per_launch"] / 1e6, "full launch fetch/write KB", fe[kmax], wr[kmax])
+def sec4():
+    global traffic, fe, wr, sw, kmax, bench
+    # ---- SQ counters of the sweep (tools/pmc_kernel.sh summaries) -> what bounds it: VALU issue
+    for tag, key, benchfile, outname in (("sq_direct7", "271x65536:omp:direct7:1.0", "bench.json", f"{TAG}_valu.json"),
+                                         ("sq_pca_direct1", "271x65536:pca:direct1:1.0", "bench_pca_d1.json", f"{TAG}_valu_pca_direct1.json"),
+                                         ("sq_cfg5_d1", "128x131072:pca:direct1:0.5", "bench_cfg5_d1.json", f"{TAG}_valu_cfg5_d1.json")):
+        pth = os.path.join(SRC, f"pmc_{tag}.txt")
+        if not os.path.exists(pth) or not os.path.exists(os.path.join(SRC, benchfile)):
+            continue
+        open(os.path.join(OUT, f"{TAG}_pmc_{tag}.txt"), "w").write(open(pth).read())
+        c = pmc_summary(pth)
+        if "SQ_ACTIVE_INST_VALU" not in c:
+            continue
+        b = load_line(os.path.join(SRC, benchfile))
+        hits_per_launch = b["roofline"]["hits_per_point"] * (b["roofline"]["alg_bytes_per_launch"] / (12 + 4 * {"direct7": 7, "direct1": 1}[b["config"]["neighbor_mode"]] + 64 * b["roofline"]["hits_per_point"]))
+        cycles = c["GRBM_GUI_ACTIVE"] / 8.0                       # the counter sums the eight XCDs
+        valu = {
+            "workload_key": key, "kernel": "k_sweep", "source_counters": f"profiles/{TAG}_pmc_{tag}.txt (rocprofv3 --pmc passes of tools/pmc_kernel.sh, mean per dispatch)",
+            "kernel_cycles_mean_per_dispatch": cycles,
+            "valu_active_frac": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * cycles), 3),      # SQ_ACTIVE_INST_VALU counts quad-cycles; 1024 SIMDs
+            "valu_wave_insts_per_64_hits": round(64.0 * c["SQ_INSTS_VALU"] / hits_per_launch, 1),  # one wave-instruction serves 64 (point, voxel) evaluations
+            "valu_lane_insts_per_hit": round(c["SQ_INSTS_VALU"] / hits_per_launch, 2),
+            "wave_wait_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3),
+            "tcp_busy_frac": round(c.get("TCP_GATE_EN1_sum", 0.0) / (256.0 * cycles), 3),
+            "tcp_line_accesses_per_dispatch": c.get("TCP_TOTAL_CACHE_ACCESSES_sum"),
+            "l2_hit_frac": round(c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3) if "TCC_HIT_sum" in c else None,
+            "physical_hbm_frac_of_peak": round(traffic["traffic_bytes_per_launch"] / (cycles / 2.4e9) / 8.0e12, 4) if tag == "sq_direct7" else None,
+            "note": "mean over every sweep dispatch of a short bench run (full launches, the shrinking tail and the empty ones alike); cycles at 2.4 GHz",
+        }
+        json.dump(valu, open(os.path.join(OUT, outname), "w"), indent=1)
+
+
+section(sec4)
+
+def sec5():
+    global traffic, fe, wr, sw, kmax, bench
+    # ---- build / update kernels: counter summaries + reduced ratios (profiles/reduce_pmc.py)
+    import subprocess
+    for name in ("build", "update"):
+        pth = os.path.join(SRC, f"pmc_{name}.txt")
+        if os.path.exists(pth) and os.path.getsize(pth) > 100:
+            open(os.path.join(OUT, f"{TAG}_pmc_{name}.txt"), "w").write(open(pth).read())
+            red = subprocess.run([sys.executable, os.path.join(HERE, "reduce_pmc.py"), pth], capture_output=True, text=True).stdout
+            open(os.path.join(OUT, f"{TAG}_{name}_counters.json"), "w").write(red)
+
+    for name in ("kstats_pca_d1.txt", "kstats_cfg5_d1.txt"):
+        pth = os.path.join(SRC, name)
+        if os.path.exists(pth):
+            txt = [l for l in open(pth).read().splitlines() if l.startswith("kernel ") or l.startswith("k_") or l.startswith("void k_")]
+            open(os.path.join(OUT, f"{TAG}_{name}"), "w").write("\n".join(txt) + "\n")
+
+    for src, dst in (("bench_cfg5_d1.json", f"{TAG}_bench_cfg5_d1.json"), ("bench_cfg4_1gpu.json", f"{TAG}_bench_cfg4_1gpu.json"),
+                     ("bench_2ranks_1gpu_gloo.json", f"{TAG}_bench_2ranks_1gpu_gloo.json"), ("bench.json", f"{TAG}_bench.json"), ("bench_pca_d1.json", f"{TAG}_bench_pca_d1.json"),
+                     ("bench_cfg5.json", f"{TAG}_bench_cfg5.json"), ("bench_1536.json", f"{TAG}_bench_1536pairs.json"), ("bench_prefiltered.json", f"{TAG}_bench_prefiltered.json"),
+                     ("kt_bench.json", f"{TAG}_bench_under_rocprof.json")):
+        p = os.path.join(SRC, src)
+        if os.path.exists(p) and os.path.getsize(p) > 10:
+            json.dump(load_line(p), open(os.path.join(OUT, dst), "w"), indent=1)
+    for src, dst in (("upload_rate.txt", f"{TAG}_upload_rate.txt"), ("latency.txt", f"{TAG}_latency.txt"), ("sequence.txt", f"{TAG}_sequence.txt")):
+        if os.path.exists(os.path.join(SRC, src)):
+            open(os.path.join(OUT, dst), "w").write(open(os.path.join(SRC, src)).read())
+    print("sweep launches", len(sw), "avg us", sum((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) for r in sw) / 1e3 / max(1, len(sw)))
+    print("traffic per launch MB", traffic["traffic_bytes_per_launch"] / 1e6, "full launch fetch/write KB", fe[kmax], wr[kmax])
+
+
+section(sec5)
+

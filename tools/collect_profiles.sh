@@ -57,4 +57,10 @@ extra)
   ;;
 esac
 done
-ls -la $O
+# reduce on the box (the raw traces are far too large to travel back) and drop the raw directories
+cd $R
+python profiles/summarize.py r03 $O/reduced > $O/summarize.log 2>&1
+rm -rf $O/kt $O/fetch $O/write $R/gpurun_out/final_kd1/kt $R/gpurun_out/final_kc5/kt $R/gpurun_out/pmc_sq_*
+tail -5 $O/summarize.log
+for f in bench.log kt.log; do echo "== $f"; tail -4 $O/$f; done
+ls -la $O $O/reduced; du -sh $R/gpurun_out
