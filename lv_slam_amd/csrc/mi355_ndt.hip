@@ -32,7 +32,6 @@
 #include "ndt_types.hpp"
 #include "ndt_build.hpp"
 #include "ndt_segsort.hpp"
-#include "ndt_build_runs.hpp"
 #include "ndt_sweep.hpp"
 #include "ndt_update.hpp"
 #include "ndt_hessian.hpp"
@@ -76,11 +75,6 @@ struct mi355ndt_handle {
   unsigned* d_seg_start = nullptr; double* d_sums = nullptr; float* d_cent = nullptr; double* d_icov64 = nullptr; size_t icov64_cap = 0;
   int* d_kdw = nullptr; size_t kdw_cap = 0; bool kdw_built = false;   // per-leaf weights for ndt_pca + KDTREE (dead leaves included)
   unsigned* d_rs_hist = nullptr; unsigned* d_rs_offs = nullptr; size_t rs_cap = 0;   // segmented radix sort: tile histograms / offsets
-  // run-compressed build (ndt_build_runs.hpp): point keys, per-block head counts / offsets, runs per target, run starts, sorted (first point, length), leaf-head flags
-  bool build_runs = true;                         // MI355NDT_BUILD=points selects the point-level build
-  bool points_sorted = false;                     // d_keys_b / d_vals_b hold the target's POINTS sorted by cell (what getFitnessScore searches)
-  unsigned *d_pkeys = nullptr, *d_blk_heads = nullptr, *d_blk_off = nullptr, *d_run_cnt = nullptr, *d_run_start = nullptr, *d_sst = nullptr, *d_slen = nullptr;
-  unsigned char* d_lhead = nullptr; size_t runs_cap = 0, runs_blk_cap = 0, runs_pairs_cap = 0;
   unsigned *d_cstart = nullptr, *d_cend = nullptr; size_t cell_cap = 0; bool cells_ready = false; int last_cb = 0;
   double* d_fit = nullptr; size_t fit_cap = 0;
   // prefilter workspace
@@ -301,7 +295,6 @@ int mi355ndt_create(const mi355ndt_params* params, int device, mi355ndt_handle**
   h->device = device;
   h->prm = p;
   { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
-  if (const char* e = std::getenv("MI355NDT_BUILD")) h->build_runs = std::string(e) != "points";
   if (const char* e = std::getenv("MI355NDT_FINE_TILES")) { const int v = std::atoi(e); if (v == 1 || v == 2) h->fine_tiles = v; }
   if (const char* e = std::getenv("MI355NDT_SWEEP_DYN_SHIFT")) { const int v = std::atoi(e); if (v >= 0 && v <= 30) h->dyn_shift = v; }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -337,8 +330,7 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
                   h->d_cent, h->d_icov64, h->d_kdw, h->d_rs_hist, h->d_rs_offs, h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit, h->d_pf_in, h->d_pf_out, h->d_pf_keep, h->d_pf_keys,
                   h->d_pf_vals, h->d_pf_flag, h->d_pf_pos, h->d_pf_mm, h->d_pf_grid, h->d_pf_tmp};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  for (void* p : {(void*)h->d_grid_of, (void*)h->d_seq, (void*)h->d_seq_out, (void*)h->d_stamps, (void*)h->d_pkeys, (void*)h->d_blk_heads, (void*)h->d_blk_off,
-                  (void*)h->d_run_cnt, (void*)h->d_run_start, (void*)h->d_sst, (void*)h->d_slen, (void*)h->d_lhead}) if (p) (void)hipFree(p);
+  for (void* p : {(void*)h->d_grid_of, (void*)h->d_seq, (void*)h->d_seq_out, (void*)h->d_stamps}) if (p) (void)hipFree(p);
   if (h->h_seq_flags) (void)hipHostFree((void*)h->h_seq_flags);
   for (hipStream_t cs : h->copy_stream) if (cs) (void)hipStreamSynchronize(cs);
   for (auto& u : h->up) { if (u.h) (void)hipHostFree(u.h); if (u.d) (void)hipFree(u.d); if (u.ev) (void)hipEventDestroy(u.ev); }
@@ -800,57 +792,18 @@ static int build_targets_impl(mi355ndt_handle* h) {
     }
     unsigned *kin = (npass & 1) ? ka : kb, *kout = (npass & 1) ? kb : ka;      // an odd number of hops must end in kb
     unsigned *vin = (npass & 1) ? h->d_vals_a : h->d_vals_b, *vout = (npass & 1) ? h->d_vals_b : h->d_vals_a;
-    if (h->build_runs) {
-      // ---- run-compressed build (ndt_build_runs.hpp): sort ~10 k run records per target instead of 65,536 points, no gather in the leaf sums
-      const int nblk = (int)((pitch + RUN_BLOCK - 1) / RUN_BLOCK);
-      if (total > h->runs_cap) {
-        for (void** p : {(void**)&h->d_pkeys, (void**)&h->d_sst, (void**)&h->d_slen, (void**)&h->d_lhead}) if (*p) { HIPCHK(h, hipFree(*p)); *p = nullptr; }
-        h->runs_cap = 0;
-        HIPCHK(h, hipMalloc((void**)&h->d_pkeys, total * sizeof(unsigned)));
-        HIPCHK(h, hipMalloc((void**)&h->d_sst, total * sizeof(unsigned)));
-        HIPCHK(h, hipMalloc((void**)&h->d_slen, total * sizeof(unsigned)));
-        HIPCHK(h, hipMalloc((void**)&h->d_lhead, total));
-        h->runs_cap = total;
-      }
-      if ((size_t)B * nblk > h->runs_blk_cap || (size_t)B * (pitch + 1) > h->runs_pairs_cap) {
-        for (void** p : {(void**)&h->d_blk_heads, (void**)&h->d_blk_off, (void**)&h->d_run_cnt, (void**)&h->d_run_start}) if (*p) { HIPCHK(h, hipFree(*p)); *p = nullptr; }
-        h->runs_blk_cap = h->runs_pairs_cap = 0;
-        HIPCHK(h, hipMalloc((void**)&h->d_blk_heads, (size_t)B * nblk * sizeof(unsigned)));
-        HIPCHK(h, hipMalloc((void**)&h->d_blk_off, (size_t)B * nblk * sizeof(unsigned)));
-        HIPCHK(h, hipMalloc((void**)&h->d_run_cnt, (size_t)B * sizeof(unsigned)));
-        HIPCHK(h, hipMalloc((void**)&h->d_run_start, (size_t)B * (pitch + 1) * sizeof(unsigned)));
-        h->runs_blk_cap = (size_t)B * nblk; h->runs_pairs_cap = (size_t)B * (pitch + 1);
-      }
-      k_keys_runs<<<dim3((unsigned)nblk, B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_grid, h->d_pkeys, h->d_blk_heads, cb);
-      k_run_offsets<<<B, 256, 0, s>>>(h->d_blk_heads, h->d_blk_off, h->d_run_cnt, nblk);
-      k_run_write<<<dim3((unsigned)nblk, B), 256, 0, s>>>(h->d_pkeys, pitch, h->d_blk_off, h->d_run_cnt, kin, vin, h->d_run_start);
-      for (int p = 0; p < npass; p++) {
-        rs_pass(s, plan.bits, kin, vin, kout, vout, pitch, p * plan.bits, h->d_rs_hist, h->d_rs_offs, tiles, B, false, h->d_run_cnt);
-        std::swap(kin, kout); std::swap(vin, vout);
-      }
-      k_mark_runs<<<dim3(gx, B), 256, 0, s>>>(kb, h->d_vals_b, pitch, h->d_run_cnt, h->d_run_start, h->d_grid, h->d_words, h->d_sst, h->d_slen, h->d_lhead, minpts, cb);
-      k_rank<<<B, 1024, 0, s>>>(h->d_grid, h->d_words);
-      k_segstart_runs<<<dim3(gx, B), 256, 0, s>>>(kb, h->d_lhead, pitch, h->d_run_cnt, h->d_grid, h->d_words, h->d_seg_start);
-      if (want_cent) k_leafsum_runs<true><<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_sst, h->d_slen, h->d_run_cnt, h->d_grid, h->d_seg_start,
-                                                                                  h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent, lb, B);
-      else k_leafsum_runs<false><<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_sst, h->d_slen, h->d_run_cnt, h->d_grid, h->d_seg_start,
-                                                                        h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent, lb, B);
-      h->points_sorted = false;
-    } else {
-      k_keys<unsigned><<<dim3(gx, B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_grid, kin, nullptr, cb);
-      for (int p = 0; p < npass; p++) {
-        rs_pass(s, plan.bits, kin, vin, kout, vout, pitch, p * plan.bits, h->d_rs_hist, h->d_rs_offs, tiles, B, p == 0);
-        std::swap(kin, kout); std::swap(vin, vout);
-      }
-      k_mark<unsigned><<<dim3(gx4, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, minpts, cb);
-      k_rank<<<B, 1024, 0, s>>>(h->d_grid, h->d_words);
-      k_segstart<unsigned><<<dim3(gx4, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, h->d_seg_start, minpts, cb);
-      if (want_cent) k_leafsum<unsigned, true><<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start,
-                                                                                      h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent, lb, B);
-      else k_leafsum<unsigned, false><<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start,
-                                                                            h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent, lb, B);
-      h->points_sorted = true;
+    k_keys<unsigned><<<dim3(gx, B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_grid, kin, nullptr, cb);
+    for (int p = 0; p < npass; p++) {
+      rs_pass(s, plan.bits, kin, vin, kout, vout, pitch, p * plan.bits, h->d_rs_hist, h->d_rs_offs, tiles, B, p == 0);
+      std::swap(kin, kout); std::swap(vin, vout);
     }
+    k_mark<unsigned><<<dim3(gx4, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, minpts, cb);
+    k_rank<<<B, 1024, 0, s>>>(h->d_grid, h->d_words);
+    k_segstart<unsigned><<<dim3(gx4, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, h->d_seg_start, minpts, cb);
+    if (want_cent) k_leafsum<unsigned, true><<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start,
+                                                                                    h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent, lb, B);
+    else k_leafsum<unsigned, false><<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start,
+                                                                          h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent, lb, B);
   }
   k_voxels<<<dim3((unsigned)((rpp + 255) / 256), B), 256, 0, s>>>(h->d_grid, h->d_sums, h->d_recs, h->d_vox_n,
                                                                   h->prm.min_covar_eigvalue_mult, h->prm.variant == MI355NDT_VARIANT_PCA,
@@ -1387,21 +1340,6 @@ int mi355ndt_fitness_score_T(mi355ndt_handle* h, const float T_colmajor[16], dou
   HIPCHK(h, hipMemcpyAsync(&g, h->d_grid, sizeof g, hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
   if (g.status != GRID_OK) { *score = 1.7976931348623157e308; if (n_inliers) *n_inliers = 0; return MI355NDT_OK; }
-  if (!h->points_sorted) {
-    // the run-compressed build leaves no point-level order behind: group the target's points by cell now (pair slot 0 only)
-    const RsPlan plan = rs_plan(h->last_cb);
-    const int tiles = (int)((h->tgt_pitch + RS_TILE - 1) / RS_TILE);
-    unsigned *ka = h->d_keys_a, *kb = h->d_keys_b;
-    unsigned *kin = (plan.passes & 1) ? ka : kb, *kout = (plan.passes & 1) ? kb : ka;
-    unsigned *vin = (plan.passes & 1) ? h->d_vals_a : h->d_vals_b, *vout = (plan.passes & 1) ? h->d_vals_b : h->d_vals_a;
-    k_keys<unsigned><<<dim3((unsigned)((h->tgt_pitch + 255) / 256), 1), 256, 0, s>>>(h->d_tgt, h->tgt_pitch, h->d_tgt_cnt, h->d_grid, kin, nullptr, h->last_cb);
-    for (int p = 0; p < plan.passes; p++) {
-      rs_pass(s, plan.bits, kin, vin, kout, vout, h->tgt_pitch, p * plan.bits, h->d_rs_hist, h->d_rs_offs, tiles, 1, p == 0);
-      std::swap(kin, kout); std::swap(vin, vout);
-    }
-    h->points_sorted = true;
-    h->cells_ready = false;
-  }
   if (!h->cells_ready) {
     const size_t nc = (size_t)g.ncells;
     if (nc > h->cell_cap) {

@@ -46,15 +46,11 @@ __device__ __forceinline__ unsigned long long rs_match(unsigned d, bool valid) {
 // digit histogram of every tile: hist[(b * tiles + tile) * RS_NB + d]
 template <int BITS>
 __global__ void __launch_bounds__(RS_THREADS) k_rs_hist(const unsigned* __restrict__ kin, size_t pitch, int shift, unsigned* hist, int tiles,
-                                                        int n_targets, const unsigned* __restrict__ seg_n) {
+                                                        int n_targets) {
   constexpr int RS_NB = 1 << BITS;
   __shared__ unsigned cnt[RS_THREADS / 64][RS_NB];
   int b, tile;
   if (!xcd_map(tiles, n_targets, tile, b)) return;
-  // `seg_n` (may be null): number of entries of every segment (the run-compressed target build sorts ~10 k run records per target in
-  // rows of `pitch`); tiles past the end do nothing -- k_rs_scan skips them too
-  const size_t bound = seg_n ? (size_t)seg_n[b] : pitch;
-  if ((size_t)tile * RS_TILE >= bound) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int d = threadIdx.x; d < (RS_THREADS / 64) * RS_NB; d += RS_THREADS) (&cnt[0][0])[d] = 0;
   __syncthreads();
@@ -64,7 +60,7 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_hist(const unsigned* __restri
 #pragma unroll
   for (int r = 0; r < RS_ROUNDS; r++) {
     const size_t i = wbase + r * 64 + lane;
-    key[r] = i < bound ? K[i] : 0u;
+    key[r] = i < pitch ? K[i] : 0u;
   }
   // Counting needs no ranks, only totals: equal digits mostly come in runs (neighbouring points of a scan fall into the same
   // cell), so the head of each run adds the run's length with one LDS atomic -- a dozen instructions per round instead of the
@@ -72,7 +68,7 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_hist(const unsigned* __restri
 #pragma unroll
   for (int r = 0; r < RS_ROUNDS; r++) {
     const size_t i = wbase + r * 64 + lane;
-    const bool valid = i < bound;                              // valid lanes form a prefix of the wave
+    const bool valid = i < pitch;                              // valid lanes form a prefix of the wave
     const unsigned d = (key[r] >> shift) & (RS_NB - 1);
     const unsigned prev = __shfl_up(d, 1);
     const bool head = valid && (lane == 0 || d != prev);
@@ -91,14 +87,12 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_hist(const unsigned* __restri
 
 // per segment: where does digit d of tile t start?  (digit-major, tile-minor exclusive scan; one block per segment)
 template <int BITS>
-__global__ void __launch_bounds__((1 << BITS) > 1024 ? 1024 : (1 << BITS)) k_rs_scan(const unsigned* __restrict__ hist, unsigned* offs, int tiles_alloc,
-                                                                                       const unsigned* __restrict__ seg_n) {
+__global__ void __launch_bounds__((1 << BITS) > 1024 ? 1024 : (1 << BITS)) k_rs_scan(const unsigned* __restrict__ hist, unsigned* offs, int tiles) {
   constexpr int RS_NB = 1 << BITS, NT = RS_NB > 1024 ? 1024 : RS_NB, PER = RS_NB / NT;   // PER consecutive digits per thread
   __shared__ unsigned sm[NT / 64 + 1];
   const int b = blockIdx.x;
-  const unsigned* H = hist + (size_t)b * tiles_alloc * RS_NB;
-  unsigned* O = offs + (size_t)b * tiles_alloc * RS_NB;
-  const int tiles = seg_n ? (int)(((size_t)seg_n[b] + RS_TILE - 1) / RS_TILE) : tiles_alloc;   // tiles that hold entries
+  const unsigned* H = hist + (size_t)b * tiles * RS_NB;
+  unsigned* O = offs + (size_t)b * tiles * RS_NB;
   unsigned tot[PER], sum = 0;
 #pragma unroll
   for (int u = 0; u < PER; u++) {
@@ -125,14 +119,11 @@ __global__ void __launch_bounds__((1 << BITS) > 1024 ? 1024 : (1 << BITS)) k_rs_
 template <int BITS, bool FIRST>
 __global__ void __launch_bounds__(RS_THREADS) k_rs_scatter(const unsigned* __restrict__ kin, const unsigned* __restrict__ vin,
                                                             unsigned* kout, unsigned* vout, size_t pitch, int shift,
-                                                            const unsigned* __restrict__ offs, int tiles, int n_targets,
-                                                            const unsigned* __restrict__ seg_n) {
+                                                            const unsigned* __restrict__ offs, int tiles, int n_targets) {
   constexpr int RS_NB = 1 << BITS;
   __shared__ unsigned run[RS_THREADS / 64][RS_NB];
   int b, tile;
   if (!xcd_map(tiles, n_targets, tile, b)) return;   // a target's tiles on one XCD: its scattered writes combine in that L2
-  const size_t bound = seg_n ? (size_t)seg_n[b] : pitch;
-  if ((size_t)tile * RS_TILE >= bound) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int d = threadIdx.x; d < (RS_THREADS / 64) * RS_NB; d += RS_THREADS) (&run[0][0])[d] = 0;
   __syncthreads();
@@ -144,14 +135,14 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_scatter(const unsigned* __res
 #pragma unroll
   for (int r = 0; r < RS_ROUNDS; r++) {
     const size_t i = wbase + r * 64 + lane;
-    key[r] = i < bound ? K[i] : 0u;
-    val[r] = FIRST ? (unsigned)i : (i < bound ? V[i] : 0u);
+    key[r] = i < pitch ? K[i] : 0u;
+    val[r] = FIRST ? (unsigned)i : (i < pitch ? V[i] : 0u);
   }
   // phase 1: this wave's digit counts, and for every position its rank inside its (wave, round, digit) group
 #pragma unroll
   for (int r = 0; r < RS_ROUNDS; r++) {
     const size_t i = wbase + r * 64 + lane;
-    const bool valid = i < bound;
+    const bool valid = i < pitch;
     const unsigned d = (key[r] >> shift) & (RS_NB - 1);
     const unsigned long long m = rs_match<BITS>(d, valid);
     const unsigned rank = (unsigned)__popcll(m & lt), c = (unsigned)__popcll(m);
@@ -173,7 +164,7 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_scatter(const unsigned* __res
 #pragma unroll
   for (int r = 0; r < RS_ROUNDS; r++) {
     const size_t i = wbase + r * 64 + lane;
-    const bool valid = i < bound;
+    const bool valid = i < pitch;
     const unsigned d = (key[r] >> shift) & (RS_NB - 1);
     const unsigned rank = info[r] & 0xffu, leader = (info[r] >> 8) & 0xffu, c = info[r] >> 16;
     unsigned prev = 0;
@@ -187,16 +178,16 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_scatter(const unsigned* __res
 // One stable pass over `field` bits starting at bit `shift` of the keys of every segment: histogram, scan, scatter.
 template <int BITS>
 static inline void rs_pass_bits(hipStream_t s, const unsigned* kin, const unsigned* vin, unsigned* kout, unsigned* vout, size_t pitch, int shift,
-                                unsigned* hist, unsigned* offs, int tiles, int n_segments, bool first, const unsigned* seg_n) {
-  k_rs_hist<BITS><<<xcd_grid(tiles, n_segments), RS_THREADS, 0, s>>>(kin, pitch, shift, hist, tiles, n_segments, seg_n);
-  k_rs_scan<BITS><<<n_segments, (1 << BITS) > 1024 ? 1024 : (1 << BITS), 0, s>>>(hist, offs, tiles, seg_n);
-  if (first) k_rs_scatter<BITS, true><<<xcd_grid(tiles, n_segments), RS_THREADS, 0, s>>>(kin, vin, kout, vout, pitch, shift, offs, tiles, n_segments, seg_n);
-  else k_rs_scatter<BITS, false><<<xcd_grid(tiles, n_segments), RS_THREADS, 0, s>>>(kin, vin, kout, vout, pitch, shift, offs, tiles, n_segments, seg_n);
+                                unsigned* hist, unsigned* offs, int tiles, int n_segments, bool first) {
+  k_rs_hist<BITS><<<xcd_grid(tiles, n_segments), RS_THREADS, 0, s>>>(kin, pitch, shift, hist, tiles, n_segments);
+  k_rs_scan<BITS><<<n_segments, (1 << BITS) > 1024 ? 1024 : (1 << BITS), 0, s>>>(hist, offs, tiles);
+  if (first) k_rs_scatter<BITS, true><<<xcd_grid(tiles, n_segments), RS_THREADS, 0, s>>>(kin, vin, kout, vout, pitch, shift, offs, tiles, n_segments);
+  else k_rs_scatter<BITS, false><<<xcd_grid(tiles, n_segments), RS_THREADS, 0, s>>>(kin, vin, kout, vout, pitch, shift, offs, tiles, n_segments);
 }
-// `first`: the point id of position i is i itself (no id array to read yet).  `seg_n` (may be null): entries per segment (device array).
+// `first`: the point id of position i is i itself (no id array to read yet)
 static inline void rs_pass(hipStream_t s, int bits, const unsigned* kin, const unsigned* vin, unsigned* kout, unsigned* vout, size_t pitch, int shift,
-                           unsigned* hist, unsigned* offs, int tiles, int n_segments, bool first, const unsigned* seg_n = nullptr) {
-  if (bits == 8) rs_pass_bits<8>(s, kin, vin, kout, vout, pitch, shift, hist, offs, tiles, n_segments, first, seg_n);
-  else if (bits == 10) rs_pass_bits<10>(s, kin, vin, kout, vout, pitch, shift, hist, offs, tiles, n_segments, first, seg_n);
-  else rs_pass_bits<11>(s, kin, vin, kout, vout, pitch, shift, hist, offs, tiles, n_segments, first, seg_n);
+                           unsigned* hist, unsigned* offs, int tiles, int n_segments, bool first) {
+  if (bits == 8) rs_pass_bits<8>(s, kin, vin, kout, vout, pitch, shift, hist, offs, tiles, n_segments, first);
+  else if (bits == 10) rs_pass_bits<10>(s, kin, vin, kout, vout, pitch, shift, hist, offs, tiles, n_segments, first);
+  else rs_pass_bits<11>(s, kin, vin, kout, vout, pitch, shift, hist, offs, tiles, n_segments, first);
 }
