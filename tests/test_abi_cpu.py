@@ -36,8 +36,10 @@ def test_struct_layouts_match_header(lib, tmp_path):
 #include "mi355_ndt.h"
 int main(void) {
   printf("%zu %zu %zu %zu ", sizeof(mi355ndt_params), sizeof(mi355ndt_result), sizeof(mi355ndt_voxel), sizeof(mi355ndt_profile));
-  printf("%zu %zu %zu %zu\\n", offsetof(mi355ndt_params, min_covar_eigvalue_mult), offsetof(mi355ndt_result, hits_last),
+  printf("%zu %zu %zu %zu ", offsetof(mi355ndt_params, min_covar_eigvalue_mult), offsetof(mi355ndt_result, hits_last),
          offsetof(mi355ndt_voxel, weight), offsetof(mi355ndt_profile, update_launches));
+  printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(mi355ndt_seq_params), sizeof(mi355ndt_seq_frame), sizeof(mi355ndt_seq_stats),
+         offsetof(mi355ndt_seq_frame, tf_s2k_colmajor), offsetof(mi355ndt_seq_frame, key_id), offsetof(mi355ndt_seq_stats, update_launches));
   return 0;
 }''')
     exe = tmp_path / "sz"
@@ -45,7 +47,9 @@ int main(void) {
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     exp = [C.sizeof(ndt.Params), C.sizeof(ndt.Result), C.sizeof(ndt.Voxel), C.sizeof(ndt.Profile),
            ndt.Params.min_covar_eigvalue_mult.offset, ndt.Result.hits_last.offset, ndt.Voxel.weight.offset,
-           ndt.Profile.update_launches.offset]
+           ndt.Profile.update_launches.offset,
+           C.sizeof(ndt.SeqParams), C.sizeof(ndt.SeqFrame), C.sizeof(ndt.SeqStats), ndt.SeqFrame.tf_s2k_colmajor.offset, ndt.SeqFrame.key_id.offset,
+           ndt.SeqStats.update_launches.offset]
     assert got == exp
 
 

@@ -205,3 +205,42 @@ def test_latency_mode_single_registration_vs_oracle(mode, variant, tiles, monkey
     assert rp["iterations"] == r["iterations"]
     dt, dr = se3_err(rp["final"], r["final"])
     assert dt < 1e-4 and dr < 1e-5
+
+
+@pytest.mark.gpu
+def test_sequence_run_edge_cases():
+    """ragged frames (every frame its own point count), runs of one and two frames, what the entry point refuses, and the engine's
+    ordinary surface after a run."""
+    from lv_slam_amd import ndt, synth
+    scans, _ = synth.make_sequence(7, 256, n_beams=32)
+    scans = [s.numpy() for s in scans]
+    ragged = [s[: len(s) - 137 * k] for k, s in enumerate(scans)]            # 8192, 8055, 7918, ... points
+    stamps = [0.1 * k for k in range(len(ragged))]
+    prm_kw = dict(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=3, variant=1)
+    eng = ndt.Engine(ndt.default_params(**prm_kw))
+    dev, stats = eng.sequence_run(ragged, stamps, keyframe_delta_trans=2.0)
+    ora = O.sequence(ragged, stamps, O.default_params(**prm_kw), keyframe_delta_trans=2.0)
+    _compare_runs(dev, ora)
+    one, st1 = eng.sequence_run(ragged[:1], stamps[:1])
+    assert len(one) == 1 and one[0]["new_keyframe"] and np.array_equal(one[0]["odom"], np.eye(4)) and st1["aligns"] == 0
+    two, st2 = eng.sequence_run(ragged[:2], stamps[:2])
+    assert two[1]["aligns"] == 2 and st2["aligns"] == 2
+    dt, dr = se3_err(ora[1]["tf_s2k"], two[1]["tf_s2k"])
+    assert two[1]["iterations"] == ora[1]["iterations"] and dt < 1e-4 and dr < 1e-5
+    # refused: an empty frame; KDTREE and the live More-Thuente configuration are served by the batch kernels only
+    with pytest.raises(ndt.NDTError) as e:
+        eng.sequence_run([ragged[0], np.zeros((0, 3), np.float32)], [0.0, 0.1])
+    assert e.value.code == -2
+    for kw in (dict(neighbor_mode=0), dict(step_size=0.004)):
+        bad = ndt.Engine(ndt.default_params(**{**prm_kw, **kw}))
+        with pytest.raises(ndt.NDTError) as e:
+            bad.sequence_run(ragged[:3], stamps[:3])
+        assert e.value.code == -6
+    # the handle is an ordinary registration object again afterwards (batch mode unless asked otherwise)
+    eng.set_target(scans[0])
+    eng.set_source(scans[1])
+    G = np.eye(4, dtype=np.float32)
+    G[0, 3] = 1.5
+    r = eng.align(G)
+    ro = O.align(O.Grid(scans[0], O.default_params(**prm_kw)), scans[1], G)
+    assert r["iterations"] == ro["iterations"] and np.array_equal(r["final"], ro["final"])
