@@ -374,7 +374,7 @@ class Engine:
         Returns (list of per-frame dicts, stats dict)."""
         clouds = [_as_points(f) for f in frames]
         n = len(clouds)
-        strides = {c.strides[0] for c in clouds}
+        strides = {c.strides[0] for c in clouds if c.shape[0]} or {12}       # (numpy gives empty arrays zero strides)
         if len(strides) != 1:
             raise ValueError("all frames must share one record stride")
         ptrs = np.array([c.ctypes.data for c in clouds], np.uint64)
