@@ -244,3 +244,36 @@ def test_sequence_run_edge_cases():
     r = eng.align(G)
     ro = O.align(O.Grid(scans[0], O.default_params(**prm_kw)), scans[1], G)
     assert r["iterations"] == ro["iterations"] and np.array_equal(r["final"], ro["final"])
+
+
+@pytest.mark.gpu
+def test_latency_mode_small_batch_vs_oracle():
+    """Latency mode is chosen for any SMALL batch, not only for one pair: five pairs of different sizes through the fine-grained sweep,
+    the block-level chunk sums and the pump, each against the oracle and against the batch-mode engine."""
+    from lv_slam_amd import ndt, synth
+    prm_kw = dict(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=2, variant=0)
+    pairs = []
+    for k, cut in enumerate((0, 1000, 4097, 130, 7777)):
+        t, s, _ = synth.make_pair(20 + k, 512)
+        pairs.append((t.numpy(), s.numpy()[: 32768 - cut]))
+    G = synth.default_guess()
+    out = {}
+    for lat in (False, True):
+        eng = ndt.Engine(ndt.default_params(**prm_kw))
+        eng.set_latency_mode(lat)
+        eng.batch_reserve(len(pairs), 32768, 32768)
+        for k, (t, s) in enumerate(pairs):
+            eng.batch_set_target(k, t)
+            eng.batch_set_source(k, s)
+        out[lat] = eng.batch_align(np.broadcast_to(G, (len(pairs), 4, 4)))
+        again = eng.batch_align(np.broadcast_to(G, (len(pairs), 4, 4)))
+        for a, b in zip(out[lat], again):
+            assert np.array_equal(a["final"], b["final"]) and a["score"] == b["score"]
+    op = O.default_params(**prm_kw)
+    for k, (t, s) in enumerate(pairs):
+        ro = O.align(O.Grid(t, op), s, G)
+        for lat in (False, True):
+            r = out[lat][k]
+            assert r["iterations"] == ro["iterations"] and r["converged"] == ro["converged"], (k, lat)
+            dt, dr = se3_err(ro["final"], r["final"])
+            assert dt < 1e-4 and dr < 1e-5, (k, lat, dt, dr)
