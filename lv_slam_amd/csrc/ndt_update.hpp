@@ -245,6 +245,29 @@ __device__ __forceinline__ double reduce_pair_rows(const double* __restrict__ ro
 
 enum { NEWTON_DONE = 0, NEWTON_SWEEP = 1, NEWTON_HESSIAN = 2 };
 
+// impl2:138-140: JacobiSVD(H).solve(-g).  Well-conditioned H: exact LU solve (same answer to rounding); anything else
+// (rank-deficient, H = 0, ill-conditioned): the thresholded pseudo-inverse itself.  (Non-finite g or H: the SVD route answers NaN,
+// as Eigen's does, and the pair ends with converged = 0.)
+__device__ __forceinline__ void newton_solve(const PairState& S, double d[6]) {
+  double neg[6];
+  for (int a = 0; a < 6; a++) neg[a] = -S.g[a];
+  bool fin = true;
+  for (int a = 0; a < 36; a++) fin = fin && isfinite(S.H[a]);
+  for (int a = 0; a < 6; a++) fin = fin && isfinite(S.g[a]);
+  if (!fin || !ndtm::lu_solve6(S.H, neg, d)) ndtm::svd_solve6(S.H, neg, d);
+}
+// When the More-Thuente loop is dead (mt = 0) the solve depends only on the reduced (g, H) -- not on the re-basing of p that
+// wave 0 runs first -- so a second wave of the block computes it at the same time and hands it over through LDS
+// (`sol`: d[6], then a ready flag).  Same function, same inputs: same bits.
+__device__ __forceinline__ void newton_solve_side(const PairState& S, volatile double* sol) {
+  if ((threadIdx.x & 63) != 0) return;
+  double d[6];
+  newton_solve(S, d);
+  for (int a = 0; a < 6; a++) sol[a] = d[a];
+  __threadfence_block();
+  sol[6] = 1.0;
+}
+
 // The body of the while loop of computeTransformation (impl2:131-183) with computeStepLengthMT (impl2:841-1003), for one pair
 // whose reduced (score, g, H) are in S.  Called by every lane of one wave; lane 0 carries the state, the others only help where
 // the same function is needed on several arguments at once (the SE(3) exponentials of the re-basing step: SIMT runs them for
@@ -252,7 +275,8 @@ enum { NEWTON_DONE = 0, NEWTON_SWEEP = 1, NEWTON_HESSIAN = 2 };
 // in the next derivative sweep), NEWTON_HESSIAN (live More-Thuente case: waiting for the computeHessian pass).
 // mt = 0: step_size > eps/2, the More-Thuente loop is dead (every shipped configuration);
 // mt = 1: live case, called after a derivative sweep;  mt = 2: live case, called after the computeHessian pass.
-__device__ __forceinline__ int newton_update(PairState& S, mi355ndt_result* res, double step_max, double eps, int max_iterations, int mt) {
+__device__ __forceinline__ int newton_update(PairState& S, mi355ndt_result* res, double step_max, double eps, int max_iterations, int mt,
+                                             volatile double* sol = nullptr /* non-null: the solve comes from newton_solve_side */) {
   const int lane = threadIdx.x & 63;
   // exp(delta_p) and exp(p) of impl2:163-166, side by side on two lanes (same bits as one after the other on one lane)
   ndtm::SE3 e_dp, e_p;
@@ -310,15 +334,14 @@ __device__ __forceinline__ int newton_update(PairState& S, mi355ndt_result* res,
   }
   for (int guard = 0; guard < 4; guard++) {
     for (int a = 0; a < 16; a++) S.prev_inc_cm[a] = S.inc_cm[a];                 // impl2:134
-    double neg[6], d[6];
-    for (int a = 0; a < 6; a++) neg[a] = -S.g[a];
-    // impl2:138-140: JacobiSVD(H).solve(-g).  Well-conditioned H: exact LU solve (same answer to rounding);
-    // anything else (rank-deficient, H = 0, ill-conditioned): the thresholded pseudo-inverse itself.
-    // (non-finite g or H: the SVD route answers NaN, as Eigen's does, and the pair ends with converged = 0)
-    bool fin = true;
-    for (int a = 0; a < 36; a++) fin = fin && isfinite(S.H[a]);
-    for (int a = 0; a < 6; a++) fin = fin && isfinite(S.g[a]);
-    if (!fin || !ndtm::lu_solve6(S.H, neg, d)) ndtm::svd_solve6(S.H, neg, d);
+    double d[6];
+    if (sol) {                                                                   // impl2:138-140, computed by the block's second wave meanwhile
+      while (sol[6] == 0.0) __builtin_amdgcn_s_sleep(1);
+      __threadfence_block();
+      for (int a = 0; a < 6; a++) d[a] = sol[a];
+    } else {
+      newton_solve(S, d);
+    }
     double nrm = 0;
     for (int a = 0; a < 6; a++) nrm += d[a] * d[a];
     nrm = sqrt(nrm);
@@ -369,9 +392,11 @@ k_update(PairState* st, const double* __restrict__ partials, int rows_per_pair, 
          int* active_counter, int* active_list, SweepCtl* ctl, unsigned long long* hits_total,
          double step_max, double eps, int max_iterations, int reduce_only, int mt) {
   __shared__ double sm[UPD_WAVES][NACC];
+  __shared__ double sol[8];
   const int b = blockIdx.x;
   PairState& S = st[b];
   if (S.phase == PH_DONE) return;                                                // (block-uniform)
+  if (threadIdx.x == 0) sol[6] = 0.0;
   if (mt == 2 && S.phase != PH_HESS) return;                                     // only pairs whose Hessian pass just ran
   const int lane = threadIdx.x & 63;
   const int nchunks = (S.n_src + pts_per_chunk - 1) / pts_per_chunk;
@@ -384,8 +409,9 @@ k_update(PairState* st, const double* __restrict__ partials, int rows_per_pair, 
     else { S.hits = (long long)v; if (hits_total) atomicAdd(hits_total, (unsigned long long)v); }
   }
   __syncthreads();                                                               // lane 0 reads what lanes 0..43 just stored
-  if (threadIdx.x >= 64 || reduce_only) return;
-  const int rc = newton_update(S, &results[b], step_max, eps, max_iterations, mt);
+  if (threadIdx.x >= 128 || reduce_only) return;
+  if (threadIdx.x >= 64) { if (mt == 0) newton_solve_side(S, sol); return; }
+  const int rc = newton_update(S, &results[b], step_max, eps, max_iterations, mt, mt == 0 ? sol : nullptr);
   if (lane == 0 && rc == NEWTON_SWEEP) {
     atomicAdd(active_counter, 1);
     active_list[atomicAdd(&ctl->n_active, 1)] = b;                               // this pair takes part in the next sweep
