@@ -88,30 +88,44 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_hist(const unsigned* __restri
 // per segment: where does digit d of tile t start?  (digit-major, tile-minor exclusive scan; one block per segment)
 template <int BITS>
 __global__ void __launch_bounds__((1 << BITS) > 1024 ? 1024 : (1 << BITS)) k_rs_scan(const unsigned* __restrict__ hist, unsigned* offs, int tiles) {
-  constexpr int RS_NB = 1 << BITS, NT = RS_NB > 1024 ? 1024 : RS_NB, PER = RS_NB / NT;   // PER consecutive digits per thread
+  constexpr int RS_NB = 1 << BITS, NT = RS_NB > 1024 ? 1024 : RS_NB, PER = RS_NB / NT;   // PER digits per thread
   __shared__ unsigned sm[NT / 64 + 1];
   const int b = blockIdx.x;
   const unsigned* H = hist + (size_t)b * tiles * RS_NB;
   unsigned* O = offs + (size_t)b * tiles * RS_NB;
-  unsigned tot[PER], sum = 0;
+  // Thread t owns digits t, t + NT, ... (coalesced rows of the histogram); the digit-major exclusive scan is one block scan per
+  // group of NT digits, each started at the total of the groups before it.  The tile loops are chains of dependent adds over
+  // independent loads: eight loads are issued together (one memory round trip per eight tiles instead of one per tile -- a
+  // 131,072-point segment has 32 tiles, and this kernel is one block per segment).
+  unsigned carry = 0;
 #pragma unroll
   for (int u = 0; u < PER; u++) {
-    const int d = threadIdx.x * PER + u;
-    tot[u] = 0;
-    for (int t = 0; t < tiles; t++) tot[u] += H[(size_t)t * RS_NB + d];
-    sum += tot[u];
-  }
-  unsigned all;
-  unsigned base = block_exscan<NT>(sum, &all, sm);
+    const int d = u * NT + (int)threadIdx.x;
+    unsigned tot = 0;
+    int t = 0;
+    for (; t + 8 <= tiles; t += 8) {
+      unsigned v[8];
 #pragma unroll
-  for (int u = 0; u < PER; u++) {
-    const int d = threadIdx.x * PER + u;
-    unsigned o = base;
-    for (int t = 0; t < tiles; t++) {
+      for (int k = 0; k < 8; k++) v[k] = H[(size_t)(t + k) * RS_NB + d];
+#pragma unroll
+      for (int k = 0; k < 8; k++) tot += v[k];
+    }
+    for (; t < tiles; t++) tot += H[(size_t)t * RS_NB + d];
+    unsigned all;
+    unsigned o = carry + block_exscan<NT>(tot, &all, sm);
+    carry += all;
+    t = 0;
+    for (; t + 8 <= tiles; t += 8) {
+      unsigned v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = H[(size_t)(t + k) * RS_NB + d];
+#pragma unroll
+      for (int k = 0; k < 8; k++) { O[(size_t)(t + k) * RS_NB + d] = o; o += v[k]; }
+    }
+    for (; t < tiles; t++) {
       O[(size_t)t * RS_NB + d] = o;
       o += H[(size_t)t * RS_NB + d];
     }
-    base += tot[u];
   }
 }
 
