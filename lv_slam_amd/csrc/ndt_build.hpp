@@ -160,24 +160,46 @@ __global__ void __launch_bounds__(256) k_mark(const KeyT* __restrict__ keys, siz
     if (head[u]) atomicOr(&words[gd[b].word_off + (cell[u] >> 6)].bits, 1ull << (cell[u] & 63));
 }
 // exclusive popcount prefix over the bitmap words of each target: voxel id = rank in ascending cell order.
-// One block per target; a thread owns RANK_W consecutive words per round (their popcounts are summed locally, the thread totals go
-// through one block scan), so a 0.5 m grid of ~21 k words takes 3 rounds of 1024 x 8 words instead of 82 rounds of 256.
-#define RANK_W 8
+// One block of 16 waves per target; per round a wave owns 512 consecutive words as eight rows of 64 (lane = word: coalesced 16-byte
+// accesses), scans every row with shuffles and carries the row totals along; the 16 wave totals go through one small LDS scan.
+// A 0.5 m grid of ~21 k words takes 3 rounds.
+#define RANK_ROWS 8
 __global__ void __launch_bounds__(1024) k_rank(GridDesc* gd, BitWord* words) {
-  __shared__ unsigned sm[17];
+  __shared__ unsigned wtot[17];
   const int b = blockIdx.x;
   BitWord* W = words + gd[b].word_off;
   const int nw = gd[b].nwords;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   unsigned base = 0;
-  for (int w0 = 0; w0 < nw; w0 += 1024 * RANK_W) {
-    const int w = w0 + (int)threadIdx.x * RANK_W;
-    unsigned c[RANK_W], mine = 0, tot;
+  for (int w0 = 0; w0 < nw; w0 += 1024 * RANK_ROWS) {
+    const int wbase = w0 + wv * 64 * RANK_ROWS;
+    unsigned c[RANK_ROWS], ex[RANK_ROWS], run = 0;
 #pragma unroll
-    for (int u = 0; u < RANK_W; u++) { c[u] = (w + u < nw) ? (unsigned)__popcll(W[w + u].bits) : 0u; mine += c[u]; }
-    unsigned ex = base + block_exscan<1024>(mine, &tot, sm);
+    for (int u = 0; u < RANK_ROWS; u++) { const int w = wbase + u * 64 + lane; c[u] = (w < nw) ? (unsigned)__popcll(W[w].bits) : 0u; }
 #pragma unroll
-    for (int u = 0; u < RANK_W; u++) { if (w + u < nw) W[w + u].prefix = ex; ex += c[u]; }
-    base += tot;
+    for (int u = 0; u < RANK_ROWS; u++) {
+      unsigned inc = c[u];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+      ex[u] = run + inc - c[u];
+      run += __shfl(inc, 63);
+    }
+    if (lane == 0) wtot[wv] = run;
+    __syncthreads();
+    if (wv == 0) {
+      const unsigned v = lane < 16 ? wtot[lane] : 0u;
+      unsigned inc = v;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { const unsigned t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+      if (lane < 16) wtot[lane] = inc - v;
+      if (lane == 15) wtot[16] = inc;
+    }
+    __syncthreads();
+    const unsigned off = base + wtot[wv];
+#pragma unroll
+    for (int u = 0; u < RANK_ROWS; u++) { const int w = wbase + u * 64 + lane; if (w < nw) W[w].prefix = off + ex[u]; }
+    base += wtot[16];
+    __syncthreads();
   }
   if (threadIdx.x == 0) gd[b].n_voxels = (int)base;
 }
