@@ -1544,10 +1544,11 @@ int mi355ndt_sequence_run(mi355ndt_handle* h, int n_frames, const void* const* c
   for (hipStream_t cs : h->copy_stream) HIPCHK(h, hipStreamSynchronize(cs));     // (upload time is reported on its own)
   const auto t_up1 = std::chrono::steady_clock::now();
   const bool keep_prof = h->prof;
+  struct ProfBack { mi355ndt_handle* h; bool v; ~ProfBack() { h->prof = v; } } profback{h, keep_prof};   // (every exit restores it)
   h->prof = false;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-  for (auto& e : ev) HIPCHK(h, hipEventCreate(&e));
   struct EvFree { hipEvent_t* e; ~EvFree() { for (int i = 0; i < 3; i++) if (e[i]) (void)hipEventDestroy(e[i]); } } evfree{ev};
+  for (auto& e : ev) HIPCHK(h, hipEventCreate(&e));
   hipStream_t s = h->stream;
   HIPCHK(h, hipEventRecord(ev[0], s));
   rc = mi355ndt_batch_build_targets(h);
