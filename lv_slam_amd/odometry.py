@@ -102,3 +102,21 @@ class ScanMatchingOdometry:
         row = " ".join("%e" % odom[r, c] for r in range(3) for c in range(4))  # "%le" x 12 (:157-160)
         self.scan_count += 1
         return pose, row
+
+
+def kitti_row(odom_velo: np.ndarray, tf_velo2cam: np.ndarray | None = None) -> str:
+    """One line of the odometry file the nodelet writes (:156-160): odom = tf_velo2cam * pose * tf_velo2cam^-1, twelve "%le" numbers."""
+    T = np.eye(4) if tf_velo2cam is None else np.asarray(tf_velo2cam, np.float64)
+    odom = T @ np.asarray(odom_velo, np.float64) @ np.linalg.inv(T)
+    return " ".join("%e" % odom[r, c] for r in range(3) for c in range(4))
+
+
+def run_on_device(engine, frames, stamps, keyframe_delta_trans: float = 5.0, keyframe_delta_angle: float = 0.17,
+                  keyframe_delta_time: float = 1.0, tf_velo2cam: np.ndarray | None = None):
+    """The whole cloud_callback loop (:144-183, 192-261) for a recorded run of frames with the per-frame policy ON THE DEVICE
+    (lv_slam_amd.ndt.Engine.sequence_run -> mi355ndt_sequence_run): returns (poses [n,4,4] f64, KITTI rows, per-frame records, stats).
+    `engine` carries the registration parameters (configure it like the nodelet: 1.0 m, DIRECT1, eps 0.01, 64 iterations)."""
+    recs, stats = engine.sequence_run(frames, stamps, keyframe_delta_trans, keyframe_delta_angle, keyframe_delta_time)
+    poses = np.stack([r["odom"] for r in recs])
+    rows = [kitti_row(p, tf_velo2cam) for p in poses]
+    return poses, rows, recs, stats

@@ -119,3 +119,26 @@ def test_sequence_gpu_vs_oracle_registration():
     # and the odometry follows the true drive (scene-noise level over 7 frames)
     dt, dr = se3_err(np.linalg.inv(truth[0]) @ truth[-1], pg)
     assert dt < 0.3 and dr < 0.03, (dt, dr)
+
+
+def test_kitti_rows_of_a_device_run_match_the_host_policy_rows():
+    """lv_slam_amd.odometry.run_on_device formats the device run's poses exactly as cloud_callback does (:156-160); driven here by a fake
+    engine that replays the poses of the host-side policy."""
+    from lv_slam_amd.odometry import run_on_device, kitti_row
+    reg = FakeReg()
+    od = ScanMatchingOdometry(reg, keyframe_delta_trans=3.0, keyframe_delta_time=1e9, tf_velo2cam=np.array(
+        [[0, -1, 0, 0.1], [0, 0, -1, -0.2], [1, 0, 0, 0.3], [0, 0, 0, 1.0]]))
+    poses, rows = [], []
+    for k in range(6):
+        p, row = od.cloud_callback(0.1 * k, frame(k))
+        poses.append(p)
+        rows.append(row)
+
+    class FakeEngine:
+        def sequence_run(self, frames, stamps, dtr, dan, dti):
+            assert (dtr, dan, dti) == (3.0, 0.17, 1e9) and len(frames) == len(stamps) == 6
+            return [dict(odom=p) for p in poses], dict(track_ms=1.0)
+
+    P, R, recs, stats = run_on_device(FakeEngine(), [frame(k) for k in range(6)], [0.1 * k for k in range(6)], 3.0, 0.17, 1e9, od.tf_velo2cam)
+    assert R == rows and np.array_equal(P, np.stack(poses)) and stats["track_ms"] == 1.0
+    assert len(kitti_row(np.eye(4)).split()) == 12
