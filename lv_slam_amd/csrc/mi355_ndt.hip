@@ -1540,7 +1540,8 @@ int mi355ndt_sequence_run(mi355ndt_handle* h, int n_frames, const void* const* c
   for (int k = 0; k < n_frames; k++) h->h_src_cnt[k] = h->h_tgt_cnt[k];
   h->have_source = true;
   struct Unalias { mi355ndt_handle* h; ~Unalias() { h->d_src = h->d_src_own; h->src_pitch = h->own_src_pitch; std::fill(h->h_src_cnt.begin(), h->h_src_cnt.end(), 0);
-                                                     h->have_source = false; h->d_grid_of_use = nullptr; h->aligned_once = false; } } unalias{h};
+                                                     h->have_source = false; h->d_grid_of_use = nullptr; h->aligned_once = false;
+                                                     if (h->ev_compute) (void)compute_enqueued(h); } } unalias{h};   // (error exits too: later uploads wait for what was enqueued)
   for (hipStream_t cs : h->copy_stream) HIPCHK(h, hipStreamSynchronize(cs));     // (upload time is reported on its own)
   const auto t_up1 = std::chrono::steady_clock::now();
   const bool keep_prof = h->prof;
