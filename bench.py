@@ -151,6 +151,15 @@ def host_info():
     return model, phys, os.cpu_count() or 1
 
 
+def baseline_config_name(a, n_points):
+    """Which BASELINE.json config a weak-scaling run is (only the literal one is called by its name)."""
+    if a.variant == "omp" and a.mode == "direct7" and a.resolution == 1.0 and n_points == 65536:
+        return "BASELINE config 3" if a.pairs == 271 else "BASELINE config 3's workload at another batch size"
+    if a.variant == "pca" and a.resolution == 0.5 and n_points == 131072:
+        return "BASELINE config 5's per-GPU share" + ("" if a.mode == "direct7" else f" with {a.mode.upper()} (the nodelet's neighbour mode)")
+    return "a variation of BASELINE config 3"
+
+
 def static_profile(name, workload_key):
     """A measurement that cannot be taken inside the timed run (PMC counters need their own rocprofv3 passes): read the committed
     file under profiles/ -- only when it was taken on this very workload -- and say so in the JSON line."""
@@ -792,7 +801,7 @@ def main():
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32 terms, f64 accumulation",
         "data": "synthetic",
         "config": {"workload": (f"BASELINE config 4: {total} synthetic HDL-64E scan pairs sharded round-robin over {world} GPU(s) " if strong else
-                                f"BASELINE config 3: batch of {a.pairs} synthetic HDL-64E scan pairs per GPU ") +
+                                f"{baseline_config_name(a, N)}: batch of {a.pairs} synthetic HDL-64E scan pairs per GPU ") +
                                f"({N} pts per cloud), ndt_{a.variant}, {a.resolution} m voxels, {a.mode.upper()}, eps 0.01, max_iter 64; "
                                "one step = voxelise every target + align every pair (+ RCCL pose all-gather when N>1)",
                    "pairs_total": total, "pairs_rank0": B, "points_per_cloud": N, "neighbor_mode": a.mode, "variant": a.variant,

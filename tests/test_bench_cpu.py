@@ -53,3 +53,17 @@ def test_parity_sample_order_spans_the_index_range():
     first = sorted(o[:285])
     gaps = [b - a for a, b in zip(first, first[1:])]
     assert max(gaps) <= 32 and first[-1] == 4540                         # ~every 16th pair, no hole wider than 32
+
+
+def test_workload_label_names_the_baseline_config_only_when_it_is_that_config(monkeypatch):
+    import bench
+    def args(*extra):
+        monkeypatch.setattr(sys, "argv", ["bench.py", *extra])
+        return bench.parse()
+    assert bench.baseline_config_name(args(), 65536) == "BASELINE config 3"
+    assert "another batch size" in bench.baseline_config_name(args("--pairs", "1536"), 65536)
+    a5 = args("--variant", "pca", "--resolution", "0.5", "--azimuth", "2048", "--pairs", "128")
+    assert bench.baseline_config_name(a5, 131072) == "BASELINE config 5's per-GPU share"
+    a5d1 = args("--variant", "pca", "--mode", "direct1", "--resolution", "0.5", "--azimuth", "2048", "--pairs", "128")
+    assert "DIRECT1" in bench.baseline_config_name(a5d1, 131072)
+    assert bench.baseline_config_name(args("--variant", "pca", "--mode", "direct1"), 65536) == "a variation of BASELINE config 3"
