@@ -311,11 +311,17 @@ __device__ inline void svd_solve6(const double* H, const double b[6], double x[6
     for (int i = 0; i < 6; i++) fin = fin && isfinite(b[i]);
     if (!fin) { for (int i = 0; i < 6; i++) x[i] = __longlong_as_double(0x7ff8000000000000ll); return; }
   }
+  // Eigen 3.3 JacobiSVD::compute works on matrix / scale, scale = matrix.cwiseAbs().maxCoeff() (1 for a zero matrix), and multiplies
+  // the singular values back at the end: without it the squared column norms below overflow (H entries beyond ~1e77: ndt_pca's
+  // weights compound multiplicatively over DIRECT26 neighbours) or vanish, and the rotations are skipped.
+  double scale = 0;
+  for (int i = 0; i < 36; i++) scale = fabs(H[i]) > scale ? fabs(H[i]) : scale;
+  if (scale == 0.0) scale = 1.0;
   double A[6][6], V[6][6];
 #pragma unroll
   for (int i = 0; i < 6; i++)
 #pragma unroll
-    for (int j = 0; j < 6; j++) { A[i][j] = H[i * 6 + j]; V[i][j] = (i == j) ? 1.0 : 0.0; }
+    for (int j = 0; j < 6; j++) { A[i][j] = H[i * 6 + j] / scale; V[i][j] = (i == j) ? 1.0 : 0.0; }
 #pragma unroll 1
   for (int sweep = 0; sweep < 60; sweep++) {
     int rotated = 0;
@@ -346,25 +352,26 @@ __device__ inline void svd_solve6(const double* H, const double b[6], double x[6
     }
     if (!rotated) break;
   }
-  double sig[6], smax = 0;
+  double sig[6], sval[6], smax = 0;                  // sig: of the scaled work matrix; sval = sig * scale: the singular values
 #pragma unroll
   for (int j = 0; j < 6; j++) {
     double s2 = 0;
 #pragma unroll
     for (int i = 0; i < 6; i++) s2 += A[i][j] * A[i][j];
     sig[j] = sqrt(s2);
-    if (sig[j] > smax) smax = sig[j];
+    sval[j] = sig[j] * scale;
+    if (sval[j] > smax) smax = sval[j];
   }
   double thr = smax * (6.0 * DBL_EPSILON);
   if (thr < DBL_MIN) thr = DBL_MIN;
   for (int i = 0; i < 6; i++) x[i] = 0;
 #pragma unroll
   for (int j = 0; j < 6; j++) {
-    if (!(sig[j] >= thr) || sig[j] == 0.0) continue;
+    if (!(sval[j] >= thr) || sig[j] == 0.0) continue;
     double ub = 0;
 #pragma unroll
-    for (int i = 0; i < 6; i++) ub += (A[i][j] / sig[j]) * b[i];
-    double w = ub / sig[j];
+    for (int i = 0; i < 6; i++) ub += (A[i][j] / sig[j]) * b[i];       // column j of U, times b
+    double w = ub / sval[j];
 #pragma unroll
     for (int i = 0; i < 6; i++) x[i] += V[i][j] * w;
   }

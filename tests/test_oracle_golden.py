@@ -55,6 +55,26 @@ def test_svd_solve_semantics():
     assert np.all(O.svd_solve6(np.zeros((6, 6)), b) == 0)
 
 
+def test_svd_solve_is_scale_invariant():
+    """Eigen 3.3's JacobiSVD works on matrix / max|coeff| (JacobiSVD.h, compute(): `scale`), so the solve neither overflows nor
+    underflows: ndt_pca's weights compound multiplicatively over the DIRECT26 neighbours (ndt_pca_impl2.hpp:294-296) and put
+    Hessian entries at 1e87 and beyond (found by tools/fuzz_parity.py: seed 6, case 109)."""
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        H = rng.normal(size=(6, 6))
+        H = H + H.T                                             # symmetric, indefinite: what the Newton step sees
+        b = rng.normal(size=6)
+        x1 = np.linalg.solve(H, b)
+        for k in (1e-250, 1e-150, 1e-90, 1.0, 1e90, 1e150, 1e250):
+            xs = O.svd_solve6(H * k, b * k)
+            assert np.allclose(xs, x1, rtol=1e-8, atol=1e-11), (k, xs, x1)
+        # rank-deficient at a huge magnitude: still the minimum-norm solution
+        H2 = H.copy()
+        H2[:, 5] = H2[:, 0] * 2 - H2[:, 3]
+        x2 = np.linalg.pinv(H2, rcond=6 * np.finfo(float).eps) @ b
+        assert np.allclose(O.svd_solve6(H2 * 1e120, b * 1e120), x2, rtol=1e-6, atol=1e-9)
+
+
 def test_eigen_sym3():
     rng = np.random.default_rng(1)
     for _ in range(50):

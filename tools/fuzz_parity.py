@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""Randomised differential test: the HIP path (through the C-ABI) against the oracle on seeded random cases -- GPU box only.
+
+Every case draws a scene (synthetic scan pair or random planes / blobs, optionally far from the origin, with non-finite and
+duplicated points), a parameter set (variant, neighbour mode, resolution, step size, outlier ratio, epsilon, iteration cap,
+min_points_per_voxel, eigenvalue factor), a guess near the true motion, and an entry path (single-pair API, a ragged batch,
+latency mode), then checks what tests/test_gpu_parity.py checks on its fixed cases: voxel grid exact, sweep within rtol 1e-11,
+align with the same iteration count / convergence flag / sweep count and the pose inside (1e-4 m, 1e-5 rad).
+
+  python tools/fuzz_parity.py --cases 300 --seed 1            -> gpurun_out/fuzz/fuzz_<seed>.json (+ one line per failure on stdout)
+
+Test infrastructure (it calls the oracle); nothing in the product imports it."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from lv_slam_amd import ndt, synth          # noqa: E402
+from oracle import oracle_py as O           # noqa: E402
+from conftest import se3_err                # noqa: E402
+
+MODES = [ndt.DIRECT7, ndt.DIRECT1, ndt.DIRECT26, ndt.KDTREE]
+
+
+def small_motion(rng, scale=1.0):
+    p = np.concatenate([rng.normal(0, 0.15 * scale, 3), rng.normal(0, 0.01 * scale, 3)])
+    return O.se3_exp(p)
+
+
+def scene(rng, case):
+    """-> (target [n,3] f32, source [m,3] f32, guess 4x4 f32)"""
+    kind = rng.choice(["scan", "scan", "planes", "blobs"])
+    if kind == "scan":
+        az = int(rng.choice([64, 128, 256, 512, 1024], p=[0.25, 0.25, 0.25, 0.2, 0.05]))
+        beams = int(rng.choice([16, 32, 64]))
+        tgt, src, dT = synth.make_pair(int(rng.integers(0, 4000)), az, n_beams=beams)
+        tgt, src = tgt.numpy().copy(), src.numpy().copy()
+        G = synth.default_guess().astype(np.float64)
+    else:
+        n = int(rng.integers(200, 6000))
+        if kind == "planes":
+            pts = []
+            for _ in range(int(rng.integers(2, 7))):
+                o, u, v = rng.uniform(-15, 15, 3), rng.normal(size=3), rng.normal(size=3)
+                u /= np.linalg.norm(u); v -= u * (u @ v); v /= np.linalg.norm(v)
+                k = n // 4 + 1
+                pts.append(o + np.outer(rng.uniform(-8, 8, k), u) + np.outer(rng.uniform(-8, 8, k), v) + rng.normal(0, 0.03, (k, 3)))
+            tgt = np.concatenate(pts)
+        else:
+            c = rng.uniform(-20, 20, (int(rng.integers(3, 40)), 3))
+            tgt = c[rng.integers(0, len(c), n)] + rng.normal(0, rng.uniform(0.05, 1.0), (n, 3))
+        M = small_motion(rng)
+        sel = rng.permutation(len(tgt))[: max(1, int(len(tgt) * rng.uniform(0.3, 1.0)))]
+        src = (tgt[sel] - M[:3, 3]) @ M[:3, :3] + rng.normal(0, 0.01, (len(sel), 3))       # src = M^-1 tgt
+        G = M @ small_motion(rng, 0.3)
+    tgt, src = tgt.astype(np.float32), src.astype(np.float32)
+    if rng.random() < 0.25:                       # far from the origin (cell indices / f32 keys away from zero), both clouds + guess consistent
+        off = rng.choice([-1.0, 1.0], 3) * rng.choice([50.0, 300.0, 2000.0]) * rng.uniform(0.5, 1.0, 3)
+        tgt = (tgt + off).astype(np.float32)
+        Gt = np.eye(4); Gt[:3, 3] = off
+        G = Gt @ G
+    if rng.random() < 0.2:                        # non-finite points on either side
+        tgt[rng.integers(0, len(tgt), max(1, len(tgt) // 50)), rng.integers(0, 3)] = rng.choice([np.nan, np.inf, -np.inf])
+        src[rng.integers(0, len(src), max(1, len(src) // 50)), rng.integers(0, 3)] = np.nan
+    if rng.random() < 0.2:                        # duplicated points (equal keys, equal coordinates)
+        tgt = np.concatenate([tgt, tgt[rng.integers(0, len(tgt), len(tgt) // 5)]])
+    if rng.random() < 0.15:                       # a ragged, tiny source
+        src = src[: int(rng.integers(1, 130))]
+    return tgt, src, G.astype(np.float32)
+
+
+def params(rng):
+    kw = dict(variant=int(rng.integers(0, 2)), neighbor_mode=int(rng.choice(MODES, p=[0.4, 0.3, 0.15, 0.15])),
+              resolution=float(rng.choice([0.5, 0.7, 1.0, 1.0, 1.3, 2.0, 3.7])),
+              trans_epsilon=float(rng.choice([0.01, 0.01, 0.001, 0.05])), max_iterations=int(rng.choice([1, 2, 5, 35, 64])),
+              outlier_ratio=float(rng.choice([0.55, 0.55, 0.3, 0.8])), step_size=float(rng.choice([0.1, 0.1, 0.05, 0.5])),
+              min_points_per_voxel=int(rng.choice([6, 6, 3, 10])), min_covar_eigvalue_mult=float(rng.choice([0.01, 0.01, 0.1])))
+    if rng.random() < 0.08:                       # the live More-Thuente configuration (step_size <= eps / 2)
+        kw["step_size"], kw["trans_epsilon"], kw["max_iterations"] = 0.004, 0.01, int(rng.choice([3, 8]))
+    return kw
+
+
+ORA_VARIANTS = [("acc_chunk_8", 0, 8), ("acc_chunk_2048", 0, 2048), ("solve_lu", 16, 256), ("solve_svd_two_sided", 32, 256)]
+
+
+def classify(align_again, r_gpu, r_canonical):
+    """A failing align is replayed with the oracle's own legitimate variants (tools/order_sensitivity.py: another f64 partial-sum
+    length, LU / two-sided SVD for the Newton solve).  If one of them moves the ORACLE away from its canonical result by more than
+    the tolerance -- or lands on the HIP result -- the case is order-sensitive (a chaotic run), not a defect of the HIP path."""
+    import ctypes as C
+    L = O.lib()
+    L.ora_set_variant.argtypes = [C.c_uint, C.c_int]
+    out = {}
+    try:
+        for name, flags, chunk in ORA_VARIANTS:
+            L.ora_set_variant(flags, chunk)
+            rv = align_again()
+            dt, dr = se3_err(r_canonical["final"], rv["final"])
+            gt, gr = se3_err(r_gpu["final"], rv["final"])
+            out[name] = dict(it=int(rv["iterations"]), d_vs_canonical=[float(dt), float(dr)], d_vs_hip=[float(gt), float(gr)])
+    finally:
+        L.ora_set_variant(0, 256)
+    sens = any(v["d_vs_canonical"][0] > 1e-4 or v["d_vs_canonical"][1] > 1e-5 or v["it"] != r_canonical["iterations"] for v in out.values())
+    same = [k for k, v in out.items() if v["d_vs_hip"][0] < 1e-9 and v["d_vs_hip"][1] < 1e-9 and v["it"] == r_gpu["iterations"]]
+    return dict(order_sensitive=bool(sens), hip_equals_oracle_variant=same, variants=out)
+
+
+STATS = {"aligns": 0, "iterations": 0, "zero_hit_aligns": 0, "not_converged": 0, "hit_iteration_cap": 0, "paths": {}, "modes": {}, "mt_live": 0,
+         "voxel_checks": 0, "sweep_checks": 0, "searchable_leaves": 0}
+
+
+def compare(r, ro, what, fails, ctx, align_again=None):
+    STATS["aligns"] += 1
+    STATS["iterations"] += int(ro["iterations"])
+    STATS["zero_hit_aligns"] += int(ro["hits_last"] == 0)
+    STATS["not_converged"] += int(not ro["converged"])
+    STATS["hit_iteration_cap"] += int(ro["iterations"] >= ctx["max_iterations"])
+    ok = r["iterations"] == ro["iterations"] and r["converged"] == ro["converged"] and r["sweeps"] == ro["sweeps"]
+    dt, dr = se3_err(ro["final"], r["final"])
+    if not (np.isfinite(dt) and np.isfinite(dr)):
+        same = np.array_equal(np.asarray(r["final"]), np.asarray(ro["final"]), equal_nan=True)
+        ok = ok and same
+    else:
+        ok = ok and dt < 1e-4 and dr < 1e-5
+    if not ok:
+        f = dict(ctx, what=what, it=[r["iterations"], ro["iterations"]], conv=[bool(r["converged"]), bool(ro["converged"])],
+                 sweeps=[r["sweeps"], ro["sweeps"]], dtrans=float(dt), drot=float(dr), hits_last=int(ro["hits_last"]))
+        if align_again is not None:
+            f["classification"] = classify(align_again, r, ro)
+        fails.append(f)
+    return ok
+
+
+def run_sequence(case, rng, kw, fails, oracle_only):
+    """mi355ndt_sequence_run against the oracle driving the same call-site policy (oracle_py.sequence)."""
+    kw = dict(kw)
+    kw["neighbor_mode"] = int(rng.choice([ndt.DIRECT7, ndt.DIRECT1]))
+    if kw["step_size"] <= kw["trans_epsilon"] / 2:
+        kw["step_size"] = 0.1
+    gp, op = ndt.default_params(**kw), O.default_params(**kw)
+    n = int(rng.integers(2, 9))
+    az, beams = int(rng.choice([64, 128, 256])), int(rng.choice([16, 32, 64]))
+    frames, _ = synth.make_sequence(n, az, n_beams=beams, seed=int(rng.integers(1, 1 << 30)))
+    frames = [f.numpy() for f in frames]
+    stamps = np.cumsum(rng.uniform(0.05, 0.6, n))
+    thr = (float(rng.choice([0.5, 2.0, 5.0])), float(rng.choice([0.02, 0.17])), float(rng.choice([0.3, 1.0, 100.0])))
+    ctx = dict(case=case, path="sequence", frames=n, thresholds=thr, **kw)
+    STATS["paths"]["sequence"] = STATS["paths"].get("sequence", 0) + 1
+    ref = O.sequence(frames, stamps, op, *thr)
+    if oracle_only:
+        return
+    eng = ndt.Engine(gp)
+    try:
+        got, _ = eng.sequence_run(frames, stamps, *thr)
+        for k in range(n):
+            a, b = got[k], ref[k]
+            STATS["aligns"] += int(k > 0)
+            STATS["iterations"] += int(b["iterations"])
+            dt, dr = se3_err(b["odom"], a["odom"])
+            ok = (a["key_id"] == b["key_id"] and a["new_keyframe"] == b["new_keyframe"] and a["iterations"] == b["iterations"]
+                  and a["converged"] == b["converged"] and dt < 1e-4 * max(1, k) and dr < 1e-5 * max(1, k))
+            if not ok:
+                fails.append(dict(ctx, what=f"sequence frame {k}", key=[a["key_id"], b["key_id"]], newkey=[a["new_keyframe"], b["new_keyframe"]],
+                                  it=[a["iterations"], b["iterations"]], dtrans=float(dt), drot=float(dr)))
+                break
+    finally:
+        eng.close()
+
+
+def run_case(case, seed, fails, oracle_only=False):
+    rng = np.random.default_rng([seed, case])
+    kw = params(rng)
+    gp, op = ndt.default_params(**kw), O.default_params(**kw)
+    path = rng.choice(["single", "single_latency", "batch", "batch_latency", "sequence"], p=[0.25, 0.2, 0.25, 0.2, 0.1])
+    if path == "sequence":
+        return run_sequence(case, rng, kw, fails, oracle_only)
+    n_pairs = 1 if path.startswith("single") else int(rng.integers(2, 6))
+    scenes = [scene(rng, case) for _ in range(n_pairs)]
+    ctx = dict(case=case, path=str(path), **kw)
+    STATS["paths"][str(path)] = STATS["paths"].get(str(path), 0) + 1
+    mk = f"v{kw['variant']}_m{kw['neighbor_mode']}"
+    STATS["modes"][mk] = STATS["modes"].get(mk, 0) + 1
+    STATS["mt_live"] += int(kw["step_size"] <= kw["trans_epsilon"] / 2)
+    if oracle_only:
+        for t, s, G in scenes:
+            O.align(O.Grid(t, op), s, G)
+        return
+    eng = ndt.Engine(gp)
+    try:
+        if "latency" in path:
+            eng.set_latency_mode(True)
+        grids = [O.Grid(t, op) for t, _, _ in scenes]
+        oracle_res = [O.align(g, s, G) for g, (_, s, G) in zip(grids, scenes)]
+        if n_pairs == 1:
+            tgt, src, G = scenes[0]
+            eng.set_target(tgt)
+            eng.set_source(src)
+            # voxel grid and one sweep, as tests/test_gpu_parity.py checks them
+            from test_gpu_parity import check_voxels, check_sweep
+            try:
+                STATS["voxel_checks"] += 1
+                STATS["searchable_leaves"] += int(check_voxels(eng, grids[0]) or 0)
+            except AssertionError as e:
+                fails.append(dict(ctx, what="voxels", detail=str(e)[:200]))
+            p = O.se3_log(G.astype(np.float64)) + np.concatenate([rng.normal(0, 0.05, 3), rng.normal(0, 0.01, 3)])
+            try:
+                STATS["sweep_checks"] += 1
+                check_sweep(eng.derivatives(p), O.derivatives_at(grids[0], src, p))
+            except AssertionError as e:
+                fails.append(dict(ctx, what="sweep", detail=str(e)[:200]))
+            compare(eng.align(G), oracle_res[0], "align", fails, ctx, lambda: O.align(grids[0], src, G))
+        else:
+            eng.batch_reserve(n_pairs, max(len(t) for t, _, _ in scenes), max(len(s) for _, s, _ in scenes))
+            for b, (t, s, _) in enumerate(scenes):
+                eng.batch_set_target(b, t)
+                eng.batch_set_source(b, s)
+            eng.batch_build_targets()
+            res = eng.batch_align(np.stack([G for _, _, G in scenes]))
+            for b in range(n_pairs):
+                compare(res[b], oracle_res[b], f"batch_align[{b}]", fails, ctx, lambda b=b: O.align(grids[b], scenes[b][1], scenes[b][2]))
+    finally:
+        eng.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=200)
+    ap.add_argument("--first", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--oracle-only", action="store_true", help="CPU dry run: scenes + oracle only")
+    ap.add_argument("--seconds", type=float, default=1e9, help="stop after this much wall time")
+    a = ap.parse_args()
+    fails, errors, done = [], [], 0
+    t0 = time.time()
+    for case in range(a.first, a.first + a.cases):
+        if time.time() - t0 > a.seconds:
+            break
+        try:
+            run_case(case, a.seed, fails, a.oracle_only)
+        except ndt.NDTError as e:                # an error code is a legitimate outcome only if the oracle agrees there is nothing to align
+            errors.append(dict(case=case, error=str(e)[:200]))
+        done += 1
+    out = dict(seed=a.seed, first=a.first, cases_run=done, seconds=round(time.time() - t0, 1), failures=fails, errors=errors, stats=STATS)
+    od = os.path.join(ROOT, "gpurun_out", "fuzz")
+    os.makedirs(od, exist_ok=True)
+    json.dump(out, open(os.path.join(od, f"fuzz_{a.seed}_{a.first}.json"), "w"), indent=1)
+    for f in fails:
+        print("FAIL", json.dumps(f))
+    for e in errors:
+        print("ERROR", json.dumps(e))
+    print("stats", json.dumps(STATS))
+    unexplained = [f for f in fails if not (f.get("classification", {}).get("order_sensitive") or f.get("classification", {}).get("hip_equals_oracle_variant"))]
+    out["unexplained"] = len(unexplained)
+    json.dump(out, open(os.path.join(od, f"fuzz_{a.seed}_{a.first}.json"), "w"), indent=1)
+    print(f"fuzz: {done} cases, {len(fails)} failures ({len(unexplained)} not explained by the oracle's own order sensitivity), {len(errors)} errors, {out['seconds']} s")
+
+
+if __name__ == "__main__":
+    main()
