@@ -260,10 +260,25 @@ __device__ __forceinline__ void newton_solve(const PairState& S, double d[6]) {
 // wave 0 runs first -- so a second wave of the block computes it at the same time and hands it over through LDS
 // (`sol`: d[6], then a ready flag).  Same function, same inputs: same bits.
 __device__ __forceinline__ void newton_solve_side(const PairState& S, volatile double* sol) {
-  if ((threadIdx.x & 63) != 0) return;
-  double d[6];
-  newton_solve(S, d);
-  for (int a = 0; a < 6; a++) sol[a] = d[a];
+  // lanes 0..5 eliminate [H | e_k] (the columns of H^-1, for the condition estimate), lane 6 [H | -g]: the seven eliminations of
+  // ndtm::lu_solve6 side by side -- same functions, same operands, same order of the final sum: same bits, same decision
+  const int lane = threadIdx.x & 63;
+  if (lane > 6) return;
+  double rhs[6], x[6];
+  for (int a = 0; a < 6; a++) rhs[a] = lane < 6 ? (a == lane ? 1.0 : 0.0) : -S.g[a];
+  bool fin = true;
+  for (int a = 0; a < 36; a++) fin = fin && isfinite(S.H[a]);
+  for (int a = 0; a < 6; a++) fin = fin && isfinite(S.g[a]);
+  double pmin, pmax;
+  bool ok = fin && ndtm::lu_solve6_rhs(S.H, rhs, x, pmin, pmax);                 // (the pivots depend on H only: `ok` is the same on all seven lanes)
+  const double c2 = (ok && lane < 6) ? ndtm::norm2_6(x) : 0.0;                   // column `lane` of H^-1
+  const double r2 = lane < 6 ? ndtm::norm2_6(S.H + 6 * lane) : 0.0;              // row `lane` of H
+  double hF2 = 0, invF2 = 0;
+  for (int k = 0; k < 6; k++) { invF2 += __shfl(c2, k); hF2 += __shfl(r2, k); }
+  if (lane != 6) return;
+  ok = ok && ndtm::lu_accept(hF2, invF2);
+  if (!ok) ndtm::svd_solve6(S.H, rhs, x);
+  for (int a = 0; a < 6; a++) sol[a] = x[a];
   __threadfence_block();
   sol[6] = 1.0;
 }
