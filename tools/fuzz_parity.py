@@ -229,14 +229,48 @@ def run_case(case, seed, fails, oracle_only=False):
         eng.close()
 
 
+def summarize(paths, out_path):
+    """Merge per-seed result files into one committed summary (profiles/)."""
+    runs = [json.load(open(p)) for p in paths]
+    tot = {"aligns": 0, "iterations": 0, "zero_hit_aligns": 0, "hit_iteration_cap": 0, "mt_live": 0, "voxel_checks": 0, "sweep_checks": 0, "searchable_leaves": 0}
+    paths_n, modes_n, fails = {}, {}, []
+    for r in runs:
+        for k in tot:
+            tot[k] += r["stats"].get(k, 0)
+        for k, v in r["stats"]["paths"].items():
+            paths_n[k] = paths_n.get(k, 0) + v
+        for k, v in r["stats"]["modes"].items():
+            modes_n[k] = modes_n.get(k, 0) + v
+        for f in r["failures"]:
+            c = f.get("classification", {})
+            fails.append({"seed": r["seed"], "case": f["case"], "path": f["path"], "what": f["what"], "variant": f.get("variant"), "neighbor_mode": f.get("neighbor_mode"),
+                          "resolution": f.get("resolution"), "max_iterations": f.get("max_iterations"), "iterations_hip_oracle": f.get("it"),
+                          "dtrans_m": f.get("dtrans"), "drot_rad": f.get("drot"), "hits_last": f.get("hits_last"), "detail": f.get("detail"),
+                          "oracle_variant_moves_the_oracle": c.get("order_sensitive"), "hip_equals_oracle_variant": c.get("hip_equals_oracle_variant"),
+                          "oracle_variants": {k: {"iterations": v["it"], "d_vs_canonical": v["d_vs_canonical"]} for k, v in c.get("variants", {}).items()}})
+    out = {"what": "tools/fuzz_parity.py: randomised differential test, HIP path (C-ABI) vs oracle; same bars as tests/test_gpu_parity.py (voxels exact, sweep rtol 1e-11, "
+                   "align: iterations / converged / sweeps equal, pose inside 1e-4 m and 1e-5 rad)",
+           "seeds": [r["seed"] for r in runs], "cases": sum(r["cases_run"] for r in runs), "totals": tot, "entry_paths": paths_n,
+           "variant_mode_counts (v = variant, m = pclomp::NeighborSearchMethod value)": modes_n,
+           "errors": sum(len(r["errors"]) for r in runs), "failures": len(fails),
+           "failures_not_explained_by_the_oracles_own_order_sensitivity": sum(r.get("unexplained", 0) for r in runs),
+           "failing_aligns": fails}
+    json.dump(out, open(out_path, "w"), indent=1)
+    print(f"{out['cases']} cases, {tot['aligns']} aligns, {len(fails)} failing aligns, {out['failures_not_explained_by_the_oracles_own_order_sensitivity']} unexplained -> {out_path}")
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--summarize", nargs="+", help="merge result files (gpurun_out/fuzz/fuzz_*.json) into --out and exit")
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_fuzz.json"))
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--oracle-only", action="store_true", help="CPU dry run: scenes + oracle only")
     ap.add_argument("--seconds", type=float, default=1e9, help="stop after this much wall time")
     a = ap.parse_args()
+    if a.summarize:
+        return summarize(a.summarize, a.out)
     fails, errors, done = [], [], 0
     t0 = time.time()
     for case in range(a.first, a.first + a.cases):
