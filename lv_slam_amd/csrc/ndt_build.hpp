@@ -56,10 +56,7 @@ __global__ void k_griddesc(const int* __restrict__ mm, GridDesc* gd, unsigned* n
   } else {
     float mn[3], mx[3];
     for (int a = 0; a < 3; a++) { mn[a] = ord2f(mm[b * 6 + a]); mx[a] = ord2f(mm[b * 6 + 3 + a]); }
-    long long d0 = (long long)((mx[0] - mn[0]) * g.inv_leaf) + 1;
-    long long d1 = (long long)((mx[1] - mn[1]) * g.inv_leaf) + 1;
-    long long d2 = (long long)((mx[2] - mn[2]) * g.inv_leaf) + 1;
-    if (d0 * d1 * d2 > (long long)INT_MAX) {
+    if (grid_too_big((mx[0] - mn[0]) * g.inv_leaf, (mx[1] - mn[1]) * g.inv_leaf, (mx[2] - mn[2]) * g.inv_leaf)) {
       g.status = GRID_OVERFLOW;                  // impl:79-84: empty grid
     } else {
       for (int a = 0; a < 3; a++) {

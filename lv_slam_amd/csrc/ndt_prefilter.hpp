@@ -43,9 +43,7 @@ __global__ void k_pf_grid(const int* __restrict__ mm, float leaf, PfGrid* out) {
   if (mm[0] == INT_MAX) { g.status = 1; *out = g; return; }
   float mn[3], mx[3];
   for (int a = 0; a < 3; a++) { mn[a] = ord2f(mm[a]); mx[a] = ord2f(mm[3 + a]); }
-  const long long d0 = (long long)((mx[0] - mn[0]) * g.inv_leaf) + 1, d1 = (long long)((mx[1] - mn[1]) * g.inv_leaf) + 1,
-                  d2 = (long long)((mx[2] - mn[2]) * g.inv_leaf) + 1;
-  if (d0 * d1 * d2 > (long long)INT_MAX) { g.status = 2; *out = g; return; }      // "Leaf size is too small": output = input
+  if (grid_too_big((mx[0] - mn[0]) * g.inv_leaf, (mx[1] - mn[1]) * g.inv_leaf, (mx[2] - mn[2]) * g.inv_leaf)) { g.status = 2; *out = g; return; }   // "Leaf size is too small": output = input
   int maxb[3];
   for (int a = 0; a < 3; a++) { g.min_b[a] = (int)floorf(mn[a] * g.inv_leaf); maxb[a] = (int)floorf(mx[a] * g.inv_leaf); }
   g.mul1 = maxb[0] - g.min_b[0] + 1;

@@ -91,6 +91,20 @@ __constant__ int c_off[3][26][3] = {
 // ------------------------------------------------------------------------------------ helpers
 __device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+
+// The "leaf size is too small" guard of pcl::VoxelGrid / VoxelGridCovariance (voxel_grid_covariance_omp_impl.hpp:75-84): dx*dy*dz >
+// INT32_MAX with d = int64((max - min) * inv_leaf) + 1, e = that f32 extent in cells.  The reference multiplies three int64 factors;
+// beyond 2^63 cells (a 1e-4 m leaf over a 240 m cloud, a stray point at 1e30) that product, and for extents beyond 2^63 the
+// float -> int64 cast, is undefined behaviour.  What the guard means is not in doubt; it is evaluated without overflowing.
+__device__ __forceinline__ bool grid_too_big(float e0, float e1, float e2) {
+  const float e[3] = {e0, e1, e2};
+  double prod = 1.0;
+  for (int a = 0; a < 3; a++) {
+    if (!(e[a] < 2147483648.0f)) return true;    // (also NaN / inf extents)
+    prod *= (double)((long long)e[a] + 1);
+  }
+  return prod > 2147483647.0;
+}
 __device__ __forceinline__ bool finite3(float x, float y, float z) { return isfinite(x) && isfinite(y) && isfinite(z); }
 
 // XCD-aware placement for kernels that give every target `nx` workgroups: a fresh launch hands workgroup L to XCD L % 8

@@ -159,6 +159,20 @@ void ora_eigen_sym3(const double Ain[9], double evals[3], double evecs[9]) {
   }
 }
 
+/* The "leaf size is too small" guard of pcl::VoxelGrid / VoxelGridCovariance (voxel_grid_covariance_omp_impl.hpp:75-84): dx*dy*dz >
+ * INT32_MAX with d = int64((max - min) * inv_leaf) + 1.  The reference multiplies the three int64 factors; beyond 2^63 cells (a 1e-4 m
+ * leaf over a 240 m cloud, or a stray point at 1e30) that product -- and, for extents beyond 2^63, the float -> int64 cast -- is
+ * undefined behaviour.  What the guard means is not in doubt; it is evaluated here without overflowing (HIP path: the same). */
+static int grid_too_big(float e0, float e1, float e2) {
+  const float e[3] = {e0, e1, e2};
+  double prod = 1.0;
+  for (int a = 0; a < 3; a++) {
+    if (!(e[a] < 2147483648.0f)) return 1;             /* (also NaN / inf extents) */
+    prod *= (double)((int64_t)e[a] + 1);
+  }
+  return prod > 2147483647.0;
+}
+
 /* Eigen::JacobiSVD<Matrix6d>(H, FullU|FullV).solve(b): x = V S^+ U^T b with
  * rank = #{ sigma_i >= max(sigma_max * 6*eps, DBL_MIN) } (ndt_omp_impl2.hpp:138-140).
  * Algorithm here: one-sided (Hestenes) Jacobi. */
@@ -578,9 +592,7 @@ ora_grid* ora_grid_build(const float* x, const float* y, const float* z, size_t 
   }
   if (nfinite == 0) { free(g); return NULL; }
   /* overflow guard impl:75-84 (f32 arithmetic, then int64) */
-  int64_t d[3];
-  for (int a = 0; a < 3; a++) d[a] = (int64_t)((mx[a] - mn[a]) * g->inv_leaf[a]) + 1;
-  if (d[0] * d[1] * d[2] > (int64_t)INT32_MAX) { free(g); return NULL; }
+  if (grid_too_big((mx[0] - mn[0]) * g->inv_leaf[0], (mx[1] - mn[1]) * g->inv_leaf[1], (mx[2] - mn[2]) * g->inv_leaf[2])) { free(g); return NULL; }
   /* impl:87-103 */
   for (int a = 0; a < 3; a++) {
     g->min_b[a] = (int)floorf(mn[a] * g->inv_leaf[a]);
@@ -1230,8 +1242,7 @@ size_t ora_prefilter(const float* x, const float* y, const float* z, size_t n, i
   float inv = down ? 1.0f / leaf : 0.f;
   int min_b[3] = {0, 0, 0}, mul1 = 0, mul2 = 0;
   if (down) {
-    int64_t d0 = (int64_t)((mx[0] - mn[0]) * inv) + 1, d1 = (int64_t)((mx[1] - mn[1]) * inv) + 1, d2 = (int64_t)((mx[2] - mn[2]) * inv) + 1;
-    if (d0 * d1 * d2 > (int64_t)INT32_MAX) down = 0;
+    if (grid_too_big((mx[0] - mn[0]) * inv, (mx[1] - mn[1]) * inv, (mx[2] - mn[2]) * inv)) down = 0;
     else {
       int maxb[3];
       for (int a = 0; a < 3; a++) { min_b[a] = (int)floorf(mn[a] * inv); maxb[a] = (int)floorf(mx[a] * inv); }

@@ -838,3 +838,29 @@ def test_compounded_pca_weights_keep_the_newton_solve_finite():
             mt, mr = se3_err(G, r["final"])
             assert mt + mr > 1e-3, (mt, mr)                      # real steps were taken (each at least eps / 2 long, impl2:890-892)
         eng.close()
+
+
+def test_leaf_too_small_guards_beyond_the_int64_range():
+    """The "leaf size is too small" guards (voxel_grid_covariance_omp_impl.hpp:75-84, pcl::VoxelGrid::applyFilter) where the
+    reference's own int64 product overflows: a 1e-4 m prefilter leaf over a 240 m cloud (1.5e19 cells) leaves the cloud as it is,
+    in input order; a target with a stray point at 1e30 has no grid (per-pair status MI355NDT_ERR_GRID) and aligns like an empty one."""
+    rng = np.random.default_rng(9)
+    pts = rng.uniform(-120, 120, (4000, 3)).astype(np.float32)
+    eng = ndt.Engine(ndt.default_params(trans_epsilon=0.01, max_iterations=64))
+    for gate in (False, True):
+        got, exp = eng.prefilter(pts, 0.5, 100.0, 1e-4, gate), O.prefilter(pts, 0.5, 100.0, 1e-4, gate)
+        assert np.array_equal(got, exp)
+    assert np.array_equal(eng.prefilter(pts, 0.5, 100.0, 1e-4, False), pts)
+    stray = pts.copy()
+    stray[7] = [1e30, 0.0, 0.0]
+    for target, prm in ((stray, ndt.default_params(trans_epsilon=0.01, max_iterations=64)), (pts, ndt.default_params(resolution=1e-4, trans_epsilon=0.01, max_iterations=64))):
+        e = ndt.Engine(prm)
+        e.set_target(target)
+        with pytest.raises(ndt.NDTError) as ex:
+            e.get_grid()
+        assert ex.value.code == -4
+        e.set_source(pts[:500])
+        G = np.eye(4, dtype=np.float32)
+        r = e.align(G)
+        assert r["status"] == -4 and r["hits_last"] == 0 and r["iterations"] == 0 and np.array_equal(r["final"], G)
+        e.close()

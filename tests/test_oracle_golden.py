@@ -343,3 +343,20 @@ def test_reference_shaped_mode_equals_the_port(kw):
         assert dt < 1e-6 and dr < 1e-7
         assert abs(r1["score"] - r2["score"]) <= 1e-9 * max(1.0, abs(r1["score"]))
     O.lib().ora_set_threads(0)
+
+
+def test_leaf_too_small_guard_does_not_overflow():
+    """voxel_grid_covariance_omp_impl.hpp:75-84 / pcl::VoxelGrid: dx*dy*dz > INT32_MAX -> no grid / cloud not down-sampled.  The
+    reference's int64 product itself overflows beyond 2^63 cells (undefined behaviour); the restatement evaluates the guard without
+    overflowing (found by tools/fuzz_parity.py: a 1e-4 m leaf over a 240 m cloud gave 1.5e19 cells, the wrapped product was negative
+    and the points were binned with wrapped int32 indices)."""
+    rng = np.random.default_rng(9)
+    pts = rng.uniform(-120, 120, (4000, 3)).astype(np.float32)
+    assert np.array_equal(O.prefilter(pts, 0.5, 1000.0, 1e-4, False), pts)            # 2.4e6 cells per axis: output = input, input order
+    assert np.array_equal(O.prefilter(pts, 0.5, 100.0, 1e-4, True), O.prefilter(pts, 0.5, 100.0, 0.0, True))   # = the distance gate alone
+    # the NDT target grid: a stray point at 1e30 (the f32 extent in cells is beyond 2^63), and a plain too-fine grid
+    stray = pts.copy()
+    stray[7] = [1e30, 0.0, 0.0]
+    assert not O.Grid(stray, O.default_params()).ok
+    assert not O.Grid(pts, O.default_params(resolution=1e-4)).ok
+    assert O.Grid(pts, O.default_params(resolution=1.0)).ok

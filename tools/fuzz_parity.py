@@ -138,6 +138,57 @@ def compare(r, ro, what, fails, ctx, align_again=None):
     return ok
 
 
+def run_aux(case, rng, kw, fails, oracle_only):
+    """The surfaces around align: the device prefilter (prefiltering_nodelet.cpp:137-181) against ora_prefilter -- same points, same
+    f32 centroids, same order; getFitnessScore(max_range) (loop_detector.hpp:249-262); the output cloud of align and
+    getLastIncrementalTransformation's two matrices against the oracle's."""
+    ctx = dict(case=case, path="aux", **kw)
+    STATS["paths"]["aux"] = STATS["paths"].get("aux", 0) + 1
+    tgt, src, G = scene(rng, case)
+    raw = np.concatenate([tgt, src]) if rng.random() < 0.5 else tgt
+    if rng.random() < 0.5:
+        raw = raw - raw[np.isfinite(raw).all(1)].mean(0).astype(np.float32)          # around the sensor, where the distance gate bites
+    near, far = float(rng.choice([0.5, 1.0, 3.0])), float(rng.choice([100.0, 40.0, 8.0]))
+    leaf = float(rng.choice([0.1, 0.0, 0.25, 1.0, 1e-4, 0.033]))
+    use_gate = bool(rng.random() < 0.8)
+    exp = O.prefilter(raw, near, far, leaf, use_gate)
+    op = O.default_params(**kw)
+    if oracle_only:
+        return
+    eng = ndt.Engine(ndt.default_params(**kw))
+    try:
+        got = eng.prefilter(raw, near, far, leaf, use_gate)
+        STATS["prefilter_checks"] = STATS.get("prefilter_checks", 0) + 1
+        if got.shape != exp.shape or not np.array_equal(got, exp, equal_nan=True):
+            fails.append(dict(ctx, what="prefilter", near=near, far=far, leaf=leaf, gate=use_gate, shapes=[list(got.shape), list(exp.shape)]))
+        fin_t = tgt[np.isfinite(tgt).all(1)]
+        if len(fin_t) == 0:
+            return
+        eng.set_target(tgt); eng.set_source(src)
+        r = eng.align(G)
+        ro = O.align(O.Grid(tgt, op), src, G)
+        if r["iterations"] == ro["iterations"] and np.array_equal(np.asarray(r["final"]), np.asarray(ro["final"])):
+            # (only meaningful when the two aligns ended on the same bits: see the chaotic ndt_pca / DIRECT26 runs)
+            STATS["aux_align_checks"] = STATS.get("aux_align_checks", 0) + 1
+            a, b = eng.get_incremental()
+            if not (np.array_equal(a, ro["transformation"], equal_nan=True) and np.array_equal(b, ro["previous_transformation"], equal_nan=True)):
+                fails.append(dict(ctx, what="incremental transforms"))
+            out = eng.get_aligned()
+            F = np.asarray(ro["final"], np.float32)
+            s32 = src.astype(np.float32)
+            want = np.stack([((F[a_, 0] * s32[:, 0] + F[a_, 1] * s32[:, 1]) + F[a_, 2] * s32[:, 2]) + F[a_, 3] for a_ in range(3)], 1).astype(np.float32)
+            if not np.array_equal(out, want, equal_nan=True):
+                fails.append(dict(ctx, what="aligned cloud", max_abs=float(np.nanmax(np.abs(out - want)))))
+            for mr in (float(rng.choice([0.04, 1.0, 25.0])), float("inf")):
+                gs, gn = eng.fitness_score(mr)
+                es, en = O.fitness_score(tgt, src, F, mr)
+                ok = gn == en and (abs(gs - es) <= 1e-12 * max(1.0, abs(es)) or (gs == es))
+                if not ok:
+                    fails.append(dict(ctx, what="fitness score", max_range=mr, got=[float(gs), int(gn)], want=[float(es), int(en)]))
+    finally:
+        eng.close()
+
+
 def run_sequence(case, rng, kw, fails, oracle_only):
     """mi355ndt_sequence_run against the oracle driving the same call-site policy (oracle_py.sequence)."""
     kw = dict(kw)
@@ -181,6 +232,8 @@ def run_case(case, seed, fails, oracle_only=False):
     path = rng.choice(["single", "single_latency", "batch", "batch_latency", "sequence"], p=[0.25, 0.2, 0.25, 0.2, 0.1])
     if path == "sequence":
         return run_sequence(case, rng, kw, fails, oracle_only)
+    if rng.random() < 0.15:
+        run_aux(case, rng, kw, fails, oracle_only)
     n_pairs = 1 if path.startswith("single") else int(rng.integers(2, 6))
     scenes = [scene(rng, case) for _ in range(n_pairs)]
     ctx = dict(case=case, path=str(path), **kw)
