@@ -1339,8 +1339,9 @@ int mi355ndt_fitness_score_T(mi355ndt_handle* h, const float T_colmajor[16], dou
   GridDesc g;
   HIPCHK(h, hipMemcpyAsync(&g, h->d_grid, sizeof g, hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
-  if (g.status != GRID_OK) { *score = 1.7976931348623157e308; if (n_inliers) *n_inliers = 0; return MI355NDT_OK; }
-  if (!h->cells_ready) {
+  if (g.status == GRID_EMPTY) { *score = 1.7976931348623157e308; if (n_inliers) *n_inliers = 0; return MI355NDT_OK; }
+  const bool brute = g.status != GRID_OK;        // no voxel grid (leaf-too-small guard / cell cap): the score does not need one
+  if (!brute && !h->cells_ready) {
     const size_t nc = (size_t)g.ncells;
     if (nc > h->cell_cap) {
       size_t c1 = 0, c2 = 0;
@@ -1368,8 +1369,9 @@ int mi355ndt_fitness_score_T(mi355ndt_handle* h, const float T_colmajor[16], dou
   // a query outside the grid may sit further away than the grid is wide: allow its distance to the box on top
   ring_max = std::min(ring_max, (1 << 20));
   (void)extent;
-  k_fitness<<<blocks, 256, 0, s>>>(h->d_src, h->src_pitch, n, h->d_tgt, h->tgt_pitch, h->d_vals_b, h->d_grid, h->d_cstart, h->d_cend,
-                                   h->d_hook, mr, ring_max, h->d_fit);
+  if (brute) k_fitness_brute<<<blocks, 256, 0, s>>>(h->d_src, h->src_pitch, n, h->d_tgt, h->tgt_pitch, h->h_tgt_cnt[0], h->d_hook, mr, h->d_fit);
+  else k_fitness<<<blocks, 256, 0, s>>>(h->d_src, h->src_pitch, n, h->d_tgt, h->tgt_pitch, h->d_vals_b, h->d_grid, h->d_cstart, h->d_cend,
+                                        h->d_hook, mr, ring_max, h->d_fit);
   std::vector<double> part((size_t)2 * blocks);
   HIPCHK(h, hipMemcpyAsync(part.data(), h->d_fit, part.size() * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));

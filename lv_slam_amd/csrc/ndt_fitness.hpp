@@ -86,3 +86,50 @@ __global__ void __launch_bounds__(256) k_fitness(const float* __restrict__ src, 
   }
 }
 
+// The same score for a target that has no voxel grid (the leaf-too-small guard or the engine's cell cap: GRID_OVERFLOW / GRID_CAP) --
+// pcl::Registration::getFitnessScore searches a kd-tree over the target CLOUD and does not care.  Exhaustive search, the target
+// staged through LDS 256 points at a time; same distance arithmetic, same reduction as k_fitness.
+__global__ void __launch_bounds__(256) k_fitness_brute(const float* __restrict__ src, size_t spitch, int n_src,
+                                                       const float* __restrict__ tgt, size_t tpitch, int n_tgt,
+                                                       const float* __restrict__ Tcm, float max_range, double* partial) {
+  __shared__ float tx[256], ty[256], tz[256];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float q[3] = {0.f, 0.f, 0.f};
+  bool live = false;
+  if (i < n_src) {
+    const float px = src[i], py = src[spitch + i], pz = src[2 * spitch + i];
+#pragma unroll
+    for (int a = 0; a < 3; a++) q[a] = ((Tcm[0 * 4 + a] * px + Tcm[1 * 4 + a] * py) + Tcm[2 * 4 + a] * pz) + Tcm[3 * 4 + a];   // PCL 1.8 scalar form
+    live = finite3(q[0], q[1], q[2]);
+  }
+  float best = __int_as_float(0x7f800000);
+  for (int j0 = 0; j0 < n_tgt; j0 += 256) {
+    const int j = j0 + threadIdx.x;
+    float x = __int_as_float(0x7fc00000), y = x, z = x;                            // past the end: NaN, skipped below
+    if (j < n_tgt) { x = tgt[j]; y = tgt[tpitch + j]; z = tgt[2 * tpitch + j]; }
+    __syncthreads();
+    tx[threadIdx.x] = x; ty[threadIdx.x] = y; tz[threadIdx.x] = z;
+    __syncthreads();
+    if (live) {
+      for (int k = 0; k < 256; k++) {
+        if (!finite3(tx[k], ty[k], tz[k])) continue;                                // non-finite target points are in no tree
+        const float dx = q[0] - tx[k], dy = q[1] - ty[k], dz = q[2] - tz[k];
+        const float d2 = (dx * dx + dy * dy) + dz * dz;                             // FLANN L2_Simple accumulation order
+        best = d2 < best ? d2 : best;
+      }
+    }
+  }
+  double sum = 0.0;
+  unsigned long long cnt = 0;
+  if (live && best <= max_range) { sum = (double)best; cnt = 1; }
+  for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); cnt += __shfl_xor(cnt, o); }
+  __shared__ double rs[4];
+  __shared__ unsigned long long rc[4];
+  if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = sum; rc[threadIdx.x >> 6] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = ((rs[0] + rs[1]) + rs[2]) + rs[3];
+    partial[2 * blockIdx.x + 1] = (double)(rc[0] + rc[1] + rc[2] + rc[3]);
+  }
+}
+

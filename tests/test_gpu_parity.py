@@ -863,4 +863,11 @@ def test_leaf_too_small_guards_beyond_the_int64_range():
         G = np.eye(4, dtype=np.float32)
         r = e.align(G)
         assert r["status"] == -4 and r["hits_last"] == 0 and r["iterations"] == 0 and np.array_equal(r["final"], G)
+        # getFitnessScore searches the target CLOUD (pcl::Registration's kd-tree), grid or no grid
+        T = np.eye(4, dtype=np.float32)
+        T[:3, 3] = [0.3, -0.2, 0.1]
+        for mr in (0.5, 25.0, float("inf")):
+            got, n = e.fitness_score(mr, T)
+            exp, m = O.fitness_score(target, pts[:500], T, mr)
+            assert n == m and n > 0 and abs(got - exp) <= 1e-12 * max(1.0, exp), (mr, got, exp, n, m)
         e.close()

@@ -71,6 +71,9 @@ def scene(rng, case):
         src[rng.integers(0, len(src), max(1, len(src) // 50)), rng.integers(0, 3)] = np.nan
     if rng.random() < 0.2:                        # duplicated points (equal keys, equal coordinates)
         tgt = np.concatenate([tgt, tgt[rng.integers(0, len(tgt), len(tgt) // 5)]])
+    if rng.random() < 0.05:                       # a stray point far outside everything (the guards of the cell arithmetic)
+        which = tgt if rng.random() < 0.6 else src
+        which[int(rng.integers(0, len(which)))] = rng.choice([-1.0, 1.0], 3) * float(rng.choice([1e4, 1e7, 1e12, 1e30]))
     if rng.random() < 0.15:                       # a ragged, tiny source
         src = src[: int(rng.integers(1, 130))]
     return tgt, src, G.astype(np.float32)
@@ -85,6 +88,9 @@ def params(rng):
     if rng.random() < 0.08:                       # the live More-Thuente configuration (step_size <= eps / 2)
         kw["step_size"], kw["trans_epsilon"], kw["max_iterations"] = 0.004, 0.01, int(rng.choice([3, 8]))
     return kw
+
+
+AUX_P = 0.15          # share of cases that also check the surfaces around align (--aux)
 
 
 ORA_VARIANTS = [("acc_chunk_8", 0, 8), ("acc_chunk_2048", 0, 2048), ("solve_lu", 16, 256), ("solve_svd_two_sided", 32, 256)]
@@ -110,6 +116,15 @@ def classify(align_again, r_gpu, r_canonical):
     sens = any(v["d_vs_canonical"][0] > 1e-4 or v["d_vs_canonical"][1] > 1e-5 or v["it"] != r_canonical["iterations"] for v in out.values())
     same = [k for k, v in out.items() if v["d_vs_hip"][0] < 1e-9 and v["d_vs_hip"][1] < 1e-9 and v["it"] == r_gpu["iterations"]]
     return dict(order_sensitive=bool(sens), hip_equals_oracle_variant=same, variants=out)
+
+
+def ora_align(grid, src, G):
+    """O.align, plus the case the oracle's wrapper refuses: no grid at all (the leaf-too-small guard, voxel_grid_covariance_omp_impl.hpp:
+    75-84) is an empty grid -- nothing is hit, the first Newton step is zero: converged, 0 iterations, final == guess (impl2:147-152)."""
+    if not grid.ok:
+        return dict(iterations=0, converged=True, sweeps=1, final=np.asarray(G, np.float32).copy(), hits_last=0, score=0.0, trans_probability=0.0,
+                    transformation=np.eye(4, dtype=np.float32), previous_transformation=np.eye(4, dtype=np.float32), no_grid=True)
+    return O.align(grid, src, G)
 
 
 STATS = {"aligns": 0, "iterations": 0, "zero_hit_aligns": 0, "not_converged": 0, "hit_iteration_cap": 0, "paths": {}, "modes": {}, "mt_live": 0,
@@ -166,7 +181,7 @@ def run_aux(case, rng, kw, fails, oracle_only):
             return
         eng.set_target(tgt); eng.set_source(src)
         r = eng.align(G)
-        ro = O.align(O.Grid(tgt, op), src, G)
+        ro = ora_align(O.Grid(tgt, op), src, G)
         if r["iterations"] == ro["iterations"] and np.array_equal(np.asarray(r["final"]), np.asarray(ro["final"])):
             # (only meaningful when the two aligns ended on the same bits: see the chaotic ndt_pca / DIRECT26 runs)
             STATS["aux_align_checks"] = STATS.get("aux_align_checks", 0) + 1
@@ -232,7 +247,7 @@ def run_case(case, seed, fails, oracle_only=False):
     path = rng.choice(["single", "single_latency", "batch", "batch_latency", "sequence"], p=[0.25, 0.2, 0.25, 0.2, 0.1])
     if path == "sequence":
         return run_sequence(case, rng, kw, fails, oracle_only)
-    if rng.random() < 0.15:
+    if rng.random() < AUX_P:
         run_aux(case, rng, kw, fails, oracle_only)
     n_pairs = 1 if path.startswith("single") else int(rng.integers(2, 6))
     scenes = [scene(rng, case) for _ in range(n_pairs)]
@@ -243,20 +258,30 @@ def run_case(case, seed, fails, oracle_only=False):
     STATS["mt_live"] += int(kw["step_size"] <= kw["trans_epsilon"] / 2)
     if oracle_only:
         for t, s, G in scenes:
-            O.align(O.Grid(t, op), s, G)
+            ora_align(O.Grid(t, op), s, G)
         return
     eng = ndt.Engine(gp)
     try:
         if "latency" in path:
             eng.set_latency_mode(True)
         grids = [O.Grid(t, op) for t, _, _ in scenes]
-        oracle_res = [O.align(g, s, G) for g, (_, s, G) in zip(grids, scenes)]
+        oracle_res = [ora_align(g, s, G) for g, (_, s, G) in zip(grids, scenes)]
         if n_pairs == 1:
             tgt, src, G = scenes[0]
             eng.set_target(tgt)
             eng.set_source(src)
             # voxel grid and one sweep, as tests/test_gpu_parity.py checks them
             from test_gpu_parity import check_voxels, check_sweep
+            if not grids[0].ok:                   # no grid (guard): the engine says so per pair, and aligns like an empty target
+                STATS["no_grid_cases"] = STATS.get("no_grid_cases", 0) + 1
+                try:
+                    eng.get_grid()
+                    fails.append(dict(ctx, what="grid guard: the oracle has no grid, the engine has one"))
+                except ndt.NDTError as e:
+                    if e.code != -4:
+                        fails.append(dict(ctx, what="grid guard", code=e.code))
+                compare(eng.align(G), oracle_res[0], "align (no grid)", fails, ctx)
+                return
             try:
                 STATS["voxel_checks"] += 1
                 STATS["searchable_leaves"] += int(check_voxels(eng, grids[0]) or 0)
@@ -268,7 +293,7 @@ def run_case(case, seed, fails, oracle_only=False):
                 check_sweep(eng.derivatives(p), O.derivatives_at(grids[0], src, p))
             except AssertionError as e:
                 fails.append(dict(ctx, what="sweep", detail=str(e)[:200]))
-            compare(eng.align(G), oracle_res[0], "align", fails, ctx, lambda: O.align(grids[0], src, G))
+            compare(eng.align(G), oracle_res[0], "align", fails, ctx, lambda: ora_align(grids[0], src, G))
         else:
             eng.batch_reserve(n_pairs, max(len(t) for t, _, _ in scenes), max(len(s) for _, s, _ in scenes))
             for b, (t, s, _) in enumerate(scenes):
@@ -277,7 +302,7 @@ def run_case(case, seed, fails, oracle_only=False):
             eng.batch_build_targets()
             res = eng.batch_align(np.stack([G for _, _, G in scenes]))
             for b in range(n_pairs):
-                compare(res[b], oracle_res[b], f"batch_align[{b}]", fails, ctx, lambda b=b: O.align(grids[b], scenes[b][1], scenes[b][2]))
+                compare(res[b], oracle_res[b], f"batch_align[{b}]", fails, ctx, lambda b=b: ora_align(grids[b], scenes[b][1], scenes[b][2]))
     finally:
         eng.close()
 
@@ -320,10 +345,14 @@ def main():
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--oracle-only", action="store_true", help="CPU dry run: scenes + oracle only")
+    ap.add_argument("--aux", type=float, default=None, help="probability of the prefilter / fitness / output-cloud checks per case (default 0.15)")
     ap.add_argument("--seconds", type=float, default=1e9, help="stop after this much wall time")
     a = ap.parse_args()
     if a.summarize:
         return summarize(a.summarize, a.out)
+    global AUX_P
+    if a.aux is not None:
+        AUX_P = a.aux
     fails, errors, done = [], [], 0
     t0 = time.time()
     for case in range(a.first, a.first + a.cases):
