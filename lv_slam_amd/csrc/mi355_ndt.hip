@@ -1365,9 +1365,9 @@ int mi355ndt_fitness_score_T(mi355ndt_handle* h, const float T_colmajor[16], dou
   // rings needed to cover sqrt(max_range) (+1 cell of slack), capped by the grid's extent
   const int extent = std::max(g.div_b[0], std::max(g.div_b[1], g.div_b[2])) + 2;
   double rr = std::sqrt(std::min(max_range, 1e30)) / (double)g.leaf + 2.0;
-  int ring_max = rr > (double)(1 << 28) ? (1 << 28) : (int)rr;
-  // a query outside the grid may sit further away than the grid is wide: allow its distance to the box on top
-  ring_max = std::min(ring_max, (1 << 20));
+  // (a query outside the grid may sit further away than the grid is wide: the kernel clamps its cell to 2^29 cells from the grid's
+  //  origin, so 2^30 rings reach every target cell from anywhere)
+  const int ring_max = rr > (double)(1 << 30) ? (1 << 30) : (int)rr;
   (void)extent;
   if (brute) k_fitness_brute<<<blocks, 256, 0, s>>>(h->d_src, h->src_pitch, n, h->d_tgt, h->tgt_pitch, h->h_tgt_cnt[0], h->d_hook, mr, h->d_fit);
   else k_fitness<<<blocks, 256, 0, s>>>(h->d_src, h->src_pitch, n, h->d_tgt, h->tgt_pitch, h->d_vals_b, h->d_grid, h->d_cstart, h->d_cend,

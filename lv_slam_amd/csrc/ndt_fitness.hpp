@@ -36,8 +36,17 @@ __global__ void __launch_bounds__(256) k_fitness(const float* __restrict__ src, 
 #pragma unroll
     for (int a = 0; a < 3; a++) q[a] = ((Tcm[0 * 4 + a] * px + Tcm[1 * 4 + a] * py) + Tcm[2 * 4 + a] * pz) + Tcm[3 * 4 + a];   // PCL 1.8 scalar form
     if (finite3(q[0], q[1], q[2])) {
-      const int c0 = (int)floorf(q[0] * g.inv_leaf) - g.min_b[0], c1 = (int)floorf(q[1] * g.inv_leaf) - g.min_b[1],
-                c2 = (int)floorf(q[2] * g.inv_leaf) - g.min_b[2];
+      // the query's cell relative to the grid, clamped to +-2^29 cells: a query further out than that (a stray source point at
+      // 1e12 m) still sees every target cell in rings r_first .. r_first + extent, and (r - 1) * leaf stays a lower bound of its distances
+      int cq[3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const float cf = floorf(q[a] * g.inv_leaf);
+        const long long ci = cf >= 1.0e9f ? 1000000000ll : (cf <= -1.0e9f ? -1000000000ll : (long long)cf);
+        const long long cl = ci - (long long)g.min_b[a];
+        cq[a] = (int)(cl > (1ll << 29) ? (1ll << 29) : (cl < -(1ll << 29) ? -(1ll << 29) : cl));
+      }
+      const int c0 = cq[0], c1 = cq[1], c2 = cq[2];
       // distance from the query's cell to the grid box in cells (0 inside): rings closer than that are empty
       const int o0 = c0 < 0 ? -c0 : (c0 >= g.div_b[0] ? c0 - g.div_b[0] + 1 : 0);
       const int o1 = c1 < 0 ? -c1 : (c1 >= g.div_b[1] ? c1 - g.div_b[1] + 1 : 0);

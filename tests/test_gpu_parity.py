@@ -851,6 +851,21 @@ def test_leaf_too_small_guards_beyond_the_int64_range():
         got, exp = eng.prefilter(pts, 0.5, 100.0, 1e-4, gate), O.prefilter(pts, 0.5, 100.0, 1e-4, gate)
         assert np.array_equal(got, exp)
     assert np.array_equal(eng.prefilter(pts, 0.5, 100.0, 1e-4, False), pts)
+    # a source point 1e7 / 1e12 m outside the target's grid is still matched to its nearest target point (and counted when
+    # max_range allows it): the ring walk must reach the grid from any distance
+    e = ndt.Engine(ndt.default_params(trans_epsilon=0.01, max_iterations=64))
+    e.set_target(pts)
+    far_src = pts[:300].copy()
+    far_src[5] = [1e7, -1e7, 1e7]
+    far_src[9] = [-1e12, 1e12, 1e12]
+    far_src[11] = [1e30, 0.0, 0.0]                       # squared distance overflows f32: inf <= max_range is false, as in PCL
+    e.set_source(far_src)
+    for mr in (1.0, 1e16, float("inf")):
+        got, n = e.fitness_score(mr, np.eye(4, dtype=np.float32))
+        exp, m = O.fitness_score(pts, far_src, np.eye(4, dtype=np.float32), mr)
+        assert n == m and abs(got - exp) <= 1e-12 * max(1.0, exp), (mr, got, exp, n, m)
+    assert n == 299
+    e.close()
     stray = pts.copy()
     stray[7] = [1e30, 0.0, 0.0]
     for target, prm in ((stray, ndt.default_params(trans_epsilon=0.01, max_iterations=64)), (pts, ndt.default_params(resolution=1e-4, trans_epsilon=0.01, max_iterations=64))):
