@@ -144,7 +144,8 @@ int mi355ndt_get_incremental(mi355ndt_handle* h, int pair, float transformation_
  * (include/global_graph/loop_detector.hpp:249-262; identical recipe in-tree:
  * src/global_graph/information_matrix_calculator.cpp:53-87): source moved by the final pose of the last align()
  * (identity before any align), exact nearest target point per source point, mean of the SQUARED distances that are
- * <= max_range (squared distance vs max_range, as the reference compares them); DBL_MAX when nothing is in range. */
+ * <= max_range (squared distance vs max_range, as the reference compares them); DBL_MAX when nothing is in range.
+ * Works for any target cloud, also one whose voxel grid could not be built (status MI355NDT_ERR_GRID: exhaustive search). */
 int mi355ndt_get_fitness_score(mi355ndt_handle* h, double max_range, double* score, long long* n_inliers);
 /* same with an explicit transform (column-major 4x4) */
 int mi355ndt_fitness_score_T(mi355ndt_handle* h, const float T_colmajor[16], double max_range, double* score, long long* n_inliers);

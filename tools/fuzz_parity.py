@@ -310,7 +310,8 @@ def run_case(case, seed, fails, oracle_only=False):
 def summarize(paths, out_path):
     """Merge per-seed result files into one committed summary (profiles/)."""
     runs = [json.load(open(p)) for p in paths]
-    tot = {"aligns": 0, "iterations": 0, "zero_hit_aligns": 0, "hit_iteration_cap": 0, "mt_live": 0, "voxel_checks": 0, "sweep_checks": 0, "searchable_leaves": 0}
+    tot = {"aligns": 0, "iterations": 0, "zero_hit_aligns": 0, "hit_iteration_cap": 0, "mt_live": 0, "voxel_checks": 0, "sweep_checks": 0, "searchable_leaves": 0,
+           "prefilter_checks": 0, "aux_align_checks": 0, "no_grid_cases": 0}
     paths_n, modes_n, fails = {}, {}, []
     for r in runs:
         for k in tot:
