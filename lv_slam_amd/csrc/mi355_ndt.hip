@@ -1364,7 +1364,7 @@ int mi355ndt_fitness_score_T(mi355ndt_handle* h, const float T_colmajor[16], dou
   const float mr = max_range >= 3.0e38 ? 3.0e38f : (float)max_range;
   // rings needed to cover sqrt(max_range) (+1 cell of slack), capped by the grid's extent
   const int extent = std::max(g.div_b[0], std::max(g.div_b[1], g.div_b[2])) + 2;
-  double rr = std::sqrt(std::min(max_range, 1e30)) / (double)g.leaf + 2.0;
+  double rr = brute ? 0.0 : std::sqrt(std::min(max_range, 1e30)) / (double)g.leaf + 2.0;   // (a target without a grid has no leaf size to divide by)
   // (a query outside the grid may sit further away than the grid is wide: the kernel clamps its cell to 2^29 cells from the grid's
   //  origin, so 2^30 rings reach every target cell from anywhere)
   const int ring_max = rr > (double)(1 << 30) ? (1 << 30) : (int)rr;
