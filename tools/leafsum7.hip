@@ -7,7 +7,9 @@
 //   k_leafsum7, f64 staging, 1 wave per workgroup                               207 us     (leaves in cell order instead of by length: 264 us)
 //   k_leafsum7, f32 staging (-DL7_F32), 1 wave per workgroup (-DL7_WAVES=1)     187 us     (LDS reads batched by 4 / 8 / 16: 189 / 187 / 196 us)
 //   single point ids in random order (argv[3] = 1): product 342 us, k_leafsum7 360-390 us -- both bound by the gathers there
-// i.e. -17 % at best, and only with the leaves ordered by run length.
+// i.e. -17 % at best, and only with the leaves ordered by run length.  Knock-outs of the 187 us variant (wrong results, timing only):
+// without the ordered adds 143 us, without the point gathers 122 us, without both 54 us -- here the gathers (21 per lane per window,
+// all in flight together) are the larger half, where the product kernel hides them behind its LDS traffic.
 //
 // A self-checking micro-benchmark for the formulation of the leaf sums that DESIGN.md 9.3 names as the one with a future:
 //   lane = (leaf slot, sum): 63 lanes = 7 leaves x 9 sums (S0 S1 S2 C00 C01 C02 C11 C12 C22), the seven ordered chains of a wave
