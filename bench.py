@@ -27,6 +27,11 @@ import time
 if os.environ.get("LV_SLAM_CPUS"):                   # e.g. "0-63": keep the process (and the memory it first touches) on one socket
     lo, hi = os.environ["LV_SLAM_CPUS"].split("-")
     os.sched_setaffinity(0, range(int(lo), int(hi) + 1))
+# RCCL's intra-node transport shares device buffers between the ranks' processes through HIP IPC handles.  The host driver of these
+# boxes only implements the dmabuf flavour of IPC: with the HSA runtime's legacy IPC mode left on, hipIpcGetMemHandle fails with
+# "invalid argument" and ncclCommInitRank / the first collective of an N > 1 run dies.  The HSA runtime reads the variable when it
+# starts (first `import torch` that touches the GPU), so it is set here, before any import -- the driver's environment need not carry it.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 os.environ.setdefault("OMP_PROC_BIND", "close")      # pinned OpenMP threads for the CPU leg (read when libgomp starts)
 # ... and a libgomp that starts with OMP_PROC_BIND set binds the thread that loaded it to ONE cpu, which every thread created
 # later inherits: remember what the process may use, and give it back to the threads that are not OpenMP's (apply_affinity)
@@ -66,7 +71,47 @@ def parse():
                          "launch/dlo_kitti.launch:30-36) -> target / source -> align, one registration at a time (use with --azimuth 2048 --pairs 64)")
     ap.add_argument("--seq-frames", type=int, default=271, help="frames of the latency-mode leg (value_sequential; 0 = skip; single-GPU run only)")
     ap.add_argument("--traffic", type=float, default=None, help="HBM bytes per sweep launch from separate rocprofv3 --pmc passes")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the `other_configs` block of the single-GPU line (the nodelet's ndt_pca / DIRECT1 and BASELINE config 5 with DIRECT7 and "
+                         "DIRECT1, each timed for --other-seconds with its own roofline and oracle parity sample)")
+    ap.add_argument("--other-seconds", type=float, default=0.35, help="timed region of every `other_configs` entry")
+    ap.add_argument("--kitti-dir", default=None,
+                    help="a KITTI odometry sequence's velodyne directory (<seq>/velodyne/*.bin, N x 4 f32): consecutive frames (k, k+1) become the "
+                         "pairs of the run instead of the synthetic scans (scripts/lidar_odom_kitti.sh:6); clouds are ragged, `data` says \"kitti\"")
+    ap.add_argument("--kitti-prefilter", action="store_true",
+                    help="with --kitti-dir: every scan first goes through the device prefilter (0.5-100 m gate + 0.1 m VoxelGrid, launch/dlo_kitti.launch:30-36)")
     return ap.parse_args()
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_command(n_gpus, argv, port):
+    """The command `bench.py --gpus N` turns itself into when nobody launched it as N ranks: exactly the driver's form
+    (one rank per GPU on one node, rendezvous on 127.0.0.1 -- the container's hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(a, argv, visible_devices=None, execve=None):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: become N ranks (torch.distributed.run) instead of
+    running ONE rank that reports n_gpus = 1.  Refuses (non-zero exit) when fewer than N devices are visible -- never a silent
+    smaller run.  (LV_SLAM_BENCH_BACKEND=gloo, the functional check of tests/test_bench_gpu.py, lets ranks share a GPU.)"""
+    backend = os.environ.get("LV_SLAM_BENCH_BACKEND", "nccl")
+    visible = torch.cuda.device_count() if visible_devices is None else visible_devices
+    if visible < (a.gpus if backend == "nccl" else 1):
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {visible} GPU(s) visible to this process; refusing to run a smaller job under that name")
+    cmd = launch_command(a.gpus, argv, free_port())
+    env = dict(os.environ)
+    env["LV_SLAM_BENCH_LAUNCHER"] = "bench.py re-executed itself under torch.distributed.run"
+    print("bench: " + " ".join(cmd), file=sys.stderr, flush=True)
+    (execve or os.execve)(cmd[0], cmd, env)
 
 
 def se3_err(A, B):
@@ -173,7 +218,7 @@ def static_profile(name, workload_key):
     return None, None
 
 
-def cpu_leg(a, T, S, G, res_np, B):
+def cpu_leg(a, W, G, res_np, B):
     """(1) the reference-shaped arrangement on pair 0 at 4 threads (the nodelet's setting,
     scan_matching_odom_nodelet.cpp:110,116), 8 (launch/dlo_lfa_ggo_kitti.launch:112) and all physical cores: 3 warm-ups, then
     median / p10 / p90 over 20 repeats, target build and align separately; (2) the optimised port the same way; (3) a bounded
@@ -182,8 +227,8 @@ def cpu_leg(a, T, S, G, res_np, B):
     model, phys, logical = host_info()
     kw = dict(resolution=a.resolution, trans_epsilon=0.01, max_iterations=64, neighbor_mode=MODES[a.mode], variant=1 if a.variant == "pca" else 0)
     op = O.default_params(**kw)
-    tg0 = T[0].T.contiguous().cpu().numpy()
-    sr0 = S[0].T.contiguous().cpu().numpy()
+    tg0 = cloud_np(W, "T", 0)
+    sr0 = cloud_np(W, "S", 0)
     refshape_ok = a.mode != "kdtree"
 
     def stats(v):
@@ -216,7 +261,7 @@ def cpu_leg(a, T, S, G, res_np, B):
     best_port = max(port, key=lambda k: port[k]["registrations_per_s"])
     best_shaped = max(shaped, key=lambda k: shaped[k]["registrations_per_s"]) if shaped else None
     # (3) batch sample with the port at its best thread count; pose-by-pose parity of the GPU results (sample spread over the index range)
-    parity, port_batch = parity_leg(a, T, S, G, res_np, B, seconds=a.cpu_seconds, threads=int(best_port))
+    parity, port_batch = parity_leg(a, W, G, res_np, B, seconds=a.cpu_seconds, threads=int(best_port))
     label = "CPU restatement of ndt_omp (reference not buildable in this environment)"
     # `value` = the FASTEST CPU arrangement measured (the optimised port at its best thread count), so that any GPU/CPU ratio taken
     # from it is the conservative one; the reference-shaped arrangement SURVEY 8(d) asks for stands next to it under its own name
@@ -476,7 +521,7 @@ def spread_order(n):
     return order
 
 
-def parity_leg(a, T, S, G, res_np, B, seconds, threads):
+def parity_leg(a, W, G, res_np, B, seconds, threads):
     """Pose-by-pose check of the GPU results of one job against the oracle on a time-bounded sample that is spread over the whole
     index range of the job (spread_order); doubles as the batch rate of the optimised port."""
     from oracle import oracle_py as O
@@ -487,8 +532,8 @@ def parity_leg(a, T, S, G, res_np, B, seconds, threads):
     for k in spread_order(B):
         if done >= 3 and t_cpu >= seconds:
             break
-        tg = T[k].T.contiguous().cpu().numpy()
-        sr = S[k].T.contiguous().cpu().numpy()
+        tg = cloud_np(W, "T", k)
+        sr = cloud_np(W, "S", k)
         c0 = time.perf_counter()
         ro = O.align(O.Grid(tg, op), sr, G)
         t_cpu += time.perf_counter() - c0
@@ -507,19 +552,263 @@ def parity_leg(a, T, S, G, res_np, B, seconds, threads):
     return parity, {"registrations_per_s": round(done / max(t_cpu, 1e-9), 3), "threads": int(threads), "sample": f"{done} of the {B} pairs, total wall / count"}
 
 
+class Ctx:
+    """What every leg of a run shares: the rank's place in the job, its device, the process group (or None)."""
+    rank = 0; world = 1; local = 0; dev = None; dist = None; backend = "nccl"; use_dist = False; on_dev = True; shard = None; ndt = None; G = None
+
+
+def cloud_np(W, side, k):
+    """Pair slot k's target ("T") or source ("S") cloud of workload W as an [n, 3] f32 host array (ragged clouds: their own count)."""
+    n = int(W["tcnt" if side == "T" else "scnt"][k])
+    return W[side][k, :, :n].T.contiguous().cpu().numpy()
+
+
+def generate_synthetic(ctx, synth, ids, azimuth):
+    """This rank's scan pairs, ray-cast on ITS GPU and left resident in HBM as [pair][3][N] SoA rows.  The CPU only draws every pair's
+    seeded noise (torch's CPU generator releases the GIL: a few Python threads, each inside the CPUs the container may use) and
+    looks up the cached street primitives; eight ranks of a node therefore do not queue on the host's CPU quota."""
+    N = azimuth * 64
+    t0 = time.perf_counter()
+    T = torch.empty(len(ids), 3, N, device=ctx.dev, dtype=torch.float32)
+    S = torch.empty(len(ids), 3, N, device=ctx.dev, dtype=torch.float32)
+    quota = cpu_quota() or os.cpu_count() or 8
+    # torch sizes its CPU thread pool to the CPUs it can see; under a cgroup quota (16 of 256 CPUs on the GPU boxes) that many threads
+    # only throttle each other: keep torch's pool within the quota
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), quota // 2)))
+
+    def gen(k):
+        apply_affinity()
+        torch.cuda.set_device(ctx.local)
+        t, s, _ = synth.make_pair(ids[k], azimuth, device=ctx.dev)
+        T[k] = t.T
+        S[k] = s.T
+
+    if len(ids) > 8:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=max(2, min(8, quota // 2))) as pool:
+            list(pool.map(gen, range(len(ids))))
+    else:
+        for k in range(len(ids)):
+            gen(k)
+    torch.cuda.synchronize()
+    cnt = [N] * len(ids)
+    return {"T": T, "S": S, "tcnt": cnt, "scnt": list(cnt), "pitch": N, "ids": list(ids), "data": "synthetic", "max_points": N,
+            "generated_on": f"cuda:{ctx.local} (ray casting in torch on the device; per-pair noise drawn on the CPU)"}, time.perf_counter() - t0
+
+
+def load_kitti(ctx, a, ndt, ids):
+    """--kitti-dir: pair k = (target frame k, source frame k + 1) of a KITTI odometry sequence (scripts/lidar_odom_kitti.sh:6 plays the
+    same files), optionally through the device prefilter the reference's launch file puts in front of the odometry node
+    (launch/dlo_kitti.launch:30-36).  Ragged point counts: rows padded to the longest cloud, the counts travel with the batch."""
+    from lv_slam_amd import kitti
+    t0 = time.perf_counter()
+    files = kitti.list_frames(a.kitti_dir)
+    need = max(ids) + 2
+    if len(files) < need:
+        raise SystemExit(f"--kitti-dir {a.kitti_dir}: {len(files)} frames, the job needs {need}")
+    pf = ndt.Engine(ndt.default_params(), device=ctx.local) if a.kitti_prefilter else None
+    cache = {}
+
+    def frame(f):
+        if f not in cache:
+            xyz = kitti.load_frame(files[f])
+            cache[f] = pf.prefilter(xyz, 0.5, 100.0, 0.1, fetch=True) if pf is not None else xyz
+            for old in [q for q in cache if q < f - 1]:
+                del cache[old]
+        return cache[f]
+    clouds = [(frame(k), frame(k + 1)) for k in ids]
+    if pf is not None:
+        pf.close()
+    T, S, tcnt, scnt, pitch = kitti.pack_soa(clouds, ctx.dev)
+    return {"T": T, "S": S, "tcnt": tcnt, "scnt": scnt, "pitch": pitch, "ids": list(ids), "data": "kitti", "max_points": max(max(tcnt), max(scnt)),
+            "generated_on": f"{os.path.abspath(a.kitti_dir)} ({len(files)} frames)" + (", device prefilter 0.5-100 m + 0.1 m VoxelGrid" if pf is not None else "")}, time.perf_counter() - t0
+
+
+def timed_job(ctx, eng, W, nb, job_total, steps, warmup, min_seconds=0.5):
+    """`warmup` untimed + `steps` timed passes over the first `nb` pair slots of workload W (this rank's shard of a job of `job_total`
+    pairs): voxelise every target, align every pair, and -- when a process group exists -- pack the pose records on the device and
+    all-gather them.  Barrier + synchronize on both sides of the timed steps, MAX over ranks.  steps = None: as many as fill
+    `min_seconds`.  Returns timings, results, profile, gather check."""
+    ndt, shard, dist, dev, on_dev, use_dist = ctx.ndt, ctx.shard, ctx.dist, ctx.dev, ctx.on_dev, ctx.use_dist
+    ids = W["ids"][:nb]
+    cap = shard.shard_capacity(job_total, ctx.world)
+    eng.batch_bind_device(W["T"].data_ptr(), W["tcnt"][:nb], W["pitch"], W["S"].data_ptr(), W["scnt"][:nb], W["pitch"])
+    guesses = np.ascontiguousarray(np.broadcast_to(ctx.G.T.reshape(1, 16), (nb, 16)), dtype=np.float32)
+    res = (ndt.Result * nb)()
+    res_np = np.frombuffer(res, dtype=RES_DT)
+    # pose records: packed by the engine on the device into this tensor, which goes straight into the all-gather
+    rec_dev = torch.empty(cap, shard.REC_WORDS, device=dev, dtype=torch.int32)
+    rec_host = None if on_dev else torch.empty(cap, shard.REC_WORDS, dtype=torch.int32).pin_memory()   # gloo functional check only
+    gathered = torch.empty(ctx.world * cap, shard.REC_WORDS, device=dev if on_dev else "cpu", dtype=torch.int32) if use_dist else None
+    gather_ev, gather_host_s = [], [0.0]
+
+    def step(timed=False):
+        eng.batch_build_targets()                 # setInputTarget for every pair: voxelise
+        eng.batch_align_raw(guesses, res)         # align every pair (synchronous: results on the host)
+        if use_dist:                              # pose gather: 96 B per pair, no host hop on the RCCL path
+            if gather_ev:
+                gather_ev[-1][1].synchronize()    # the previous gather has read rec_dev before it is packed again
+            eng.batch_pose_records(ctx.rank, ctx.world, rec_dev.data_ptr(), cap)
+            h0 = time.perf_counter()
+            if on_dev:                            # HIP events on torch's current stream, which the collective is ordered on
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                shard.gather_records(rec_dev, gathered)
+                e1.record()
+                if timed:
+                    gather_ev.append((e0, e1))
+            else:
+                rec_host.copy_(rec_dev)
+                shard.gather_records(rec_host, gathered)
+                if timed:
+                    gather_host_s[0] += time.perf_counter() - h0
+
+    eng.profile_enable(True)                      # the warm-up runs exactly what the timed steps run (event pool touched, too)
+    gc.collect()
+    gc.disable()                                  # a generation-2 collection (torch + numpy object graphs) costs ~15 ms: keep it out of
+    for _ in range(warmup):                       # the timed loop -- and out of the gap before it, where an idle GPU drops its clocks
+        step()
+    if steps is None:                             # no --steps: size the timed region (the driver passes --steps and is obeyed)
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        one = max(time.perf_counter() - c0, 1e-4)
+        st = torch.tensor([float(max(20 if min_seconds >= 0.5 else 5, int(np.ceil(min_seconds / one))))], dtype=torch.float64, device=dev if on_dev else "cpu")
+        if dist is not None:
+            dist.all_reduce(st, op=dist.ReduceOp.MAX)
+        steps = int(st.item())
+    eng.profile_reset()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step_ms, tp = [], t0
+    for _ in range(steps):
+        step(True)                                # synchronous: batch_align returns with the results on the host
+        tn = time.perf_counter()
+        step_ms.append(1e3 * (tn - tp))
+        tp = tn
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    prof = eng.profile_get()
+    eng.profile_enable(False)
+    gather_ms = None
+    if use_dist:
+        gather_ms = (sum(e0.elapsed_time(e1) for e0, e1 in gather_ev) if on_dev else 1e3 * gather_host_s[0]) / max(1, steps)
+    gather_check = None
+    if dist is not None:
+        tt = torch.tensor([dt, gather_ms], device=dev if on_dev else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, gather_ms = float(tt[0].item()), float(tt[1].item())
+        # gather check: pair ids form a permutation of the global index space, and my own records came back bit-identical
+        got = shard.unpack_records(gathered)
+        perm = sorted(got) == list(range(job_total))
+        same = all(np.array_equal(got[pid]["final"], res_np["final"][k].reshape(4, 4).T) and got[pid]["iterations"] == int(res_np["it"][k])
+                   and got[pid]["converged"] == bool(res_np["conv"][k]) and np.float32(res_np["score"][k]) == np.float32(got[pid]["score"])
+                   for k, pid in enumerate(ids))
+        assert perm, "pose gather lost or duplicated pairs"
+        assert same, "gathered records differ from this rank's results"
+        ok = torch.tensor([int(perm and same)], dtype=torch.int32, device=dev if on_dev else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        gather_check = {"pairs_gathered": len(got), "permutation_of_all_pair_ids": bool(perm), "own_records_bit_identical_on_every_rank": bool(ok.item()),
+                        "record_bytes": 96, "records_per_rank": cap, "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                        "packed_on_device": True, "host_hop": not on_dev,
+                        "timed_with": "HIP events around all_gather_into_tensor on the stream the collective is ordered on, max over ranks" if on_dev else
+                                      "host clock around the device-to-host copy + gloo all_gather (functional check only), max over ranks"}
+    return {"dt": dt, "steps": steps, "step_ms": step_ms, "prof": prof, "res": res, "res_np": res_np, "guesses": guesses,
+            "gather_ms_per_step": None if gather_ms is None else round(gather_ms, 4), "gather_check": gather_check, "B": nb}
+
+
+F32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: vector f32 peak (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz, x2 for packed)
+FLOP_PER_HIT = 450.0          # SURVEY.md 8(d): ~450 flop per (point, voxel) evaluation
+
+
+def sweep_roofline(J):
+    prof, dt, steps = J["prof"], J["dt"], J["steps"]
+    sw_s = prof["sweep_ms"] * 1e-3
+    ach = (prof["sweep_alg_bytes"] / sw_s / 1e9) if sw_s > 0 else 0.0
+    tfl = (FLOP_PER_HIT * prof["sweep_hits"] / sw_s / 1e12) if sw_s > 0 else 0.0
+    return {"bound": "hbm", "kernel": "k_sweep", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4),
+            "frac_of_achievable_6290": round(ach / 6290.0, 4),     # MI355X_MICROARCH.md: measured-achievable HBM rate
+            "launches": prof["sweep_launches"], "avg_launch_us": round(1e3 * prof["sweep_ms"] / max(1, prof["sweep_launches"]), 2),
+            "alg_bytes_per_launch": round(prof["sweep_alg_bytes"] / max(1, prof["sweep_launches"])),
+            "hits_per_point": round(prof["sweep_hits"] / max(1, prof["sweep_points"]), 3),
+            # the secondary figure of SURVEY 8(d): ~450 flop per (point, voxel) evaluation against the vector f32 peak (no MFMA on this path)
+            "flops": {"achieved_tflops": round(tfl, 2), "peak_tflops": F32_PEAK_TFLOPS, "frac": round(tfl / F32_PEAK_TFLOPS, 4), "flop_per_hit": FLOP_PER_HIT,
+                      "hits": int(prof["sweep_hits"])},
+            "sweep_share_of_step": round(sw_s / dt, 3),
+            "build_ms_per_step": round(prof["build_ms"] / max(1, steps), 3),
+            "update_ms_per_step": round(prof["update_ms"] / max(1, steps), 3),
+            "sweep_ms_per_step": round(prof["sweep_ms"] / max(1, steps), 3),
+            "step_ms_min_median_max": [round(min(J["step_ms"]), 3), round(float(np.median(J["step_ms"])), 3), round(max(J["step_ms"]), 3)],
+            "build_achieved_gbs": round(prof["build_alg_bytes"] / max(1e-9, prof["build_ms"] * 1e-3) / 1e9, 1),
+            "build_frac": round(prof["build_alg_bytes"] / max(1e-9, prof["build_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
+def other_configs_block(ctx, a, synth, W_head):
+    """The BASELINE configurations the headline does not time, each as its own small job on this GPU (own engine, >= --other-seconds of
+    timed steps, HIP-event roofline of its sweep, oracle parity on a bounded sample): the live nodelet's registration (ndt_pca, DIRECT1,
+    1 m: scan_matching_odom_nodelet.cpp:109-119) on the headline's clouds, and BASELINE config 5's per-GPU share (ndt_pca, 0.5 m, clouds
+    of twice the points) with DIRECT7 and with DIRECT1.  Sizes follow --pairs / --azimuth (271 x 65,536 and 128 x 131,072 by default)."""
+    import argparse
+    ndt = ctx.ndt
+    p5, az5 = max(1, a.pairs * 128 // 271), 2 * a.azimuth
+    t0 = time.perf_counter()
+    W5, gen5 = generate_synthetic(ctx, synth, list(range(p5)), az5)
+    specs = [("ndt_pca_direct1", dict(variant="pca", mode="direct1", resolution=1.0), W_head, min(a.pairs, len(W_head["ids"])), a.azimuth),
+             ("config5_direct7", dict(variant="pca", mode="direct7", resolution=0.5), W5, p5, az5),
+             ("config5_direct1", dict(variant="pca", mode="direct1", resolution=0.5), W5, p5, az5)]
+    out = {}
+    for name, kw, W, nb, az in specs:
+        b = argparse.Namespace(**{**vars(a), **kw, "pairs": nb, "azimuth": az})
+        prm = ndt.default_params(resolution=b.resolution, trans_epsilon=0.01, max_iterations=64, neighbor_mode=MODES[b.mode], variant=1)
+        eng = ndt.Engine(prm, device=ctx.local)
+        J = timed_job(ctx, eng, W, nb, nb, None, 2, min_seconds=a.other_seconds)
+        r = sweep_roofline(J)
+        res_np = np.frombuffer(np.frombuffer(J["res"], dtype=np.uint8).copy(), dtype=RES_DT)
+        eng.close()
+        parity = None
+        if a.cpu_seconds > 0:
+            parity, _ = parity_leg(b, W, ctx.G, res_np, nb, seconds=min(4.0, a.cpu_seconds / 3.0), threads=cpu_quota() or os.cpu_count() or 8)
+        N = az * 64
+        out[name] = {"workload": f"{baseline_config_name(b, N)}: {nb} synthetic HDL-64E scan pairs ({N} pts per cloud), ndt_pca, {b.resolution} m voxels, {b.mode.upper()}, "
+                                 "eps 0.01, max_iter 64; one step = voxelise every target + align every pair",
+                     "value": round(nb * J["steps"] / J["dt"], 2), "unit": "registrations/s", "steps": J["steps"], "warmup": 2,
+                     "ms_per_step": round(1e3 * J["dt"] / J["steps"], 3), "timed_s": round(J["dt"], 3),
+                     "mean_iterations": round(float(res_np["it"].mean()), 2), "converged": int(res_np["conv"].sum()),
+                     "roofline": {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us", "alg_bytes_per_launch",
+                                                   "hits_per_point", "flops", "build_ms_per_step", "update_ms_per_step", "sweep_ms_per_step", "build_frac")},
+                     "parity": parity}
+    del W5
+    return {"configs": out, "seconds": round(time.perf_counter() - t0, 2), "input_generation_s": round(gen5, 2),
+            "what": "same timed-step definition as the headline (barrier-free single rank, HIP events inside the engine for the sweep's roofline); "
+                    "never `value`: the headline stays BASELINE config 3"}
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        self_launch(a, sys.argv[1:])                  # (does not return: the process becomes torch.distributed.run)
+        raise SystemExit("bench.py: the launcher returned")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # one process per GPU; LV_SLAM_BENCH_BACKEND=gloo lets several ranks share one GPU for a functional check of
     # the N>1 path on a single-GPU box (the driver's scaling runs use the default: nccl = RCCL over xGMI)
     backend = os.environ.get("LV_SLAM_BENCH_BACKEND", "nccl")
-    local = local % torch.cuda.device_count() if backend != "nccl" else local
+    visible = torch.cuda.device_count()
+    if backend == "nccl" and visible < world:
+        raise SystemExit(f"{world} ranks but only {visible} GPU(s) visible: one rank per GPU, never two ranks on one device under the RCCL backend")
+    local = local % visible if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pinned_to = pin_to_gpu_numa_node(local)
@@ -535,6 +824,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} but the process group has {dist.get_world_size()} ranks")
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -550,6 +841,11 @@ def main():
         prefiltered_row(a, ndt, synth, dev, local)
         return
 
+    ctx = Ctx()
+    ctx.rank, ctx.world, ctx.local, ctx.dev, ctx.dist, ctx.backend, ctx.use_dist = rank, world, local, dev, dist, backend, use_dist
+    ctx.on_dev, ctx.shard, ctx.ndt, ctx.G = backend == "nccl", shard, ndt, synth.default_guess()
+    G = ctx.G
+
     strong = a.total_pairs > 0
     total = a.total_pairs if strong else a.pairs * world
     if total < world:
@@ -563,155 +859,20 @@ def main():
     c4_ids = shard.shard_pairs(c4_total, rank, world) if c4_total else []
     all_ids = pair_ids if len(pair_ids) >= len(c4_ids) else c4_ids
     assert all_ids[:len(pair_ids)] == pair_ids and all_ids[:len(c4_ids)] == c4_ids
-    B, N = len(pair_ids), a.azimuth * 64
-    # ---- synthetic inputs, generated on the GPU and left resident in HBM: [pair][3][N] SoA
-    t_gen = time.perf_counter()
-    T = torch.empty(len(all_ids), 3, N, device=dev, dtype=torch.float32)
-    S = torch.empty(len(all_ids), 3, N, device=dev, dtype=torch.float32)
-    # torch sizes its CPU thread pool to the CPUs it can see; under a cgroup quota (16 of 256 CPUs on the GPU boxes) that many threads
-    # only throttle each other: keep torch's pool within the quota, and draw the pairs' noise / ray-cast the scans from a few Python
-    # threads (torch releases the GIL inside its kernels; every pair has its own seeded generator, so the clouds do not change)
-    quota = cpu_quota() or os.cpu_count() or 8
-    torch.set_num_threads(max(1, min(torch.get_num_threads(), quota // 2)))
-
-    def gen(k):
-        apply_affinity()
-        torch.cuda.set_device(local)
-        t, s, dT = synth.make_pair(all_ids[k], a.azimuth, device=dev)
-        T[k] = t.T
-        S[k] = s.T
-
-    if len(all_ids) > 8:
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=max(2, min(8, quota // 2))) as pool:
-            list(pool.map(gen, range(len(all_ids))))
+    B = len(pair_ids)
+    # ---- inputs, resident in HBM before any timed region: [pair][3][pitch] SoA
+    if a.kitti_dir:
+        W, t_gen = load_kitti(ctx, a, ndt, all_ids)
     else:
-        for k in range(len(all_ids)):
-            gen(k)
-    torch.cuda.synchronize()
-    t_gen = time.perf_counter() - t_gen
+        W, t_gen = generate_synthetic(ctx, synth, all_ids, a.azimuth)
+    N = W["max_points"]
 
     prm = ndt.default_params(resolution=a.resolution, trans_epsilon=0.01, max_iterations=64, neighbor_mode=MODES[a.mode],
                              variant=1 if a.variant == "pca" else 0)
     eng = ndt.Engine(prm, device=local)
-    G = synth.default_guess()
-    on_dev = backend == "nccl"
-
-    def timed_job(ids, job_total, steps, warmup):
-        """`warmup` untimed + `steps` timed passes over this rank's pairs `ids` of a job of `job_total` pairs: voxelise every target,
-        align every pair, and -- when a process group exists -- pack the pose records on the device and all-gather them.
-        Barrier + synchronize on both sides of the timed steps, MAX over ranks.  Returns timings, results, profile, gather check."""
-        nb = len(ids)
-        cap = shard.shard_capacity(job_total, world)
-        eng.batch_bind_device(T.data_ptr(), [N] * nb, N, S.data_ptr(), [N] * nb, N)
-        guesses = np.ascontiguousarray(np.broadcast_to(G.T.reshape(1, 16), (nb, 16)), dtype=np.float32)
-        res = (ndt.Result * nb)()
-        res_np = np.frombuffer(res, dtype=RES_DT)
-        # pose records: packed by the engine on the device into this tensor, which goes straight into the all-gather
-        rec_dev = torch.empty(cap, shard.REC_WORDS, device=dev, dtype=torch.int32)
-        rec_host = None if on_dev else torch.empty(cap, shard.REC_WORDS, dtype=torch.int32).pin_memory()   # gloo functional check only
-        gathered = torch.empty(world * cap, shard.REC_WORDS, device=dev if on_dev else "cpu", dtype=torch.int32) if use_dist else None
-        gather_ev, gather_host_s = [], [0.0]
-
-        def step(timed=False):
-            eng.batch_build_targets()                 # setInputTarget for every pair: voxelise
-            eng.batch_align_raw(guesses, res)         # align every pair (synchronous: results on the host)
-            if use_dist:                              # pose gather: 96 B per pair, no host hop on the RCCL path
-                if gather_ev:
-                    gather_ev[-1][1].synchronize()    # the previous gather has read rec_dev before it is packed again
-                eng.batch_pose_records(rank, world, rec_dev.data_ptr(), cap)
-                h0 = time.perf_counter()
-                if on_dev:                            # HIP events on torch's current stream, which the collective is ordered on
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    shard.gather_records(rec_dev, gathered)
-                    e1.record()
-                    if timed:
-                        gather_ev.append((e0, e1))
-                else:
-                    rec_host.copy_(rec_dev)
-                    shard.gather_records(rec_host, gathered)
-                    if timed:
-                        gather_host_s[0] += time.perf_counter() - h0
-
-        eng.profile_enable(True)                      # the warm-up runs exactly what the timed steps run (event pool touched, too)
-        gc.collect()
-        gc.disable()                                  # a generation-2 collection (torch + numpy object graphs) costs ~15 ms: keep it out of
-        for _ in range(warmup):                       # the timed loop -- and out of the gap before it, where an idle GPU drops its clocks
-            step()
-        if steps is None:                             # no --steps: size the timed region to >= 0.5 s (the driver passes --steps and is obeyed)
-            torch.cuda.synchronize()
-            c0 = time.perf_counter()
-            step()
-            torch.cuda.synchronize()
-            one = max(time.perf_counter() - c0, 1e-4)
-            st = torch.tensor([float(max(20, int(np.ceil(0.5 / one))))], dtype=torch.float64, device=dev if on_dev else "cpu")
-            if dist is not None:
-                dist.all_reduce(st, op=dist.ReduceOp.MAX)
-            steps = int(st.item())
-        eng.profile_reset()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        step_ms, tp = [], t0
-        for _ in range(steps):
-            step(True)                                # synchronous: batch_align returns with the results on the host
-            tn = time.perf_counter()
-            step_ms.append(1e3 * (tn - tp))
-            tp = tn
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        gc.enable()
-        prof = eng.profile_get()
-        eng.profile_enable(False)
-        gather_ms = None
-        if use_dist:
-            gather_ms = (sum(e0.elapsed_time(e1) for e0, e1 in gather_ev) if on_dev else 1e3 * gather_host_s[0]) / max(1, steps)
-        gather_check = None
-        if dist is not None:
-            tt = torch.tensor([dt, gather_ms], device=dev if on_dev else "cpu", dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt, gather_ms = float(tt[0].item()), float(tt[1].item())
-            # gather check: pair ids form a permutation of the global index space, and my own records came back bit-identical
-            got = shard.unpack_records(gathered)
-            perm = sorted(got) == list(range(job_total))
-            same = all(np.array_equal(got[pid]["final"], res_np["final"][k].reshape(4, 4).T) and got[pid]["iterations"] == int(res_np["it"][k])
-                       and got[pid]["converged"] == bool(res_np["conv"][k]) and np.float32(res_np["score"][k]) == np.float32(got[pid]["score"])
-                       for k, pid in enumerate(ids))
-            assert perm, "pose gather lost or duplicated pairs"
-            assert same, "gathered records differ from this rank's results"
-            ok = torch.tensor([int(perm and same)], dtype=torch.int32, device=dev if on_dev else "cpu")
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            gather_check = {"pairs_gathered": len(got), "permutation_of_all_pair_ids": bool(perm), "own_records_bit_identical_on_every_rank": bool(ok.item()),
-                            "record_bytes": 96, "records_per_rank": cap, "backend": backend, "packed_on_device": True, "host_hop": not on_dev,
-                            "timed_with": "HIP events around all_gather_into_tensor on the stream the collective is ordered on, max over ranks" if on_dev else
-                                          "host clock around the device-to-host copy + gloo all_gather (functional check only), max over ranks"}
-        return {"dt": dt, "steps": steps, "step_ms": step_ms, "prof": prof, "res": res, "res_np": res_np, "guesses": guesses,
-                "gather_ms_per_step": None if gather_ms is None else round(gather_ms, 4), "gather_check": gather_check, "B": nb}
-
-    def sweep_roofline(J, nb):
-        prof, dt, steps = J["prof"], J["dt"], J["steps"]
-        sw_s = prof["sweep_ms"] * 1e-3
-        ach = (prof["sweep_alg_bytes"] / sw_s / 1e9) if sw_s > 0 else 0.0
-        return {"bound": "hbm", "kernel": "k_sweep", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4),
-                "frac_of_achievable_6290": round(ach / 6290.0, 4),     # MI355X_MICROARCH.md: measured-achievable HBM rate
-                "launches": prof["sweep_launches"], "avg_launch_us": round(1e3 * prof["sweep_ms"] / max(1, prof["sweep_launches"]), 2),
-                "alg_bytes_per_launch": round(prof["sweep_alg_bytes"] / max(1, prof["sweep_launches"])),
-                "hits_per_point": round(prof["sweep_hits"] / max(1, prof["sweep_points"]), 3),
-                "sweep_share_of_step": round(sw_s / dt, 3),
-                "build_ms_per_step": round(prof["build_ms"] / max(1, steps), 3),
-                "update_ms_per_step": round(prof["update_ms"] / max(1, steps), 3),
-                "sweep_ms_per_step": round(prof["sweep_ms"] / max(1, steps), 3),
-                "step_ms_min_median_max": [round(min(J["step_ms"]), 3), round(float(np.median(J["step_ms"])), 3), round(max(J["step_ms"]), 3)],
-                "build_achieved_gbs": round(prof["build_alg_bytes"] / max(1e-9, prof["build_ms"] * 1e-3) / 1e9, 1),
-                "build_frac": round(prof["build_alg_bytes"] / max(1e-9, prof["build_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
     # ---- the headline job
-    J = timed_job(pair_ids, total, a.steps, a.warmup)
+    J = timed_job(ctx, eng, W, B, total, a.steps, a.warmup)
     res, res_np, guesses, dt, steps = J["res"], J["res_np"], J["guesses"], J["dt"], J["steps"]
     # SURVEY 8(d) asks for the rate with and without setInputTarget: the same pairs again against the now-resident grids
     torch.cuda.synchronize()
@@ -730,8 +891,8 @@ def main():
 
     # ---- the drop-in path: host AoS clouds (pcl::PointXYZI records) in, PCIe inclusive -- rank 0's pairs
     host_path = None
-    if rank == 0 and not a.no_host_clouds and (a.host_clouds or world == 1):
-        host_path, hres = host_clouds_leg(a, ndt, prm, local, T[:B], S[:B], guesses, B, N, steps=max(2, min(steps, 40) // 2), uploaders=a.uploaders or None)
+    if rank == 0 and not a.no_host_clouds and (a.host_clouds or world == 1) and W["data"] == "synthetic":
+        host_path, hres = host_clouds_leg(a, ndt, prm, local, W["T"][:B], W["S"][:B], guesses, B, N, steps=max(2, min(steps, 40) // 2), uploaders=a.uploaders or None)
         # same bits as the device-resident run of the same pairs
         nh = len(np.frombuffer(hres[0], dtype=RES_DT))      # the leg's pairs: the first min(B, 271) of the batch
         host_path["pairs_per_batch"] = nh
@@ -741,15 +902,15 @@ def main():
 
     # ---- latency mode: the nodelet's own per-frame loop on a drive (never `value`)
     seq_leg = None
-    if rank == 0 and world == 1 and a.seq_frames > 1:
+    if rank == 0 and world == 1 and a.seq_frames > 1 and W["data"] == "synthetic":
         seq_leg = sequential_leg(a, ndt, local, dev, a.seq_frames)
 
     # ---- BASELINE config 4 beside it: the fixed 4,541-pair job, strong-scaled over the same ranks
     cfg4 = None
     if c4_total:
-        J4 = timed_job(c4_ids, c4_total, max(3, steps // 4) if a.steps is not None else None, min(a.warmup, 2))
-        r4 = sweep_roofline(J4, len(c4_ids))
-        cfg4 = {"workload": f"BASELINE config 4: ONE job of {c4_total} synthetic HDL-64E scan pairs ({N} pts per cloud) sharded round-robin over {world} GPU(s), "
+        J4 = timed_job(ctx, eng, W, len(c4_ids), c4_total, max(3, steps // 4) if a.steps is not None else None, min(a.warmup, 2))
+        r4 = sweep_roofline(J4)
+        cfg4 = {"workload": f"BASELINE config 4: ONE job of {c4_total} {'KITTI' if W['data'] == 'kitti' else 'synthetic HDL-64E'} scan pairs ({N} pts per cloud) sharded round-robin over {world} GPU(s), "
                             f"ndt_{a.variant}, {a.resolution} m voxels, {a.mode.upper()}; one step = voxelise + align this rank's shard + the pose all-gather of all {c4_total} records",
                 "scaling": "strong", "pairs_total": c4_total, "pairs_rank0": len(c4_ids), "n_gpus": world, "steps": J4["steps"],
                 "value": round(c4_total * J4["steps"] / J4["dt"], 2), "unit": "registrations/s", "ms_per_step": round(1e3 * J4["dt"] / J4["steps"], 3),
@@ -758,8 +919,13 @@ def main():
                 "update_ms_per_step": r4["update_ms_per_step"], "sweep_ms_per_step": r4["sweep_ms_per_step"],
                 "mean_iterations": round(float(J4["res_np"]["it"].mean()), 2), "converged": int(J4["res_np"]["conv"].sum()), "parity": None}
         if rank == 0 and a.cpu_seconds > 0 and world == 1:
-            cfg4["parity"], _ = parity_leg(a, T, S, G, J4["res_np"], len(c4_ids), seconds=a.cpu_seconds / 2.0, threads=cpu_quota() or os.cpu_count() or 8)
+            cfg4["parity"], _ = parity_leg(a, W, G, J4["res_np"], len(c4_ids), seconds=a.cpu_seconds / 2.0, threads=cpu_quota() or os.cpu_count() or 8)
 
+    pg = {"world_size": dist.get_world_size() if dist is not None else 1, "backend": dist.get_backend() if dist is not None else None,
+          "launcher": os.environ.get("LV_SLAM_BENCH_LAUNCHER") or ("torch.distributed.run (external)" if "TORCHELASTIC_RUN_ID" in os.environ else "plain process"),
+          "devices_visible": visible, "device_of_rank0": torch.cuda.get_device_name(local),
+          "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if (dist is not None and backend == "nccl") else None,
+          "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
     if rank != 0:
         eng.close()
         if dist is not None:
@@ -771,10 +937,11 @@ def main():
     sweeps = res_np["sweeps"].astype(np.float64)
     # ---- roofline of the dominant kernel (derivative sweep): algorithmic bytes / HIP-event time
     wkey = f"{a.pairs if not strong else B}x{N}:{a.variant}:{a.mode}:{a.resolution}"
-    roof = sweep_roofline(J, B)
+    roof = sweep_roofline(J)
     traffic, traffic_source = a.traffic, "command line" if a.traffic is not None else None
     if traffic is None:       # PMC counters cannot be read from inside the timed run: the committed separate-pass measurement of this workload
-        for name in ("r03_traffic.json", "r02_traffic.json"):
+        tp_ = None
+        for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
             tp_, traffic_source = static_profile(name, wkey)
             if tp_:
                 break
@@ -782,10 +949,15 @@ def main():
     roof["traffic"], roof["traffic_source"] = traffic, traffic_source
     # what really bounds the sweep: vector-ALU issue (SQ counters of separate rocprofv3 --pmc passes, committed under profiles/)
     roof_valu = None
-    for name in ("r03_valu.json", "r03_valu_pca_direct1.json", "r03_valu_cfg5_d1.json", "r02_valu.json", "r02_valu_pca_direct1.json"):
+    for name in ("r04_valu.json", "r04_valu_pca_direct1.json", "r04_valu_cfg5_d1.json", "r03_valu.json", "r03_valu_pca_direct1.json", "r03_valu_cfg5_d1.json",
+                 "r02_valu.json", "r02_valu_pca_direct1.json"):
         valu, valu_source = static_profile(name, wkey)
         if valu:
-            roof_valu = {"bound": "valu issue", "kernel": "k_sweep", "active_frac": valu["valu_active_frac"],
+            roof_valu = {"bound": "valu issue", "kernel": "k_sweep",
+                         # calibrated (r04 on): the sweep's VALU-busy counter per elapsed cycle divided by the same ratio of a kernel that does
+                         # nothing but issue dependent-free f32 VALU work at the same occupancy -- <= 1 by construction; older files carry the raw figure
+                         "active_frac": valu.get("valu_active_frac_calibrated", valu["valu_active_frac"]),
+                         "active_frac_uncalibrated": valu["valu_active_frac"], "calibration": valu.get("calibration"),
                          "wave_insts_per_64_hits": valu["valu_wave_insts_per_64_hits"],       # one wave-instruction serves 64 (point, voxel) evaluations
                          "lane_insts_per_hit": round(valu["valu_wave_insts_per_64_hits"] / 64.0, 2),
                          "physical_hbm_frac_of_peak": valu.get("physical_hbm_frac_of_peak"), "source": valu_source}
@@ -793,16 +965,23 @@ def main():
 
     cpu, parity = (None, None)
     if a.cpu_seconds > 0 and world == 1:          # the CPU leg runs on rank 0 of the single-GPU run only
-        cpu, parity = cpu_leg(a, T, S, G, res_np, B)
+        cpu, parity = cpu_leg(a, W, G, res_np, B)
 
+    # ---- the other BASELINE configurations, in the same line (single-GPU run of the default workload family)
+    others = None
+    if world == 1 and not a.no_other_configs and not strong and W["data"] == "synthetic" and a.variant == "omp" and a.mode == "direct7" and a.resolution == 1.0:
+        others = other_configs_block(ctx, a, synth, W)
+
+    kind = "KITTI" if W["data"] == "kitti" else "synthetic HDL-64E"
     out = {
         "metric": "NDT registrations/sec (64k-pt Velodyne pairs)", "value": round(value, 2), "unit": "registrations/s",
         "n_gpus": world, "steps": steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / steps, 3),
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32 terms, f64 accumulation",
-        "data": "synthetic",
-        "config": {"workload": (f"BASELINE config 4: {total} synthetic HDL-64E scan pairs sharded round-robin over {world} GPU(s) " if strong else
-                                f"{baseline_config_name(a, N)}: batch of {a.pairs} synthetic HDL-64E scan pairs per GPU ") +
-                               f"({N} pts per cloud), ndt_{a.variant}, {a.resolution} m voxels, {a.mode.upper()}, eps 0.01, max_iter 64; "
+        "data": W["data"],
+        "config": {"workload": (f"BASELINE config 4: {total} {kind} scan pairs sharded round-robin over {world} GPU(s) " if strong else
+                                f"{baseline_config_name(a, N) if W['data'] == 'synthetic' else 'KITTI seq ' + os.path.basename(os.path.dirname(os.path.abspath(a.kitti_dir).rstrip('/')))}: "
+                                f"batch of {a.pairs} {kind} scan pairs per GPU ") +
+                               f"({N} pts per cloud{' at most' if W['data'] == 'kitti' else ''}), ndt_{a.variant}, {a.resolution} m voxels, {a.mode.upper()}, eps 0.01, max_iter 64; "
                                "one step = voxelise every target + align every pair (+ RCCL pose all-gather when N>1)",
                    "pairs_total": total, "pairs_rank0": B, "points_per_cloud": N, "neighbor_mode": a.mode, "variant": a.variant,
                    "resolution_m": a.resolution, "sharding": "pair i -> rank i mod N (round-robin)",
@@ -812,10 +991,12 @@ def main():
                    "rank0_registrations_per_s_resident_targets": round(B * steps / dt_resident, 1),
                    "target_leaf_statistics": leaf_stats,
                    "steps_chosen_by": "--steps" if a.steps is not None else "timed region sized to >= 0.5 s",
-                   "input_generation_s": round(t_gen, 2)},
+                   "input_generation_s": round(t_gen, 2), "inputs": W["generated_on"],
+                   "mean_points_per_source": round(float(np.mean(W["scnt"][:B])), 1)},
+        "world_size": pg["world_size"], "process_group": pg,
         "gather_ms_per_step": J["gather_ms_per_step"],
         "roofline": roof, "roofline_valu": roof_valu, "cpu_baseline": cpu, "parity": parity, "gather_check": J["gather_check"],
-        "config4": cfg4,
+        "config4": cfg4, "other_configs": others,
     }
     if seq_leg is not None:
         out["value_sequential"] = seq_leg["frames_per_s"]

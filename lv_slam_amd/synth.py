@@ -13,6 +13,7 @@ Range noise N(0, 0.02 m).  RNG seed = 0x5EED0000 + pair index.  Points are order
 """
 from __future__ import annotations
 
+import functools
 import math
 import numpy as np
 import torch
@@ -22,7 +23,10 @@ SLOT = 24.0
 BASE_SEED = 0x5EED0000
 
 
+@functools.lru_cache(maxsize=4096)
 def _slot_primitives(seed: int, slot: int):
+    """Primitives of one 24 m street slot (cached: a scan looks at ~11 slots and consecutive scans share all but one; the ~25 scalar
+    draws per slot were the largest single CPU cost of generating a benchmark batch).  Callers must not mutate the result."""
     rng = np.random.default_rng([seed & 0xFFFFFFFF, slot & 0xFFFFFFFF, 0xC0FFEE])
     x0 = slot * SLOT
     boxes, cyls, sph = [], [], []
@@ -63,6 +67,17 @@ def street_primitives(x_center: float, seed: int = BASE_SEED, reach: float = 130
 
 
 def beam_directions(n_azimuth: int, device, n_beams: int = 64):
+    key = (int(n_azimuth), str(device), int(n_beams))
+    d = _BEAMS.get(key)
+    if d is None:
+        d = _BEAMS[key] = _beam_directions(n_azimuth, device, n_beams)
+    return d
+
+
+_BEAMS: dict = {}
+
+
+def _beam_directions(n_azimuth: int, device, n_beams: int = 64):
     el = torch.deg2rad(torch.linspace(2.0, -24.9, n_beams, dtype=torch.float64, device=device))
     az = torch.arange(n_azimuth, dtype=torch.float64, device=device) * (2.0 * math.pi / n_azimuth)
     ce, se = torch.cos(el)[:, None], torch.sin(el)[:, None]

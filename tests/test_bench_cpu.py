@@ -67,3 +67,70 @@ def test_workload_label_names_the_baseline_config_only_when_it_is_that_config(mo
     a5d1 = args("--variant", "pca", "--mode", "direct1", "--resolution", "0.5", "--azimuth", "2048", "--pairs", "128")
     assert "DIRECT1" in bench.baseline_config_name(a5d1, 131072)
     assert bench.baseline_config_name(args("--variant", "pca", "--mode", "direct1"), 65536) == "a variation of BASELINE config 3"
+
+
+def test_gpus_n_without_a_launcher_re_executes_itself_as_n_ranks(monkeypatch):
+    """`python bench.py --gpus 8` with no WORLD_SIZE in the environment must become 8 ranks under torch.distributed.run (the driver's own
+    launch form, rendezvous on 127.0.0.1) -- never ONE rank that reports n_gpus = 1 -- and must refuse when fewer devices are visible."""
+    import bench
+    import pytest
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    a = bench.parse()
+    seen = {}
+    def fake_execve(path, argv, env):
+        seen.update(path=path, argv=list(argv), env=dict(env))
+    monkeypatch.delenv("LV_SLAM_BENCH_BACKEND", raising=False)
+    bench.self_launch(a, sys.argv[1:], visible_devices=8, execve=fake_execve)
+    cmd = seen["argv"]
+    assert seen["path"] == sys.executable and cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 <= int(cmd[cmd.index("--master-port") + 1]) < 65536
+    k = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[k + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]          # the caller's flags, untouched
+    assert "re-executed itself" in seen["env"]["LV_SLAM_BENCH_LAUNCHER"]
+    assert cmd == bench.launch_command(8, sys.argv[1:], cmd[cmd.index("--master-port") + 1])
+    with pytest.raises(SystemExit) as e:                                              # 4 devices for 8 ranks: refuse, non-zero exit
+        bench.self_launch(a, sys.argv[1:], visible_devices=4, execve=fake_execve)
+    assert e.value.code not in (0, None) and "only 4 GPU(s) visible" in str(e.value.code)
+    # a world size that contradicts --gpus is refused too (main reads WORLD_SIZE before anything else)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=1" in str(e.value.code)
+
+
+def test_hsa_ipc_mode_is_owned_by_bench_py():
+    """RCCL's intra-node transport needs the dmabuf IPC mode on these hosts; bench.py sets the variable itself, before torch starts HSA."""
+    import bench  # noqa: F401
+    assert os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index('setdefault("HSA_ENABLE_IPC_MODE_LEGACY"') < src.index("\nimport torch\n")
+
+
+def test_kitti_loader_round_trip(tmp_path):
+    """--kitti-dir's loader on a two-frame fake sequence: N x 4 f32 records, x,y,z kept bit for bit, ragged clouds packed into the
+    engine's [pair][3][pitch] rows with their counts (scripts/lidar_odom_kitti.sh:6 is the reference's use of the same files)."""
+    import numpy as np
+    import pytest
+    from lv_slam_amd import kitti
+    vel = tmp_path / "sequences" / "04" / "velodyne"
+    vel.mkdir(parents=True)
+    rng = np.random.default_rng(3)
+    a, b = rng.normal(size=(1000, 3)).astype(np.float32), rng.normal(size=(777, 3)).astype(np.float32)
+    kitti.write_frame(str(vel / "000000.bin"), a, 0.25)
+    kitti.write_frame(str(vel / "000001.bin"), b)
+    (vel / "notes.txt").write_text("not a scan")
+    files = kitti.list_frames(str(vel))
+    assert [os.path.basename(f) for f in files] == ["000000.bin", "000001.bin"]
+    assert kitti.list_frames(str(vel.parent)) == files                                # the sequence directory works too
+    assert os.path.getsize(files[0]) == 1000 * 16
+    assert np.array_equal(kitti.load_frame(files[0]), a) and np.array_equal(kitti.load_frame(files[1]), b)
+    T, S, tc, sc, pitch = kitti.pack_soa([(a, b)], "cpu")
+    assert (tc, sc, pitch) == ([1000], [777], 1024) and T.shape == (1, 3, 1024)
+    assert np.array_equal(T[0, :, :1000].numpy().T, a) and np.array_equal(S[0, :, :777].numpy().T, b)
+    assert float(S[0, :, 777:].abs().sum()) == 0.0                                    # padding is zero
+    (vel / "000002.bin").write_bytes(b"\0" * 20)                                      # 1.25 records: refuse, do not truncate
+    with pytest.raises(ValueError):
+        kitti.load_frame(str(vel / "000002.bin"))
+    with pytest.raises(FileNotFoundError):
+        kitti.list_frames(str(tmp_path / "nowhere"))

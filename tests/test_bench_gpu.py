@@ -63,15 +63,75 @@ def test_single_gpu_line_contract():
     assert d["value_sequential"] == q["frames_per_s"] > 0 and q["frames"] == 9 and q["aligns"] == 9 and q["converged"] == 8
     assert q["parity"]["frames_checked"] == 8 and q["parity"]["iterations_equal"] == 8 and q["parity"]["keyframe_decisions_equal"] == 8
     assert q["parity"]["max_dtrans_m"] < 1e-4 and q["parity"]["max_drot_rad"] < 1e-5 and q["host_round_trips_between_frames"] == 0
-    d2 = run_bench(["--pairs", "4", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-host-clouds", "--config4-pairs", "0", "--seq-frames", "0"])
-    assert "value_host_clouds" not in d2 and d2["config4"] is None and "value_sequential" not in d2
+    # the process-group record: a plain single process, one rank, no backend
+    assert d["world_size"] == 1 and d["process_group"]["backend"] is None and d["process_group"]["launcher"] == "plain process"
+    assert d["process_group"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # the secondary roofline figure (~450 flop per hit against the vector f32 peak)
+    f = r["flops"]
+    assert f["peak_tflops"] > 100 and abs(f["frac"] - f["achieved_tflops"] / f["peak_tflops"]) < 1e-3 and f["hits"] > 0
+    # the other BASELINE configurations ride along in the same line (sizes follow --pairs / --azimuth: 6 x 16,384 and 2 x 32,768 here)
+    oc = d["other_configs"]["configs"]
+    assert set(oc) == {"ndt_pca_direct1", "config5_direct7", "config5_direct1"}
+    for name, c in oc.items():
+        assert c["value"] > 0 and c["ms_per_step"] > 0 and c["steps"] >= 5 and c["timed_s"] >= 0.3, name
+        rr = c["roofline"]
+        assert rr["bound"] == "hbm" and 0 < rr["frac"] < 1.2 and rr["avg_launch_us"] > 0 and abs(rr["frac"] - rr["achieved"] / 8000.0) < 1e-3, name
+        pp = c["parity"]
+        assert pp["pairs_checked"] >= 2 and pp["iterations_equal"] == pp["pairs_checked"] and pp["max_dtrans_m"] < 1e-4 and pp["max_drot_rad"] < 1e-5, name
+    assert "DIRECT1" in oc["config5_direct1"]["workload"] and "32768 pts" in oc["config5_direct7"]["workload"]
+    d2 = run_bench(["--pairs", "4", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-host-clouds", "--config4-pairs", "0", "--seq-frames", "0",
+                    "--no-other-configs"])
+    assert "value_host_clouds" not in d2 and d2["config4"] is None and "value_sequential" not in d2 and d2["other_configs"] is None
+
+
+def test_plain_gpus_2_launches_two_ranks_by_itself():
+    """`python bench.py --gpus 2` -- no torch.distributed.run in front, no WORLD_SIZE -- must come back as a TWO-rank job (it re-executes
+    itself under the launcher), and says so: world_size as the process group reports it, the backend, who launched.  (gloo override: the
+    two ranks share this box's one GPU; with the default RCCL backend the same command refuses when fewer than two devices are visible.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["LV_SLAM_BENCH_BACKEND"] = "gloo"
+    args = ["--gpus", "2", "--pairs", "3", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--config4-pairs", "5"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["process_group"]["backend"] == "gloo" and "re-executed itself" in d["process_group"]["launcher"]
+    assert d["config"]["pairs_total"] == 6 and d["gather_check"]["pairs_gathered"] == 6 and d["gather_check"]["world_size"] == 2
+    assert d["config4"]["gather_check"]["pairs_gathered"] == 5
+    import torch
+    if torch.cuda.device_count() < 2:                       # the default backend on a one-GPU box: refuse, never a one-rank run under that name
+        env.pop("LV_SLAM_BENCH_BACKEND")
+        bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert bad.returncode != 0 and "GPU(s) visible" in bad.stderr and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
+
+
+def test_kitti_directory_as_input(tmp_path):
+    """--kitti-dir: a KITTI-shaped sequence (here five synthetic scans written as velodyne/%06d.bin, one of them cut short so the
+    clouds are ragged) -> consecutive frame pairs -> the same timed step, `data` = "kitti", parity against the oracle on the same clouds."""
+    import numpy as np
+    from lv_slam_amd import kitti, synth
+    vel = tmp_path / "sequences" / "04" / "velodyne"
+    vel.mkdir(parents=True)
+    scans, _ = synth.make_sequence(5, 256)
+    for k, sc in enumerate(scans):
+        xyz = sc.numpy()
+        kitti.write_frame(str(vel / f"{k:06d}.bin"), xyz[: len(xyz) - 1000 * (k == 2)])
+    d = run_bench(["--kitti-dir", str(vel), "--pairs", "4", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2", "--config4-pairs", "0", "--seq-frames", "0"])
+    assert d["data"] == "kitti" and "KITTI seq 04" in d["config"]["workload"] and d["config"]["pairs_total"] == 4
+    assert d["config"]["points_per_cloud"] == 16384 and 16384 - 250 - 1 < d["config"]["mean_points_per_source"] < 16384
+    p = d["parity"]
+    assert p["pairs_checked"] >= 3 and p["iterations_equal"] == p["pairs_checked"] and p["max_dtrans_m"] < 1e-4 and p["max_drot_rad"] < 1e-5
+    assert d["other_configs"] is None and "value_host_clouds" not in d
+    dp = run_bench(["--kitti-dir", str(vel), "--kitti-prefilter", "--pairs", "3", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--config4-pairs", "0", "--seq-frames", "0"])
+    assert dp["data"] == "kitti" and 0 < dp["config"]["mean_points_per_source"] < 16384 and "prefilter" in dp["config"]["inputs"]
 
 
 @pytest.mark.parametrize("extra,total", [(["--pairs", "5"], 10), (["--total-pairs", "11"], 11)])
 def test_two_ranks_on_one_gpu_gather(extra, total):
     """weak scaling (5 pairs per rank) and the config-4-literal mode with uneven shards (11 pairs: 6 + 5)."""
     d = run_bench(["--gpus", "2", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--config4-pairs", "13"] + extra, nproc=2,
-                  env_extra={"LV_SLAM_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+                  env_extra={"LV_SLAM_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["config"]["pairs_total"] == total
     assert d["scaling"] == ("strong" if "--total-pairs" in extra else "weak")
     g = d["gather_check"]
@@ -93,7 +153,7 @@ def test_single_rank_through_rccl():
     """The N > 1 code path with the backend the driver's scaling runs use (nccl = RCCL), as far as one GPU can take it: a single
     rank made to go through the process group, the records packed on the device and all_gather_into_tensor on device memory."""
     d = run_bench(["--pairs", "7", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-host-clouds", "--seq-frames", "0"],
-                  env_extra={"LV_SLAM_BENCH_FORCE_DIST": "1", "MASTER_PORT": str(free_port()), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+                  env_extra={"LV_SLAM_BENCH_FORCE_DIST": "1", "MASTER_PORT": str(free_port())})
     g = d["gather_check"]
     assert g["backend"] == "nccl" and g["host_hop"] is False and g["packed_on_device"] is True
     assert g["pairs_gathered"] == 7 and g["permutation_of_all_pair_ids"] is True and g["own_records_bit_identical_on_every_rank"] is True
@@ -106,7 +166,7 @@ def test_config4_job_on_one_gpu_parity_over_the_index_range_and_rccl_gather():
     WHOLE index range (every ~16th pair incl. 4540, not the first 271), and the single rank is made to go through RCCL so that the
     gather of 4,541 device-packed 96-byte records is checked too.  Independence of the pairs: scan_matching_odom_nodelet.cpp:240-250."""
     d = run_bench(["--total-pairs", "4541", "--steps", "3", "--warmup", "1", "--cpu-seconds", "10", "--no-host-clouds", "--seq-frames", "0"],
-                  env_extra={"LV_SLAM_BENCH_FORCE_DIST": "1", "MASTER_PORT": str(free_port()), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+                  env_extra={"LV_SLAM_BENCH_FORCE_DIST": "1", "MASTER_PORT": str(free_port())})
     assert d["scaling"] == "strong" and d["config"]["pairs_total"] == 4541 and d["config"]["pairs_rank0"] == 4541 and d["config"]["converged"] == 4541
     p = d["parity"]
     assert p["pairs_checked"] >= 285 and p["iterations_equal"] == p["pairs_checked"] and p["converged_flags_equal"] == p["pairs_checked"]
