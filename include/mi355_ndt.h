@@ -150,6 +150,34 @@ int mi355ndt_get_fitness_score(mi355ndt_handle* h, double max_range, double* sco
 /* same with an explicit transform (column-major 4x4) */
 int mi355ndt_fitness_score_T(mi355ndt_handle* h, const float T_colmajor[16], double max_range, double* score, long long* n_inliers);
 
+/* replaces calculateScore(cloud) (ndt_omp.h:232, ndt_omp_impl2.hpp:1006-1040; ndt_pca.h:244, ndt_pca_impl2.hpp:1013-1047): the negative
+ * log-likelihood of an ALREADY TRANSFORMED cloud against the target grid, all in f64: per point the radiusSearch(point, resolution)
+ * neighbourhood over the f32 leaf centroids (no nr_points re-check, voxel_grid_covariance_omp.h:505-534), per neighbour
+ * (-d1 * exp(-d2 * x'^T icov x' / 2) - d3) / neighbourhood.size(), summed and divided by cloud.size().  d1, d2, d3 are the members
+ * gauss_d1_/d2_/d3_ as the reference holds them when the call is made: the constructor's values (resolution 1.0, outlier ratio 0.55,
+ * impl2:70-76) until the first align(), after that those of the last align()'s parameters (impl2:93-100).  No caller inside lv_slam.
+ * `pts`: host records, x,y,z first, `stride_bytes` apart (typically the output cloud of align()). */
+int mi355ndt_calculate_score(mi355ndt_handle* h, const void* pts, size_t n, size_t stride_bytes, double* score);
+
+/* replaces the two static convertTransform helpers (ndt_omp.h:209-228): x = [x, y, z, roll, pitch, yaw] (f64) ->
+ * Translation3f * AngleAxisf(roll, X) * AngleAxisf(pitch, Y) * AngleAxisf(yaw, Z) as a 4x4 f32 matrix, column-major -- what
+ * Eigen::Affine3f::matrix() holds; evaluated in f32 the way Eigen 3.3 does (AngleAxis::toRotationMatrix, then the two 3x3 products).
+ * Plain host arithmetic, no device needed. */
+int mi355ndt_convert_transform(const double x[6], float out_colmajor[16]);
+
+/* Engine options that are no parameter of the reference classes. */
+enum mi355ndt_option {
+  /* Evaluation order of the three-term f32 sums inside updateDerivatives (ndt_omp_impl2.hpp:581, 594-613: 4-wide Eigen inner
+   * products whose fourth term is a structural zero).  The reference leaves that order to Eigen 3.3 and the SSE level it is
+   * built for (CMakeLists.txt:6,11); it cannot be observed without the reference's libraries.  0 (default): (t0 + t1) + t2,
+   * Eigen's scalar redux = the order every committed parity fixture was made with.  1: (t0 + t2) + t1, the lane pairing of Eigen 3.3's SSE
+   * predux<Packet4f>.  Same cost; lets a maintainer who pins the reference on a real build (tools/pin_reference/) select the
+   * order that build shows.  Poses differ in their last bits for about half of all pairs. */
+  MI355NDT_OPT_F32_SUM_ORDER = 1
+};
+int mi355ndt_set_option(mi355ndt_handle* h, int option, int value);
+int mi355ndt_get_option(const mi355ndt_handle* h, int option, int* value);
+
 /* parity hooks ------------------------------------------------------------------------------------ */
 /* one computeDerivatives sweep (ndt_omp_impl2.hpp:196-305) at tangent p = [upsilon; omega]:
  * points transformed by float(exp(p)), Jacobian from the same matrix (impl2:900-907).
@@ -243,7 +271,10 @@ typedef struct mi355ndt_seq_stats {
  * at the tail of the Newton-update kernel -- the host pumps (update, sweep) launches without waiting for any result.  Uses the
  * handle's registration parameters (the nodelet's: resolution 1.0, DIRECT1, eps 0.01, 64 iterations, :109-119) and the
  * fine-grained sweep of mi355ndt_set_latency_mode.  `stamps` = header.stamp of every frame in seconds.  out_frames: n_frames
- * records; out_results (may be NULL): the engine-level result of every frame's last align; stats (may be NULL). */
+ * records; out_results (may be NULL): the engine-level result of every frame's last align; stats (may be NULL).
+ * The call CONSUMES the handle's batch state: the frames replace whatever batch / single registration was resident (target, source,
+ * voxel grids, last align), and none is resident afterwards -- set_target / set_source again before the next align(), or use a
+ * handle of its own for the drive. */
 int mi355ndt_sequence_run(mi355ndt_handle* h, int n_frames, const void* const* clouds, const size_t* counts, size_t stride_bytes,
                           const double* stamps, const mi355ndt_seq_params* policy,
                           mi355ndt_seq_frame* out_frames, mi355ndt_result* out_results, mi355ndt_seq_stats* stats);

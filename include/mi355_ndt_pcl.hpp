@@ -57,6 +57,21 @@ class NormalDistributionsTransform : public pcl::Registration<PointSource, Point
   // not in the reference: the engine's opt-in fine-grained sweep for one registration at a time (mi355ndt_set_latency_mode) --
   // what a live nodelet wants; results stay inside the parity tolerance, the f64 summation tree is that mode's own
   inline void setLatencyMode(bool on) { mi355ndt_set_latency_mode(h_, on ? 1 : 0); }
+  // not in the reference: evaluation order of the three-term f32 sums of updateDerivatives (mi355ndt_set_option, MI355NDT_OPT_F32_SUM_ORDER)
+  inline void setF32SumOrder(int order) { mi355ndt_set_option(h_, MI355NDT_OPT_F32_SUM_ORDER, order); }
+  // ndt_omp.h:232 (impl2:1006-1040): negative log-likelihood of an already transformed cloud against the target grid
+  inline double calculateScore(const PointCloudSource& cloud) const {
+    double s = 0;
+    mi355ndt_calculate_score(h_, cloud.points.data(), cloud.points.size(), sizeof(PointSource), &s);
+    return s;
+  }
+  // ndt_omp.h:209-228: [x, y, z, roll, pitch, yaw] -> Translation * AngleAxis(roll, X) * AngleAxis(pitch, Y) * AngleAxis(yaw, Z), f32
+  static void convertTransform(const Eigen::Matrix<double, 6, 1>& x, Eigen::Matrix4f& trans) {
+    float m[16];
+    mi355ndt_convert_transform(x.data(), m);
+    trans = Eigen::Map<const Eigen::Matrix4f>(m);
+  }
+  static void convertTransform(const Eigen::Matrix<double, 6, 1>& x, Eigen::Affine3f& trans) { convertTransform(x, trans.matrix()); }
   inline double getTransformationProbability() const { return trans_probability_; }
   inline int getFinalNumIteration() const { return nr_iterations_; }
   // pclpca's getTargetCells() (ndt_pca.h:129-133) hands out the VoxelGridCovariance itself; that container lives on the GPU here,

@@ -91,6 +91,9 @@ struct mi355ndt_handle {
   int chunks_per_pair = 0;
   int rows_per_pair = 0, pts_per_chunk = CHUNK_PTS;   // stored partial rows per pair / points covered by one chunk of k_update's tree
   int items_per_pair = 0;                         // sweep work items per pair (= rows_per_pair in batch mode, 4 x rows_per_pair in latency mode)
+  int f32_sum_order = 0;                          // MI355NDT_OPT_F32_SUM_ORDER: 0 = (t0 + t1) + t2 (canonical), 1 = (t0 + t2) + t1 (Eigen 3.3 SSE predux pairing)
+  double gauss_last[3] = {0, 0, 0};               // gauss_d1_/d2_/d3_ as the constructor / the last computeTransformation left them (calculateScore reads them)
+  float* d_score_pts = nullptr; size_t score_pts_cap = 0; double* d_score_part = nullptr; size_t score_part_cap = 0;   // calculateScore workspace
   bool latency_mode = false;                      // mi355ndt_set_latency_mode
   bool seq_running = false;                       // inside mi355ndt_sequence_run
   int fine_it = 0;                                // 0: batch-mode sweep items (512 points); 1 / 2: fine items of fine_it * 64 points (latency mode)
@@ -121,7 +124,7 @@ struct mi355ndt_handle {
   static constexpr int UP_SLOTS = 16;
   UpSlot up[UP_SLOTS];
   int up_next = 0;
-  static constexpr int UP_STREAMS = 4;            // an upload rides copy stream (2 * pair + side) % UP_STREAMS: per-transfer latencies of the SDMA queues
+  static constexpr int UP_STREAMS = 4;            // an upload rides copy stream (pair + 2 * side) % UP_STREAMS: per-transfer latencies of the SDMA queues
                                                   // overlap across pairs, uploads into the same rows stay ordered
   hipStream_t copy_stream[UP_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_uploads[UP_STREAMS] = {nullptr, nullptr, nullptr, nullptr}, ev_compute = nullptr;   // copy streams -> compute stream, compute stream -> copy streams
@@ -168,13 +171,18 @@ static void build_offsets(int mode, SweepConst& sc) {
   else { sc.K = 27; sc.table = 2; }            // KDTREE: 27-cell block + centroid radius test
 }
 
+static void gauss_constants3(double outlier_ratio, float resolution, double d[3]) {
+  // ndt_omp_impl2.hpp:93-100 (and the constructor, impl2:70-76)
+  double c1 = 10 * (1 - outlier_ratio);
+  double c2 = outlier_ratio / pow((double)resolution, 3);
+  d[2] = -log(c2);
+  d[0] = -log(c1 + c2) - d[2];
+  d[1] = -2 * log((-log(c1 * exp(-0.5) + c2) - d[2]) / d[0]);
+}
 static void gauss_constants(const mi355ndt_params& p, double& d1, double& d2) {
-  // ndt_omp_impl2.hpp:93-100
-  double c1 = 10 * (1 - p.outlier_ratio);
-  double c2 = p.outlier_ratio / pow((double)p.resolution, 3);
-  double d3 = -log(c2);
-  d1 = -log(c1 + c2) - d3;
-  d2 = -2 * log((-log(c1 * exp(-0.5) + c2) - d3) / d1);
+  double d[3];
+  gauss_constants3(p.outlier_ratio, p.resolution, d);
+  d1 = d[0]; d2 = d[1];
 }
 
 static int check_params(const mi355ndt_params& p) {
@@ -294,6 +302,7 @@ int mi355ndt_create(const mi355ndt_params* params, int device, mi355ndt_handle**
   mi355ndt_handle* h = new mi355ndt_handle();
   h->device = device;
   h->prm = p;
+  gauss_constants3(0.55, 1.0f, h->gauss_last);    // the constructor's gauss_d*_ (impl2:70-76: resolution_ 1.0f, outlier_ratio_ 0.55), whatever the setters say later
   { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
   if (const char* e = std::getenv("MI355NDT_FINE_TILES")) { const int v = std::atoi(e); if (v == 1 || v == 2) h->fine_tiles = v; }
   if (const char* e = std::getenv("MI355NDT_SWEEP_DYN_SHIFT")) { const int v = std::atoi(e); if (v >= 0 && v <= 30) h->dyn_shift = v; }
@@ -328,7 +337,7 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
                   h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, h->d_words, h->d_recs, h->d_vox_idx, h->d_vox_n,
                   h->d_state, h->d_partials, h->d_guess, h->d_results, h->d_active, h->d_hook, h->d_aligned, h->d_hits, h->d_seg_start, h->d_sums,
                   h->d_cent, h->d_icov64, h->d_kdw, h->d_rs_hist, h->d_rs_offs, h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit, h->d_pf_in, h->d_pf_out, h->d_pf_keep, h->d_pf_keys,
-                  h->d_pf_vals, h->d_pf_flag, h->d_pf_pos, h->d_pf_mm, h->d_pf_grid, h->d_pf_tmp};
+                  h->d_pf_vals, h->d_pf_flag, h->d_pf_pos, h->d_pf_mm, h->d_pf_grid, h->d_pf_tmp, h->d_score_pts, h->d_score_part};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : {(void*)h->d_grid_of, (void*)h->d_seq, (void*)h->d_seq_out, (void*)h->d_stamps}) if (p) (void)hipFree(p);
   if (h->h_seq_flags) (void)hipHostFree((void*)h->h_seq_flags);
@@ -523,7 +532,7 @@ static int upload_cloud(mi355ndt_handle* h, float* d_base, size_t pitch, int pai
     std::lock_guard<std::mutex> lk(h->up_mtx);
     // the copy stream is chosen by DESTINATION (pair slot and side), not by staging slot: two uploads into the same rows -- set_source(A)
     // then set_source(B) with no build / align in between -- ride one stream and land in call order
-    hipStream_t cs = h->copy_stream[(2 * pair + (d_base == h->d_src_own ? 1 : 0)) % mi355ndt_handle::UP_STREAMS];
+    hipStream_t cs = h->copy_stream[(pair + (d_base == h->d_src_own ? 2 : 0)) % mi355ndt_handle::UP_STREAMS];   // (one-sided batches use all four streams)
     if (n) e = hipMemcpyAsync(u->d, u->h, n * 3 * sizeof(float), hipMemcpyHostToDevice, cs);
     if (e == hipSuccess) {
       k_deinterleave<<<(unsigned)((pitch + 255) / 256), 256, 0, cs>>>(u->d, (int)n, d_base + (size_t)pair * 3 * pitch, pitch);
@@ -876,23 +885,30 @@ static int launch_sweep(mi355ndt_handle* h, const SweepConst& sc, int max_pairs 
   if (h->prof) HIPCHK(h, ev_begin(h, h->ev_sweep));
 #define NDT_SWEEP_ARGS h->d_src, h->src_pitch, h->d_state, h->d_grid, h->d_words, h->d_recs, h->d_partials, h->items_per_pair, h->d_active_list, \
       h->d_ctl + h->ctl_idx, h->d_ctl + (h->ctl_idx ^ 1), sc, h->d_cent, h->d_grid_of_use
-#define NDT_LAUNCH_SWEEP(P, KK) k_sweep<P, KK><<<grid, SWEEP_THREADS, 0, h->stream>>>(NDT_SWEEP_ARGS)
-#define NDT_LAUNCH_FINE(P, KK) do { if (h->fine_it == 1) k_sweep<P, KK, 1, true><<<grid, SWEEP_THREADS, 0, h->stream>>>(NDT_SWEEP_ARGS); \
-                                    else k_sweep<P, KK, 2, true><<<grid, SWEEP_THREADS, 0, h->stream>>>(NDT_SWEEP_ARGS); } while (0)
+  // (the f32 sum order is a template parameter: the alternative order costs no instruction, only a second set of instantiations)
+#define NDT_LAUNCH_SWEEP(P, KK) do { if (h->f32_sum_order == 1) k_sweep<P, KK, 8, false, 1><<<grid, SWEEP_THREADS, 0, h->stream>>>(NDT_SWEEP_ARGS); \
+                                     else k_sweep<P, KK, 8, false, 0><<<grid, SWEEP_THREADS, 0, h->stream>>>(NDT_SWEEP_ARGS); } while (0)
+#define NDT_LAUNCH_FINE_O(P, KK, O) do { if (h->fine_it == 1) k_sweep<P, KK, 1, true, O><<<grid, SWEEP_THREADS, 0, h->stream>>>(NDT_SWEEP_ARGS); \
+                                         else k_sweep<P, KK, 2, true, O><<<grid, SWEEP_THREADS, 0, h->stream>>>(NDT_SWEEP_ARGS); } while (0)
+#define NDT_LAUNCH_FINE(P, KK) do { if (h->f32_sum_order == 1) NDT_LAUNCH_FINE_O(P, KK, 1); else NDT_LAUNCH_FINE_O(P, KK, 0); } while (0)
   if (h->fine_it) {                              // latency mode: items dealt statically over the whole grid, sized to the work there can be
     const long long items = (long long)(max_pairs > 0 ? max_pairs : h->n_pairs) * h->items_per_pair;
     grid.x = (unsigned)std::max(1LL, std::min((long long)grid.x, (items + WAVES - 1) / WAVES));
     if (sc.pca) { if (sc.K == 1) NDT_LAUNCH_FINE(true, 1); else NDT_LAUNCH_FINE(true, 7); }
     else        { if (sc.K == 1) NDT_LAUNCH_FINE(false, 1); else NDT_LAUNCH_FINE(false, 7); }
   } else if (sc.pca && sc.K == 27) {             // ndt_pca + KDTREE: order-dependent weights, the literal kernel (ndt_sweep_kd.hpp)
-    k_sweep_pca_kd<<<dim3((unsigned)h->chunks_per_pair, (unsigned)h->n_pairs), SWEEP_THREADS, 0, h->stream>>>(
-        h->d_src, h->src_pitch, h->d_state, h->d_grid, h->d_words, h->d_recs, h->d_cent, h->d_kdw, h->d_partials, h->chunks_per_pair,
-        h->d_active_list, h->d_ctl + h->ctl_idx, h->d_ctl + (h->ctl_idx ^ 1), sc);
+#define NDT_KD_ARGS h->d_src, h->src_pitch, h->d_state, h->d_grid, h->d_words, h->d_recs, h->d_cent, h->d_kdw, h->d_partials, h->chunks_per_pair, \
+        h->d_active_list, h->d_ctl + h->ctl_idx, h->d_ctl + (h->ctl_idx ^ 1), sc
+    const dim3 kdgrid((unsigned)h->chunks_per_pair, (unsigned)h->n_pairs);
+    if (h->f32_sum_order == 1) k_sweep_pca_kd<1><<<kdgrid, SWEEP_THREADS, 0, h->stream>>>(NDT_KD_ARGS);
+    else k_sweep_pca_kd<0><<<kdgrid, SWEEP_THREADS, 0, h->stream>>>(NDT_KD_ARGS);
+#undef NDT_KD_ARGS
   } else if (sc.pca) { if (sc.K == 1) NDT_LAUNCH_SWEEP(true, 1); else if (sc.K == 7) NDT_LAUNCH_SWEEP(true, 7); else NDT_LAUNCH_SWEEP(true, 26); }
   else        { if (sc.K == 1) NDT_LAUNCH_SWEEP(false, 1); else if (sc.K == 7) NDT_LAUNCH_SWEEP(false, 7); else if (sc.K == 26) NDT_LAUNCH_SWEEP(false, 26);
                 else NDT_LAUNCH_SWEEP(false, 27); }
 #undef NDT_LAUNCH_SWEEP
 #undef NDT_LAUNCH_FINE
+#undef NDT_LAUNCH_FINE_O
 #undef NDT_SWEEP_ARGS
   h->ctl_idx ^= 1;                                // the block this sweep zeroed is the one the next update fills
   if (h->prof) HIPCHK(h, ev_end(h, h->ev_sweep));
@@ -911,12 +927,17 @@ static int batch_align_impl(mi355ndt_handle* h, const float* guesses, mi355ndt_r
 int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_result* out) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   const int rc = batch_align_impl(h, guesses, out);
-  if (rc != MI355NDT_OK && h->ev_compute) (void)compute_enqueued(h);      // see mi355ndt_batch_build_targets
+  if (rc != MI355NDT_OK) {
+    // an error exit may leave (update, sweep) rounds queued: drain them, so that no sweep of THIS align can post its progress words
+    // into the flags the next align resets (the latency-mode pump restarts its sequence numbers at 1)
+    (void)hipStreamSynchronize(h->stream);
+    if (h->ev_compute) (void)compute_enqueued(h);                         // see mi355ndt_batch_build_targets
+  }
   return rc;
 }
 static int ensure_seq_flags(mi355ndt_handle* h) {
   if (!h->h_seq_flags) {
-    HIPCHK(h, hipHostMalloc((void**)&h->h_seq_flags, 64, hipHostMallocMapped));
+    HIPCHK(h, hipHostMalloc((void**)&h->h_seq_flags, 64, hipHostMallocMapped | hipHostMallocCoherent));   // fine-grained: device writes are visible to the polling host
     HIPCHK(h, hipHostGetDevicePointer((void**)&h->d_seq_flags, (void*)h->h_seq_flags, 0));
   }
   return MI355NDT_OK;
@@ -946,7 +967,8 @@ static int align_pump(mi355ndt_handle* h, SweepConst sc, int B) {
     if (seen != seen_last) { seen_last = seen; t_progress = std::chrono::steady_clock::now(); }
     if (enq >= max_rounds || enq + 1 - seen >= depth) {
       if (std::chrono::steady_clock::now() - t_progress > std::chrono::seconds(20)) { h->err = "align: the device stopped making progress"; return MI355NDT_ERR_STATE; }
-      continue;                                  // (busy-wait: a round is ~20 us, a yield costs more than it gives)
+      __builtin_ia32_pause();                    // (busy-wait: a round is ~20 us, a yield costs more than it gives; pause frees the sibling hyperthread)
+      continue;
     }
     k_update<<<B, UPD_THREADS, 0, s>>>(h->d_state, h->d_partials, h->rows_per_pair, h->pts_per_chunk, 1, h->d_results, h->d_active,
                                        h->d_active_list, h->d_ctl + h->ctl_idx, h->prof ? h->d_hits : nullptr, h->prm.step_size, h->prm.trans_epsilon,
@@ -973,6 +995,7 @@ static int batch_align_impl(mi355ndt_handle* h, const float* guesses, mi355ndt_r
   hipStream_t s = h->stream;
   SweepConst sc;
   make_sweep_const(h, sc);
+  gauss_constants3(h->prm.outlier_ratio, h->prm.resolution, h->gauss_last);     // computeTransformation sets the members (impl2:93-100)
   // the engine's stream is idle here (every entry point returns synchronised), so the pinned staging copy is free to overwrite
   h->ev_last_fresh = false;
   memcpy(h->h_pin_guess, guesses, (size_t)B * 16 * sizeof(float));
@@ -1388,6 +1411,95 @@ int mi355ndt_get_fitness_score(mi355ndt_handle* h, double max_range, double* sco
   return mi355ndt_fitness_score_T(h, h->last_final, max_range, score, n_inliers);
 }
 
+// replaces calculateScore(cloud) (ndt_omp.h:232, ndt_omp_impl2.hpp:1006-1040)
+int mi355ndt_calculate_score(mi355ndt_handle* h, const void* pts, size_t n, size_t stride, double* score) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (!score || (!pts && n) || (n && stride < 12) || n >= (1u << 31)) return MI355NDT_ERR_BAD_ARG;
+  if (h->n_pairs != 1 || !h->have_target || h->h_tgt_cnt[0] <= 0) return MI355NDT_ERR_STATE;
+  if (n == 0) { *score = std::nan(""); return MI355NDT_OK; }                     // 0 / 0 in the reference
+  HIPCHK(h, hipSetDevice(h->device));
+  { int rcu = uploads_before_compute(h); if (rcu) return rcu; }
+  if (!h->targets_built || !h->cent_built || !h->icov64_built) {                // f32 centroids + f64 inverse covariances: the "live" build flavour
+    const mi355ndt_params keep = h->prm;
+    h->prm.step_size = 0; h->prm.trans_epsilon = 0;
+    const int rc = mi355ndt_batch_build_targets(h);
+    h->prm = keep;
+    if (rc) return rc;
+  }
+  const size_t pitch = (n + 63) & ~(size_t)63;
+  HIPCHK(h, grow(h->d_score_pts, h->score_pts_cap, 3 * pitch));
+  const int blocks = (int)((n + SCORE_THREADS - 1) / SCORE_THREADS);
+  HIPCHK(h, grow(h->d_score_part, h->score_part_cap, (size_t)blocks));
+  int rc = upload_cloud(h, h->d_score_pts, pitch, 0, pts, n, stride);
+  if (rc) return rc;
+  rc = uploads_before_compute(h);
+  if (rc) return rc;
+  SweepConst sc;
+  make_sweep_const(h, sc);
+  hipStream_t s = h->stream;
+  k_calc_score<<<blocks, SCORE_THREADS, 0, s>>>(h->d_score_pts, pitch, (int)n, h->d_grid, h->d_words, h->d_recs, h->d_icov64, h->d_cent,
+                                                h->gauss_last[0], h->gauss_last[1], h->gauss_last[2], sc.kd_r2, sc.leaf_pow2, sc.inv_leaf, h->d_score_part);
+  std::vector<double> part((size_t)blocks);
+  HIPCHK(h, hipMemcpyAsync(part.data(), h->d_score_part, part.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  HIPCHK(h, hipGetLastError());
+  double sum = 0;
+  for (int b = 0; b < blocks; b++) sum += part[(size_t)b];
+  *score = sum / (double)n;                                                      // impl2:1040
+  return compute_enqueued(h);
+}
+
+// replaces the static convertTransform helpers (ndt_omp.h:209-228); f32, the way Eigen 3.3 evaluates
+// Translation3f * AngleAxisf(X) * AngleAxisf(Y) * AngleAxisf(Z) (third-party, restated from its published algorithm: AngleAxis::toRotationMatrix,
+// Transform::rotate = linear() * R with coefficient-wise 3x3 products, a 3-term sum reduced as t0 + (t1 + t2))
+static void aa_matrix(float angle, int axis, float R[9]) {
+  const float ax[3] = {axis == 0 ? 1.f : 0.f, axis == 1 ? 1.f : 0.f, axis == 2 ? 1.f : 0.f};
+  const float sn = sinf(angle), c = cosf(angle);
+  const float sa[3] = {sn * ax[0], sn * ax[1], sn * ax[2]};
+  const float c1[3] = {(1.f - c) * ax[0], (1.f - c) * ax[1], (1.f - c) * ax[2]};
+  float tmp = c1[0] * ax[1];
+  R[0 * 3 + 1] = tmp - sa[2]; R[1 * 3 + 0] = tmp + sa[2];
+  tmp = c1[0] * ax[2];
+  R[0 * 3 + 2] = tmp + sa[1]; R[2 * 3 + 0] = tmp - sa[1];
+  tmp = c1[1] * ax[2];
+  R[1 * 3 + 2] = tmp - sa[0]; R[2 * 3 + 1] = tmp + sa[0];
+  for (int a = 0; a < 3; a++) R[a * 3 + a] = c1[a] * ax[a] + c;
+}
+static void mul33(const float A[9], const float B[9], float C[9]) {
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) C[r * 3 + c] = A[r * 3 + 0] * B[0 * 3 + c] + (A[r * 3 + 1] * B[1 * 3 + c] + A[r * 3 + 2] * B[2 * 3 + c]);
+}
+int mi355ndt_convert_transform(const double x[6], float out[16]) {
+  if (!x || !out) return MI355NDT_ERR_BAD_ARG;
+  float Rx[9], Ry[9], Rz[9], A[9], L[9];
+  aa_matrix((float)x[3], 0, Rx); aa_matrix((float)x[4], 1, Ry); aa_matrix((float)x[5], 2, Rz);
+  mul33(Rx, Ry, A);
+  mul33(A, Rz, L);
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) out[c * 4 + r] = L[r * 3 + c];
+    out[12 + r] = (float)x[r];
+    out[r * 4 + 3] = 0.f;
+  }
+  out[15] = 1.f;
+  return MI355NDT_OK;
+}
+
+int mi355ndt_set_option(mi355ndt_handle* h, int option, int value) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (option == MI355NDT_OPT_F32_SUM_ORDER) {
+    if (value != 0 && value != 1) return MI355NDT_ERR_BAD_ARG;
+    h->f32_sum_order = value;
+    return MI355NDT_OK;
+  }
+  return MI355NDT_ERR_BAD_ARG;
+}
+int mi355ndt_get_option(const mi355ndt_handle* h, int option, int* value) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (!value) return MI355NDT_ERR_BAD_ARG;
+  if (option == MI355NDT_OPT_F32_SUM_ORDER) { *value = h->f32_sum_order; return MI355NDT_OK; }
+  return MI355NDT_ERR_BAD_ARG;
+}
+
 // replaces PrefilteringNodelet::distance_filter + downsample (prefiltering_nodelet.cpp:137-181)
 int mi355ndt_prefilter(mi355ndt_handle* h, const void* pts, size_t n, size_t stride,
                        int use_distance_filter, double distance_near, double distance_far, float downsample_resolution,
@@ -1592,6 +1704,7 @@ int mi355ndt_sequence_run(mi355ndt_handle* h, int n_frames, const void* const* c
   h->d_grid_of_use = h->d_grid_of;
   SweepConst sc;
   make_sweep_const(h, sc);
+  gauss_constants3(h->prm.outlier_ratio, h->prm.resolution, h->gauss_last);
   k_seq_begin<<<1, 64, 0, s>>>(h->d_seq, h->d_state, h->d_grid, h->d_src_cnt, h->d_stamps, h->d_seq_out, h->d_active_list, h->d_ctl, h->d_grid_of, h->d_seq_flags);
   rc = launch_sweep(h, sc, 1);
   // The pump: (update, sweep), (update, sweep), ... enqueued blindly, at most `depth` rounds ahead of what the device has executed;

@@ -125,3 +125,63 @@ k_hessian(const float* __restrict__ src, size_t pitch, const PairState* __restri
     for (int qd = 1; qd < QUARTERS; qd++) P[qd * NACC + 7 + a] = 0.0;
   }
 }
+
+
+// ------------------------------------------------------------------------------------ calculateScore
+// calculateScore (include/ndt_omp/ndt_omp_impl2.hpp:1006-1040; ndt_pca_impl2.hpp:1013-1047): negative log-likelihood of an already
+// transformed cloud, f64 throughout, kd-tree neighbourhoods (27-cell probe + centroid radius test = radiusSearch, as in k_hessian).
+// One lane per point: the neighbours are counted first (the reference divides every term by neighborhood.size(), impl2:1036), then
+// summed; per-block partial sums with a fixed tree, added in block order on the host.  No caller in lv_slam: fidelity, not speed.
+#define SCORE_THREADS 256
+__global__ void __launch_bounds__(SCORE_THREADS)
+k_calc_score(const float* __restrict__ pts, size_t pitch, int n, const GridDesc* __restrict__ gd, const BitWord* __restrict__ words,
+             const VoxelRec* __restrict__ recs, const double* __restrict__ icov64, const float* __restrict__ cent,
+             double d1, double d2, double d3, float kd_r2, int leaf_pow2, float inv_leaf, double* part) {
+  const GridDesc& g = gd[0];
+  const BitWord* W = words + g.word_off;
+  const VoxelRec* R = recs + g.rec_off;
+  const double* IC = icov64 + (size_t)g.rec_off * 9;
+  const float* CE = cent + (size_t)g.rec_off * 3;
+  __shared__ double red[SCORE_THREADS / 64];
+  const int i = blockIdx.x * SCORE_THREADS + threadIdx.x;
+  double s = 0.0;
+  if (i < n && g.status == GRID_OK) {
+    const float xt[3] = {pts[i], pts[pitch + i], pts[2 * pitch + i]};
+    if (finite3(xt[0], xt[1], xt[2])) {
+      const int c0 = (int)floorf(leaf_pow2 ? xt[0] * inv_leaf : xt[0] / g.leaf);
+      const int c1 = (int)floorf(leaf_pow2 ? xt[1] * inv_leaf : xt[1] / g.leaf);
+      const int c2 = (int)floorf(leaf_pow2 ? xt[2] * inv_leaf : xt[2] / g.leaf);
+      unsigned ids[27];
+      int m = 0;
+      for (int q = 0; q < 27; q++) {
+        const int q0 = c0 + (q % 3 - 1), q1 = c1 + ((q / 3) % 3 - 1), q2 = c2 + (q / 9 - 1);
+        if (q0 < g.min_b[0] || q0 > g.max_b[0] || q1 < g.min_b[1] || q1 > g.max_b[1] || q2 < g.min_b[2] || q2 > g.max_b[2]) continue;
+        const unsigned cell = (unsigned)((q0 - g.min_b[0]) + (q1 - g.min_b[1]) * g.mul1 + (q2 - g.min_b[2]) * g.mul2);
+        const BitWord bw = W[cell >> 6];
+        if (!((bw.bits >> (cell & 63u)) & 1ull)) continue;
+        const unsigned id = bw.prefix + (unsigned)__popcll(bw.bits & ((1ull << (cell & 63u)) - 1ull));
+        const float dx = xt[0] - CE[3 * id], dy = xt[1] - CE[3 * id + 1], dz = xt[2] - CE[3 * id + 2];
+        if (!(((dx * dx + dy * dy) + dz * dz) < kd_r2)) continue;          // radiusSearch: strict <, no nr_points re-check
+        ids[m++] = id;
+      }
+      const double cnt = (double)m;
+      for (int k = 0; k < m; k++) {
+        const unsigned id = ids[k];
+        const VoxelRec& vr = R[id];
+        const double u[3] = {(double)xt[0] - vr.mean[0], (double)xt[1] - vr.mean[1], (double)xt[2] - vr.mean[2]};   // impl2:1025-1028
+        double Cu[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) Cu[a] = (IC[(size_t)id * 9 + a * 3 + 0] * u[0] + IC[(size_t)id * 9 + a * 3 + 1] * u[1]) + IC[(size_t)id * 9 + a * 3 + 2] * u[2];
+        const double e = exp(-d2 * ((u[0] * Cu[0] + u[1] * Cu[1]) + u[2] * Cu[2]) / 2);   // impl2:1033
+        const double inc = -d1 * e - d3;                                                 // impl2:1035
+        s += inc / cnt;                                                                  // impl2:1037
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) red[wv] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}

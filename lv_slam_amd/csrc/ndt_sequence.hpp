@@ -131,7 +131,7 @@ k_seq_update(SeqState* seq, PairState* st, const double* __restrict__ partials, 
   seqm::inv4(Q.pre_tf_s2k, inv);
   seqm::mul4(inv, tf, s2s);                                                      // tf_s2s = pre_tf_s2k.inverse() * tf_s2k (:231)
   seqm::mul4(Q.key_pose, tf, odom);                                              // odom_velo = key_pose * tf_s2k (:234)
-  const double dx = sqrt((tf[3] * tf[3] + tf[7] * tf[7]) + tf[11] * tf[11]);      // :237
+  const double dx = sqrt(tf[3] * tf[3] + (tf[7] * tf[7] + tf[11] * tf[11]));      // :237 (Eigen 3.3's unrolled 3-vector redux: x0^2 + (x1^2 + x2^2))
   float Rf[9];
   for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Rf[r * 3 + c] = F[c * 4 + r];
   const double da = (double)(2.f * acosf(seqm::quat_w_f32(Rf)));                 // :238: std::acos(float) -> float, times int

@@ -17,7 +17,16 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // SAN (KDTREE modes only): radiusSearch also returns leaves whose inverse covariance is non-finite (no nr_points re-check,
 // voxel_grid_covariance_omp.h:505-534); the reference rejects such a hit before touching the sums (impl2:588-589), so the
 // operands of a rejected hit are zeroed first -- "e = 0" alone would still add 0 * NaN.
-template <bool PCA, typename Mid = NoHook, bool SAN = false>
+// ORD: evaluation order of the three-term f32 sums of impl2:581, 594-613 (4-wide Eigen inner products whose fourth term is a structural
+// zero).  The reference leaves it to Eigen 3.3 and the SSE level it is compiled for (CMakeLists.txt:6,11: -msse4.2), and neither can
+// be observed here.  0 = (t0 + t1) + t2: Eigen's scalar redux, the canonical choice of the committed parity fixtures;
+// 1 = (t0 + t2) + t1: the lane pairing of Eigen 3.3's SSE predux<Packet4f>, (a0 + a2) + (a1 + a3) with a3 = 0.  Same instruction count
+// either way; selected per engine with mi355ndt_set_option(MI355NDT_OPT_F32_SUM_ORDER) so that a maintainer who pins the reference on
+// a real build (tools/pin_reference) can switch to the order that build shows.
+template <int ORD>
+__device__ __forceinline__ float sum3(float t0, float t1, float t2) { return ORD == 1 ? (t0 + t2) + t1 : (t0 + t1) + t2; }
+
+template <bool PCA, typename Mid = NoHook, bool SAN = false, int ORD = 0>
 __device__ __forceinline__ void eval_hit(const float u_in[3], const float r[3], const float C_in[9],
                                          const double d1, const float d2f, const double w, const bool ok_in, double acc[43],
                                          const double* __restrict__ exp_tab, Mid mid = Mid()) {
@@ -26,8 +35,8 @@ __device__ __forceinline__ void eval_hit(const float u_in[3], const float r[3], 
   for (int a = 0; a < 9; a++) C[a] = C_in[a];
   float y[3];
 #pragma unroll
-  for (int j = 0; j < 3; j++) y[j] = (u[0] * C[j] + u[1] * C[3 + j]) + u[2] * C[6 + j];
-  const float qf = (u[0] * y[0] + u[1] * y[1]) + u[2] * y[2];
+  for (int j = 0; j < 3; j++) y[j] = sum3<ORD>(u[0] * C[j], u[1] * C[3 + j], u[2] * C[6 + j]);
+  const float qf = sum3<ORD>(u[0] * y[0], u[1] * y[1], u[2] * y[2]);
   const float e0 = ndtm::exp_f32arg((-d2f * qf) * 0.5f, exp_tab);                // impl2:581: exp in f64 on the f32 argument, rounded to f32
   float s_inc = (float)(-d1 * (double)e0);                                       // impl2:583
   const float e1 = d2f * e0;                                                     // impl2:585
@@ -54,7 +63,7 @@ __device__ __forceinline__ void eval_hit(const float u_in[3], const float r[3], 
   }
   float v[6];
 #pragma unroll
-  for (int k = 0; k < 6; k++) v[k] = (u[0] * CJ[0][k] + u[1] * CJ[1][k]) + u[2] * CJ[2][k];   // impl2:595
+  for (int k = 0; k < 6; k++) v[k] = sum3<ORD>(u[0] * CJ[0][k], u[1] * CJ[1][k], u[2] * CJ[2][k]);   // impl2:595
   // w * term: the product is a single rounding away from the reference's nested multiplies (both ~1e-16)
 #define NDT_ACC(slot, val) do { if (PCA) acc[slot] = fma(w, (double)(val), acc[slot]); else acc[slot] += (double)(val); } while (0)
   NDT_ACC(0, s_inc);
@@ -154,7 +163,7 @@ static inline int sweep_wpe(bool pca, int K) { (void)pca; (void)K; return SWEEP_
 // points: its own fixed tree, not the batch mode's (results agree to the f64 rounding of the sums, ~1e-16 relative).
 // `grid_of` (may be null): pair b is aligned against the target grid gd[grid_of[b]] instead of gd[b] (sequence mode: the frames'
 // grids are built once, the keyframe policy picks which one a frame is matched against).
-template <bool PCA, int K, int IT = 8, bool FINE = false>
+template <bool PCA, int K, int IT = 8, bool FINE = false, int ORD = 0>
 __global__ void __launch_bounds__(SWEEP_THREADS, (SweepTune<PCA, K>::WPE))
 k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict__ st,
         const GridDesc* __restrict__ gd, const BitWord* __restrict__ words, const VoxelRec* __restrict__ recs,
@@ -305,7 +314,7 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
       // ndt_omp: leaves with nr_points = -1 (eigen / inverse failure) are not neighbours (impl:395): filtered here
       const bool live = lane < m && (PCAQ || KD || B.weight != VOX_DEAD);
       float u[3] = {(float)((double)xt0 - B.m0), (float)((double)xt1 - B.m1), (float)((double)xt2 - B.m2)};   // impl2:276-279, 574
-      eval_hit<PCA, decltype(mid), KD>(u, r, B.C, sc.d1, sc.d2f, B.w, live, acc, exp_tab, mid);
+      eval_hit<PCA, decltype(mid), KD, ORD>(u, r, B.C, sc.d1, sc.d2f, B.w, live, acc, exp_tab, mid);
       nhits += PCAQ ? (unsigned)m : (unsigned)__popcll(__ballot(live));
       qhead = (qhead + m) & (Q_CAP - 1);
       qcount -= m;

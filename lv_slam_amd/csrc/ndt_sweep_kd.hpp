@@ -9,6 +9,7 @@
 #include "ndt_math.hpp"
 #include "ndt_sweep.hpp"
 
+template <int ORD>
 __global__ void __launch_bounds__(SWEEP_THREADS)
 k_sweep_pca_kd(const float* __restrict__ src, size_t pitch, const PairState* __restrict__ st, const GridDesc* __restrict__ gd,
                const BitWord* __restrict__ words, const VoxelRec* __restrict__ recs, const float* __restrict__ cent,
@@ -79,7 +80,7 @@ k_sweep_pca_kd(const float* __restrict__ src, size_t pitch, const PairState* __r
         float Cf[9];
 #pragma unroll
         for (int a = 0; a < 9; a++) Cf[a] = vr.icov[a];
-        eval_hit<false, NoHook, true>(u, r, Cf, sc.d1, sc.d2f, 1.0, true, pt, exp_tab);
+        eval_hit<false, NoHook, true, ORD>(u, r, Cf, sc.d1, sc.d2f, 1.0, true, pt, exp_tab);
         const double w = (double)KW[ids[k]];                     // (int)dimension_2d_, 0 for an eigen-failed leaf
 #pragma unroll
         for (int a = 0; a < 43; a++) pt[a] *= w;

@@ -82,7 +82,9 @@ SYMBOLS = [
     "mi355ndt_batch_build_targets", "mi355ndt_batch_align", "mi355ndt_batch_size", "mi355ndt_batch_pose_records",
     "mi355ndt_profile_enable", "mi355ndt_profile_reset", "mi355ndt_profile_get", "mi355ndt_synchronize",
     "mi355ndt_set_latency_mode", "mi355ndt_sequence_run",
+    "mi355ndt_calculate_score", "mi355ndt_convert_transform", "mi355ndt_set_option", "mi355ndt_get_option",
 ]
+OPT_F32_SUM_ORDER = 1          # mi355ndt_option: 0 = (t0 + t1) + t2 (canonical), 1 = (t0 + t2) + t1 (Eigen 3.3 SSE predux pairing)
 
 _LIB = None
 
@@ -136,6 +138,10 @@ def load_library(path: str = LIB_PATH):
     L.mi355ndt_synchronize.argtypes = [vp]
     L.mi355ndt_set_latency_mode.argtypes = [vp, i]
     L.mi355ndt_sequence_run.argtypes = [vp, i, vp, vp, sz, vp, C.POINTER(SeqParams), vp, vp, C.POINTER(SeqStats)]
+    L.mi355ndt_calculate_score.argtypes = [vp, vp, sz, sz, C.POINTER(C.c_double)]
+    L.mi355ndt_convert_transform.argtypes = [vp, vp]
+    L.mi355ndt_set_option.argtypes = [vp, i, i]
+    L.mi355ndt_get_option.argtypes = [vp, i, C.POINTER(i)]
     _LIB = L
     return L
 
@@ -241,6 +247,21 @@ class Engine:
             t = _colmajor(T)
             self._chk(self.lib.mi355ndt_fitness_score_T(self.h, t.ctypes.data_as(C.c_void_p), mr, C.byref(s), C.byref(n)), "fitness_score_T")
         return s.value, n.value
+
+    def calculate_score(self, cloud) -> float:
+        """calculateScore(cloud) (ndt_omp.h:232): negative log-likelihood of an ALREADY TRANSFORMED cloud against the target grid."""
+        a = _as_points(cloud)
+        s = C.c_double()
+        self._chk(self.lib.mi355ndt_calculate_score(self.h, a.ctypes.data_as(C.c_void_p), a.shape[0], a.strides[0] if a.shape[0] else 12, C.byref(s)), "calculate_score")
+        return s.value
+
+    def set_option(self, option: int, value: int):
+        self._chk(self.lib.mi355ndt_set_option(self.h, option, value), "set_option")
+
+    def get_option(self, option: int) -> int:
+        v = C.c_int()
+        self._chk(self.lib.mi355ndt_get_option(self.h, option, C.byref(v)), "get_option")
+        return v.value
 
     def prefilter(self, cloud, distance_near=0.5, distance_far=100.0, downsample_resolution=0.1, use_distance_filter=True,
                   fetch=True):
@@ -505,6 +526,27 @@ class NormalDistributionsTransform:
 
     def getFinalTransformation(self) -> np.ndarray:
         return self._final.copy()
+
+    def calculateScore(self, cloud) -> float:
+        """ndt_omp.h:232 / ndt_pca.h:244: negative log-likelihood of an already transformed cloud (lower is better)."""
+        if not self._has_target:
+            raise NDTError(-7, "calculateScore")
+        return self._eng.calculate_score(cloud)
+
+    @staticmethod
+    def convertTransform(x) -> np.ndarray:
+        """static convertTransform (ndt_omp.h:209-228): [x, y, z, roll, pitch, yaw] -> 4x4 f32 (Translation * Rx * Ry * Rz)."""
+        v = np.ascontiguousarray(x, np.float64)
+        if v.shape != (6,):
+            raise ValueError("x must have six entries: x, y, z, roll, pitch, yaw")
+        out = np.zeros(16, np.float32)
+        rc = load_library().mi355ndt_convert_transform(v.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        if rc != OK:
+            raise NDTError(rc, "convert_transform")
+        return out.reshape(4, 4).T.copy()
+
+    def setF32SumOrder(self, order: int):              # not in the reference: mi355ndt_set_option(MI355NDT_OPT_F32_SUM_ORDER)
+        self._eng.set_option(OPT_F32_SUM_ORDER, int(order))
 
     def getLastIncrementalTransformation(self) -> np.ndarray:
         """pcl::Registration::getLastIncrementalTransformation(): transformation_ = f32 exp(delta_p) of the last step (impl2:163)."""

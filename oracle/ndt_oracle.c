@@ -956,6 +956,67 @@ void ora_compute_hessian(const ora_grid* g, const ora_params* prm,
   }
 }
 
+/* calculateScore (ndt_omp_impl2.hpp:1006-1040; identical in ndt_pca_impl2.hpp:1013-1047): negative log-likelihood of an ALREADY
+ * TRANSFORMED cloud.  f64 throughout; neighbourhoods from radiusSearch(point, resolution) (distance order, no nr_points re-check);
+ * every term divided by neighborhood.size() (impl2:1037); the running sum in (point, neighbour) order; / cloud.size() (impl2:1040).
+ * gauss = {d1, d2, d3}: the members gauss_d1_/d2_/d3_ at the time of the call (constructor values before the first align, impl2:70-76). */
+double ora_calculate_score(const ora_grid* g, const double gauss[3], float resolution,
+                           const float* x, const float* y, const float* z, size_t n) {
+  double score = 0;
+  for (size_t i = 0; i < n; i++) {
+    const float xt[3] = {x[i], y[i], z[i]};
+    if (!finite3(xt[0], xt[1], xt[2])) continue;                  /* FLANN on a non-finite query: canonical choice = no neighbours */
+    kd_hit hits[64];
+    const int kh = g ? radius_search(g, xt, (double)resolution, hits, 64) : 0;
+    for (int k = 0; k < kh; k++) {
+      const ora_leaf* L = &g->leaves[hits[k].li];
+      double u[3];
+      for (int a = 0; a < 3; a++) u[a] = (double)xt[a] - L->mean[a];                          /* impl2:1025-1028 */
+      const double* C = L->icov;
+      double Cu[3];
+      for (int a = 0; a < 3; a++) Cu[a] = (C[a * 3 + 0] * u[0] + C[a * 3 + 1] * u[1]) + C[a * 3 + 2] * u[2];
+      const double e = exp(-gauss[1] * ((u[0] * Cu[0] + u[1] * Cu[1]) + u[2] * Cu[2]) / 2);   /* impl2:1033 */
+      const double inc = -gauss[0] * e - gauss[2];                                           /* impl2:1035 */
+      score += inc / (double)kh;                                                             /* impl2:1037 */
+    }
+  }
+  return score / (double)n;                                                                  /* impl2:1040 */
+}
+
+/* the static convertTransform helpers (ndt_omp.h:209-228): Translation3f * AngleAxisf(roll, X) * AngleAxisf(pitch, Y) * AngleAxisf(yaw, Z),
+ * f32, as Eigen 3.3 evaluates it (third-party, not in the tree; restated from its published algorithm: AngleAxis::toRotationMatrix --
+ * sin_axis = sin(a) * axis, cos1_axis = (1 - cos a) * axis, off-diagonals tmp -/+ sin_axis, diagonal cos1_axis * axis + c -- then
+ * Transform::rotate = linear() * R, coefficient-wise 3x3 products whose 3-term sums reduce as t0 + (t1 + t2)).  out: 4x4 column-major. */
+static void aa_matrix_f(float angle, int axis, float R[9]) {
+  const float ax[3] = {axis == 0 ? 1.f : 0.f, axis == 1 ? 1.f : 0.f, axis == 2 ? 1.f : 0.f};
+  const float sn = sinf(angle), c = cosf(angle);
+  const float sa[3] = {sn * ax[0], sn * ax[1], sn * ax[2]};
+  const float c1[3] = {(1.f - c) * ax[0], (1.f - c) * ax[1], (1.f - c) * ax[2]};
+  float tmp = c1[0] * ax[1];
+  R[0 * 3 + 1] = tmp - sa[2]; R[1 * 3 + 0] = tmp + sa[2];
+  tmp = c1[0] * ax[2];
+  R[0 * 3 + 2] = tmp + sa[1]; R[2 * 3 + 0] = tmp - sa[1];
+  tmp = c1[1] * ax[2];
+  R[1 * 3 + 2] = tmp - sa[0]; R[2 * 3 + 1] = tmp + sa[0];
+  for (int a = 0; a < 3; a++) R[a * 3 + a] = c1[a] * ax[a] + c;
+}
+static void mul33_f(const float A[9], const float B[9], float C[9]) {
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) C[r * 3 + c] = A[r * 3 + 0] * B[0 * 3 + c] + (A[r * 3 + 1] * B[1 * 3 + c] + A[r * 3 + 2] * B[2 * 3 + c]);
+}
+void ora_convert_transform(const double x[6], float out[16]) {
+  float Rx[9], Ry[9], Rz[9], A[9], L[9];
+  aa_matrix_f((float)x[3], 0, Rx); aa_matrix_f((float)x[4], 1, Ry); aa_matrix_f((float)x[5], 2, Rz);
+  mul33_f(Rx, Ry, A);
+  mul33_f(A, Rz, L);
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) out[c * 4 + r] = L[r * 3 + c];
+    out[12 + r] = (float)x[r];
+    out[r * 4 + 3] = 0.f;
+  }
+  out[15] = 1.f;
+}
+
 /* std::min / std::max as the reference's libstdc++ evaluates them: a NaN first argument is returned unchanged */
 static double cmin(double a, double b) { return b < a ? b : a; }
 static double cmax(double a, double b) { return a < b ? b : a; }
@@ -1164,7 +1225,8 @@ int ora_policy_step(double pre_tf_s2k[16], double key_pose[16], double* keyframe
   inv4(pre_tf_s2k, inv);
   mul4(inv, tf, s2s);                                                            /* :231 */
   mul4(key_pose, tf, odom);                                                      /* :234 */
-  const double dx = sqrt((tf[3] * tf[3] + tf[7] * tf[7]) + tf[11] * tf[11]);      /* :237 */
+  /* :237 block<3,1>(0,3).norm(): Eigen 3.3's unrolled redux of a fixed 3-vector is x0^2 + (x1^2 + x2^2) (same tree as ORA_VAR_NORM_TREE notes for mean_.norm()) */
+  const double dx = sqrt(tf[3] * tf[3] + (tf[7] * tf[7] + tf[11] * tf[11]));
   float Rf[9];
   for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Rf[r * 3 + c] = final_cm[c * 4 + r];
   const double da = (double)(2.f * acosf(quat_w_f32(Rf)));                       /* :238: std::acos(float) is the float overload */

@@ -112,6 +112,12 @@ void ora_compute_hessian(const ora_grid* g, const ora_params* prm,
                          const float* x, const float* y, const float* z, size_t n,
                          const float T_colmajor[16], const double p[6], double H[36]);
 
+/* calculateScore (impl2:1006-1040): x, y, z = the ALREADY TRANSFORMED cloud; gauss = {d1, d2, d3} as the members hold them */
+double ora_calculate_score(const ora_grid* g, const double gauss[3], float resolution,
+                           const float* x, const float* y, const float* z, size_t n);
+/* static convertTransform (ndt_omp.h:209-228): [x, y, z, roll, pitch, yaw] -> 4x4 f32 column-major */
+void ora_convert_transform(const double x[6], float out_colmajor[16]);
+
 /* Sophus a621ff2 (non-templated) SE3 exp/log, tangent order [upsilon; omega]. */
 void ora_se3_exp(const double p[6], double M_rowmajor[16]);
 void ora_se3_log(const double M_rowmajor[16], double p[6]);   /* SE3(R,t).log() incl. quaternion normalise */

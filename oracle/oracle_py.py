@@ -71,6 +71,10 @@ def lib():
         L.ora_compute_hessian.restype = None
         L.ora_compute_hessian.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                           C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ora_calculate_score.restype = C.c_double
+        L.ora_calculate_score.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.ora_convert_transform.restype = None
+        L.ora_convert_transform.argtypes = [C.c_void_p, C.c_void_p]
         L.ora_se3_exp.argtypes = [C.c_void_p, C.c_void_p]
         L.ora_se3_log.argtypes = [C.c_void_p, C.c_void_p]
         L.ora_se3_compose_log.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -192,6 +196,22 @@ def compute_hessian(grid: Grid, src: np.ndarray, p: np.ndarray):
     H = np.zeros(36)
     lib().ora_compute_hessian(grid.h, C.byref(grid.prm), _p(x), _p(y), _p(z), len(src), _p(Tc), _p(p), _p(H))
     return H.reshape(6, 6)
+
+
+def calculate_score(grid: Grid, cloud: np.ndarray, gauss=None):
+    """calculateScore(cloud) (impl2:1006-1040): `cloud` is the ALREADY TRANSFORMED cloud; gauss = (d1, d2, d3) as the members hold them
+    (default: those of the grid's parameters, i.e. what an align() with them leaves behind)."""
+    x, y, z = _soa(cloud)
+    g = np.ascontiguousarray(gauss_constants(grid.prm.outlier_ratio, grid.prm.resolution) if gauss is None else gauss, np.float64)
+    return float(lib().ora_calculate_score(grid.h, _p(g), grid.prm.resolution, _p(x), _p(y), _p(z), len(cloud)))
+
+
+def convert_transform(x) -> np.ndarray:
+    """static convertTransform (ndt_omp.h:209-228): [x, y, z, roll, pitch, yaw] -> 4x4 f32."""
+    v = np.ascontiguousarray(x, np.float64)
+    out = np.zeros(16, np.float32)
+    lib().ora_convert_transform(_p(v), _p(out))
+    return out.reshape(4, 4, order="F").copy()
 
 
 def align(grid: Grid, src: np.ndarray, guess: np.ndarray):

@@ -594,7 +594,54 @@ def make_mt_case(name, pair, n_az, n_beams, mode, variant, n_src=400):
     print(f"{name}: -> {os.path.getsize(path)} B")
 
 
+def calculate_score(grid, cloud, d1, d2, d3):
+    """omp:1006-1040 (pca: ndt_pca_impl2.hpp:1013-1047), literally: `cloud` is the already transformed cloud; f64 throughout."""
+    score = 0.0
+    for p in np.asarray(cloud, f32):
+        hood = radius_search(grid, p, float(grid["leaf"]))              # omp:1018
+        for L in hood:
+            x_trans = p.astype(f64) - L.mean                            # omp:1025-1028
+            e_x_cov_x = np.exp(-d2 * x_trans.dot(L.icov @ x_trans) / 2)  # omp:1033
+            score_inc = -d1 * e_x_cov_x - d3                            # omp:1035
+            score += score_inc / len(hood)                              # omp:1037
+    return score / len(cloud)                                           # omp:1040
+
+
+def convert_transform(x):
+    """ndt_omp.h:209-228 through an independent route: scipy rotations in f64, cast at the end (Eigen works in f32 throughout)."""
+    from scipy.spatial.transform import Rotation as Rot
+    M = np.eye(4)
+    M[:3, :3] = (Rot.from_euler("x", float(f32(x[3]))) * Rot.from_euler("y", float(f32(x[4]))) * Rot.from_euler("z", float(f32(x[5])))).as_matrix()
+    M[:3, 3] = [float(f32(v)) for v in x[:3]]
+    return M.astype(f32)
+
+
+def make_score_cases():
+    """calculateScore / convertTransform vectors on the clouds of two committed fixtures (nothing else is rewritten)."""
+    out = {}
+    for tag, name, variant in (("omp", "omp_direct7_r1", 0), ("pca", "pca_direct1_r05", 1)):
+        fx = np.load(os.path.join(HERE, name + ".npz"))
+        res = float(fx["params"][0])
+        grid = build_grid(fx["target"], res, pca=(variant == 1))
+        T = fx["align_final"].astype(f32)
+        cloud = np.array([transform_point(T, p) for p in fx["src_align"]], f32)
+        ctor = gauss_constants(0.55, 1.0)                                # the constructor's members (omp:70-76)
+        own = gauss_constants(0.55, res)                                 # after an align() with the fixture's parameters (omp:93-100)
+        out.update({f"{tag}_fixture": np.array(name), f"{tag}_cloud": cloud, f"{tag}_gauss_ctor": np.array(ctor), f"{tag}_gauss_align": np.array(own),
+                    f"{tag}_score_ctor": np.float64(calculate_score(grid, cloud, *ctor)), f"{tag}_score_align": np.float64(calculate_score(grid, cloud, *own)),
+                    f"{tag}_score_raw_source": np.float64(calculate_score(grid, fx["src_align"], *own))})
+        print(tag, out[f"{tag}_score_ctor"], out[f"{tag}_score_align"], out[f"{tag}_score_raw_source"])
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([rng.normal(0, 1, (24, 6)) * np.array([5, 5, 5, 1.5, 1.5, 1.5]), np.zeros((1, 6)), [[1, 2, 3, np.pi, -np.pi / 2, 0.25]]])
+    out.update(ct_x=xs, ct_M=np.array([convert_transform(x) for x in xs]))
+    np.savez_compressed(os.path.join(HERE, "calc_score.npz"), **out)
+    print("calc_score.npz:", os.path.getsize(os.path.join(HERE, "calc_score.npz")), "B")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "score":       # calculateScore / convertTransform vectors (round 4), on committed clouds
+        make_score_cases()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "mt":          # cases added after the first fixtures were frozen
         make_mt_case("omp_direct7_mt", pair=15, n_az=128, n_beams=32, mode=DIRECT7, variant=0)
         make_mt_case("pca_direct1_mt", pair=17, n_az=128, n_beams=32, mode=DIRECT1, variant=1)
@@ -613,3 +660,4 @@ if __name__ == "__main__":
     make_case("pca_direct1_r05", pair=11, n_az=256, n_beams=32, resolution=0.5, mode=DIRECT1, variant=1)
     make_case("omp_kdtree_r1", pair=13, n_az=128, n_beams=32, resolution=1.0, mode=KDTREE, variant=0)
     make_case("pca_kdtree_r1", pair=21, n_az=128, n_beams=32, resolution=1.0, mode=KDTREE, variant=1, n_src_sweep=150, n_src_align=300)
+    make_score_cases()

@@ -5,6 +5,7 @@
 // converged, trans_probability, visualizer calls, fitness score) and the first 4 output points.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include "mi355_ndt_pcl.hpp"
 
 typedef pcl::PointXYZI PointT;
@@ -55,5 +56,16 @@ int main(int argc, char** argv) {
   for (int i = 0; i < 4 && i < (int)out.points.size(); i++)
     printf("%.9g %.9g %.9g %.9g %.9g\n", out.points[i].x, out.points[i].y, out.points[i].z, out.points[i].data[3], out.points[i].intensity);
   printf("%zu\n", reg.getTargetCells().size());
+  // calculateScore of the output cloud (ndt_omp.h:232) and the static convertTransform (ndt_omp.h:209-228)
+  Eigen::Matrix<double, 6, 1> x6;
+  const double xv[6] = {1.0, 2.0, 3.0, 0.1, 0.2, 0.3};
+  for (int i = 0; i < 6; i++) x6(i) = xv[i];
+  Eigen::Matrix4f M;
+  Eigen::Affine3f A;
+  mi355ndt::NormalDistributionsTransform<PointT, PointT>::convertTransform(x6, M);
+  mi355ndt::NormalDistributionsTransform<PointT, PointT>::convertTransform(x6, A);
+  printf("%.17g", reg.calculateScore(out));
+  for (int i = 0; i < 16; i++) printf(" %.9g", M.data()[i]);
+  printf(" %d\n", (int)(std::memcmp(M.data(), A.matrix().data(), 64) == 0));
   return 0;
 }

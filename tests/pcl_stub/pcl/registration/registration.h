@@ -19,6 +19,18 @@ struct Matrix4f {                       // column-major 4x4 float, like Eigen::M
   float& operator()(int r, int c) { return m[c * 4 + r]; }
   float operator()(int r, int c) const { return m[c * 4 + r]; }
 };
+template <typename S, int R, int C> struct Matrix {   // just enough of a fixed-size dense matrix: contiguous column-major storage
+  S m[R * C];
+  const S* data() const { return m; }
+  S* data() { return m; }
+  S& operator()(int i) { return m[i]; }
+  S operator()(int i) const { return m[i]; }
+};
+struct Affine3f {                       // Eigen::Transform<float, 3, Affine>: a 4x4 matrix with matrix() access
+  Matrix4f mat;
+  Matrix4f& matrix() { return mat; }
+  const Matrix4f& matrix() const { return mat; }
+};
 template <typename T> struct Map;
 template <> struct Map<const Matrix4f> {
   const float* p;

@@ -27,7 +27,8 @@ def test_adaptor_compiles_and_links_against_pcl_stub():
     # the ABI symbols the adaptor needs are undefined in the binary and exported by the library
     und = subprocess.check_output(["nm", "-u", exe], text=True)
     for sym in ["mi355ndt_create", "mi355ndt_set_target", "mi355ndt_set_source", "mi355ndt_align", "mi355ndt_get_aligned",
-                "mi355ndt_get_incremental", "mi355ndt_set_params", "mi355ndt_get_fitness_score", "mi355ndt_get_voxels", "mi355ndt_set_latency_mode"]:
+                "mi355ndt_get_incremental", "mi355ndt_set_params", "mi355ndt_get_fitness_score", "mi355ndt_get_voxels", "mi355ndt_set_latency_mode",
+                "mi355ndt_calculate_score", "mi355ndt_convert_transform"]:
         assert sym in und, sym
 
 
@@ -75,3 +76,9 @@ def test_adaptor_end_to_end(tmp_path, variant, mode, res, lat):
         p = np.array(out[1 + i].split(), np.float64)
         assert np.array_equal(p[:3].astype(np.float32), a[i]) and p[3] == 1.0 and p[4] == float(i)
     assert int(out[5]) == eng.get_grid()[3]
+    # calculateScore(output cloud) and the static convertTransform through the adaptor == through the python mirror
+    w = out[6].split()
+    full = ndt.NormalDistributionsTransform(variant=variant)
+    assert float(w[0]) == eng.calculate_score(a)
+    assert np.array_equal(np.array(w[1:17], np.float32).reshape(4, 4).T, full.convertTransform([1.0, 2.0, 3.0, 0.1, 0.2, 0.3])) and int(w[17]) == 1
+    full.engine.close()

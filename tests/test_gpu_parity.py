@@ -886,3 +886,104 @@ def test_leaf_too_small_guards_beyond_the_int64_range():
             exp, m = O.fitness_score(target, pts[:500], T, mr)
             assert n == m and n > 0 and abs(got - exp) <= 1e-12 * max(1.0, exp), (mr, got, exp, n, m)
         e.close()
+
+
+def test_calculate_score_golden_and_gauss_members(golden_dir):
+    """mi355ndt_calculate_score (calculateScore, ndt_omp_impl2.hpp:1006-1040) on the fixture clouds: before any align the members hold
+    the CONSTRUCTOR's Gauss constants (resolution 1.0 whatever setResolution said, impl2:70-76), after an align those of its parameters."""
+    z = np.load(os.path.join(golden_dir, "calc_score.npz"))
+    for tag in ("omp", "pca"):
+        fx, kw = golden(golden_dir, str(z[f"{tag}_fixture"]))
+        p, po = both_params(**kw)
+        grid = O.Grid(fx["target"], po)
+        eng = ndt.Engine(p)
+        eng.set_target(fx["target"])
+        cloud = z[f"{tag}_cloud"]
+        got = eng.calculate_score(cloud)
+        want = float(z[f"{tag}_score_ctor"])
+        assert abs(got - want) <= 1e-9 * abs(want)                                    # NumPy restatement (eigh icov): 1e-9
+        assert abs(got - O.calculate_score(grid, cloud, z[f"{tag}_gauss_ctor"])) <= 1e-12 * abs(want)   # oracle: f64 summation order only
+        eng.set_source(fx["src_align"])
+        eng.align(fx["guess"])                                                        # computeTransformation sets gauss_d*_ (impl2:93-100)
+        got = eng.calculate_score(cloud)
+        want = float(z[f"{tag}_score_align"])
+        assert abs(got - want) <= 1e-9 * abs(want)
+        assert abs(got - O.calculate_score(grid, cloud)) <= 1e-12 * abs(want)
+        assert eng.calculate_score(cloud + np.float32(1e4)) == 0.0                    # nothing within one resolution of any centroid
+        assert np.isnan(eng.calculate_score(np.zeros((0, 3), np.float32)))
+        # the registration still works afterwards (calculateScore builds the f64 inverse covariances on demand)
+        r, ro = eng.align(fx["guess"]), O.align(grid, fx["src_align"], fx["guess"])
+        assert r["iterations"] == ro["iterations"] and se3_err(r["final"], ro["final"])[0] < 1e-4
+        eng.close()
+
+
+@pytest.mark.parametrize("variant,mode,res", [(0, ndt.DIRECT7, 1.0), (1, ndt.DIRECT1, 1.0)])
+def test_calculate_score_full_size_vs_oracle(variant, mode, res):
+    """65,536-point clouds, both classes, through the class mirror: calculateScore of the aligned output cloud within 1e-12 relative."""
+    tgt, src, _ = synth.make_pair(7, 1024)
+    tgt, src = tgt.numpy(), src.numpy()
+    kw = dict(resolution=res, trans_epsilon=0.01, max_iterations=64, neighbor_mode=mode, variant=variant)
+    _, po = both_params(**kw)
+    reg = ndt.NormalDistributionsTransform(variant=variant)
+    reg.setResolution(res); reg.setTransformationEpsilon(0.01); reg.setMaximumIterations(64); reg.setNeighborhoodSearchMethod(mode)
+    reg.setInputTarget(tgt)
+    reg.setInputSource(src)
+    out = reg.align(synth.default_guess())
+    got = reg.calculateScore(out)
+    grid = O.Grid(tgt, po)
+    want = O.calculate_score(grid, out)
+    assert want != 0 and abs(got - want) <= 1e-12 * abs(want), (got, want)
+    raw = reg.calculateScore(src)
+    assert abs(raw - O.calculate_score(grid, src)) <= 1e-12 * abs(want) and raw < got   # the aligned cloud is the more likely one
+    reg.engine.close()
+
+
+def test_convert_transform_matches_oracle_bit_for_bit(golden_dir):
+    z = np.load(os.path.join(golden_dir, "calc_score.npz"))
+    for x, M in zip(z["ct_x"], z["ct_M"]):
+        got = ndt.NormalDistributionsTransform.convertTransform(x)
+        assert np.array_equal(got, O.convert_transform(x)) and np.abs(got.astype(np.float64) - M).max() < 1e-6
+    with pytest.raises(ValueError):
+        ndt.NormalDistributionsTransform.convertTransform(np.zeros(5))
+
+
+@pytest.mark.parametrize("variant,mode", [(0, ndt.DIRECT7), (1, ndt.DIRECT1), (0, ndt.KDTREE)])
+def test_f32_sum_order_option_vs_oracle_variant(variant, mode):
+    """MI355NDT_OPT_F32_SUM_ORDER = 1 evaluates the three-term f32 sums of impl2:581, 594-613 as (t0 + t2) + t1 -- the lane pairing of
+    Eigen 3.3's SSE predux<Packet4f> -- exactly as the oracle does under ORA_VAR_SUM3_02_1: sweeps to 1e-11, align to the same iteration
+    count and inside the SE(3) tolerance, for the single registration, the batch path and the latency mode; order 0 is the default."""
+    tgt, src, _ = synth.make_pair(9, 512)
+    tgt, src = tgt.numpy(), src.numpy()
+    kw = dict(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=mode, variant=variant)
+    p, po = both_params(**kw)
+    grid = O.Grid(tgt, po)
+    G = synth.default_guess()
+    eng = ndt.Engine(p)
+    assert eng.get_option(ndt.OPT_F32_SUM_ORDER) == 0
+    eng.set_target(tgt); eng.set_source(src)
+    pt = np.array([1.0, 0.02, -0.01, 0.003, -0.002, 0.01])
+    base = eng.derivatives(pt)
+    try:
+        O.lib().ora_set_variant(1, 256)                                               # ORA_VAR_SUM3_02_1
+        eng.set_option(ndt.OPT_F32_SUM_ORDER, 1)
+        assert eng.get_option(ndt.OPT_F32_SUM_ORDER) == 1
+        alt = eng.derivatives(pt)
+        check_sweep(alt, O.derivatives_at(grid, src, pt))
+        assert alt[3] == base[3] and (alt[0] != base[0] or not np.array_equal(alt[2], base[2]))   # same hits, other last bits
+        ro = O.align(grid, src, G)
+        for lat in (False, True):
+            eng.set_latency_mode(lat)
+            r = eng.align(G)
+            assert r["iterations"] == ro["iterations"] and r["converged"] == ro["converged"]
+            dt, dr = se3_err(r["final"], ro["final"])
+            assert dt < 1e-4 and dr < 1e-5
+    finally:
+        O.lib().ora_set_variant(0, 256)
+    eng.set_option(ndt.OPT_F32_SUM_ORDER, 0)
+    eng.set_latency_mode(False)
+    check_sweep(eng.derivatives(pt), base, rtol=0.0)                                  # back to the canonical order: same bits as before
+    with pytest.raises(ndt.NDTError):
+        eng.set_option(ndt.OPT_F32_SUM_ORDER, 2)
+    with pytest.raises(ndt.NDTError):
+        eng.set_option(99, 0)
+    eng.close()

@@ -360,3 +360,34 @@ def test_leaf_too_small_guard_does_not_overflow():
     assert not O.Grid(stray, O.default_params()).ok
     assert not O.Grid(pts, O.default_params(resolution=1e-4)).ok
     assert O.Grid(pts, O.default_params(resolution=1.0)).ok
+
+
+def test_calculate_score_vs_numpy_restatement(golden_dir):
+    """calculateScore (ndt_omp_impl2.hpp:1006-1040 / ndt_pca_impl2.hpp:1013-1047): the oracle against the literal NumPy restatement, with
+    the constructor's Gauss constants (what the members hold before any align, impl2:70-76) and with those of the fixture's parameters."""
+    z = np.load(os.path.join(golden_dir, "calc_score.npz"))
+    for tag in ("omp", "pca"):
+        fx, prm = load(golden_dir, str(z[f"{tag}_fixture"]))
+        grid = O.Grid(fx["target"], prm)
+        assert np.allclose(O.gauss_constants(0.55, 1.0), z[f"{tag}_gauss_ctor"], rtol=1e-14)
+        for kind, cloud in (("ctor", z[f"{tag}_cloud"]), ("align", z[f"{tag}_cloud"])):
+            got = O.calculate_score(grid, cloud, z[f"{tag}_gauss_{kind}"])
+            want = float(z[f"{tag}_score_{kind}"])
+            assert abs(got - want) <= 1e-9 * abs(want), (tag, kind, got, want)       # eigh-vs-Jacobi icov differences, as for the sweeps
+        got = O.calculate_score(grid, fx["src_align"])                                # default constants = the grid's parameters
+        assert abs(got - float(z[f"{tag}_score_raw_source"])) <= 1e-9 * abs(float(z[f"{tag}_score_raw_source"]))
+    # a cloud nowhere near the grid: every neighbourhood is empty, the score is exactly 0; an empty cloud: 0 / 0
+    fx, prm = load(golden_dir, "omp_direct7_r1")
+    grid = O.Grid(fx["target"], prm)
+    assert O.calculate_score(grid, fx["src_align"] + np.float32(1e4)) == 0.0
+    assert np.isnan(O.calculate_score(grid, np.zeros((0, 3), np.float32)))
+
+
+def test_convert_transform_vs_scipy(golden_dir):
+    """static convertTransform (ndt_omp.h:209-228): Translation * Rx(roll) * Ry(pitch) * Rz(yaw) in f32; fixture = scipy rotations in f64."""
+    z = np.load(os.path.join(golden_dir, "calc_score.npz"))
+    for x, M in zip(z["ct_x"], z["ct_M"]):
+        got = O.convert_transform(x)
+        assert got.dtype == np.float32 and np.abs(got.astype(np.float64) - M).max() < 1e-6
+        assert np.array_equal(got[3], [0, 0, 0, 1]) and np.array_equal(got[:3, 3], x[:3].astype(np.float32))
+    assert np.array_equal(O.convert_transform(np.zeros(6)), np.eye(4, dtype=np.float32))
