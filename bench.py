@@ -71,6 +71,9 @@ def parse():
                          "launch/dlo_kitti.launch:30-36) -> target / source -> align, one registration at a time (use with --azimuth 2048 --pairs 64)")
     ap.add_argument("--seq-frames", type=int, default=271, help="frames of the latency-mode leg (value_sequential; 0 = skip; single-GPU run only)")
     ap.add_argument("--traffic", type=float, default=None, help="HBM bytes per sweep launch from separate rocprofv3 --pmc passes")
+    ap.add_argument("--f32-sum-order", type=int, default=0, choices=[0, 1],
+                    help="MI355NDT_OPT_F32_SUM_ORDER of every engine of the run: 0 = (t0 + t1) + t2, the canonical order of the fixtures; 1 = (t0 + t2) + t1, "
+                         "the lane pairing of Eigen 3.3's SSE predux -- the parity legs then check against the oracle's matching variant (ORA_VAR_SUM3_02_1)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the `other_configs` block of the single-GPU line (the nodelet's ndt_pca / DIRECT1 and BASELINE config 5 with DIRECT7 and "
                          "DIRECT1, each timed for --other-seconds with its own roofline and oracle parity sample)")
@@ -305,6 +308,7 @@ def host_clouds_leg(a, ndt, prm, dev_index, T, S, guesses, B, N, steps, uploader
     def drive(idx, nsteps, out):
         out["cpus%d" % idx] = apply_affinity()        # not the one cpu an OpenMP runtime may have bound the main thread to
         eng = ndt.Engine(prm, device=dev_index)
+        eng.set_option(ndt.OPT_F32_SUM_ORDER, a.f32_sum_order)
         eng.batch_reserve(B, N, N)
         res = (ndt.Result * B)()
         tptr = tgp + np.arange(B, dtype=np.uint64) * np.uint64(N * stride)
@@ -528,6 +532,7 @@ def parity_leg(a, W, G, res_np, B, seconds, threads):
     kw = dict(resolution=a.resolution, trans_epsilon=0.01, max_iterations=64, neighbor_mode=MODES[a.mode], variant=1 if a.variant == "pca" else 0)
     op = O.default_params(**kw)
     O.lib().ora_set_threads(int(threads))
+    O.lib().ora_set_variant(1 if getattr(a, "f32_sum_order", 0) == 1 else 0, 256)     # the oracle's matching f32 sum order (ORA_VAR_SUM3_02_1)
     done, t_cpu, worst, it_match, conv_match, idx_seen = 0, 0.0, (0.0, 0.0), 0, 0, []
     for k in spread_order(B):
         if done >= 3 and t_cpu >= seconds:
@@ -544,7 +549,9 @@ def parity_leg(a, W, G, res_np, B, seconds, threads):
         idx_seen.append(k)
         done += 1
     O.lib().ora_set_threads(0)
+    O.lib().ora_set_variant(0, 256)
     parity = {"pairs_checked": done, "max_dtrans_m": worst[0], "max_drot_rad": worst[1], "iterations_equal": it_match, "converged_flags_equal": conv_match,
+              "f32_sum_order": getattr(a, "f32_sum_order", 0),
               "sample": f"{done} of the {B} pairs of rank 0, spread over the whole index range (bit-reversal order; slots {min(idx_seen)}..{max(idx_seen)} touched)",
               "tolerance": "trans<1e-4 m, rot<1e-5 rad", "oracle": "parity unpinned (no reference-originated vectors exist, DESIGN.md 2; error bar: BASELINE.md 5)",
               "note": "pairs that never converge (iterations = max_iterations + 2, e.g. ndt_pca with DIRECT26 where the compounding "
@@ -768,6 +775,7 @@ def other_configs_block(ctx, a, synth, W_head):
         b = argparse.Namespace(**{**vars(a), **kw, "pairs": nb, "azimuth": az})
         prm = ndt.default_params(resolution=b.resolution, trans_epsilon=0.01, max_iterations=64, neighbor_mode=MODES[b.mode], variant=1)
         eng = ndt.Engine(prm, device=ctx.local)
+        eng.set_option(ndt.OPT_F32_SUM_ORDER, a.f32_sum_order)
         J = timed_job(ctx, eng, W, nb, nb, None, 2, min_seconds=a.other_seconds)
         r = sweep_roofline(J)
         res_np = np.frombuffer(np.frombuffer(J["res"], dtype=np.uint8).copy(), dtype=RES_DT)
@@ -870,6 +878,7 @@ def main():
     prm = ndt.default_params(resolution=a.resolution, trans_epsilon=0.01, max_iterations=64, neighbor_mode=MODES[a.mode],
                              variant=1 if a.variant == "pca" else 0)
     eng = ndt.Engine(prm, device=local)
+    eng.set_option(ndt.OPT_F32_SUM_ORDER, a.f32_sum_order)
 
     # ---- the headline job
     J = timed_job(ctx, eng, W, B, total, a.steps, a.warmup)
@@ -984,7 +993,7 @@ def main():
                                f"({N} pts per cloud{' at most' if W['data'] == 'kitti' else ''}), ndt_{a.variant}, {a.resolution} m voxels, {a.mode.upper()}, eps 0.01, max_iter 64; "
                                "one step = voxelise every target + align every pair (+ RCCL pose all-gather when N>1)",
                    "pairs_total": total, "pairs_rank0": B, "points_per_cloud": N, "neighbor_mode": a.mode, "variant": a.variant,
-                   "resolution_m": a.resolution, "sharding": "pair i -> rank i mod N (round-robin)",
+                   "resolution_m": a.resolution, "f32_sum_order": a.f32_sum_order, "sharding": "pair i -> rank i mod N (round-robin)",
                    "mean_iterations": round(float(its.mean()), 2), "max_iterations_seen": int(its.max()),
                    "mean_sweeps_per_align": round(float(sweeps.mean()), 2),
                    "converged": int(res_np["conv"].sum()),

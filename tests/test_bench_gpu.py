@@ -177,12 +177,16 @@ def test_config4_job_on_one_gpu_parity_over_the_index_range_and_rccl_gather():
     assert d["gather_ms_per_step"] > 0
 
 
-def test_default_workload_parity_leg_covers_the_whole_batch():
+@pytest.mark.parametrize("order", [0, 1])
+def test_default_workload_parity_leg_covers_the_whole_batch(order):
     """BASELINE config 3 as bench.py runs it by default (271 pairs x 65,536 pts, ndt_omp, 1 m, DIRECT7): the line's parity leg
     checks every pair of the batch against the oracle -- same iteration counts, SE(3) inside the north-star tolerance -- and the
-    roofline block is internally consistent."""
-    d = run_bench(["--steps", "5", "--warmup", "2", "--cpu-seconds", "20", "--config4-pairs", "0", "--seq-frames", "0"])
+    roofline block is internally consistent.  Both evaluation orders of the three-term f32 sums (ndt_omp_impl2.hpp:581, 594-613):
+    the canonical one, and the lane pairing of Eigen 3.3's SSE predux against the oracle's matching variant."""
+    d = run_bench(["--steps", "5", "--warmup", "2", "--cpu-seconds", "30", "--config4-pairs", "0", "--seq-frames", "0", "--no-other-configs", "--no-host-clouds",
+                   "--f32-sum-order", str(order)])
     p = d["parity"]
+    assert p["f32_sum_order"] == order and d["config"]["f32_sum_order"] == order
     assert p["pairs_checked"] == 271 and p["iterations_equal"] == 271 and p["max_dtrans_m"] < 1e-4 and p["max_drot_rad"] < 1e-5
     assert d["config"]["converged"] == 271 and d["config"]["pairs_total"] == 271
     r = d["roofline"]

@@ -130,6 +130,20 @@ def test_full_size_pair_vs_oracle(mode, variant, res):
     if not (mode == ndt.KDTREE and variant == 1):
         dt, dr = se3_err(dT, r["final"])
         assert dt < 0.1 and dr < 0.01, (dt, dr)
+    # the same pair with the other evaluation order of the three-term f32 sums (MI355NDT_OPT_F32_SUM_ORDER = 1) against the oracle's
+    # matching variant: the engine a maintainer selects if a real build of the reference shows Eigen 3.3's SSE pairing
+    if not (mode == ndt.KDTREE and variant == 1):
+        try:
+            O.lib().ora_set_variant(1, 256)
+            eng.set_option(ndt.OPT_F32_SUM_ORDER, 1)
+            check_sweep(eng.derivatives(p0), O.derivatives_at(grid, src, p0))
+            r1, ro1 = eng.align(G), O.align(grid, src, G)
+            assert r1["iterations"] == ro1["iterations"] and r1["converged"] == ro1["converged"]
+            dt, dr = se3_err(ro1["final"], r1["final"])
+            assert dt < 1e-4 and dr < 1e-5, (dt, dr)
+        finally:
+            O.lib().ora_set_variant(0, 256)
+    eng.close()
 
 
 def test_window_map_target_vs_oracle():

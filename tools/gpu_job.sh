@@ -25,6 +25,7 @@ for stage in "$@"; do
     seq)        timeout 300 python tools/seq_run.py 129 2>&1 | grep -v amdgpu.ids > $O/seq.txt; cat $O/seq.txt
                 cd /tmp && export TMPDIR=/tmp; timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt -- python $R/tools/seq_run.py 65 > $O/seq_traced.txt 2> $O/kt.log; cd $R
                 python tools/seq_kernels.py $O/kt > $O/seq_kernels.txt; rm -rf $O/kt; cat $O/seq_kernels.txt ;;
+    tests_r4)   timeout 2400 python -m pytest tests/test_reference_golden.py tests/test_adaptor.py tests/test_gpu_parity.py -m gpu -x -q -k "reference or adaptor or calculate_score or convert_transform or f32_sum_order" 2>&1 | tail -25 > $O/pytest.txt; cat $O/pytest.txt ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
