@@ -173,7 +173,13 @@ enum mi355ndt_option {
    * Eigen's scalar redux = the order every committed parity fixture was made with.  1: (t0 + t2) + t1, the lane pairing of Eigen 3.3's SSE
    * predux<Packet4f>.  Same cost; lets a maintainer who pins the reference on a real build (tools/pin_reference/) select the
    * order that build shows.  Poses differ in their last bits for about half of all pairs. */
-  MI355NDT_OPT_F32_SUM_ORDER = 1
+  MI355NDT_OPT_F32_SUM_ORDER = 1,
+  /* 1 (default): a batch align runs as ONE persistent launch in which every pair goes through its own Newton loop to its own end, as
+   * every align() of the reference does (ndt_omp_impl2.hpp:131-183); 0: lockstep rounds of (update, sweep) launches over the pairs
+   * still iterating.  Same results bit for bit (a pair's sums never depend on what runs beside it); the environment variable
+   * MI355NDT_ASYNC=0 sets the default to 0 for engines created afterwards.  The latency mode and the live More-Thuente configuration
+   * always take the round-based path. */
+  MI355NDT_OPT_ASYNC_ALIGN = 2
 };
 int mi355ndt_set_option(mi355ndt_handle* h, int option, int value);
 int mi355ndt_get_option(const mi355ndt_handle* h, int option, int* value);

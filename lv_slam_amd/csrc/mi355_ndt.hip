@@ -39,6 +39,7 @@
 #include "ndt_fitness.hpp"
 #include "ndt_prefilter.hpp"
 #include "ndt_sequence.hpp"
+#include "ndt_async.hpp"
 
 
 // ------------------------------------------------------------------------------------ host side
@@ -91,6 +92,9 @@ struct mi355ndt_handle {
   int chunks_per_pair = 0;
   int rows_per_pair = 0, pts_per_chunk = CHUNK_PTS;   // stored partial rows per pair / points covered by one chunk of k_update's tree
   int items_per_pair = 0;                         // sweep work items per pair (= rows_per_pair in batch mode, 4 x rows_per_pair in latency mode)
+  bool async_align = true;                        // MI355NDT_OPT_ASYNC_ALIGN: batch aligns as ONE persistent launch (ndt_async.hpp); MI355NDT_ASYNC=0 turns it off
+  int* d_ring = nullptr; size_t ring_cap_total = 0; unsigned* d_arrived = nullptr; size_t arrived_cap = 0; AsyncCtl* d_actl = nullptr;
+  AsyncCtl* h_pin_actl = nullptr;
   int f32_sum_order = 0;                          // MI355NDT_OPT_F32_SUM_ORDER: 0 = (t0 + t1) + t2 (canonical), 1 = (t0 + t2) + t1 (Eigen 3.3 SSE predux pairing)
   double gauss_last[3] = {0, 0, 0};               // gauss_d1_/d2_/d3_ as the constructor / the last computeTransformation left them (calculateScore reads them)
   float* d_score_pts = nullptr; size_t score_pts_cap = 0; double* d_score_part = nullptr; size_t score_part_cap = 0;   // calculateScore workspace
@@ -305,6 +309,7 @@ int mi355ndt_create(const mi355ndt_params* params, int device, mi355ndt_handle**
   gauss_constants3(0.55, 1.0f, h->gauss_last);    // the constructor's gauss_d*_ (impl2:70-76: resolution_ 1.0f, outlier_ratio_ 0.55), whatever the setters say later
   { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
   if (const char* e = std::getenv("MI355NDT_FINE_TILES")) { const int v = std::atoi(e); if (v == 1 || v == 2) h->fine_tiles = v; }
+  if (const char* e = std::getenv("MI355NDT_ASYNC")) h->async_align = std::atoi(e) != 0;
   if (const char* e = std::getenv("MI355NDT_SWEEP_DYN_SHIFT")) { const int v = std::atoi(e); if (v >= 0 && v <= 30) h->dyn_shift = v; }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
@@ -337,7 +342,8 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
                   h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, h->d_words, h->d_recs, h->d_vox_idx, h->d_vox_n,
                   h->d_state, h->d_partials, h->d_guess, h->d_results, h->d_active, h->d_hook, h->d_aligned, h->d_hits, h->d_seg_start, h->d_sums,
                   h->d_cent, h->d_icov64, h->d_kdw, h->d_rs_hist, h->d_rs_offs, h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit, h->d_pf_in, h->d_pf_out, h->d_pf_keep, h->d_pf_keys,
-                  h->d_pf_vals, h->d_pf_flag, h->d_pf_pos, h->d_pf_mm, h->d_pf_grid, h->d_pf_tmp, h->d_score_pts, h->d_score_part};
+                  h->d_pf_vals, h->d_pf_flag, h->d_pf_pos, h->d_pf_mm, h->d_pf_grid, h->d_pf_tmp, h->d_score_pts, h->d_score_part,
+                  h->d_ring, h->d_arrived, h->d_actl};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : {(void*)h->d_grid_of, (void*)h->d_seq, (void*)h->d_seq_out, (void*)h->d_stamps}) if (p) (void)hipFree(p);
   if (h->h_seq_flags) (void)hipHostFree((void*)h->h_seq_flags);
@@ -347,6 +353,7 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
   for (hipEvent_t e : h->ev_uploads) if (e) (void)hipEventDestroy(e);
   if (h->ev_compute) (void)hipEventDestroy(h->ev_compute);
   for (hipStream_t cs : h->copy_stream) if (cs) (void)hipStreamDestroy(cs);
+  if (h->h_pin_actl) (void)hipHostFree(h->h_pin_actl);
   if (h->h_pin_u) (void)hipHostFree(h->h_pin_u);
   if (h->h_pin_active) (void)hipHostFree(h->h_pin_active);
   if (h->h_pin_guess) (void)hipHostFree(h->h_pin_guess);
@@ -981,6 +988,61 @@ static int align_pump(mi355ndt_handle* h, SweepConst sc, int B) {
   return MI355NDT_OK;
 }
 
+// One persistent launch for the whole batch align (ndt_async.hpp): served for the DIRECT / KDTREE sweeps of k_sweep with the dead
+// More-Thuente loop -- every configuration lv_slam ships.  Returns MI355NDT_ERR_UNSUPPORTED when the launch cannot be made resident
+// (the caller then takes the lockstep path).
+}  // extern "C" (templates need C++ linkage)
+template <bool PCA, int K, int ORD>
+static int launch_async_t(mi355ndt_handle* h, const SweepConst& sc, int B, int ring_cap) {
+  auto kern = k_align_async<PCA, K, ORD>;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SWEEP_THREADS, 0) != hipSuccess) { (void)hipGetLastError(); return MI355NDT_ERR_UNSUPPORTED; }
+  const int wpe = sweep_wpe(PCA, K);
+  if (per_cu < wpe) return MI355NDT_ERR_UNSUPPORTED;              // every workgroup must be resident: waves wait for each other's tickets
+  dim3 grid((unsigned)(h->n_cu * wpe));
+  kern<<<grid, SWEEP_THREADS, 0, h->stream>>>(h->d_src, h->src_pitch, h->d_state, h->d_grid, h->d_words, h->d_recs, h->d_partials, h->items_per_pair, B,
+                                             h->d_ring, ring_cap, h->d_actl, h->d_arrived, sc, h->d_cent, h->d_results, h->prof ? h->d_hits : nullptr,
+                                             h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations);
+  return MI355NDT_OK;
+}
+template <bool PCA, int K>
+static int launch_async_o(mi355ndt_handle* h, const SweepConst& sc, int B, int ring_cap) {
+  return h->f32_sum_order == 1 ? launch_async_t<PCA, K, 1>(h, sc, B, ring_cap) : launch_async_t<PCA, K, 0>(h, sc, B, ring_cap);
+}
+extern "C" {
+static int align_async(mi355ndt_handle* h, const SweepConst& sc, int B, mi355ndt_result* out) {
+  hipStream_t s = h->stream;
+  const int ring_cap = (int)(((long long)B * (h->prm.max_iterations + 4) + 7) / 8 + 1);
+  HIPCHK(h, grow(h->d_ring, h->ring_cap_total, (size_t)8 * ring_cap));
+  HIPCHK(h, grow(h->d_arrived, h->arrived_cap, (size_t)B * ASYNC_ARR_STRIDE));
+  if (!h->d_actl) HIPCHK(h, hipMalloc((void**)&h->d_actl, sizeof(AsyncCtl)));
+  if (!h->h_pin_actl) HIPCHK(h, hipHostMalloc((void**)&h->h_pin_actl, sizeof(AsyncCtl)));
+  // everything the launch polls is reset on the stream before it (never inside the kernel, never by a previous launch)
+  HIPCHK(h, hipMemsetAsync(h->d_ring, 0xFF, (size_t)8 * ring_cap * sizeof(int), s));
+  HIPCHK(h, hipMemsetAsync(h->d_arrived, 0, (size_t)B * ASYNC_ARR_STRIDE * sizeof(unsigned), s));
+  HIPCHK(h, hipMemsetAsync(h->d_actl, 0, sizeof(AsyncCtl), s));
+  k_async_begin<<<(B + 255) / 256, 256, 0, s>>>(B, h->d_ring, ring_cap, h->d_actl);
+  if (h->prof) HIPCHK(h, ev_begin(h, h->ev_sweep));
+  int rc;
+  if (sc.pca) rc = sc.K == 1 ? launch_async_o<true, 1>(h, sc, B, ring_cap) : sc.K == 7 ? launch_async_o<true, 7>(h, sc, B, ring_cap) : launch_async_o<true, 26>(h, sc, B, ring_cap);
+  else rc = sc.K == 1 ? launch_async_o<false, 1>(h, sc, B, ring_cap) : sc.K == 7 ? launch_async_o<false, 7>(h, sc, B, ring_cap)
+          : sc.K == 26 ? launch_async_o<false, 26>(h, sc, B, ring_cap) : launch_async_o<false, 27>(h, sc, B, ring_cap);
+  if (rc) { if (h->prof) { HIPCHK(h, ev_end(h, h->ev_sweep)); } return rc; }
+  if (h->prof) HIPCHK(h, ev_end(h, h->ev_sweep));
+  HIPCHK(h, hipMemcpyAsync(h->h_pin_actl, h->d_actl, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s));   // pub, done, abort_
+  HIPCHK(h, hipMemcpyAsync(out, h->d_results, (size_t)B * sizeof(mi355ndt_result), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  HIPCHK(h, hipGetLastError());
+  if (h->h_pin_actl->abort_ || h->h_pin_actl->done != (unsigned)B) { h->err = "align: the device stopped making progress"; return MI355NDT_ERR_STATE; }
+  if (h->prof) {                                   // every sweep a pair took part in streamed its points + K table probes
+    for (int b = 0; b < B; b++) {
+      h->P.sweep_alg_bytes += (double)out[b].sweeps * h->h_src_cnt[b] * (12.0 + 4.0 * sc.K);
+      h->P.sweep_points += (long long)out[b].sweeps * h->h_src_cnt[b];
+    }
+  }
+  return MI355NDT_OK;
+}
+
 static int batch_align_impl(mi355ndt_handle* h, const float* guesses, mi355ndt_result* out) {
   if (!guesses || !out) return MI355NDT_ERR_BAD_ARG;
   if (h->n_pairs <= 0 || !h->d_tgt || !h->d_src) return MI355NDT_ERR_STATE;
@@ -1003,6 +1065,11 @@ static int batch_align_impl(mi355ndt_handle* h, const float* guesses, mi355ndt_r
   HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, 2 * sizeof(SweepCtl), s));
   h->ctl_idx = 0;
   k_init_state<<<(B + 63) / 64, 64, 0, s>>>(h->d_state, h->d_guess, h->d_src_cnt, h->d_grid, B, h->d_active_list, h->d_ctl);
+  if (h->async_align && !h->fine_it && !mt_live && !pca_kd) {       // one launch for the whole align (ndt_async.hpp)
+    rc = align_async(h, sc, B, out);
+    if (rc == MI355NDT_OK) { h->aligned_once = true; return MI355NDT_OK; }
+    if (rc != MI355NDT_ERR_UNSUPPORTED) return rc;                  // (not resident: the lockstep rounds below)
+  }
   if (h->fine_it) {                                // latency mode: the pump (no bursts, no counter copies, no event waits)
     rc = align_pump(h, sc, B);
     if (rc) return rc;
@@ -1491,12 +1558,18 @@ int mi355ndt_set_option(mi355ndt_handle* h, int option, int value) {
     h->f32_sum_order = value;
     return MI355NDT_OK;
   }
+  if (option == MI355NDT_OPT_ASYNC_ALIGN) {
+    if (value != 0 && value != 1) return MI355NDT_ERR_BAD_ARG;
+    h->async_align = value != 0;
+    return MI355NDT_OK;
+  }
   return MI355NDT_ERR_BAD_ARG;
 }
 int mi355ndt_get_option(const mi355ndt_handle* h, int option, int* value) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   if (!value) return MI355NDT_ERR_BAD_ARG;
   if (option == MI355NDT_OPT_F32_SUM_ORDER) { *value = h->f32_sum_order; return MI355NDT_OK; }
+  if (option == MI355NDT_OPT_ASYNC_ALIGN) { *value = h->async_align ? 1 : 0; return MI355NDT_OK; }
   return MI355NDT_ERR_BAD_ARG;
 }
 
@@ -1758,7 +1831,7 @@ int mi355ndt_sequence_run(mi355ndt_handle* h, int n_frames, const void* const* c
 
 #ifdef NDT_TIMELINE
 extern "C" int mi355ndt_debug_timeline(unsigned long long* out) {
-  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (hipDeviceSynchronize() != hipSuccess) return -1;
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tl), sizeof(z)) != hipSuccess) return -1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_tl), z, sizeof(z)) != hipSuccess) return -1;

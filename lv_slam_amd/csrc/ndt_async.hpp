@@ -1,0 +1,192 @@
+// ndt_async.hpp -- ONE launch per batch align: every pair runs its own Newton loop to its own end, as every reference align() does
+// (include/ndt_omp/ndt_omp_impl2.hpp:131-183: one while loop per computeTransformation), instead of the batch advancing in lockstep
+// rounds of (k_update, k_sweep) launches that each wait for the slowest pair.
+//
+// Persistent waves (the sweep's grid: 2 workgroups of 4 waves per CU).  Work arrives as TICKETS: one ticket = one derivative sweep of
+// one pair = `items_per_pair` work items (sweep_item, ndt_sweep.hpp -- the very code of the lockstep kernel, so a pair's partial rows,
+// and with them every result bit, are the same).  Tickets are numbered globally in publication order; ticket g lives in slot g >> 3 of
+// ring g & 7, and ring x is served by the waves of the workgroups with blockIdx.x % 8 == x (observed to be XCD x: a sweep's points,
+// bitmap and records then stay in one L2 -- speed only, nothing below depends on it).  Within a ring the positions of the item stream
+// (ticket 0's items, ticket 1's, ...) are claimed with one returning fetch-add per item, issued at the END of the previous item together
+// with that item's arrival -- behind the item's loads, never in front of them (a returning atomic at the head of a wave's in-order memory
+// queue delays every load behind it); a wave whose position falls into a ticket that does not exist yet waits for it.
+// The wave that retires a pair's last item (one returning agent-scope fetch-add per item on a per-pair counter) becomes that pair's UPDATER: it adds the pair's rows with k_update's fixed tree, runs the Newton step
+// (newton_update, ndt_update.hpp -- same code, same bits) and either publishes the pair's next ticket or finalises the pair.
+// Publication is round-robin over the rings, so the rings stay balanced to one ticket however the iteration counts are distributed.
+//
+// Visibility inside one launch (MI355X: per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed by another CU's
+// stores): every word that crosses workgroups -- partial rows, PairState, ring slots, counters -- is written AND read with agent-scope
+// relaxed atomics (8-byte / 4-byte sc1 accesses: write-through stores, L1-bypassing loads), every storing wave drains its stores
+// (s_waitcnt vmcnt(0), inline asm so that the compiler cannot drop it) before the word that announces them, and no flag is ever a plain
+// store.  No cache-wide fence anywhere: tools/fence_cost.hip priced those at 12-28 us per work item.
+// Everything polled is zeroed / poisoned by the host before every launch (hipMemsetAsync on the stream).
+#pragma once
+#include "ndt_types.hpp"
+#include "ndt_math.hpp"
+#include "ndt_sweep.hpp"
+#include "ndt_update.hpp"
+
+#define ASYNC_POS_STRIDE 32      // unsigned words between the rings' position counters (one 128-B line each: eight hot atomics, eight lines)
+#define ASYNC_ARR_STRIDE 16      // ... between the pairs' arrival counters (64 B: pairs in flight together do not share an atomic's line)
+struct AsyncCtl {
+  unsigned pub;                 // tickets published so far (ticket numbers are handed out by fetch-add)
+  unsigned done;                // pairs finalised; n_pairs = the launch is over
+  unsigned abort_;              // a wave gave up waiting (bounded spins): the host reports an error
+  unsigned pad_[29];
+  unsigned pos[8 * ASYNC_POS_STRIDE];   // per ring: positions of its item stream handed out so far
+};
+
+#define ASYNC_SPIN_LIMIT (1u << 23)      // polls of ~1 us: a device that stopped making progress ends the launch after seconds, not never
+
+// ring / counters for pair b's first sweep (runs right after k_init_state, before the persistent launch: ordered by the stream)
+__global__ void k_async_begin(int n_pairs, int* ring, int ring_cap, AsyncCtl* ctl) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b == 0) ctl->pub = (unsigned)n_pairs;
+  if (b < n_pairs) ring[(size_t)(b & 7) * ring_cap + (b >> 3)] = b;
+}
+
+// The pair's rows -> (score, g, H, hits), Newton step, publication.  Called by every lane of ONE wave; `Ssh` / `sol` are that wave's LDS.
+__device__ __forceinline__ void async_update(const int b, PairState* st, const double* partials, const int rows_per_pair, PairState& Ssh, volatile double* sol,
+                                             mi355ndt_result* results, int* ring, const int ring_cap, AsyncCtl* ctl, unsigned long long* hits_total,
+                                             const double step_max, const double eps, const int max_iterations) {
+  const int lane = threadIdx.x & 63;
+  static_assert(sizeof(PairState) % 8 == 0, "PairState travels as 8-byte words");
+  constexpr int NW = (int)(sizeof(PairState) / 8);
+  gu64* sg = (gu64*)reinterpret_cast<unsigned long long*>(&st[b]);
+  unsigned long long* sl = reinterpret_cast<unsigned long long*>(&Ssh);
+  // the pair's state: written by its previous updater (another wave, maybe another XCD) -> LDS copy of this wave
+  for (int i = lane; i < NW; i += 64) sl[i] = __hip_atomic_load(sg + i, RLX_AGENT);
+  if (lane == 0) sol[6] = 0.0;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  // reduce_pair_rows' tree (ndt_update.hpp) on one wave: chunk = ((r0 + r1) + r2) + r3; group = 8 chunks in order; group k belongs to
+  // "wave" k % 4, whose groups add up in ascending order; the four sums add up in order.  Same operands, same order: same bits.
+  const int nchunks = (Ssh.n_src + CHUNK_PTS - 1) / CHUNK_PTS;
+  if (lane < NACC) {
+    const gu64* P = (const gu64*)reinterpret_cast<const unsigned long long*>(partials + (size_t)b * rows_per_pair * NACC + lane);
+    double aw0 = 0.0, aw1 = 0.0, aw2 = 0.0, aw3 = 0.0;
+#pragma unroll 1
+    for (int c0 = 0; c0 < nchunks; c0 += 8) {
+      double gs = 0.0;
+      if (c0 + 8 <= nchunks) {
+        double q[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+          for (int k = 0; k < 4; k++) q[u][k] = __longlong_as_double((long long)__hip_atomic_load(P + ((size_t)(c0 + u) * 4 + k) * NACC, RLX_AGENT));
+#pragma unroll
+        for (int u = 0; u < 8; u++) gs += ((q[u][0] + q[u][1]) + q[u][2]) + q[u][3];
+      } else {
+        for (int c = c0; c < nchunks; c++) {
+          double r[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) r[k] = __longlong_as_double((long long)__hip_atomic_load(P + ((size_t)c * 4 + k) * NACC, RLX_AGENT));
+          gs += ((r[0] + r[1]) + r[2]) + r[3];
+        }
+      }
+      const int w = (c0 >> 3) & 3;
+      if (w == 0) aw0 += gs; else if (w == 1) aw1 += gs; else if (w == 2) aw2 += gs; else aw3 += gs;
+    }
+    double v = 0.0;
+    v += aw0; v += aw1; v += aw2; v += aw3;
+    if (lane == 0) Ssh.score = v;
+    else if (lane < 7) Ssh.g[lane - 1] = v;
+    else if (lane < 43) Ssh.H[lane - 7] = v;
+    else { Ssh.hits = (long long)v; if (hits_total) atomicAdd(hits_total, (unsigned long long)v); }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  newton_solve_side(Ssh, sol);                     // lanes 0..6: impl2:138-140 (same functions and operands as k_update's second wave)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  int rc = newton_update(Ssh, &results[b], step_max, eps, max_iterations, 0, sol);
+  rc = __builtin_amdgcn_readfirstlane(rc);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  // the state goes back write-through; it is complete in memory before the ticket that lets other waves read it exists
+  for (int i = lane; i < NW; i += 64) __hip_atomic_store(sg + i, sl[i], RLX_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) {
+    if (rc == NEWTON_SWEEP) {
+      const unsigned g = __hip_atomic_fetch_add((gu32*)&ctl->pub, 1u, RLX_AGENT);
+      __hip_atomic_store((gu32*)reinterpret_cast<unsigned*>(ring + (size_t)(g & 7u) * ring_cap + (g >> 3)), (unsigned)b, RLX_AGENT);
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (finalize_pair's result record)
+      __hip_atomic_fetch_add((gu32*)&ctl->done, 1u, RLX_AGENT);
+    }
+  }
+}
+
+template <bool PCA, int K, int ORD>
+__global__ void __launch_bounds__(SWEEP_THREADS, (SweepTune<PCA, K>::WPE))
+k_align_async(const float* __restrict__ src, size_t pitch, PairState* st, const GridDesc* __restrict__ gd, const BitWord* __restrict__ words,
+              const VoxelRec* __restrict__ recs, double* partials, int items_per_pair, int n_pairs, int* ring, int ring_cap, AsyncCtl* ctl,
+              unsigned* arrived, SweepConst sc, const float* __restrict__ cent, mi355ndt_result* results, unsigned long long* hits_total,
+              double step_max, double eps, int max_iterations) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __shared__ double exp_tab[64];
+  __shared__ PairState Ssh[WAVES];
+  __shared__ double sol[WAVES][8];
+  if (threadIdx.x < 64) exp_tab[threadIdx.x] = ndtm::c_exp2_64[threadIdx.x];
+  __syncthreads();                                 // (the only block barrier: the four waves are independent from here on)
+  const int x = blockIdx.x & 7;                    // the ring this workgroup serves
+  const gu32* ringx = (const gu32*)reinterpret_cast<const unsigned*>(ring + (size_t)x * ring_cap);
+  const gu32* done_p = (const gu32*)&ctl->done;
+  gu32* pos_p = (gu32*)&ctl->pos[x * ASYNC_POS_STRIDE];
+  const int I = items_per_pair;
+#ifdef NDT_TIMELINE
+  unsigned long long tl[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tl_last = __builtin_readcyclecounter();
+#endif
+  // Positions of the ring's item stream (ticket 0's items, ticket 1's, ...) are CLAIMED, one returning fetch-add per item, issued together
+  // with the previous item's arrival (one memory round trip for both).  Static dealing (wave w takes positions w, w + W, ...) was built and
+  // measured first: every update makes its wave late for good, a ticket completes when its latest wave does, and with nothing to rebalance
+  // them the waves spent 38 % of the launch waiting for tickets.
+  unsigned pos = 0;
+  if (lane == 0) pos = __hip_atomic_fetch_add(pos_p, 1u, RLX_AGENT);
+  pos = __builtin_amdgcn_readfirstlane(pos);
+#pragma unroll 1
+  for (;;) {
+    const int t = (int)(pos / (unsigned)I), rem = (int)(pos % (unsigned)I);
+    int b = -1;
+    if (lane == 0) {
+      if (t < ring_cap) b = (int)__hip_atomic_load(ringx + t, RLX_AGENT);
+      unsigned spins = 0;
+      while (b < 0) {                              // not published yet: poll (one lane, relaxed, with sleeps), or find out that the launch is over
+        if (__hip_atomic_load(done_p, RLX_AGENT) >= (unsigned)n_pairs) { b = -2; break; }
+        __builtin_amdgcn_s_sleep(32);
+        if (t < ring_cap) b = (int)__hip_atomic_load(ringx + t, RLX_AGENT);
+        if (++spins > ASYNC_SPIN_LIMIT) {          // never hang: end the launch for everybody and tell the host
+          __hip_atomic_store((gu32*)&ctl->abort_, 1u, RLX_AGENT);
+          __hip_atomic_store((gu32*)&ctl->done, (unsigned)n_pairs, RLX_AGENT);
+          b = -2; break;
+        }
+      }
+    }
+    b = __builtin_amdgcn_readfirstlane(b);
+    if (b < 0) break;
+    TL_STAMP(10);                                  // waiting for the ticket
+    sweep_item<PCA, K, 8, false, ORD, true>(b, rem, src, pitch, st, gd, words, recs, partials, I, sc, cent, nullptr, exp_tab
+#ifdef NDT_TIMELINE
+                                            , tl, tl_last
+#endif
+                                            );
+    // the row is complete in memory before the arrival that may hand it to an updater
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned old = 0;
+    if (lane == 0) {
+      old = __hip_atomic_fetch_add((gu32*)(arrived + (size_t)b * ASYNC_ARR_STRIDE), 1u, RLX_AGENT);
+      pos = __hip_atomic_fetch_add(pos_p, 1u, RLX_AGENT);                      // the next position, in the same round trip
+    }
+    old = __builtin_amdgcn_readfirstlane(old);
+    pos = __builtin_amdgcn_readfirstlane(pos);
+    TL_STAMP(8);                                   // row drain + arrival + claim
+    if ((old + 1u) % (unsigned)I == 0u) {          // this was the sweep's last item: this wave is the pair's updater
+      async_update(b, st, partials, I, Ssh[wv], sol[wv], results, ring, ring_cap, ctl, hits_total, step_max, eps, max_iterations);
+      TL_STAMP(9);
+    }
+  }
+#ifdef NDT_TIMELINE
+  if (lane == 0) for (int k = 0; k < 12; k++) atomicAdd(&g_tl[k], tl[k]);
+#endif
+}

@@ -131,7 +131,7 @@ __host__ __device__ constexpr int probe_off(int K, int q, int a) {
 // -DNDT_TIMELINE: per-phase shader-clock stamps of every work item, summed over all waves into g_tl (read back through
 // mi355ndt_debug_timeline; tools/sweep_timeline.py).  Costs ~10 % and is never part of the shipped library.
 #ifdef NDT_TIMELINE
-__device__ unsigned long long g_tl[8];
+__device__ unsigned long long g_tl[12];
 #define TL_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); tl[k] += t_ - tl_last; tl_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define TL_STAMP(k) do {} while (0)
@@ -163,28 +163,25 @@ static inline int sweep_wpe(bool pca, int K) { (void)pca; (void)K; return SWEEP_
 // points: its own fixed tree, not the batch mode's (results agree to the f64 rounding of the sums, ~1e-16 relative).
 // `grid_of` (may be null): pair b is aligned against the target grid gd[grid_of[b]] instead of gd[b] (sequence mode: the frames'
 // grids are built once, the keyframe policy picks which one a frame is matched against).
-template <bool PCA, int K, int IT = 8, bool FINE = false, int ORD = 0>
-__global__ void __launch_bounds__(SWEEP_THREADS, (SweepTune<PCA, K>::WPE))
-k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict__ st,
-        const GridDesc* __restrict__ gd, const BitWord* __restrict__ words, const VoxelRec* __restrict__ recs,
-        double* partials, int rows_per_pair, const int* __restrict__ active_list, SweepCtl* ctl, SweepCtl* ctl_next, SweepConst sc,
-        const float* __restrict__ cent, const int* __restrict__ grid_of) {
-  // K == 27 is the KDTREE mode (ndt_omp_impl2.hpp:251-253): radiusSearch(point, resolution) over the f32 centroids of the
-  // searchable leaves (voxel_grid_covariance_omp.h:505-534).  A centroid lies inside its own cell, so every centroid closer
-  // than one leaf sits in the 3x3x3 block around the point's cell: probe those 27 cells and keep d^2 < float(r*r).  The
-  // reference does not re-check nr_points there, so eigen/inverse-failed leaves DO take part (their icov is zero / non-finite).
+// One work item of the sweep: `IT` tiles of 64 consecutive points (item `rem`) of pair `b`, run by ONE wave -> one 44-double partial row.
+// Shared by the lockstep kernel (k_sweep: one launch per Newton round) and the asynchronous one (k_align_async: one launch per align).
+// ASYNC: the pair's pose is read, and its row is written, with agent-scope (sc1) accesses -- another workgroup wrote / will read them
+// inside the same launch (ndt_async.hpp) -- and the FINE block reduction does not apply.
+typedef __attribute__((address_space(1))) unsigned int gu32;
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+template <bool PCA, int K, int IT, bool FINE, int ORD, bool ASYNC>
+__device__ __forceinline__ void sweep_item(const int b, const int rem, const float* __restrict__ src, const size_t pitch, const PairState* st,
+                                           const GridDesc* __restrict__ gd, const BitWord* __restrict__ words, const VoxelRec* __restrict__ recs,
+                                           double* partials, const int rows_per_pair, const SweepConst& sc, const float* __restrict__ cent,
+                                           const int* __restrict__ grid_of, const double* exp_tab
+#ifdef NDT_TIMELINE
+                                           , unsigned long long* tl, unsigned long long& tl_last
+#endif
+                                           ) {
   constexpr bool KD = (K == 27);
-  // Persistent waves pulling work items.  One item = one wave-quarter (CHUNK_PTS/4 consecutive points) of one chunk
-  // of one active pair; every wave is independent (own LDS queue, own partial row, no block barrier), so a wave
-  // whose points have few hits simply takes the next item instead of idling at a barrier.
-  // Items are queued per XCD: pair slot a of the active list belongs to XCD a % 8 (workgroup L is observed to run on
-  // XCD L % 8, MI355X_MICROARCH.md), so one pair's records / bitmap / points stay in one L2; a wave whose XCD
-  // queue is empty steals from the others.  Which wave runs an item never changes the item's result.
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  const int n_active = ctl->n_active;
-  const int items_per_pair = rows_per_pair;         // one partial row per work item
-
   // ndt_pca's per-hit multiplier is the product of the hit's own weight and those of the point's LATER hits, known only in phase A.
   // With one probe per point (DIRECT1) it is just the leaf's own weight, which phase B reads with the record anyway: no weight
   // load in the probe stage, no weight queue, dead leaves filtered in phase B exactly as for ndt_omp.
@@ -207,66 +204,17 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
   // multiple of four items per pair), so the chunk level of k_update's tree -- ((r0 + r1) + r2) + r3 -- is added here through LDS and
   // one row per chunk goes to memory: a quarter of the rows for the update to fetch.
   __shared__ double red[FINE ? WAVES : 1][FINE ? NACC : 1];
-  __shared__ double exp_tab[64];                   // 2^(j/64) for ndtm::exp_f32arg
-  if (threadIdx.x < 64) exp_tab[threadIdx.x] = ndtm::c_exp2_64[threadIdx.x];
-  __syncthreads();                                 // (the only block barrier of the kernel, before the persistent loop)
-  // the control block of the NEXT round (k_update fills it after this kernel) is cleared here, not by a host memset
-  if (blockIdx.x == 0 && threadIdx.x < 9) reinterpret_cast<int*>(ctl_next)[threadIdx.x] = 0;
-  if (FINE && sc.host_flags && blockIdx.x == 0 && threadIdx.x == 0) {     // progress report of the latency-mode pump (posted writes over PCIe)
-    sc.host_flags[1] = n_active;
-    __threadfence_system();
-    sc.host_flags[0] = sc.seq_no;
-  }
-  if (n_active == 0) return;                       // nothing left to sweep (the loop's last, empty round)
-  const int my_xcd = blockIdx.x & 7;
-  // Items of a queue are handed out in two ways.  The first `n_static` rounds are STATIC: wave `wx` of the XCD's `xw` waves takes
-  // items wx, wx + xw, ...; only the rest of the queue is claimed with an atomic.  Why: VMEM operations of a wave complete in
-  // order (vmcnt), so every load issued after a returning atomic -- an agent-scope atomic takes ~4 us here -- waits for it;
-  // with one claim per item the point loads of every item sat behind one (measured with -DNDT_TIMELINE: 10 k cycles per item).
-  // The dynamic tail (1 / 2^sc.dyn_shift of the queue, more when that is no whole round) absorbs the imbalance.
-  // FLAT dealing: one queue over all active pairs, item i to wave i of the whole grid (then i + all waves, ...), no atomics and no
-  // XCD affinity.  Always in latency mode; in batch mode whenever the launch has no more items than waves -- the last rounds of a
-  // batch, when a handful of pairs are still iterating: with fewer than eight active pairs most XCDs own no queue and their waves
-  // would do nothing but steal, one returning atomic (~4 us) per item.  Which wave runs an item is no part of its result.
-  const bool flat = FINE || (n_active * items_per_pair <= (int)gridDim.x * WAVES);
-  const int xw = flat ? (int)gridDim.x * WAVES : (int)(gridDim.x >> 3) * WAVES;          // waves per XCD (flat: of the whole grid)
-  const int wx = flat ? (int)blockIdx.x * WAVES + wv : (int)(blockIdx.x >> 3) * WAVES + wv;
-#ifdef NDT_TIMELINE
-  unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long tl_last = __builtin_readcyclecounter();
-#endif
-#pragma unroll 1
-  for (int probe = 0; probe < (flat ? 1 : 8); probe++) {        // own XCD first, then steal (flat: one queue, all static)
-    const int xcd = flat ? 0 : (my_xcd + probe) & 7;
-    const int pairs_here = flat ? n_active : (n_active > xcd ? (n_active - xcd + 7) / 8 : 0);
-    const int items_here = pairs_here * items_per_pair;
-    if (items_here == 0) continue;
-    // static rounds of this queue (the same number for every wave; none when the grid is no multiple of 8 or for a thief)
-    const int n_static = flat ? (items_here + xw - 1) / xw : (((gridDim.x & 7) == 0) ? (items_here - (items_here >> sc.dyn_shift)) / xw : 0);
-    const int dyn0 = n_static * xw;               // first item of the dynamic tail
-    int round = 0;
-    const bool own = flat || ((probe == 0) && n_static > 0);
-    int item = 0;
-    if (own) item = wx;
-    else {
-      // a drained queue is recognised with a plain (L2) load; only a queue that still has items costs an atomic
-      if (dyn0 + __hip_atomic_load(&ctl->next_item[xcd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= items_here) continue;
-      if (lane == 0) item = dyn0 + atomicAdd(&ctl->next_item[xcd], 1);
-      item = __builtin_amdgcn_readfirstlane(item);
-    }
-#pragma unroll 1
-    while (item < items_here) {
-      // the next item: static while rounds are left, else claimed NOW (the atomic's round trip is hidden behind this item's work)
-      const bool next_static = own && (round + 1 < n_static);
-      int next_item = 0;
-      if (flat) next_item = items_here;             // no dynamic tail
-      else if (!next_static && lane == 0) next_item = dyn0 + atomicAdd(&ctl->next_item[xcd], 1);
-      const int b = active_list[flat ? item / items_per_pair : xcd + 8 * (item / items_per_pair)];
-      const int rem = item % items_per_pair;        // the pair's work item = its partial row
-      TL_STAMP(0);
-
   const PairState& S = st[b];
-  const int n = S.n_src;
+  // ASYNC: T (12 words), Rj (9) and n_src through agent-scope vector loads (never the scalar cache, never a stale L1 line): the
+  // updater of this pair -- some other workgroup of this launch -- rewrote them since the pair's previous sweep
+  unsigned pose_w = 0;
+  if (ASYNC) {
+    const gu32* sw = (const gu32*)reinterpret_cast<const unsigned*>(&S);
+    static_assert(offsetof(PairState, T) == 0 && offsetof(PairState, Rj) == 48, "pose words");
+    if (lane < 21) pose_w = __hip_atomic_load(sw + lane, RLX_AGENT);
+    else if (lane == 21) pose_w = __hip_atomic_load(sw + offsetof(PairState, n_src) / 4, RLX_AGENT);
+  }
+  const int n = ASYNC ? (int)__builtin_amdgcn_readlane(pose_w, 21) : S.n_src;
   const GridDesc& g = gd[grid_of ? grid_of[b] : b];
   const float* X = src + (size_t)b * 3 * pitch;
   const BitWord* W = words + g.word_off;
@@ -274,9 +222,9 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
   const bool grid_ok = (g.status == GRID_OK);
   float T[12], Rj[9];
 #pragma unroll
-  for (int a = 0; a < 12; a++) T[a] = S.T[a];
+  for (int a = 0; a < 12; a++) T[a] = ASYNC ? __uint_as_float(__builtin_amdgcn_readlane(pose_w, a)) : S.T[a];
 #pragma unroll
-  for (int a = 0; a < 9; a++) Rj[a] = S.Rj[a];
+  for (int a = 0; a < 9; a++) Rj[a] = ASYNC ? __uint_as_float(__builtin_amdgcn_readlane(pose_w, 12 + a)) : S.Rj[a];
   const float leaf = g.leaf;
   const int mb0 = g.min_b[0], mb1 = g.min_b[1], mb2 = g.min_b[2];
   const int xb0 = g.max_b[0], xb1 = g.max_b[1], xb2 = g.max_b[2];
@@ -504,9 +452,16 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
       // row 0 (lane 0) holds values 0..10, row 1: 11..21, row 2: 22..32, row 3: 33..42 (+ the pad)
       const int row = lane >> 4, base = 11 * (row & 1) + 22 * (row >> 1);
       double* P = FINE ? &red[FINE ? wv : 0][0] : partials + ((size_t)b * rows_per_pair + rem) * NACC;
+      if (ASYNC) {                                 // write-through (sc1) 8-byte stores: the pair's updater may run on another XCD
+        gu64* PG = (gu64*)reinterpret_cast<unsigned long long*>(P);
 #pragma unroll
-      for (int i = 0; i < 11; i++) if (base + i < 43) P[base + i] = P2[i];
-      if (lane == 0) P[43] = (double)nhits;
+        for (int i = 0; i < 11; i++) if (base + i < 43) __hip_atomic_store(PG + base + i, (unsigned long long)__double_as_longlong(P2[i]), RLX_AGENT);
+        if (lane == 0) __hip_atomic_store(PG + 43, (unsigned long long)__double_as_longlong((double)nhits), RLX_AGENT);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 11; i++) if (base + i < 43) P[base + i] = P2[i];
+        if (lane == 0) P[43] = (double)nhits;
+      }
     }
     if (FINE) {
       __syncthreads();                              // (uniform: the four waves of a block run the same items loop, see above)
@@ -519,6 +474,91 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
     tl[7] += 1;
 #endif
   }
+}
+
+template <bool PCA, int K, int IT = 8, bool FINE = false, int ORD = 0>
+__global__ void __launch_bounds__(SWEEP_THREADS, (SweepTune<PCA, K>::WPE))
+k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict__ st,
+        const GridDesc* __restrict__ gd, const BitWord* __restrict__ words, const VoxelRec* __restrict__ recs,
+        double* partials, int rows_per_pair, const int* __restrict__ active_list, SweepCtl* ctl, SweepCtl* ctl_next, SweepConst sc,
+        const float* __restrict__ cent, const int* __restrict__ grid_of) {
+  // K == 27 is the KDTREE mode (ndt_omp_impl2.hpp:251-253): radiusSearch(point, resolution) over the f32 centroids of the
+  // searchable leaves (voxel_grid_covariance_omp.h:505-534).  A centroid lies inside its own cell, so every centroid closer
+  // than one leaf sits in the 3x3x3 block around the point's cell: probe those 27 cells and keep d^2 < float(r*r).  The
+  // reference does not re-check nr_points there, so eigen/inverse-failed leaves DO take part (their icov is zero / non-finite).
+  // Persistent waves pulling work items.  One item = one wave-quarter (CHUNK_PTS/4 consecutive points) of one chunk
+  // of one active pair; every wave is independent (own LDS queue, own partial row, no block barrier), so a wave
+  // whose points have few hits simply takes the next item instead of idling at a barrier.
+  // Items are queued per XCD: pair slot a of the active list belongs to XCD a % 8 (workgroup L is observed to run on
+  // XCD L % 8, MI355X_MICROARCH.md), so one pair's records / bitmap / points stay in one L2; a wave whose XCD
+  // queue is empty steals from the others.  Which wave runs an item never changes the item's result.
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int n_active = ctl->n_active;
+  const int items_per_pair = rows_per_pair;         // one partial row per work item
+
+  __shared__ double exp_tab[64];                   // 2^(j/64) for ndtm::exp_f32arg
+  if (threadIdx.x < 64) exp_tab[threadIdx.x] = ndtm::c_exp2_64[threadIdx.x];
+  __syncthreads();                                 // (the only block barrier of the kernel, before the persistent loop)
+  // the control block of the NEXT round (k_update fills it after this kernel) is cleared here, not by a host memset
+  if (blockIdx.x == 0 && threadIdx.x < 9) reinterpret_cast<int*>(ctl_next)[threadIdx.x] = 0;
+  if (FINE && sc.host_flags && blockIdx.x == 0 && threadIdx.x == 0) {     // progress report of the latency-mode pump (posted writes over PCIe)
+    sc.host_flags[1] = n_active;
+    __threadfence_system();
+    sc.host_flags[0] = sc.seq_no;
+  }
+  if (n_active == 0) return;                       // nothing left to sweep (the loop's last, empty round)
+  const int my_xcd = blockIdx.x & 7;
+  // Items of a queue are handed out in two ways.  The first `n_static` rounds are STATIC: wave `wx` of the XCD's `xw` waves takes
+  // items wx, wx + xw, ...; only the rest of the queue is claimed with an atomic.  Why: VMEM operations of a wave complete in
+  // order (vmcnt), so every load issued after a returning atomic -- an agent-scope atomic takes ~4 us here -- waits for it;
+  // with one claim per item the point loads of every item sat behind one (measured with -DNDT_TIMELINE: 10 k cycles per item).
+  // The dynamic tail (1 / 2^sc.dyn_shift of the queue, more when that is no whole round) absorbs the imbalance.
+  // FLAT dealing: one queue over all active pairs, item i to wave i of the whole grid (then i + all waves, ...), no atomics and no
+  // XCD affinity.  Always in latency mode; in batch mode whenever the launch has no more items than waves -- the last rounds of a
+  // batch, when a handful of pairs are still iterating: with fewer than eight active pairs most XCDs own no queue and their waves
+  // would do nothing but steal, one returning atomic (~4 us) per item.  Which wave runs an item is no part of its result.
+  const bool flat = FINE || (n_active * items_per_pair <= (int)gridDim.x * WAVES);
+  const int xw = flat ? (int)gridDim.x * WAVES : (int)(gridDim.x >> 3) * WAVES;          // waves per XCD (flat: of the whole grid)
+  const int wx = flat ? (int)blockIdx.x * WAVES + wv : (int)(blockIdx.x >> 3) * WAVES + wv;
+#ifdef NDT_TIMELINE
+  unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tl_last = __builtin_readcyclecounter();
+#endif
+#pragma unroll 1
+  for (int probe = 0; probe < (flat ? 1 : 8); probe++) {        // own XCD first, then steal (flat: one queue, all static)
+    const int xcd = flat ? 0 : (my_xcd + probe) & 7;
+    const int pairs_here = flat ? n_active : (n_active > xcd ? (n_active - xcd + 7) / 8 : 0);
+    const int items_here = pairs_here * items_per_pair;
+    if (items_here == 0) continue;
+    // static rounds of this queue (the same number for every wave; none when the grid is no multiple of 8 or for a thief)
+    const int n_static = flat ? (items_here + xw - 1) / xw : (((gridDim.x & 7) == 0) ? (items_here - (items_here >> sc.dyn_shift)) / xw : 0);
+    const int dyn0 = n_static * xw;               // first item of the dynamic tail
+    int round = 0;
+    const bool own = flat || ((probe == 0) && n_static > 0);
+    int item = 0;
+    if (own) item = wx;
+    else {
+      // a drained queue is recognised with a plain (L2) load; only a queue that still has items costs an atomic
+      if (dyn0 + __hip_atomic_load(&ctl->next_item[xcd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= items_here) continue;
+      if (lane == 0) item = dyn0 + atomicAdd(&ctl->next_item[xcd], 1);
+      item = __builtin_amdgcn_readfirstlane(item);
+    }
+#pragma unroll 1
+    while (item < items_here) {
+      // the next item: static while rounds are left, else claimed NOW (the atomic's round trip is hidden behind this item's work)
+      const bool next_static = own && (round + 1 < n_static);
+      int next_item = 0;
+      if (flat) next_item = items_here;             // no dynamic tail
+      else if (!next_static && lane == 0) next_item = dyn0 + atomicAdd(&ctl->next_item[xcd], 1);
+      const int b = active_list[flat ? item / items_per_pair : xcd + 8 * (item / items_per_pair)];
+      const int rem = item % items_per_pair;        // the pair's work item = its partial row
+      TL_STAMP(0);
+
+      sweep_item<PCA, K, IT, FINE, ORD, false>(b, rem, src, pitch, st, gd, words, recs, partials, rows_per_pair, sc, cent, grid_of, exp_tab
+#ifdef NDT_TIMELINE
+                                               , tl, tl_last
+#endif
+                                               );
       if (next_static) { round++; item = wx + round * xw; }
       else item = __builtin_amdgcn_readfirstlane(next_item);
     }

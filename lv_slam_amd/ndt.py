@@ -84,6 +84,7 @@ SYMBOLS = [
     "mi355ndt_set_latency_mode", "mi355ndt_sequence_run",
     "mi355ndt_calculate_score", "mi355ndt_convert_transform", "mi355ndt_set_option", "mi355ndt_get_option",
 ]
+OPT_ASYNC_ALIGN = 2            # mi355ndt_option: 1 (default) = one persistent launch per batch align, 0 = lockstep (update, sweep) rounds; same bits
 OPT_F32_SUM_ORDER = 1          # mi355ndt_option: 0 = (t0 + t1) + t2 (canonical), 1 = (t0 + t2) + t1 (Eigen 3.3 SSE predux pairing)
 
 _LIB = None

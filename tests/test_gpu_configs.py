@@ -104,12 +104,15 @@ def test_results_do_not_depend_on_how_work_items_are_dealt(mode, variant, monkey
     G = synth.default_guess()
     kw = dict(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=mode, variant=variant)
     ref = None
-    for shift in ("0", "1", None, "6"):
-        if shift is None:
+    for shift in ("0", "1", None, "6", "async"):
+        if shift in (None, "async"):
             monkeypatch.delenv("MI355NDT_SWEEP_DYN_SHIFT", raising=False)
         else:
             monkeypatch.setenv("MI355NDT_SWEEP_DYN_SHIFT", shift)
         eng = ndt.Engine(ndt.default_params(**kw))          # the knob is read when the engine is created
+        # the round-based kernels are what the knob deals with; the last run is the one-launch align (ndt_async.hpp), where tickets are
+        # dealt to waves in yet another way: still the same bits
+        eng.set_option(ndt.OPT_ASYNC_ALIGN, 1 if shift == "async" else 0)
         eng.batch_bind_device(T.data_ptr(), [n] * B, n, S.data_ptr(), [n] * B, n)
         eng.batch_build_targets()
         res = eng.batch_align(G)
@@ -120,6 +123,79 @@ def test_results_do_not_depend_on_how_work_items_are_dealt(mode, variant, monkey
         for a, b in zip(ref, res):
             assert np.array_equal(a["final"], b["final"]) and a["score"] == b["score"] and a["iterations"] == b["iterations"]
             assert a["hits_last"] == b["hits_last"] and a["sweeps"] == b["sweeps"]
+
+
+@pytest.mark.parametrize("mode,variant,res", [(ndt.DIRECT7, 0, 1.0), (ndt.DIRECT1, 1, 1.0), (ndt.DIRECT26, 0, 2.0), (ndt.KDTREE, 0, 1.0), (ndt.DIRECT7, 1, 0.5)])
+def test_one_launch_align_equals_the_round_based_align(mode, variant, res):
+    """MI355NDT_OPT_ASYNC_ALIGN: every pair through its own Newton loop inside ONE persistent launch (as every reference align() runs its own
+    loop, ndt_omp_impl2.hpp:131-183) against the lockstep (update, sweep) rounds: identical poses, scores, iteration counts, hit counts and
+    incremental transforms for a ragged batch whose pairs need different numbers of iterations -- partial rows, poses and tickets cross
+    workgroups and XCDs inside the launch, so this is also the hand-off's litmus test (uneven load, every result word compared, repeated)."""
+    ids = list(range(200, 240))
+    T, S, host, n = resident_batch(ids, 512)
+    B = len(ids)
+    cnt = [n - 997 * (k % 7) for k in range(B)]             # ragged sources: the last items of a pair are short or empty
+    G = np.stack([synth.default_guess() for _ in range(B)])
+    G[::3, 0, 3] += 0.35                                    # some pairs start further away: iteration counts differ across the batch
+    kw = dict(resolution=res, trans_epsilon=0.01, max_iterations=64, neighbor_mode=mode, variant=variant)
+    out = {}
+    for a in (0, 1):
+        eng = ndt.Engine(ndt.default_params(**kw))
+        eng.set_option(ndt.OPT_ASYNC_ALIGN, a)
+        assert eng.get_option(ndt.OPT_ASYNC_ALIGN) == a
+        eng.batch_bind_device(T.data_ptr(), [n] * B, n, S.data_ptr(), cnt, n)
+        eng.batch_build_targets()
+        runs = [eng.batch_align(G) for _ in range(6 if a else 1)]
+        incs = [eng.get_incremental(k) for k in (0, B // 2, B - 1)]
+        eng.close()
+        out[a] = (runs, incs)
+    ref = out[0][0][0]
+    if mode != ndt.DIRECT26:                                # (ndt_omp + DIRECT26 at 2 m oscillates: every pair runs into max_iterations + 2 = 66 iterations, the longest loop there is)
+        assert len({r["iterations"] for r in ref}) >= 3     # the batch really is uneven
+    for rep in out[1][0]:
+        for k, (x, y) in enumerate(zip(ref, rep)):
+            assert np.array_equal(x["final"], y["final"]) and x["score"] == y["score"] and x["trans_probability"] == y["trans_probability"], k
+            assert x["iterations"] == y["iterations"] and x["converged"] == y["converged"] and x["sweeps"] == y["sweeps"] and x["hits_last"] == y["hits_last"], k
+    for (a0, p0), (a1, p1) in zip(out[0][1], out[1][1]):
+        assert np.array_equal(a0, a1) and np.array_equal(p0, p1)
+    # and the oracle agrees on a sample
+    op = O.default_params(**kw)
+    for k in (0, 3, B - 1):
+        if variant == 1 and mode in (ndt.KDTREE, ndt.DIRECT26):
+            break
+        t, s_, _ = host[k]
+        ro = O.align(O.Grid(t, op), s_[: cnt[k]], G[k])
+        assert ro["iterations"] == ref[k]["iterations"]
+        dt, dr = se3_err(ro["final"], ref[k]["final"])
+        assert dt < 1e-4 and dr < 1e-5
+
+
+def test_one_launch_align_many_small_pairs_repeated():
+    """Hand-off stress: 300 pairs of 4,096 points (8 work items per sweep, so a pair's updater changes constantly and tickets are published
+    at the highest rate the engine can produce), 20 aligns in a row, every result word of every run equal to the round-based align's."""
+    ids = list(range(300, 340))
+    T, S, host, n = resident_batch(ids, 64)
+    import torch
+    reps = 8                                                  # 320 pairs: the 40 clouds, each with 8 different guesses
+    Tb, Sb = T.repeat(reps, 1, 1), S.repeat(reps, 1, 1)
+    B = len(ids) * reps
+    G = np.stack([synth.default_guess() for _ in range(B)])
+    G[:, 0, 3] += np.repeat(np.linspace(-0.3, 0.4, reps), len(ids)).astype(np.float32)
+    G[:, 1, 3] += np.tile(np.linspace(-0.1, 0.1, len(ids)), reps).astype(np.float32)
+    kw = dict(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=ndt.DIRECT7, variant=0)
+    res = {}
+    for a in (0, 1):
+        eng = ndt.Engine(ndt.default_params(**kw))
+        eng.set_option(ndt.OPT_ASYNC_ALIGN, a)
+        eng.batch_bind_device(Tb.data_ptr(), [n] * B, n, Sb.data_ptr(), [n] * B, n)
+        eng.batch_build_targets()
+        res[a] = [eng.batch_align(G) for _ in range(20 if a else 1)]
+        eng.close()
+    ref = res[0][0]
+    for rep in res[1]:
+        for k, (x, y) in enumerate(zip(ref, rep)):
+            assert np.array_equal(x["final"], y["final"]) and x["score"] == y["score"] and x["iterations"] == y["iterations"] and x["hits_last"] == y["hits_last"], k
+    torch.cuda.synchronize()
 
 
 def test_host_cloud_batch_upload_paths_agree():

@@ -26,6 +26,10 @@ for stage in "$@"; do
                 cd /tmp && export TMPDIR=/tmp; timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/kt -- python $R/tools/seq_run.py 65 > $O/seq_traced.txt 2> $O/kt.log; cd $R
                 python tools/seq_kernels.py $O/kt > $O/seq_kernels.txt; rm -rf $O/kt; cat $O/seq_kernels.txt ;;
     tests_r4)   timeout 2400 python -m pytest tests/test_reference_golden.py tests/test_adaptor.py tests/test_gpu_parity.py -m gpu -x -q -k "reference or adaptor or calculate_score or convert_transform or f32_sum_order" 2>&1 | tail -25 > $O/pytest.txt; cat $O/pytest.txt ;;
+    tests_async) timeout 1500 python -m pytest tests/test_gpu_configs.py -m gpu -x -q -k "one_launch or dealt" 2>&1 | tail -25 > $O/pytest.txt; cat $O/pytest.txt ;;
+    bench_q)    (time timeout 900 python bench.py --cpu-seconds 8 --no-host-clouds --seq-frames 0 --config4-pairs 0) > $O/bench.json 2> $O/bench.log; tail -c 3000 $O/bench.json; tail -5 $O/bench.log ;;
+    bench_q0)   (time MI355NDT_ASYNC=0 timeout 900 python bench.py --cpu-seconds 8 --no-host-clouds --seq-frames 0 --config4-pairs 0) > $O/bench.json 2> $O/bench.log; tail -c 3000 $O/bench.json; tail -5 $O/bench.log ;;
+    timeline)   (for a in 0 1; do MI355NDT_ASYNC=$a MAXIT=64 MI355NDT_LIB=$R/lv_slam_amd/libexp_tl.so timeout 300 python tools/sweep_timeline.py; done) 2>&1 | grep -v amdgpu.ids > $O/tl.txt; cat $O/tl.txt ;;
     *) echo "unknown stage $stage" ;;
   esac
 done

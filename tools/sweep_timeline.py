@@ -15,7 +15,7 @@ T = torch.empty(B, 3, N, device=dev); S = torch.empty(B, 3, N, device=dev)
 for b in range(B):
     t, s, _ = synth.make_pair(b, NAZ, device=dev)
     T[b] = t.T; S[b] = s.T
-eng = ndt.Engine(ndt.default_params(resolution=RES, trans_epsilon=0.01, max_iterations=0, neighbor_mode=MODE, variant=VAR), device=0)
+eng = ndt.Engine(ndt.default_params(resolution=RES, trans_epsilon=0.01, max_iterations=int(os.environ.get("MAXIT", 0)), neighbor_mode=MODE, variant=VAR), device=0)
 eng.batch_bind_device(T.data_ptr(), [N] * B, N, S.data_ptr(), [N] * B, N)
 G = synth.default_guess()
 guesses = np.ascontiguousarray(np.broadcast_to(G.T.reshape(1, 16), (B, 16)), dtype=np.float32)
@@ -23,7 +23,7 @@ res = (ndt.Result * B)()
 eng.batch_build_targets()
 for _ in range(3): eng.batch_align_raw(guesses, res)
 lib = ndt.load_library()
-out = (ctypes.c_ulonglong * 8)()
+out = (ctypes.c_ulonglong * 12)()
 lib.mi355ndt_debug_timeline(out)
 eng.profile_enable(True); eng.profile_reset()
 R = 5
@@ -31,9 +31,9 @@ for _ in range(R): eng.batch_align_raw(guesses, res)
 p = eng.profile_get()
 lib.mi355ndt_debug_timeline(out)
 v = np.array(list(out), dtype=np.float64)
-names = ["claim/loop", "setup+pt issue", "pt wait+transform", "bitmap issue", "bitmap wait+push", "drain(eval)", "reduce+write"]
-tot = v[:7].sum()
+names = ["claim/loop", "setup+pt issue", "pt wait+transform", "bitmap issue", "bitmap wait+push", "drain(eval)", "reduce+write", "(items)", "row drain+arrive", "update", "ticket wait", "-"]
+tot = v[:7].sum() + v[8:11].sum()
 print(MODE, VAR, "items", int(v[7]), "sweep ms/align", p["sweep_ms"] / R, "launches", p["sweep_launches"] / R)
-for n, x in zip(names, v[:7]): print(f"  {n:22s} {x / v[7]:10.0f} cyc/item  {100 * x / tot:5.1f} %")
+for n, x in [(a, c) for k, (a, c) in enumerate(zip(names, v)) if k != 7 and k != 11]: print(f"  {n:22s} {x / v[7]:10.0f} cyc/item  {100 * x / tot:5.1f} %")
 print("  total cyc/item", tot / v[7])
 eng.close()
