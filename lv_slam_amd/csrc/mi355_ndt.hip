@@ -1000,7 +1000,7 @@ static int launch_async_t(mi355ndt_handle* h, const SweepConst& sc, int B, int r
   const int wpe = sweep_wpe(PCA, K);
   if (per_cu < wpe) return MI355NDT_ERR_UNSUPPORTED;              // every workgroup must be resident: waves wait for each other's tickets
   dim3 grid((unsigned)(h->n_cu * wpe));
-  kern<<<grid, SWEEP_THREADS, 0, h->stream>>>(h->d_src, h->src_pitch, h->d_state, h->d_grid, h->d_words, h->d_recs, h->d_partials, h->items_per_pair, B,
+  kern<<<grid, SWEEP_THREADS, 0, h->stream>>>(h->d_src, h->src_pitch, h->d_state, h->d_grid, h->d_words, h->d_recs, h->d_partials, h->items_per_pair, B, h->d_src_cnt,
                                              h->d_ring, ring_cap, h->d_actl, h->d_arrived, sc, h->d_cent, h->d_results, h->prof ? h->d_hits : nullptr,
                                              h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations);
   return MI355NDT_OK;

@@ -120,8 +120,8 @@ __device__ __forceinline__ void async_update(const int b, PairState* st, const d
 template <bool PCA, int K, int ORD>
 __global__ void __launch_bounds__(SWEEP_THREADS, (SweepTune<PCA, K>::WPE))
 k_align_async(const float* __restrict__ src, size_t pitch, PairState* st, const GridDesc* __restrict__ gd, const BitWord* __restrict__ words,
-              const VoxelRec* __restrict__ recs, double* partials, int items_per_pair, int n_pairs, int* ring, int ring_cap, AsyncCtl* ctl,
-              unsigned* arrived, SweepConst sc, const float* __restrict__ cent, mi355ndt_result* results, unsigned long long* hits_total,
+              const VoxelRec* __restrict__ recs, double* partials, int items_per_pair, int n_pairs, const int* __restrict__ src_cnt, int* ring, int ring_cap,
+              AsyncCtl* ctl, unsigned* arrived, SweepConst sc, const float* __restrict__ cent, mi355ndt_result* results, unsigned long long* hits_total,
               double step_max, double eps, int max_iterations) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   __shared__ double exp_tab[64];
@@ -138,21 +138,12 @@ k_align_async(const float* __restrict__ src, size_t pitch, PairState* st, const 
   unsigned long long tl[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tl_last = __builtin_readcyclecounter();
 #endif
-  // Positions of the ring's item stream (ticket 0's items, ticket 1's, ...) are CLAIMED, one returning fetch-add per item, issued together
-  // with the previous item's arrival (one memory round trip for both).  Static dealing (wave w takes positions w, w + W, ...) was built and
-  // measured first: every update makes its wave late for good, a ticket completes when its latest wave does, and with nothing to rebalance
-  // them the waves spent 38 % of the launch waiting for tickets.
-  unsigned pos = 0;
-  if (lane == 0) pos = __hip_atomic_fetch_add(pos_p, 1u, RLX_AGENT);
-  pos = __builtin_amdgcn_readfirstlane(pos);
-#pragma unroll 1
-  for (;;) {
-    const int t = (int)(pos / (unsigned)I), rem = (int)(pos % (unsigned)I);
-    int b = -1;
+  // wait (one lane, relaxed polls with sleeps) until ticket `t` of this ring exists; -2: the launch is over
+  auto wait_ticket = [&](const int t, int have) -> int {
+    int b = have;
     if (lane == 0) {
-      if (t < ring_cap) b = (int)__hip_atomic_load(ringx + t, RLX_AGENT);
       unsigned spins = 0;
-      while (b < 0) {                              // not published yet: poll (one lane, relaxed, with sleeps), or find out that the launch is over
+      while (b < 0) {
         if (__hip_atomic_load(done_p, RLX_AGENT) >= (unsigned)n_pairs) { b = -2; break; }
         __builtin_amdgcn_s_sleep(32);
         if (t < ring_cap) b = (int)__hip_atomic_load(ringx + t, RLX_AGENT);
@@ -163,28 +154,59 @@ k_align_async(const float* __restrict__ src, size_t pitch, PairState* st, const 
         }
       }
     }
-    b = __builtin_amdgcn_readfirstlane(b);
-    if (b < 0) break;
-    TL_STAMP(10);                                  // waiting for the ticket
-    sweep_item<PCA, K, 8, false, ORD, true>(b, rem, src, pitch, st, gd, words, recs, partials, I, sc, cent, nullptr, exp_tab
+    return __builtin_amdgcn_readfirstlane(b);
+  };
+  // Positions of the ring's item stream (ticket 0's items, ticket 1's, ...) are CLAIMED, one returning fetch-add per item.  Static dealing
+  // (wave w takes positions w, w + W, ...) was built and measured first: every update makes its wave late for good, a ticket completes when
+  // its latest wave does, and with nothing to rebalance them the waves spent 38 % of the launch waiting for tickets.
+  unsigned pos = 0;
+  if (lane == 0) pos = __hip_atomic_fetch_add(pos_p, 1u, RLX_AGENT);
+  pos = __builtin_amdgcn_readfirstlane(pos);
+  int b = -1;
+  if (lane == 0 && (int)(pos / (unsigned)I) < ring_cap) b = (int)__hip_atomic_load(ringx + pos / (unsigned)I, RLX_AGENT);
+  b = wait_ticket((int)(pos / (unsigned)I), b);
+  if (b < 0) return;
+  unsigned pose_w = sweep_pose_words(st + b);
+#pragma unroll 1
+  for (;;) {
+    const int rem = (int)(pos % (unsigned)I);
+    TL_STAMP(10);                                  // hand-over: claim, ticket, (update)
+    sweep_item<PCA, K, 8, false, ORD, true>(b, rem, src, pitch, st, gd, words, recs, partials, I, sc, cent, nullptr, exp_tab, pose_w, src_cnt[b]
 #ifdef NDT_TIMELINE
                                             , tl, tl_last
 #endif
                                             );
-    // the row is complete in memory before the arrival that may hand it to an updater
+    // Three memory round trips between two items, each carrying everything that does not depend on the next one:
+    //  1. the row stores drain (the row is complete in memory before the arrival that may hand it to an updater) -- and the claim of the
+    //     next position, which depends on nothing, returns with them;
+    unsigned npos = 0;
+    if (lane == 0) npos = __hip_atomic_fetch_add(pos_p, 1u, RLX_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    npos = __builtin_amdgcn_readfirstlane(npos);
+    const int tn = (int)(npos / (unsigned)I);
+    //  2. the arrival, and the ticket word of the next position;
     unsigned old = 0;
+    int nb = -1;
     if (lane == 0) {
       old = __hip_atomic_fetch_add((gu32*)(arrived + (size_t)b * ASYNC_ARR_STRIDE), 1u, RLX_AGENT);
-      pos = __hip_atomic_fetch_add(pos_p, 1u, RLX_AGENT);                      // the next position, in the same round trip
+      if (tn < ring_cap) nb = (int)__hip_atomic_load(ringx + tn, RLX_AGENT);
     }
     old = __builtin_amdgcn_readfirstlane(old);
-    pos = __builtin_amdgcn_readfirstlane(pos);
-    TL_STAMP(8);                                   // row drain + arrival + claim
+    nb = __builtin_amdgcn_readfirstlane(nb);
+    //  3. the next pair's pose -- in flight while this wave updates (if it has to), then together with the next item's point loads.
+    unsigned npose = 0;
+    if (nb >= 0) npose = sweep_pose_words(st + nb);
+    TL_STAMP(8);                                   // row drain + claim, arrival + ticket
     if ((old + 1u) % (unsigned)I == 0u) {          // this was the sweep's last item: this wave is the pair's updater
       async_update(b, st, partials, I, Ssh[wv], sol[wv], results, ring, ring_cap, ctl, hits_total, step_max, eps, max_iterations);
       TL_STAMP(9);
     }
+    if (nb < 0) {                                  // the next position's ticket does not exist yet
+      nb = wait_ticket(tn, nb);
+      if (nb < 0) break;
+      npose = sweep_pose_words(st + nb);
+    }
+    b = nb; pos = npos; pose_w = npose;
   }
 #ifdef NDT_TIMELINE
   if (lane == 0) for (int k = 0; k < 12; k++) atomicAdd(&g_tl[k], tl[k]);

@@ -170,11 +170,22 @@ static inline int sweep_wpe(bool pca, int K) { (void)pca; (void)K; return SWEEP_
 typedef __attribute__((address_space(1))) unsigned int gu32;
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+// ASYNC: the 21 pose words of pair state S (T: 12, Rj: 9), lane k holding word k -- one agent-scope (L1-bypassing) vector load, never the
+// scalar cache: the pair's updater, some other workgroup of the same launch, rewrote them since the pair's previous sweep
+__device__ __forceinline__ unsigned sweep_pose_words(const PairState* S) {
+  static_assert(offsetof(PairState, T) == 0 && offsetof(PairState, Rj) == 48, "pose words");
+  const int lane = threadIdx.x & 63;
+  unsigned w = 0;
+  if (lane < 21) w = __hip_atomic_load((const gu32*)reinterpret_cast<const unsigned*>(S) + lane, RLX_AGENT);
+  return w;
+}
+
 template <bool PCA, int K, int IT, bool FINE, int ORD, bool ASYNC>
 __device__ __forceinline__ void sweep_item(const int b, const int rem, const float* __restrict__ src, const size_t pitch, const PairState* st,
                                            const GridDesc* __restrict__ gd, const BitWord* __restrict__ words, const VoxelRec* __restrict__ recs,
                                            double* partials, const int rows_per_pair, const SweepConst& sc, const float* __restrict__ cent,
-                                           const int* __restrict__ grid_of, const double* exp_tab
+                                           const int* __restrict__ grid_of, const double* exp_tab,
+                                           const unsigned pose_w, const int n_async   /* ASYNC only: see sweep_pose_words */
 #ifdef NDT_TIMELINE
                                            , unsigned long long* tl, unsigned long long& tl_last
 #endif
@@ -207,14 +218,9 @@ __device__ __forceinline__ void sweep_item(const int b, const int rem, const flo
   const PairState& S = st[b];
   // ASYNC: T (12 words), Rj (9) and n_src through agent-scope vector loads (never the scalar cache, never a stale L1 line): the
   // updater of this pair -- some other workgroup of this launch -- rewrote them since the pair's previous sweep
-  unsigned pose_w = 0;
-  if (ASYNC) {
-    const gu32* sw = (const gu32*)reinterpret_cast<const unsigned*>(&S);
-    static_assert(offsetof(PairState, T) == 0 && offsetof(PairState, Rj) == 48, "pose words");
-    if (lane < 21) pose_w = __hip_atomic_load(sw + lane, RLX_AGENT);
-    else if (lane == 21) pose_w = __hip_atomic_load(sw + offsetof(PairState, n_src) / 4, RLX_AGENT);
-  }
-  const int n = ASYNC ? (int)__builtin_amdgcn_readlane(pose_w, 21) : S.n_src;
+  // (the caller issued that load -- sweep_pose_words -- as early as it knew the pair, so that it is in flight together with the point loads
+  //  below; the point count comes from the batch's constant count array for the same reason)
+  const int n = ASYNC ? n_async : S.n_src;
   const GridDesc& g = gd[grid_of ? grid_of[b] : b];
   const float* X = src + (size_t)b * 3 * pitch;
   const BitWord* W = words + g.word_off;
@@ -554,7 +560,7 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
       const int rem = item % items_per_pair;        // the pair's work item = its partial row
       TL_STAMP(0);
 
-      sweep_item<PCA, K, IT, FINE, ORD, false>(b, rem, src, pitch, st, gd, words, recs, partials, rows_per_pair, sc, cent, grid_of, exp_tab
+      sweep_item<PCA, K, IT, FINE, ORD, false>(b, rem, src, pitch, st, gd, words, recs, partials, rows_per_pair, sc, cent, grid_of, exp_tab, 0u, 0
 #ifdef NDT_TIMELINE
                                                , tl, tl_last
 #endif
