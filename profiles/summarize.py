@@ -4,7 +4,7 @@ import csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "final")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = sys.argv[2] if len(sys.argv) > 2 else HERE      # (on the GPU box: a directory under gpurun_out/, copied into profiles/ afterwards)
 os.makedirs(OUT, exist_ok=True)
@@ -51,7 +51,7 @@ def sec1():
     ours, other_calls, other_ns = [], 0, 0.0
     for r in rows:
         n = r["Name"]
-        if any(k in n for k in ("k_sweep", "k_update", "k_leafsum", "k_rs_", "k_keys", "k_mark", "k_segstart", "k_minmax", "k_voxels", "k_rank",
+        if any(k in n for k in ("k_sweep", "k_align_async", "k_async_begin", "k_calc_score", "k_update", "k_leafsum", "k_rs_", "k_keys", "k_mark", "k_segstart", "k_minmax", "k_voxels", "k_rank",
                                 "k_init_state", "k_griddesc", "k_seq_", "k_set_word_off", "k_word_offsets", "k_pose_records", "k_deinterleave", "k_hessian", "k_fitness", "k_cellrange", "k_transform", "rocprim",
                                 "rocclr")):
             ours.append(r)
@@ -71,7 +71,7 @@ def sec2():
     global traffic, fe, wr, sw, kmax, bench
     # ---- every sweep dispatch
     tr = list(csv.DictReader(open(one("kt/**/*_kernel_trace.csv"))))
-    sw = [r for r in tr if "k_sweep" in r["Kernel_Name"]]
+    sw = [r for r in tr if "k_sweep" in r["Kernel_Name"] or "k_align_async" in r["Kernel_Name"]]
     sw.sort(key=lambda r: int(r["Start_Timestamp"]))
     with open(os.path.join(OUT, f"{TAG}_final_sweep_dispatches.csv"), "w") as f:
         f.write("dispatch,duration_us,grid_size,vgpr,sgpr,lds_bytes,scratch\n")
@@ -87,7 +87,7 @@ def sec3():
     # ---- PMC passes: FETCH_SIZE / WRITE_SIZE per sweep dispatch (rocprofv3 reports them in KB)
     def counter(dirname, name):
         rows = list(csv.DictReader(open(one(f"{dirname}/**/*_counter_collection.csv"))))
-        rows = [r for r in rows if r["Counter_Name"] == name and "k_sweep" in r["Kernel_Name"]]
+        rows = [r for r in rows if r["Counter_Name"] == name and ("k_sweep" in r["Kernel_Name"] or "k_align_async" in r["Kernel_Name"])]
         rows.sort(key=lambda r: int(r["Dispatch_Id"]))
         return [float(r["Counter_Value"]) for r in rows]
 
@@ -102,24 +102,35 @@ def sec3():
     kmax = max(range(n), key=lambda k: fe[k])
     bench = load_line(os.path.join(SRC, "kt_bench.json"))
     traffic = {
-        "kernel": "k_sweep", "workload": "bench.py defaults (271 pairs x 65536 pts, ndt_omp, 1.0 m, DIRECT7)", "workload_key": "271x65536:omp:direct7:1.0",
+        "kernel": "k_align_async (one launch per batch align: derivative sweeps + Newton updates)", "workload": "bench.py defaults (271 pairs x 65536 pts, ndt_omp, 1.0 m, DIRECT7)", "workload_key": "271x65536:omp:direct7:1.0",
         "launches_counted": n, "fetch_size_kb_avg_per_launch": fe_avg, "write_size_kb_avg_per_launch": wr_avg, "fetch_correction": 2.0,
         "traffic_bytes_per_launch": (2.0 * fe_avg + wr_avg) * 1024, "traffic_bytes_per_launch_uncorrected": (fe_avg + wr_avg) * 1024,
         "full_launch": {"fetch_kb": fe[kmax], "write_kb": wr[kmax]},
         "algorithmic_bytes_per_launch": bench["roofline"]["alg_bytes_per_launch"],
         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --cpu-seconds 0 --steps 4 --warmup 1`, "
-                  "--kernel-include-regex k_sweep, no trace domains; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE x2 is the gfx950 "
+                  "--kernel-include-regex 'k_sweep|k_align_async', no trace domains; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE x2 is the gfx950 "
                   "half-counting correction of MI355X_MICROARCH.md (HBM section), calibrated on the compulsory traffic of a full launch "
-                  "(source points 213 MB + records ~25 MB + bitmap ~11 MB).  The average runs over every sweep launch of the run, including "
-                  "the empty speculative ones that close each align.",
+                  "(source points 213 MB + records ~25 MB + bitmap ~11 MB).  One launch = one whole batch align (every sweep of every pair).",
     }
     json.dump(traffic, open(os.path.join(OUT, f"{TAG}_traffic.json"), "w"), indent=1)
 
 
 section(sec3)
 
+def valu_calibration():
+    """tools/pmc_calib.sh: the same SQ counters over tools/valu_rate's kernels (nothing but independent VALU instructions, 2 waves per SIMD as
+    the sweep runs): the counter ratio the sweep's is divided by, so that `active_frac` is <= 1 by construction."""
+    pth = os.path.join(SRC, "pmc_valu_calib.json")
+    if not os.path.exists(pth):
+        return None
+    cal = json.load(open(pth))
+    json.dump(cal, open(os.path.join(OUT, f"{TAG}_valu_calibration.json"), "w"), indent=1)
+    return cal
+
+
 def sec4():
     global traffic, fe, wr, sw, kmax, bench
+    cal = valu_calibration()
     # ---- SQ counters of the sweep (tools/pmc_kernel.sh summaries) -> what bounds it: VALU issue
     for tag, key, benchfile, outname in (("sq_direct7", "271x65536:omp:direct7:1.0", "bench.json", f"{TAG}_valu.json"),
                                          ("sq_pca_direct1", "271x65536:pca:direct1:1.0", "bench_pca_d1.json", f"{TAG}_valu_pca_direct1.json"),
@@ -135,9 +146,12 @@ def sec4():
         hits_per_launch = b["roofline"]["hits_per_point"] * (b["roofline"]["alg_bytes_per_launch"] / (12 + 4 * {"direct7": 7, "direct1": 1}[b["config"]["neighbor_mode"]] + 64 * b["roofline"]["hits_per_point"]))
         cycles = c["GRBM_GUI_ACTIVE"] / 8.0                       # the counter sums the eight XCDs
         valu = {
-            "workload_key": key, "kernel": "k_sweep", "source_counters": f"profiles/{TAG}_pmc_{tag}.txt (rocprofv3 --pmc passes of tools/pmc_kernel.sh, mean per dispatch)",
+            "workload_key": key, "kernel": "k_align_async", "source_counters": f"profiles/{TAG}_pmc_{tag}.txt (rocprofv3 --pmc passes of tools/pmc_kernel.sh, mean per dispatch)",
             "kernel_cycles_mean_per_dispatch": cycles,
             "valu_active_frac": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * cycles), 3),      # SQ_ACTIVE_INST_VALU counts quad-cycles; 1024 SIMDs
+            "valu_active_frac_calibrated": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * cycles) / cal["saturated_ratio"], 3) if cal else None,
+            "calibration": (f"divided by {cal['saturated_ratio']:.3f} = the same counter ratio of {cal['kernel']} at {cal['waves_per_simd']} waves per SIMD "
+                            f"(tools/valu_rate.hip under the same rocprofv3 --pmc pass: profiles/{TAG}_valu_calibration.json)") if cal else None,
             "valu_wave_insts_per_64_hits": round(64.0 * c["SQ_INSTS_VALU"] / hits_per_launch, 1),  # one wave-instruction serves 64 (point, voxel) evaluations
             "valu_lane_insts_per_hit": round(c["SQ_INSTS_VALU"] / hits_per_launch, 2),
             "wave_wait_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3),
@@ -145,7 +159,7 @@ def sec4():
             "tcp_line_accesses_per_dispatch": c.get("TCP_TOTAL_CACHE_ACCESSES_sum"),
             "l2_hit_frac": round(c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3) if "TCC_HIT_sum" in c else None,
             "physical_hbm_frac_of_peak": round(traffic["traffic_bytes_per_launch"] / (cycles / 2.4e9) / 8.0e12, 4) if tag == "sq_direct7" else None,
-            "note": "mean over every sweep dispatch of a short bench run (full launches, the shrinking tail and the empty ones alike); cycles at 2.4 GHz",
+            "note": "mean over the k_align_async dispatches of a short bench run (one dispatch = one batch align: every sweep and every Newton update of every pair); GRBM_GUI_ACTIVE / 8 as elapsed cycles",
         }
         json.dump(valu, open(os.path.join(OUT, outname), "w"), indent=1)
 

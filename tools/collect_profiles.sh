@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/final
 mkdir -p $O
 PARTS=${@:-"trace pmc bench extra"}
-QUIET="--cpu-seconds 0 --no-host-clouds --config4-pairs 0 --seq-frames 0"
+QUIET="--cpu-seconds 0 --no-host-clouds --config4-pairs 0 --seq-frames 0 --no-other-configs"
 for part in $PARTS; do
 case $part in
 trace)
@@ -15,8 +15,8 @@ trace)
   # per-kernel times (trace only, no counters)
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py $QUIET --steps 20 --warmup 3 > $O/kt_bench.json 2> $O/kt.log
   # HBM-side traffic of the sweep: FETCH_SIZE and WRITE_SIZE in separate passes, no trace domains
-  timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex k_sweep --output-format csv -d $O/fetch -- python $R/bench.py $QUIET --steps 4 --warmup 1 > /dev/null 2> $O/fetch.log
-  timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex k_sweep --output-format csv -d $O/write -- python $R/bench.py $QUIET --steps 4 --warmup 1 > /dev/null 2> $O/write.log
+  timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex 'k_sweep|k_align_async' --output-format csv -d $O/fetch -- python $R/bench.py $QUIET --steps 4 --warmup 1 > /dev/null 2> $O/fetch.log
+  timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex 'k_sweep|k_align_async' --output-format csv -d $O/write -- python $R/bench.py $QUIET --steps 4 --warmup 1 > /dev/null 2> $O/write.log
   rm -rf $O/kt/*/*.db $O/fetch/*/*.db $O/write/*/*.db
   cd $R
   timeout 400 tools/kstats.sh final_kd1 --no-host-clouds --variant pca --mode direct1 --steps 20 --warmup 3 > $O/kstats_pca_d1.txt 2>&1
@@ -25,11 +25,12 @@ trace)
 pmc)
   cd $R
   # SQ / TCP / TCC counters: the sweep on the headline workload, the live nodelet's configuration and config 5 with DIRECT1; the build kernels; the update
-  timeout 500 tools/pmc_kernel.sh k_sweep sq_direct7 > $O/pmc_sq_direct7.txt 2>&1
-  timeout 500 tools/pmc_kernel.sh k_sweep sq_pca_direct1 --variant pca --mode direct1 > $O/pmc_sq_pca_direct1.txt 2>&1
-  timeout 500 tools/pmc_kernel.sh k_sweep sq_cfg5_d1 --variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128 > $O/pmc_sq_cfg5_d1.txt 2>&1
+  timeout 500 tools/pmc_kernel.sh 'k_sweep|k_align_async' sq_direct7 > $O/pmc_sq_direct7.txt 2>&1
+  timeout 500 tools/pmc_kernel.sh 'k_sweep|k_align_async' sq_pca_direct1 --variant pca --mode direct1 > $O/pmc_sq_pca_direct1.txt 2>&1
+  timeout 500 tools/pmc_kernel.sh 'k_sweep|k_align_async' sq_cfg5_d1 --variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128 > $O/pmc_sq_cfg5_d1.txt 2>&1
   timeout 500 tools/pmc_kernel.sh 'k_leafsum|k_rs_|k_keys|k_voxels|k_mark|k_rank|k_segstart|k_minmax' sq_build > $O/pmc_build.txt 2>&1
-  timeout 500 tools/pmc_kernel.sh 'k_update' sq_update > $O/pmc_update.txt 2>&1
+  timeout 500 tools/pmc_kernel.sh 'k_seq_update|k_update' sq_update --seq-frames 65 > $O/pmc_update.txt 2>&1
+  timeout 300 tools/pmc_calib.sh > $O/pmc_valu_calib.log 2>&1; cp $R/gpurun_out/pmc_calib/calib.json $O/pmc_valu_calib.json
   ;;
 bench)
   cd $R
@@ -38,9 +39,9 @@ bench)
   timeout 400 python bench.py --variant pca --mode direct1 --config4-pairs 0 --seq-frames 0 2>> $O/bench.log | tail -1 > $O/bench_pca_d1.json
   timeout 400 python bench.py --variant pca --mode direct7 --resolution 0.5 --azimuth 2048 --pairs 128 --config4-pairs 0 --seq-frames 0 2>> $O/bench.log | tail -1 > $O/bench_cfg5.json
   timeout 400 python bench.py --variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128 --config4-pairs 0 --seq-frames 0 2>> $O/bench.log | tail -1 > $O/bench_cfg5_d1.json
-  timeout 400 python bench.py --pairs 1536 --steps 5 --warmup 1 --cpu-seconds 30 --config4-pairs 0 --seq-frames 0 2>> $O/bench.log | tail -1 > $O/bench_1536.json
+  timeout 400 python bench.py --pairs 1536 --steps 5 --warmup 1 --cpu-seconds 30 --config4-pairs 0 --seq-frames 0 --no-other-configs 2>> $O/bench.log | tail -1 > $O/bench_1536.json
   # BASELINE config 4's whole job on one GPU, through the RCCL gather (one forced rank), parity sample spread over pairs 0..4540
-  LV_SLAM_BENCH_FORCE_DIST=1 MASTER_PORT=29541 timeout 600 python bench.py --total-pairs 4541 --steps 5 --warmup 1 --cpu-seconds 16 --no-host-clouds --seq-frames 0 2>> $O/bench.log | grep '^{' | tail -1 > $O/bench_cfg4_1gpu.json
+  LV_SLAM_BENCH_FORCE_DIST=1 MASTER_PORT=29541 timeout 600 python bench.py --total-pairs 4541 --steps 5 --warmup 1 --cpu-seconds 16 --no-host-clouds --seq-frames 0 --no-other-configs 2>> $O/bench.log | grep '^{' | tail -1 > $O/bench_cfg4_1gpu.json
   # the N > 1 branch as two ranks sharing this GPU (gloo), DEFAULT flags = what the driver's scaling runs pass: weak line + config-4 block + gather times
   LV_SLAM_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29533 \
       bench.py --gpus 2 --steps 5 --warmup 2 2>> $O/bench.log | grep '^{' | tail -1 > $O/bench_2ranks_1gpu_gloo.json
@@ -59,7 +60,7 @@ esac
 done
 # reduce on the box (the raw traces are far too large to travel back) and drop the raw directories
 cd $R
-python profiles/summarize.py r03 $O/reduced > $O/summarize.log 2>&1
+python profiles/summarize.py r04 $O/reduced > $O/summarize.log 2>&1
 rm -rf $O/kt $O/fetch $O/write $R/gpurun_out/final_kd1/kt $R/gpurun_out/final_kc5/kt $R/gpurun_out/pmc_sq_*
 tail -5 $O/summarize.log
 for f in bench.log kt.log; do echo "== $f"; tail -4 $O/$f; done

@@ -13,7 +13,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_W
            "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_WAVES SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT" \
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum" \
            "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum"; do
-  timeout 300 rocprofv3 --pmc $set --kernel-include-regex "$KRE" --output-format csv -d $O/p$k -- python $R/bench.py --cpu-seconds 0 --no-host-clouds --config4-pairs 0 --seq-frames 0 --steps 2 --warmup 1 "$@" > $O/p$k.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --kernel-include-regex "$KRE" --output-format csv -d $O/p$k -- python $R/bench.py --cpu-seconds 0 --no-host-clouds --config4-pairs 0 --seq-frames 0 --no-other-configs --steps 2 --warmup 1 "$@" > $O/p$k.log 2>&1
   k=$((k+1))
 done
 python - <<PY | tee $O/summary.txt
