@@ -739,7 +739,9 @@ def sweep_roofline(J):
     sw_s = prof["sweep_ms"] * 1e-3
     ach = (prof["sweep_alg_bytes"] / sw_s / 1e9) if sw_s > 0 else 0.0
     tfl = (FLOP_PER_HIT * prof["sweep_hits"] / sw_s / 1e12) if sw_s > 0 else 0.0
-    return {"bound": "hbm", "kernel": "k_sweep", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    one_launch = prof["sweep_launches"] == steps and prof["update_launches"] == 0     # ndt_async.hpp: the whole batch align is one launch
+    return {"bound": "hbm", "kernel": "k_align_async (one launch per batch align: every derivative sweep and Newton update of every pair)" if one_launch else "k_sweep",
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4),
             "frac_of_achievable_6290": round(ach / 6290.0, 4),     # MI355X_MICROARCH.md: measured-achievable HBM rate
             "launches": prof["sweep_launches"], "avg_launch_us": round(1e3 * prof["sweep_ms"] / max(1, prof["sweep_launches"]), 2),

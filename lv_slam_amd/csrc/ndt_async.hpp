@@ -171,7 +171,7 @@ k_align_async(const float* __restrict__ src, size_t pitch, PairState* st, const 
   for (;;) {
     const int rem = (int)(pos % (unsigned)I);
     TL_STAMP(10);                                  // hand-over: claim, ticket, (update)
-    sweep_item<PCA, K, 8, false, ORD, true>(b, rem, src, pitch, st, gd, words, recs, partials, I, sc, cent, nullptr, exp_tab, pose_w, src_cnt[b]
+    sweep_item<PCA, K, 8, false, ORD, true>(b, rem, src, pitch, st, gd, words, recs, partials, I, sc, cent, nullptr, exp_tab, pose_w, src_cnt[b], b
 #ifdef NDT_TIMELINE
                                             , tl, tl_last
 #endif

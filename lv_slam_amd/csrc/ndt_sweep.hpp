@@ -185,7 +185,7 @@ __device__ __forceinline__ void sweep_item(const int b, const int rem, const flo
                                            const GridDesc* __restrict__ gd, const BitWord* __restrict__ words, const VoxelRec* __restrict__ recs,
                                            double* partials, const int rows_per_pair, const SweepConst& sc, const float* __restrict__ cent,
                                            const int* __restrict__ grid_of, const double* exp_tab,
-                                           const unsigned pose_w, const int n_async   /* ASYNC only: see sweep_pose_words */
+                                           const unsigned pose_w, const int n_async, const int g_async   /* ASYNC only: pose words (sweep_pose_words), point count, grid index */
 #ifdef NDT_TIMELINE
                                            , unsigned long long* tl, unsigned long long& tl_last
 #endif
@@ -221,7 +221,7 @@ __device__ __forceinline__ void sweep_item(const int b, const int rem, const flo
   // (the caller issued that load -- sweep_pose_words -- as early as it knew the pair, so that it is in flight together with the point loads
   //  below; the point count comes from the batch's constant count array for the same reason)
   const int n = ASYNC ? n_async : S.n_src;
-  const GridDesc& g = gd[grid_of ? grid_of[b] : b];
+  const GridDesc& g = gd[ASYNC ? g_async : (grid_of ? grid_of[b] : b)];
   const float* X = src + (size_t)b * 3 * pitch;
   const BitWord* W = words + g.word_off;
   const VoxelRec* R = recs + g.rec_off;
@@ -458,7 +458,7 @@ __device__ __forceinline__ void sweep_item(const int b, const int rem, const flo
       // row 0 (lane 0) holds values 0..10, row 1: 11..21, row 2: 22..32, row 3: 33..42 (+ the pad)
       const int row = lane >> 4, base = 11 * (row & 1) + 22 * (row >> 1);
       double* P = FINE ? &red[FINE ? wv : 0][0] : partials + ((size_t)b * rows_per_pair + rem) * NACC;
-      if (ASYNC) {                                 // write-through (sc1) 8-byte stores: the pair's updater may run on another XCD
+      if (ASYNC && !FINE) {                        // write-through (sc1) 8-byte stores: the pair's updater may run on another XCD
         gu64* PG = (gu64*)reinterpret_cast<unsigned long long*>(P);
 #pragma unroll
         for (int i = 0; i < 11; i++) if (base + i < 43) __hip_atomic_store(PG + base + i, (unsigned long long)__double_as_longlong(P2[i]), RLX_AGENT);
@@ -471,8 +471,12 @@ __device__ __forceinline__ void sweep_item(const int b, const int rem, const flo
     }
     if (FINE) {
       __syncthreads();                              // (uniform: the four waves of a block run the same items loop, see above)
-      if (wv == 0 && lane < NACC)
-        partials[((size_t)b * (rows_per_pair >> 2) + (rem >> 2)) * NACC + lane] = ((red[0][lane] + red[FINE ? 1 : 0][lane]) + red[FINE ? 2 : 0][lane]) + red[FINE ? 3 : 0][lane];
+      if (wv == 0 && lane < NACC) {
+        const double rs = ((red[0][lane] + red[FINE ? 1 : 0][lane]) + red[FINE ? 2 : 0][lane]) + red[FINE ? 3 : 0][lane];
+        double* dst = partials + ((size_t)b * (rows_per_pair >> 2) + (rem >> 2)) * NACC + lane;
+        if (ASYNC) __hip_atomic_store((gu64*)reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(rs), RLX_AGENT);
+        else *dst = rs;
+      }
       __syncthreads();
     }
     TL_STAMP(6);
@@ -560,7 +564,7 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
       const int rem = item % items_per_pair;        // the pair's work item = its partial row
       TL_STAMP(0);
 
-      sweep_item<PCA, K, IT, FINE, ORD, false>(b, rem, src, pitch, st, gd, words, recs, partials, rows_per_pair, sc, cent, grid_of, exp_tab, 0u, 0
+      sweep_item<PCA, K, IT, FINE, ORD, false>(b, rem, src, pitch, st, gd, words, recs, partials, rows_per_pair, sc, cent, grid_of, exp_tab, 0u, 0, 0
 #ifdef NDT_TIMELINE
                                                , tl, tl_last
 #endif

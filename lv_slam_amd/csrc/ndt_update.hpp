@@ -181,6 +181,13 @@ __device__ inline int mt_loop(PairState& S, double step_max, double step_min) {
 #define UPD_WAVES   4
 #define UPD_THREADS (64 * UPD_WAVES)
 // `chunk_rows`: the rows are chunk sums already (latency mode: the sweep's blocks add the four rows of a chunk themselves).
+// SC1: the rows were written by other workgroups of THIS launch (persistent kernels): read them with agent-scope (L1-bypassing) loads.
+template <bool SC1>
+__device__ __forceinline__ double ld_row(const double* p) {
+  if (SC1) return __longlong_as_double((long long)__hip_atomic_load((const gu64*)reinterpret_cast<const unsigned long long*>(p), RLX_AGENT));
+  return *p;
+}
+template <bool SC1 = false>
 __device__ __forceinline__ double reduce_pair_rows(const double* __restrict__ rows, int nchunks, bool take, double (*sm)[NACC], bool chunk_rows = false) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane < NACC) {
@@ -198,7 +205,7 @@ __device__ __forceinline__ double reduce_pair_rows(const double* __restrict__ ro
 #pragma unroll
             for (int u = 0; u < 8; u++) {
               const int c = c0 + g * 8 * UPD_WAVES + u;
-              q[g][u] = (c < nchunks) ? P[(size_t)c * NACC] : 0.0;
+              q[g][u] = (c < nchunks) ? ld_row<SC1>(P + (size_t)c * NACC) : 0.0;
             }
 #pragma unroll
           for (int g = 0; g < 4; g++) {
@@ -219,14 +226,14 @@ __device__ __forceinline__ double reduce_pair_rows(const double* __restrict__ ro
           for (int u = 0; u < 8; u++) {
             const double* Q = P + (size_t)(c0 + u) * 4 * NACC;
 #pragma unroll
-            for (int k = 0; k < 4; k++) q[u][k] = Q[k * NACC];
+            for (int k = 0; k < 4; k++) q[u][k] = ld_row<SC1>(Q + k * NACC);
           }
 #pragma unroll
           for (int u = 0; u < 8; u++) gs += ((q[u][0] + q[u][1]) + q[u][2]) + q[u][3];
         } else {
           for (int c = c0; c < nchunks; c++) {
             const double* Q = P + (size_t)c * 4 * NACC;
-            gs += ((Q[0] + Q[NACC]) + Q[2 * NACC]) + Q[3 * NACC];
+            gs += ((ld_row<SC1>(Q) + ld_row<SC1>(Q + NACC)) + ld_row<SC1>(Q + 2 * NACC)) + ld_row<SC1>(Q + 3 * NACC);
           }
         }
         acc += gs;

@@ -118,12 +118,24 @@ def sec3():
 section(sec3)
 
 def valu_calibration():
-    """tools/pmc_calib.sh: the same SQ counters over tools/valu_rate's kernels (nothing but independent VALU instructions, 2 waves per SIMD as
-    the sweep runs): the counter ratio the sweep's is divided by, so that `active_frac` is <= 1 by construction."""
+    """tools/pmc_calib.sh: the SQ counters over tools/valu_rate's kernels (nothing but independent VALU instructions).  What they show: on gfx950
+    SQ_ACTIVE_INST_VALU is 4 x the instruction count whatever the instruction (plain f32 at 2+ waves per SIMD: one instruction per ~2.5 cycles,
+    counter ratio 1.6; f64 add / packed f32 / cvt: one per ~4.4-5.0 cycles, ratio 0.8-0.9) -- it is no busy-time counter.  The calibrated figure
+    is therefore built from elapsed cycles: instructions x the MEASURED minimum issue interval of a plain f32 instruction at the sweep's
+    occupancy, over the elapsed SIMD cycles -- a floor of the VALU's busy fraction that cannot exceed 1."""
     pth = os.path.join(SRC, "pmc_valu_calib.json")
     if not os.path.exists(pth):
         return None
-    cal = json.load(open(pth))
+    raw = json.load(open(pth))
+    timed = [o for o in raw["all"] if o["valu_wave_insts"] > 1e9 and o["waves_per_simd"] == 2]      # (the 10-iteration warm-up launches are dropped)
+    import re
+    short = lambda k: re.sub(r"^(void )?k_", "", k.strip())
+    cpi = {short(o["kernel"]): o["cycles"] * 1024.0 / o["valu_wave_insts"] for o in timed}
+    cal = {"waves_per_simd": 2, "cycles_per_wave_instruction_per_simd": {k: round(v, 3) for k, v in cpi.items()},
+           "counter_ratio_4xACTIVE_over_simd_cycles": {short(o["kernel"]): round(o["ratio"], 3) for o in timed},
+           "cpi_plain_f32": min(cpi.get("mul_f32", 9e9), cpi.get("fma_f32", 9e9)), "cpi_f64_add": cpi.get("add_f64"), "cpi_cvt_f64_f32": cpi.get("cvt_f64_f32"),
+           "what": "tools/valu_rate.hip under rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE (tools/pmc_calib.sh); cycles = GRBM_GUI_ACTIVE / 8; 1024 SIMDs",
+           "all": raw["all"]}
     json.dump(cal, open(os.path.join(OUT, f"{TAG}_valu_calibration.json"), "w"), indent=1)
     return cal
 
@@ -149,9 +161,13 @@ def sec4():
             "workload_key": key, "kernel": "k_align_async", "source_counters": f"profiles/{TAG}_pmc_{tag}.txt (rocprofv3 --pmc passes of tools/pmc_kernel.sh, mean per dispatch)",
             "kernel_cycles_mean_per_dispatch": cycles,
             "valu_active_frac": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * cycles), 3),      # SQ_ACTIVE_INST_VALU counts quad-cycles; 1024 SIMDs
-            "valu_active_frac_calibrated": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * cycles) / cal["saturated_ratio"], 3) if cal else None,
-            "calibration": (f"divided by {cal['saturated_ratio']:.3f} = the same counter ratio of {cal['kernel']} at {cal['waves_per_simd']} waves per SIMD "
-                            f"(tools/valu_rate.hip under the same rocprofv3 --pmc pass: profiles/{TAG}_valu_calibration.json)") if cal else None,
+            # floor of the VALU busy fraction, <= 1 by construction: every instruction charged the measured issue interval of the CHEAPEST class
+            "valu_active_frac_calibrated": round(c["SQ_INSTS_VALU"] * cal["cpi_plain_f32"] / (1024.0 * cycles), 3) if cal else None,
+            # the same with the evaluation's f64 adds and f32->f64 conversions (46 + 49 of ~460 wave-instructions per 64-hit batch, from the ISA) at their own intervals
+            "valu_active_frac_mix_estimate": round(c["SQ_INSTS_VALU"] * ((1 - 95.0 / 460.0) * cal["cpi_plain_f32"] + (46.0 / 460.0) * cal["cpi_f64_add"] + (49.0 / 460.0) * cal["cpi_cvt_f64_f32"]) / (1024.0 * cycles), 3) if cal else None,
+            "calibration": (f"SQ_INSTS_VALU x {cal['cpi_plain_f32']:.2f} cycles (measured issue interval of a plain f32 VALU instruction at 2 waves per SIMD, tools/valu_rate.hip under the same "
+                            f"counters: profiles/{TAG}_valu_calibration.json) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); the raw `valu_active_frac` = 4 x SQ_ACTIVE_INST_VALU / SIMD cycles "
+                            "is 4 x the instruction count on this chip and exceeds 1 for f32-heavy code") if cal else None,
             "valu_wave_insts_per_64_hits": round(64.0 * c["SQ_INSTS_VALU"] / hits_per_launch, 1),  # one wave-instruction serves 64 (point, voxel) evaluations
             "valu_lane_insts_per_hit": round(c["SQ_INSTS_VALU"] / hits_per_launch, 2),
             "wave_wait_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3),
