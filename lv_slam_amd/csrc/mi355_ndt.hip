@@ -92,8 +92,6 @@ struct mi355ndt_handle {
   int chunks_per_pair = 0;
   int rows_per_pair = 0, pts_per_chunk = CHUNK_PTS;   // stored partial rows per pair / points covered by one chunk of k_update's tree
   int items_per_pair = 0;                         // sweep work items per pair (= rows_per_pair in batch mode, 4 x rows_per_pair in latency mode)
-  bool seq_persist = true;                        // mi355ndt_sequence_run as ONE persistent launch (k_seq_persist); MI355NDT_SEQ_PERSIST=0: the pumped (update, sweep) launches
-  SeqJob* d_seq_job = nullptr; SeqCtl* d_seq_ctl = nullptr; SeqCtl* h_pin_sctl = nullptr;
   bool async_align = true;                        // MI355NDT_OPT_ASYNC_ALIGN: batch aligns as ONE persistent launch (ndt_async.hpp); MI355NDT_ASYNC=0 turns it off
   int* d_ring = nullptr; size_t ring_cap_total = 0; unsigned* d_arrived = nullptr; size_t arrived_cap = 0; AsyncCtl* d_actl = nullptr;
   AsyncCtl* h_pin_actl = nullptr;
@@ -312,7 +310,6 @@ int mi355ndt_create(const mi355ndt_params* params, int device, mi355ndt_handle**
   { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
   if (const char* e = std::getenv("MI355NDT_FINE_TILES")) { const int v = std::atoi(e); if (v == 1 || v == 2) h->fine_tiles = v; }
   if (const char* e = std::getenv("MI355NDT_ASYNC")) h->async_align = std::atoi(e) != 0;
-  if (const char* e = std::getenv("MI355NDT_SEQ_PERSIST")) h->seq_persist = std::atoi(e) != 0;
   if (const char* e = std::getenv("MI355NDT_SWEEP_DYN_SHIFT")) { const int v = std::atoi(e); if (v >= 0 && v <= 30) h->dyn_shift = v; }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
@@ -346,7 +343,7 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
                   h->d_state, h->d_partials, h->d_guess, h->d_results, h->d_active, h->d_hook, h->d_aligned, h->d_hits, h->d_seg_start, h->d_sums,
                   h->d_cent, h->d_icov64, h->d_kdw, h->d_rs_hist, h->d_rs_offs, h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit, h->d_pf_in, h->d_pf_out, h->d_pf_keep, h->d_pf_keys,
                   h->d_pf_vals, h->d_pf_flag, h->d_pf_pos, h->d_pf_mm, h->d_pf_grid, h->d_pf_tmp, h->d_score_pts, h->d_score_part,
-                  h->d_ring, h->d_arrived, h->d_actl, h->d_seq_job, h->d_seq_ctl};
+                  h->d_ring, h->d_arrived, h->d_actl};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : {(void*)h->d_grid_of, (void*)h->d_seq, (void*)h->d_seq_out, (void*)h->d_stamps}) if (p) (void)hipFree(p);
   if (h->h_seq_flags) (void)hipHostFree((void*)h->h_seq_flags);
@@ -357,7 +354,6 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
   if (h->ev_compute) (void)hipEventDestroy(h->ev_compute);
   for (hipStream_t cs : h->copy_stream) if (cs) (void)hipStreamDestroy(cs);
   if (h->h_pin_actl) (void)hipHostFree(h->h_pin_actl);
-  if (h->h_pin_sctl) (void)hipHostFree(h->h_pin_sctl);
   if (h->h_pin_u) (void)hipHostFree(h->h_pin_u);
   if (h->h_pin_active) (void)hipHostFree(h->h_pin_active);
   if (h->h_pin_guess) (void)hipHostFree(h->h_pin_guess);
@@ -1012,27 +1008,6 @@ static int launch_async_t(mi355ndt_handle* h, const SweepConst& sc, int B, int r
 template <bool PCA, int K>
 static int launch_async_o(mi355ndt_handle* h, const SweepConst& sc, int B, int ring_cap) {
   return h->f32_sum_order == 1 ? launch_async_t<PCA, K, 1>(h, sc, B, ring_cap) : launch_async_t<PCA, K, 0>(h, sc, B, ring_cap);
-}
-// mi355ndt_sequence_run as one persistent launch (ndt_sequence.hpp: k_seq_persist); MI355NDT_ERR_UNSUPPORTED: not resident, use the pump
-template <bool PCA, int K, int ORD>
-static int launch_seq_persist_t(mi355ndt_handle* h, const SweepConst& sc) {
-  auto kern = k_seq_persist<PCA, K, 2, ORD>;
-  int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SWEEP_THREADS, 0) != hipSuccess) { (void)hipGetLastError(); return MI355NDT_ERR_UNSUPPORTED; }
-  if (per_cu < 1) return MI355NDT_ERR_UNSUPPORTED;
-  // one block per chunk of the longest frame, never more blocks than are resident at once: every block waits for the others' arrivals
-  const int grid = std::max(1, std::min(h->rows_per_pair, h->n_cu * std::min(per_cu, sweep_wpe(PCA, K))));
-  kern<<<dim3((unsigned)grid), SWEEP_THREADS, 0, h->stream>>>(h->d_src, h->src_pitch, h->d_state, h->d_seq, h->d_seq_job, h->d_seq_ctl, h->d_grid, h->d_words, h->d_recs,
-                                                              h->d_partials, h->items_per_pair, h->pts_per_chunk, h->d_results, h->d_src_cnt, h->d_stamps, h->d_seq_out,
-                                                              h->d_grid_of, sc, h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations);
-  return MI355NDT_OK;
-}
-static int launch_seq_persist(mi355ndt_handle* h, const SweepConst& sc) {
-  const bool o = h->f32_sum_order == 1;
-  if (sc.pca) return sc.K == 1 ? (o ? launch_seq_persist_t<true, 1, 1>(h, sc) : launch_seq_persist_t<true, 1, 0>(h, sc))
-                               : (o ? launch_seq_persist_t<true, 7, 1>(h, sc) : launch_seq_persist_t<true, 7, 0>(h, sc));
-  return sc.K == 1 ? (o ? launch_seq_persist_t<false, 1, 1>(h, sc) : launch_seq_persist_t<false, 1, 0>(h, sc))
-                   : (o ? launch_seq_persist_t<false, 7, 1>(h, sc) : launch_seq_persist_t<false, 7, 0>(h, sc));
 }
 extern "C" {
 static int align_async(mi355ndt_handle* h, const SweepConst& sc, int B, mi355ndt_result* out) {
@@ -1804,27 +1779,7 @@ int mi355ndt_sequence_run(mi355ndt_handle* h, int n_frames, const void* const* c
   make_sweep_const(h, sc);
   gauss_constants3(h->prm.outlier_ratio, h->prm.resolution, h->gauss_last);
   k_seq_begin<<<1, 64, 0, s>>>(h->d_seq, h->d_state, h->d_grid, h->d_src_cnt, h->d_stamps, h->d_seq_out, h->d_active_list, h->d_ctl, h->d_grid_of, h->d_seq_flags);
-  bool persisted = false, stuck = false;
-  if (h->seq_persist && h->fine_it == 2) {         // the whole drive as ONE launch: no kernel boundary, no host pump between Newton rounds
-    if (!h->d_seq_job) HIPCHK(h, hipMalloc((void**)&h->d_seq_job, sizeof(SeqJob)));
-    if (!h->d_seq_ctl) HIPCHK(h, hipMalloc((void**)&h->d_seq_ctl, sizeof(SeqCtl)));
-    if (!h->h_pin_sctl) HIPCHK(h, hipHostMalloc((void**)&h->h_pin_sctl, sizeof(SeqCtl)));
-    HIPCHK(h, hipMemsetAsync(h->d_seq_ctl, 0, sizeof(SeqCtl), s));
-    k_seq_job_init<<<1, 1, 0, s>>>(h->d_seq, h->d_state, h->d_grid_of, h->d_seq_job, h->d_seq_ctl);
-    rc = launch_seq_persist(h, sc);
-    if (rc == MI355NDT_OK) {
-      persisted = true;
-      hipError_t e2 = hipEventRecord(ev[2], s);
-      if (e2 == hipSuccess) e2 = hipMemcpyAsync(h->h_pin_sctl, h->d_seq_ctl, sizeof(SeqCtl), hipMemcpyDeviceToHost, s);
-      if (e2 == hipSuccess) e2 = hipStreamSynchronize(s);
-      h->prof = keep_prof;
-      if (e2 != hipSuccess) { h->err = std::string("sequence run: ") + hipGetErrorString(e2); return MI355NDT_ERR_HIP; }
-      HIPCHK(h, hipGetLastError());
-      if (h->h_pin_sctl->abort_ || h->h_pin_sctl->epoch != SEQ_EPOCH_DONE) { h->err = "sequence run: the device stopped making progress"; return MI355NDT_ERR_STATE; }
-      h->h_seq_flags[0] = 1; h->h_seq_flags[1] = (int)h->h_pin_sctl->sweeps;
-    } else if (rc != MI355NDT_ERR_UNSUPPORTED) { h->prof = keep_prof; return rc; }
-  }
-  if (!persisted) {
+  bool stuck = false;
   rc = launch_sweep(h, sc, 1);
   // The pump: (update, sweep), (update, sweep), ... enqueued blindly, at most `depth` rounds ahead of what the device has executed;
   // whether a launch continues a frame's Newton loop, closes the frame and opens the next, or has nothing left to do is decided
@@ -1853,7 +1808,6 @@ int mi355ndt_sequence_run(mi355ndt_handle* h, int n_frames, const void* const* c
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   h->prof = keep_prof;
   if (e != hipSuccess) { h->err = std::string("sequence run: ") + hipGetErrorString(e); return MI355NDT_ERR_HIP; }
-  }  // (!persisted: the pumped form)
   if (rc) return rc;
   HIPCHK(h, hipGetLastError());
   if (stuck || !h->h_seq_flags[0]) { h->err = stuck ? "sequence run: the device stopped making progress" : "sequence run did not finish within its launch budget"; return MI355NDT_ERR_STATE; }

@@ -175,137 +175,3 @@ k_seq_update(SeqState* seq, PairState* st, const double* __restrict__ partials, 
   active_list[0] = kind == SEQ_SAME ? cur : cur + 1;
   ctl->n_active = 1;
 }
-
-// ------------------------------------------------------------------------------------ the whole drive in ONE launch
-// The pumped form above costs two kernel boundaries per Newton round (~20 us per round: sweep 7.9 + update 11.6).  Here the sweep's
-// blocks stay resident for the whole run: a sweep is an EPOCH; every block runs its chunk(s) of the current frame's sweep (the fine
-// items of the latency mode: one 4-item chunk per block, the chunk's row added through LDS exactly as k_sweep<FINE> adds it), arrives
-// at a counter, and the block that arrives LAST runs the update -- k_seq_update's body on its four waves, on LDS copies of the pair
-// state and the sequence state -- writes the next sweep's job (pose, point count, frame, grid) and moves the epoch.  Same arithmetic,
-// same summation tree as the pumped form: same bits.  Hand-offs as in ndt_async.hpp: agent-scope (sc1) stores and loads on both sides,
-// every storing wave drained before the word that announces its data, nothing polled that the host did not reset.
-struct SeqJob { float T[12]; float Rj[9]; int n_src, cur, grid; int pad[8]; };      // 32 words; lane k of a wave loads word k
-struct SeqCtl { unsigned epoch, arrived, abort_, sweeps; };
-#define SEQ_EPOCH_DONE 0xFFFFFFFFu
-static_assert(sizeof(SeqJob) == 128 && offsetof(SeqJob, n_src) == 84, "job words");
-static_assert(sizeof(SeqState) % 8 == 0, "SeqState travels as 8-byte words");
-
-__device__ inline void seq_fill_job(SeqJob& J, const PairState& S, int cur, int grid) {
-  for (int a = 0; a < 12; a++) J.T[a] = S.T[a];
-  for (int a = 0; a < 9; a++) J.Rj[a] = S.Rj[a];
-  J.n_src = S.n_src; J.cur = cur; J.grid = grid;
-}
-// after k_seq_begin: the first sweep's job (frame 1 against grid 0), epoch 1 -- or "done" for a one-frame run
-__global__ void k_seq_job_init(const SeqState* seq, const PairState* st, const int* grid_of, SeqJob* job, SeqCtl* sctl) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  sctl->arrived = 0; sctl->abort_ = 0; sctl->sweeps = 0;
-  if (seq->done) { sctl->epoch = SEQ_EPOCH_DONE; return; }
-  seq_fill_job(*job, st[seq->cur], seq->cur, grid_of[seq->cur]);
-  sctl->epoch = 1;
-}
-
-template <bool PCA, int K, int IT, int ORD>
-__global__ void __launch_bounds__(SWEEP_THREADS, (SweepTune<PCA, K>::WPE))
-k_seq_persist(const float* __restrict__ src, size_t pitch, PairState* st, SeqState* seq, SeqJob* job, SeqCtl* sctl, const GridDesc* __restrict__ gd,
-              const BitWord* __restrict__ words, const VoxelRec* __restrict__ recs, double* partials, int items_per_pair, int pts_per_chunk,
-              mi355ndt_result* results, const int* __restrict__ cnt, const double* __restrict__ stamps, mi355ndt_seq_frame* out, int* grid_of,
-              SweepConst sc, double step_max, double eps, int max_iterations) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  __shared__ double exp_tab[64];
-  __shared__ double sm[UPD_WAVES][NACC];
-  __shared__ double sol[8];
-  __shared__ PairState S, Sn;
-  __shared__ SeqState Q;
-  __shared__ SeqJob J;
-  __shared__ unsigned bc[4];
-  static_assert(UPD_WAVES == WAVES, "the update runs on the sweep's block");
-  if (threadIdx.x < 64) exp_tab[threadIdx.x] = ndtm::c_exp2_64[threadIdx.x];
-  __syncthreads();
-  gu32* epoch_p = (gu32*)&sctl->epoch;
-  const int rows_per_pair = items_per_pair >> 2;             // stored rows: one per chunk
-#ifdef NDT_TIMELINE
-  unsigned long long tl[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long tl_last = __builtin_readcyclecounter();
-#endif
-#pragma unroll 1
-  for (unsigned e = 1;; e++) {
-    // ---- wait for sweep e (one lane polls, relaxed, with short sleeps: every block of the grid is waiting for the same word)
-    if (threadIdx.x == 0) {
-      unsigned v = __hip_atomic_load(epoch_p, RLX_AGENT), spins = 0;
-      while (v != e && v != SEQ_EPOCH_DONE) {
-        __builtin_amdgcn_s_sleep(2);
-        v = __hip_atomic_load(epoch_p, RLX_AGENT);
-        if (++spins > (1u << 24)) { __hip_atomic_store((gu32*)&sctl->abort_, 1u, RLX_AGENT); __hip_atomic_store(epoch_p, SEQ_EPOCH_DONE, RLX_AGENT); v = SEQ_EPOCH_DONE; }
-      }
-      bc[0] = v;
-    }
-    __syncthreads();
-    if (bc[0] != e) break;                                   // the run is over (or was aborted)
-    // ---- the sweep's job: 24 words, lane k of every wave loads word k
-    unsigned jw = 0;
-    if (lane < 24) jw = __hip_atomic_load((const gu32*)reinterpret_cast<const unsigned*>(job) + lane, RLX_AGENT);
-    const int n = (int)__builtin_amdgcn_readlane(jw, 21), cur = (int)__builtin_amdgcn_readlane(jw, 22), gi = (int)__builtin_amdgcn_readlane(jw, 23);
-    const int nchunks = (n + pts_per_chunk - 1) / pts_per_chunk;
-#pragma unroll 1
-    for (int c = blockIdx.x; c < nchunks; c += gridDim.x)    // (block-uniform: the four waves hold the four items of ONE chunk)
-      sweep_item<PCA, K, IT, true, ORD, true>(cur, 4 * c + wv, src, pitch, st, gd, words, recs, partials, items_per_pair, sc, nullptr, nullptr, exp_tab, jw, n, gi
-#ifdef NDT_TIMELINE
-                                              , tl, tl_last
-#endif
-                                              );
-    // ---- arrival: the chunk rows (stored by wave 0) are complete in memory first
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) bc[1] = __hip_atomic_fetch_add((gu32*)&sctl->arrived, 1u, RLX_AGENT);
-    __syncthreads();
-    if ((bc[1] + 1u) % gridDim.x != 0u) continue;
-    // ---- this block arrived last: k_seq_update's body, on LDS copies of the states
-    {
-      constexpr int NWS = (int)(sizeof(PairState) / 8), NWQ = (int)(sizeof(SeqState) / 8), NWJ = (int)(sizeof(SeqJob) / 8);
-      gu64* sg = (gu64*)reinterpret_cast<unsigned long long*>(&st[cur]);
-      gu64* qg = (gu64*)reinterpret_cast<unsigned long long*>(seq);
-      for (int i = threadIdx.x; i < NWS; i += SWEEP_THREADS) reinterpret_cast<unsigned long long*>(&S)[i] = __hip_atomic_load(sg + i, RLX_AGENT);
-      for (int i = threadIdx.x; i < NWQ; i += SWEEP_THREADS) reinterpret_cast<unsigned long long*>(&Q)[i] = __hip_atomic_load(qg + i, RLX_AGENT);
-      if (threadIdx.x == 0) { sol[6] = 0.0; bc[2] = SEQ_SAME; }
-      __syncthreads();
-      const double v = reduce_pair_rows<true>(partials + (size_t)cur * rows_per_pair * NACC, nchunks, true, sm, true);
-      if (threadIdx.x < NACC) {
-        if (lane == 0) S.score = v;
-        else if (lane < 7) S.g[lane - 1] = v;
-        else if (lane < 43) S.H[lane - 7] = v;
-        else S.hits = (long long)v;
-      }
-      __syncthreads();
-      if (wv == 1) newton_solve_side(S, sol);                // the solve, next to wave 0's re-basing of p
-      if (wv == 0) {
-        const int rc = newton_update(S, &results[cur], step_max, eps, max_iterations, 0, sol);
-        if (lane == 0) {
-          Q.launches++;
-          bc[2] = rc == NEWTON_SWEEP ? (unsigned)SEQ_SAME : (unsigned)seq_policy(Q, S, Sn, cur, gi, gd, cnt, stamps, out, grid_of);
-        }
-      }
-      __syncthreads();
-      const unsigned kind = bc[2];
-      if (threadIdx.x == 0 && kind != SEQ_END) seq_fill_job(J, kind == SEQ_NEXT ? Sn : S, kind == SEQ_NEXT ? cur + 1 : cur, kind == SEQ_NEXT ? Q.key_id : gi);
-      __syncthreads();
-      // write-through: this frame's state, the next frame's (if it was set up), the sequence state, the job
-      for (int i = threadIdx.x; i < NWS; i += SWEEP_THREADS) __hip_atomic_store(sg + i, reinterpret_cast<unsigned long long*>(&S)[i], RLX_AGENT);
-      if (kind == SEQ_NEXT) {
-        gu64* ng = (gu64*)reinterpret_cast<unsigned long long*>(&st[cur + 1]);
-        for (int i = threadIdx.x; i < NWS; i += SWEEP_THREADS) __hip_atomic_store(ng + i, reinterpret_cast<unsigned long long*>(&Sn)[i], RLX_AGENT);
-      }
-      for (int i = threadIdx.x; i < NWQ; i += SWEEP_THREADS) __hip_atomic_store(qg + i, reinterpret_cast<unsigned long long*>(&Q)[i], RLX_AGENT);
-      if (kind != SEQ_END)
-        for (int i = threadIdx.x; i < NWJ; i += SWEEP_THREADS) __hip_atomic_store((gu64*)reinterpret_cast<unsigned long long*>(job) + i, reinterpret_cast<unsigned long long*>(&J)[i], RLX_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains ...
-      __syncthreads();
-      if (threadIdx.x == 0) {                                // ... before ONE lane moves the epoch
-        __hip_atomic_store((gu32*)&sctl->sweeps, e, RLX_AGENT);
-        __hip_atomic_store(epoch_p, kind == SEQ_END ? SEQ_EPOCH_DONE : e + 1u, RLX_AGENT);
-      }
-    }
-  }
-#ifdef NDT_TIMELINE
-  if (lane == 0) for (int k = 0; k < 12; k++) atomicAdd(&g_tl[k], tl[k]);
-#endif
-}

@@ -471,12 +471,8 @@ __device__ __forceinline__ void sweep_item(const int b, const int rem, const flo
     }
     if (FINE) {
       __syncthreads();                              // (uniform: the four waves of a block run the same items loop, see above)
-      if (wv == 0 && lane < NACC) {
-        const double rs = ((red[0][lane] + red[FINE ? 1 : 0][lane]) + red[FINE ? 2 : 0][lane]) + red[FINE ? 3 : 0][lane];
-        double* dst = partials + ((size_t)b * (rows_per_pair >> 2) + (rem >> 2)) * NACC + lane;
-        if (ASYNC) __hip_atomic_store((gu64*)reinterpret_cast<unsigned long long*>(dst), (unsigned long long)__double_as_longlong(rs), RLX_AGENT);
-        else *dst = rs;
-      }
+      if (wv == 0 && lane < NACC)
+        partials[((size_t)b * (rows_per_pair >> 2) + (rem >> 2)) * NACC + lane] = ((red[0][lane] + red[FINE ? 1 : 0][lane]) + red[FINE ? 2 : 0][lane]) + red[FINE ? 3 : 0][lane];
       __syncthreads();
     }
     TL_STAMP(6);
