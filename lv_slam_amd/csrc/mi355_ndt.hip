@@ -1065,7 +1065,11 @@ static int batch_align_impl(mi355ndt_handle* h, const float* guesses, mi355ndt_r
   HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, 2 * sizeof(SweepCtl), s));
   h->ctl_idx = 0;
   k_init_state<<<(B + 63) / 64, 64, 0, s>>>(h->d_state, h->d_guess, h->d_src_cnt, h->d_grid, B, h->d_active_list, h->d_ctl);
-  if (h->async_align && !h->fine_it && !mt_live && !pca_kd) {       // one launch for the whole align (ndt_async.hpp)
+  // One launch for the whole align (ndt_async.hpp) when the batch offers more work items than the GPU has resident waves.  A smaller batch
+  // -- a single registration above all -- keeps the round-based kernels, whose flat dealing spreads a pair's items over every XCD: a ticket
+  // is served by ONE ring (an eighth of the waves), which costs a lone 65,536-point pair 0.39 ms against 0.31 ms per align.
+  const bool big_batch = (long long)B * h->items_per_pair > (long long)h->n_cu * sweep_wpe(sc.pca != 0, sc.K) * WAVES;
+  if (h->async_align && big_batch && !h->fine_it && !mt_live && !pca_kd) {
     rc = align_async(h, sc, B, out);
     if (rc == MI355NDT_OK) { h->aligned_once = true; return MI355NDT_OK; }
     if (rc != MI355NDT_ERR_UNSUPPORTED) return rc;                  // (not resident: the lockstep rounds below)

@@ -158,7 +158,7 @@ k_align_async(const float* __restrict__ src, size_t pitch, PairState* st, const 
   };
   // Positions of the ring's item stream (ticket 0's items, ticket 1's, ...) are CLAIMED, one returning fetch-add per item.  Static dealing
   // (wave w takes positions w, w + W, ...) was built and measured first: every update makes its wave late for good, a ticket completes when
-  // its latest wave does, and with nothing to rebalance them the waves spent 38 % of the launch waiting for tickets.
+  // its latest wave does, and with nothing to rebalance them the waves spent 38 % of the launch waiting for tickets (docs/experiments.md 10c).
   unsigned pos = 0;
   if (lane == 0) pos = __hip_atomic_fetch_add(pos_p, 1u, RLX_AGENT);
   pos = __builtin_amdgcn_readfirstlane(pos);

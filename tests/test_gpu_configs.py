@@ -145,7 +145,12 @@ def test_one_launch_align_equals_the_round_based_align(mode, variant, res):
         assert eng.get_option(ndt.OPT_ASYNC_ALIGN) == a
         eng.batch_bind_device(T.data_ptr(), [n] * B, n, S.data_ptr(), cnt, n)
         eng.batch_build_targets()
+        eng.profile_enable(True); eng.profile_reset()
         runs = [eng.batch_align(G) for _ in range(6 if a else 1)]
+        pr = eng.profile_get()
+        eng.profile_enable(False)
+        # the option really selects the path: one launch per align and no update kernel, or rounds of (update, sweep) launches
+        assert (pr["sweep_launches"] == 6 and pr["update_launches"] == 0) if a else (pr["sweep_launches"] > 3 and pr["update_launches"] > 2)
         incs = [eng.get_incremental(k) for k in (0, B // 2, B - 1)]
         eng.close()
         out[a] = (runs, incs)
