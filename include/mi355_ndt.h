@@ -177,7 +177,8 @@ enum mi355ndt_option {
   /* 1 (default): a batch align runs as ONE persistent launch in which every pair goes through its own Newton loop to its own end, as
    * every align() of the reference does (ndt_omp_impl2.hpp:131-183); 0: lockstep rounds of (update, sweep) launches over the pairs
    * still iterating.  Same results bit for bit (a pair's sums never depend on what runs beside it); the environment variable
-   * MI355NDT_ASYNC=0 sets the default to 0 for engines created afterwards.  The latency mode and the live More-Thuente configuration
+   * MI355NDT_ASYNC=0 sets the default to 0 for engines created afterwards.  The one launch is used when the batch offers more work items
+   * than the GPU has resident waves (smaller batches are faster in rounds); 2 = use it for every batch size (testing).  The latency mode and the live More-Thuente configuration
    * always take the round-based path. */
   MI355NDT_OPT_ASYNC_ALIGN = 2
 };

@@ -92,6 +92,7 @@ struct mi355ndt_handle {
   int chunks_per_pair = 0;
   int rows_per_pair = 0, pts_per_chunk = CHUNK_PTS;   // stored partial rows per pair / points covered by one chunk of k_update's tree
   int items_per_pair = 0;                         // sweep work items per pair (= rows_per_pair in batch mode, 4 x rows_per_pair in latency mode)
+  bool async_force = false;                       // MI355NDT_OPT_ASYNC_ALIGN = 2 / MI355NDT_ASYNC=2: the one-launch align also for batches smaller than the resident waves (tests, fuzzing)
   bool async_align = true;                        // MI355NDT_OPT_ASYNC_ALIGN: batch aligns as ONE persistent launch (ndt_async.hpp); MI355NDT_ASYNC=0 turns it off
   int* d_ring = nullptr; size_t ring_cap_total = 0; unsigned* d_arrived = nullptr; size_t arrived_cap = 0; AsyncCtl* d_actl = nullptr;
   AsyncCtl* h_pin_actl = nullptr;
@@ -309,7 +310,7 @@ int mi355ndt_create(const mi355ndt_params* params, int device, mi355ndt_handle**
   gauss_constants3(0.55, 1.0f, h->gauss_last);    // the constructor's gauss_d*_ (impl2:70-76: resolution_ 1.0f, outlier_ratio_ 0.55), whatever the setters say later
   { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
   if (const char* e = std::getenv("MI355NDT_FINE_TILES")) { const int v = std::atoi(e); if (v == 1 || v == 2) h->fine_tiles = v; }
-  if (const char* e = std::getenv("MI355NDT_ASYNC")) h->async_align = std::atoi(e) != 0;
+  if (const char* e = std::getenv("MI355NDT_ASYNC")) { h->async_align = std::atoi(e) != 0; h->async_force = std::atoi(e) == 2; }
   if (const char* e = std::getenv("MI355NDT_SWEEP_DYN_SHIFT")) { const int v = std::atoi(e); if (v >= 0 && v <= 30) h->dyn_shift = v; }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
@@ -1069,7 +1070,7 @@ static int batch_align_impl(mi355ndt_handle* h, const float* guesses, mi355ndt_r
   // -- a single registration above all -- keeps the round-based kernels, whose flat dealing spreads a pair's items over every XCD: a ticket
   // is served by ONE ring (an eighth of the waves), which costs a lone 65,536-point pair 0.39 ms against 0.31 ms per align.
   const bool big_batch = (long long)B * h->items_per_pair > (long long)h->n_cu * sweep_wpe(sc.pca != 0, sc.K) * WAVES;
-  if (h->async_align && big_batch && !h->fine_it && !mt_live && !pca_kd) {
+  if (h->async_align && (big_batch || h->async_force) && !h->fine_it && !mt_live && !pca_kd) {
     rc = align_async(h, sc, B, out);
     if (rc == MI355NDT_OK) { h->aligned_once = true; return MI355NDT_OK; }
     if (rc != MI355NDT_ERR_UNSUPPORTED) return rc;                  // (not resident: the lockstep rounds below)
@@ -1563,8 +1564,9 @@ int mi355ndt_set_option(mi355ndt_handle* h, int option, int value) {
     return MI355NDT_OK;
   }
   if (option == MI355NDT_OPT_ASYNC_ALIGN) {
-    if (value != 0 && value != 1) return MI355NDT_ERR_BAD_ARG;
+    if (value < 0 || value > 2) return MI355NDT_ERR_BAD_ARG;
     h->async_align = value != 0;
+    h->async_force = value == 2;                 // 2: also for batches smaller than the GPU's resident waves (testing)
     return MI355NDT_OK;
   }
   return MI355NDT_ERR_BAD_ARG;
@@ -1573,7 +1575,7 @@ int mi355ndt_get_option(const mi355ndt_handle* h, int option, int* value) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   if (!value) return MI355NDT_ERR_BAD_ARG;
   if (option == MI355NDT_OPT_F32_SUM_ORDER) { *value = h->f32_sum_order; return MI355NDT_OK; }
-  if (option == MI355NDT_OPT_ASYNC_ALIGN) { *value = h->async_align ? 1 : 0; return MI355NDT_OK; }
+  if (option == MI355NDT_OPT_ASYNC_ALIGN) { *value = h->async_force ? 2 : (h->async_align ? 1 : 0); return MI355NDT_OK; }
   return MI355NDT_ERR_BAD_ARG;
 }
 
