@@ -36,6 +36,9 @@ struct AsyncCtl {
   unsigned pos[8 * ASYNC_POS_STRIDE];   // per ring: positions of its item stream handed out so far
 };
 
+#ifndef ASYNC_CLAIM
+#define ASYNC_CLAIM(K) ((K) == 1 ? 2 : 1)
+#endif
 #define ASYNC_SPIN_LIMIT (1u << 23)      // polls of ~1 us: a device that stopped making progress ends the launch after seconds, not never
 
 // ring / counters for pair b's first sweep (runs right after k_init_state, before the persistent launch: ordered by the stream)
@@ -134,6 +137,9 @@ k_align_async(const float* __restrict__ src, size_t pitch, PairState* st, const 
   const gu32* done_p = (const gu32*)&ctl->done;
   gu32* pos_p = (gu32*)&ctl->pos[x * ASYNC_POS_STRIDE];
   const int I = items_per_pair;
+  // DIRECT1 items are short (one probe per point, ~0.85 hits): two consecutive items of a pair per claim / arrival halve the hand-overs
+  constexpr int CLAIM = ASYNC_CLAIM(K);
+  const int Iu = I / CLAIM;                        // positions per ticket (items_per_pair is a multiple of four)
 #ifdef NDT_TIMELINE
   unsigned long long tl[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tl_last = __builtin_readcyclecounter();
@@ -163,19 +169,22 @@ k_align_async(const float* __restrict__ src, size_t pitch, PairState* st, const 
   if (lane == 0) pos = __hip_atomic_fetch_add(pos_p, 1u, RLX_AGENT);
   pos = __builtin_amdgcn_readfirstlane(pos);
   int b = -1;
-  if (lane == 0 && (int)(pos / (unsigned)I) < ring_cap) b = (int)__hip_atomic_load(ringx + pos / (unsigned)I, RLX_AGENT);
-  b = wait_ticket((int)(pos / (unsigned)I), b);
+  if (lane == 0 && (int)(pos / (unsigned)Iu) < ring_cap) b = (int)__hip_atomic_load(ringx + pos / (unsigned)Iu, RLX_AGENT);
+  b = wait_ticket((int)(pos / (unsigned)Iu), b);
   if (b < 0) return;
   unsigned pose_w = sweep_pose_words(st + b);
 #pragma unroll 1
   for (;;) {
-    const int rem = (int)(pos % (unsigned)I);
+    const int rem = (int)(pos % (unsigned)Iu) * CLAIM;
     TL_STAMP(10);                                  // hand-over: claim, ticket, (update)
-    sweep_item<PCA, K, 8, false, ORD, true>(b, rem, src, pitch, st, gd, words, recs, partials, I, sc, cent, nullptr, exp_tab, pose_w, src_cnt[b], b
+    const int n_b = src_cnt[b];
+#pragma unroll 1
+    for (int k = 0; k < CLAIM; k++)
+      sweep_item<PCA, K, 8, false, ORD, true>(b, rem + k, src, pitch, st, gd, words, recs, partials, I, sc, cent, nullptr, exp_tab, pose_w, n_b, b
 #ifdef NDT_TIMELINE
-                                            , tl, tl_last
+                                              , tl, tl_last
 #endif
-                                            );
+                                              );
     // Three memory round trips between two items, each carrying everything that does not depend on the next one:
     //  1. the row stores drain (the row is complete in memory before the arrival that may hand it to an updater) -- and the claim of the
     //     next position, which depends on nothing, returns with them;
@@ -183,12 +192,12 @@ k_align_async(const float* __restrict__ src, size_t pitch, PairState* st, const 
     if (lane == 0) npos = __hip_atomic_fetch_add(pos_p, 1u, RLX_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     npos = __builtin_amdgcn_readfirstlane(npos);
-    const int tn = (int)(npos / (unsigned)I);
+    const int tn = (int)(npos / (unsigned)Iu);
     //  2. the arrival, and the ticket word of the next position;
     unsigned old = 0;
     int nb = -1;
     if (lane == 0) {
-      old = __hip_atomic_fetch_add((gu32*)(arrived + (size_t)b * ASYNC_ARR_STRIDE), 1u, RLX_AGENT);
+      old = __hip_atomic_fetch_add((gu32*)(arrived + (size_t)b * ASYNC_ARR_STRIDE), (unsigned)CLAIM, RLX_AGENT);
       if (tn < ring_cap) nb = (int)__hip_atomic_load(ringx + tn, RLX_AGENT);
     }
     old = __builtin_amdgcn_readfirstlane(old);
@@ -197,7 +206,7 @@ k_align_async(const float* __restrict__ src, size_t pitch, PairState* st, const 
     unsigned npose = 0;
     if (nb >= 0) npose = sweep_pose_words(st + nb);
     TL_STAMP(8);                                   // row drain + claim, arrival + ticket
-    if ((old + 1u) % (unsigned)I == 0u) {          // this was the sweep's last item: this wave is the pair's updater
+    if ((old + (unsigned)CLAIM) % (unsigned)I == 0u) {   // this was the sweep's last item: this wave is the pair's updater
       async_update(b, st, partials, I, Ssh[wv], sol[wv], results, ring, ring_cap, ctl, hits_total, step_max, eps, max_iterations);
       TL_STAMP(9);
     }
