@@ -49,47 +49,78 @@ __global__ void k_async_begin(int n_pairs, int* ring, int ring_cap, AsyncCtl* ct
 }
 
 // The pair's rows -> (score, g, H, hits), Newton step, publication.  Called by every lane of ONE wave; `Ssh` / `sol` are that wave's LDS.
-__device__ __forceinline__ void async_update(const int b, PairState* st, const double* partials, const int rows_per_pair, PairState& Ssh, volatile double* sol,
+__device__ __forceinline__ void async_update(const int b, const int n_pts, PairState* st, const double* partials, const int rows_per_pair, PairState& Ssh, volatile double* sol,
                                              mi355ndt_result* results, int* ring, const int ring_cap, AsyncCtl* ctl, unsigned long long* hits_total,
-                                             const double step_max, const double eps, const int max_iterations) {
+                                             const double step_max, const double eps, const int max_iterations
+#ifdef NDT_TIMELINE
+                                             , unsigned long long* tl, unsigned long long& tl_last
+#endif
+                                             ) {
   const int lane = threadIdx.x & 63;
+  // the update is a chain of dependent instructions on the critical path of its pair (and of the whole batch once few pairs are left):
+  // it goes first at the SIMD's issue arbiter while it runs next to a wave that streams independent evaluation work
+  __builtin_amdgcn_s_setprio(3);
   static_assert(sizeof(PairState) % 8 == 0, "PairState travels as 8-byte words");
   constexpr int NW = (int)(sizeof(PairState) / 8);
   gu64* sg = (gu64*)reinterpret_cast<unsigned long long*>(&st[b]);
   unsigned long long* sl = reinterpret_cast<unsigned long long*>(&Ssh);
-  // the pair's state: written by its previous updater (another wave, maybe another XCD) -> LDS copy of this wave
+  // the pair's state (written by its previous updater: another wave, maybe another XCD -> LDS copy of this wave) and the first rows of the
+  // reduction are requested together: the row addresses need only the constant point count
   for (int i = lane; i < NW; i += 64) sl[i] = __hip_atomic_load(sg + i, RLX_AGENT);
   if (lane == 0) sol[6] = 0.0;
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
   // reduce_pair_rows' tree (ndt_update.hpp) on one wave: chunk = ((r0 + r1) + r2) + r3; group = 8 chunks in order; group k belongs to
   // "wave" k % 4, whose groups add up in ascending order; the four sums add up in order.  Same operands, same order: same bits.
-  const int nchunks = (Ssh.n_src + CHUNK_PTS - 1) / CHUNK_PTS;
+  // Two groups (64 rows) are in flight per lane at a time: the rows come from memory (write-through), ~2 us per dependent batch.
+  const int nchunks = (n_pts + CHUNK_PTS - 1) / CHUNK_PTS;
+  double aw0 = 0.0, aw1 = 0.0, aw2 = 0.0, aw3 = 0.0;
   if (lane < NACC) {
     const gu64* P = (const gu64*)reinterpret_cast<const unsigned long long*>(partials + (size_t)b * rows_per_pair * NACC + lane);
-    double aw0 = 0.0, aw1 = 0.0, aw2 = 0.0, aw3 = 0.0;
+    auto ldq = [&](int c, int k) -> double { return __longlong_as_double((long long)__hip_atomic_load(P + ((size_t)c * 4 + k) * NACC, RLX_AGENT)); };
+    auto addw = [&](int g, double gs) { const int w = g & 3; if (w == 0) aw0 += gs; else if (w == 1) aw1 += gs; else if (w == 2) aw2 += gs; else aw3 += gs; };
 #pragma unroll 1
-    for (int c0 = 0; c0 < nchunks; c0 += 8) {
-      double gs = 0.0;
-      if (c0 + 8 <= nchunks) {
-        double q[8][4];
+    for (int c0 = 0; c0 < nchunks; c0 += 16) {
+      if (c0 + 16 <= nchunks) {
+        double q[16][4];
 #pragma unroll
-        for (int u = 0; u < 8; u++)
+        for (int u = 0; u < 16; u++)
 #pragma unroll
-          for (int k = 0; k < 4; k++) q[u][k] = __longlong_as_double((long long)__hip_atomic_load(P + ((size_t)(c0 + u) * 4 + k) * NACC, RLX_AGENT));
+          for (int k = 0; k < 4; k++) q[u][k] = ldq(c0 + u, k);
+        double gs = 0.0;
 #pragma unroll
         for (int u = 0; u < 8; u++) gs += ((q[u][0] + q[u][1]) + q[u][2]) + q[u][3];
-      } else {
-        for (int c = c0; c < nchunks; c++) {
-          double r[4];
+        addw(c0 >> 3, gs);
+        gs = 0.0;
 #pragma unroll
-          for (int k = 0; k < 4; k++) r[k] = __longlong_as_double((long long)__hip_atomic_load(P + ((size_t)c * 4 + k) * NACC, RLX_AGENT));
-          gs += ((r[0] + r[1]) + r[2]) + r[3];
+        for (int u = 8; u < 16; u++) gs += ((q[u][0] + q[u][1]) + q[u][2]) + q[u][3];
+        addw((c0 >> 3) + 1, gs);
+      } else {
+#pragma unroll 1
+        for (int g0 = c0; g0 < nchunks; g0 += 8) {
+          double gs = 0.0;
+          if (g0 + 8 <= nchunks) {
+            double q[8][4];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+#pragma unroll
+              for (int k = 0; k < 4; k++) q[u][k] = ldq(g0 + u, k);
+#pragma unroll
+            for (int u = 0; u < 8; u++) gs += ((q[u][0] + q[u][1]) + q[u][2]) + q[u][3];
+          } else {
+            for (int c = g0; c < nchunks; c++) {
+              double r[4];
+#pragma unroll
+              for (int k = 0; k < 4; k++) r[k] = ldq(c, k);
+              gs += ((r[0] + r[1]) + r[2]) + r[3];
+            }
+          }
+          addw(g0 >> 3, gs);
         }
       }
-      const int w = (c0 >> 3) & 3;
-      if (w == 0) aw0 += gs; else if (w == 1) aw1 += gs; else if (w == 2) aw2 += gs; else aw3 += gs;
     }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  if (lane < NACC) {
     double v = 0.0;
     v += aw0; v += aw1; v += aw2; v += aw3;
     if (lane == 0) Ssh.score = v;
@@ -99,13 +130,16 @@ __device__ __forceinline__ void async_update(const int b, PairState* st, const d
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
+  TL_STAMP(12);                                    // state + rows
   newton_solve_side(Ssh, sol);                     // lanes 0..6: impl2:138-140 (same functions and operands as k_update's second wave)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
+  TL_STAMP(13);                                    // solve
   int rc = newton_update(Ssh, &results[b], step_max, eps, max_iterations, 0, sol);
   rc = __builtin_amdgcn_readfirstlane(rc);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
+  TL_STAMP(14);                                    // Newton step
   // the state goes back write-through; it is complete in memory before the ticket that lets other waves read it exists
   for (int i = lane; i < NW; i += 64) __hip_atomic_store(sg + i, sl[i], RLX_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -118,6 +152,7 @@ __device__ __forceinline__ void async_update(const int b, PairState* st, const d
       __hip_atomic_fetch_add((gu32*)&ctl->done, 1u, RLX_AGENT);
     }
   }
+  __builtin_amdgcn_s_setprio(0);
 }
 
 template <bool PCA, int K, int ORD>
@@ -141,7 +176,7 @@ k_align_async(const float* __restrict__ src, size_t pitch, PairState* st, const 
   constexpr int CLAIM = ASYNC_CLAIM(K);
   const int Iu = I / CLAIM;                        // positions per ticket (items_per_pair is a multiple of four)
 #ifdef NDT_TIMELINE
-  unsigned long long tl[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tl[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tl_last = __builtin_readcyclecounter();
 #endif
   // wait (one lane, relaxed polls with sleeps) until ticket `t` of this ring exists; -2: the launch is over
@@ -207,7 +242,11 @@ k_align_async(const float* __restrict__ src, size_t pitch, PairState* st, const 
     if (nb >= 0) npose = sweep_pose_words(st + nb);
     TL_STAMP(8);                                   // row drain + claim, arrival + ticket
     if ((old + (unsigned)CLAIM) % (unsigned)I == 0u) {   // this was the sweep's last item: this wave is the pair's updater
-      async_update(b, st, partials, I, Ssh[wv], sol[wv], results, ring, ring_cap, ctl, hits_total, step_max, eps, max_iterations);
+      async_update(b, n_b, st, partials, I, Ssh[wv], sol[wv], results, ring, ring_cap, ctl, hits_total, step_max, eps, max_iterations
+#ifdef NDT_TIMELINE
+                   , tl, tl_last
+#endif
+                   );
       TL_STAMP(9);
     }
     if (nb < 0) {                                  // the next position's ticket does not exist yet
@@ -218,6 +257,6 @@ k_align_async(const float* __restrict__ src, size_t pitch, PairState* st, const 
     b = nb; pos = npos; pose_w = npose;
   }
 #ifdef NDT_TIMELINE
-  if (lane == 0) for (int k = 0; k < 12; k++) atomicAdd(&g_tl[k], tl[k]);
+  if (lane == 0) for (int k = 0; k < 16; k++) atomicAdd(&g_tl[k], tl[k]);
 #endif
 }

@@ -131,7 +131,7 @@ __host__ __device__ constexpr int probe_off(int K, int q, int a) {
 // -DNDT_TIMELINE: per-phase shader-clock stamps of every work item, summed over all waves into g_tl (read back through
 // mi355ndt_debug_timeline; tools/sweep_timeline.py).  Costs ~10 % and is never part of the shipped library.
 #ifdef NDT_TIMELINE
-__device__ unsigned long long g_tl[12];
+__device__ unsigned long long g_tl[16];
 #define TL_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); tl[k] += t_ - tl_last; tl_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define TL_STAMP(k) do {} while (0)

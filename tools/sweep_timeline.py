@@ -23,7 +23,7 @@ res = (ndt.Result * B)()
 eng.batch_build_targets()
 for _ in range(3): eng.batch_align_raw(guesses, res)
 lib = ndt.load_library()
-out = (ctypes.c_ulonglong * 12)()
+out = (ctypes.c_ulonglong * 16)()
 lib.mi355ndt_debug_timeline(out)
 eng.profile_enable(True); eng.profile_reset()
 R = 5
@@ -31,9 +31,9 @@ for _ in range(R): eng.batch_align_raw(guesses, res)
 p = eng.profile_get()
 lib.mi355ndt_debug_timeline(out)
 v = np.array(list(out), dtype=np.float64)
-names = ["claim/loop", "setup+pt issue", "pt wait+transform", "bitmap issue", "bitmap wait+push", "drain(eval)", "reduce+write", "(items)", "row drain+arrive", "update", "ticket wait", "-"]
-tot = v[:7].sum() + v[8:11].sum()
+names = ["claim/loop", "setup+pt issue", "pt wait+transform", "bitmap issue", "bitmap wait+push", "drain(eval)", "reduce+write", "(items)", "row drain+arrive", "update: write-back + publish", "ticket wait", "-", "update: state + rows", "update: solve", "update: Newton step", "-"]
+tot = v[:7].sum() + v[8:11].sum() + v[12:15].sum()
 print(MODE, VAR, "items", int(v[7]), "sweep ms/align", p["sweep_ms"] / R, "launches", p["sweep_launches"] / R)
-for n, x in [(a, c) for k, (a, c) in enumerate(zip(names, v)) if k != 7 and k != 11]: print(f"  {n:22s} {x / v[7]:10.0f} cyc/item  {100 * x / tot:5.1f} %")
+for n, x in [(a, c) for k, (a, c) in enumerate(zip(names, v)) if k not in (7, 11, 15)]: print(f"  {n:22s} {x / v[7]:10.0f} cyc/item  {100 * x / tot:5.1f} %")
 print("  total cyc/item", tot / v[7])
 eng.close()
