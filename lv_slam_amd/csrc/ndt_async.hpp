@@ -131,11 +131,34 @@ __device__ __forceinline__ void async_update(const int b, const int n_pts, PairS
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
   TL_STAMP(12);                                    // state + rows
+  // The re-basing of p for this step was computed by the previous updater after it published this sweep (below).  Its words are fetched
+  // AFTER its tag has been seen (the state above was one multi-word load: a new tag does not vouch for the words that came with it), and the
+  // fetch rides under the solve.
+  constexpr int RB0 = (int)(offsetof(PairState, reb_pn) / 8), RBT = (int)(offsetof(PairState, reb_tag) / 8);
+  static_assert(RBT - RB0 == 14, "6 + 8 words of re-basing");
+  const bool want_reb = Ssh.phase == PH_STEP;
+  bool reb_ok = want_reb && Ssh.reb_tag == (long long)Ssh.sweeps;
+  unsigned long long rbw = 0;
+  if (reb_ok && lane < 14) rbw = __hip_atomic_load(sg + RB0 + lane, RLX_AGENT);
   newton_solve_side(Ssh, sol);                     // lanes 0..6: impl2:138-140 (same functions and operands as k_update's second wave)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
   TL_STAMP(13);                                    // solve
-  int rc = newton_update(Ssh, &results[b], step_max, eps, max_iterations, 0, sol);
+  if (want_reb && !reb_ok) {                       // rare: the tag had not landed yet -- wait for it (bounded), then fetch the words
+    unsigned spins = 0;
+    while (!reb_ok && spins++ < (1u << 16)) {
+      __builtin_amdgcn_s_sleep(2);
+      long long tg = 0;
+      if (lane == 0) tg = (long long)__hip_atomic_load(sg + RBT, RLX_AGENT);
+      reb_ok = __shfl(tg, 0) == (long long)Ssh.sweeps;
+    }
+    if (reb_ok && lane < 14) rbw = __hip_atomic_load(sg + RB0 + lane, RLX_AGENT);
+  }
+  if (reb_ok && lane < 14) sl[RB0 + lane] = rbw;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  const bool rebased = reb_ok;                     // (a tag that never came: newton_update computes the re-basing itself, same bits)
+  int rc = newton_update(Ssh, &results[b], step_max, eps, max_iterations, 0, sol, rebased);
   rc = __builtin_amdgcn_readfirstlane(rc);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
@@ -150,6 +173,21 @@ __device__ __forceinline__ void async_update(const int b, const int n_pts, PairS
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (finalize_pair's result record)
       __hip_atomic_fetch_add((gu32*)&ctl->done, 1u, RLX_AGENT);
+    }
+  }
+  TL_STAMP(9);
+  if (rc == NEWTON_SWEEP) {
+    // Off the pair's critical path -- its next sweep is already running --: the re-basing the NEXT update starts with (impl2:163-166) depends
+    // only on what this update decided (p, dir, a_t).  Written behind the state, announced by a tag = the sweep count.
+    constexpr int RBI = (int)(offsetof(PairState, reb_inc) / 8);
+    double pn[6]; float inc[16];
+    newton_rebase(Ssh.p, Ssh.dir, Ssh.a_t, pn, inc);
+    if (lane == 0) {
+      for (int a = 0; a < 6; a++) __hip_atomic_store(sg + RB0 + a, (unsigned long long)__double_as_longlong(pn[a]), RLX_AGENT);
+      for (int a = 0; a < 8; a++)
+        __hip_atomic_store(sg + RBI + a, (unsigned long long)__float_as_uint(inc[2 * a]) | ((unsigned long long)__float_as_uint(inc[2 * a + 1]) << 32), RLX_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(sg + RBT, (unsigned long long)(long long)Ssh.sweeps, RLX_AGENT);
     }
   }
   __builtin_amdgcn_s_setprio(0);
@@ -247,7 +285,7 @@ k_align_async(const float* __restrict__ src, size_t pitch, PairState* st, const 
                    , tl, tl_last
 #endif
                    );
-      TL_STAMP(9);
+      TL_STAMP(15);                                // the deferred re-basing (off the pair's critical path)
     }
     if (nb < 0) {                                  // the next position's ticket does not exist yet
       nb = wait_ticket(tn, nb);

@@ -61,6 +61,11 @@ struct PairState {
   // pcl::Registration::transformation_ / previous_transformation_ as computeTransformation leaves them (impl2:134, 163):
   // float(exp(delta_p)) of the last and of the one-before-last Newton step, column-major
   float  inc_cm[16], prev_inc_cm[16];
+  // one-launch align only (ndt_async.hpp): the re-basing of p for the NEXT update -- log(exp(delta_p) exp(p)) and float(exp(delta_p)), impl2:163-166 --
+  // computed by the updater AFTER it published the pair's next sweep, i.e. off the pair's critical path; valid when reb_tag == sweeps
+  double reb_pn[6];
+  float  reb_inc[16];
+  long long reb_tag;
 };
 
 struct SweepConst {

@@ -59,6 +59,7 @@ __device__ inline void init_pair_state(PairState& S, const float G[16] /* column
   for (int a = 0; a < 16; a++) S.inc_cm[a] = S.prev_inc_cm[a] = (a % 5 == 0) ? 1.f : 0.f;    // align(): transformation_ = previous_ = I
   S.n_src = n_src;
   S.grid_status = grid_status;
+  S.reb_tag = -1;
 }
 
 // p = SE3(R,t).log(); first sweep moves the cloud by the caller's f32 guess itself (impl2:102-129)
@@ -297,12 +298,32 @@ __device__ __forceinline__ void newton_solve_side(const PairState& S, volatile d
 // in the next derivative sweep), NEWTON_HESSIAN (live More-Thuente case: waiting for the computeHessian pass).
 // mt = 0: step_size > eps/2, the More-Thuente loop is dead (every shipped configuration);
 // mt = 1: live case, called after a derivative sweep;  mt = 2: live case, called after the computeHessian pass.
+// The re-basing step of impl2:163-166 on its own: pn = log(exp(delta_p) exp(p)), inc = float(exp(delta_p)) column-major, delta_p = dir * a_t.
+// Called by every lane of a wave (the two exponentials run side by side on lanes 0 and 1, as inside newton_update); results on lane 0.
+__device__ __forceinline__ void newton_rebase(const double p[6], const double dir[6], const double a_t, double pn[6], float inc_cm[16]) {
+  const int lane = threadIdx.x & 63;
+  double in[6];
+  for (int a = 0; a < 6; a++) in[a] = (lane & 1) ? p[a] : dir[a] * a_t;          // impl2:156
+  const ndtm::SE3 e = ndtm::se3_exp(in);
+  const ndtm::SE3 e_dp = shfl_se3(e, 0), e_p = shfl_se3(e, 1);
+  double R[9];
+  ndtm::q_to_matrix(e_dp.q, R);                                                  // set_increment_se3
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) inc_cm[c * 4 + r] = (float)R[r * 3 + c];
+    inc_cm[12 + r] = (float)e_dp.t[r];
+    inc_cm[r * 4 + 3] = 0.f;
+  }
+  inc_cm[15] = 1.f;
+  ndtm::se3_log(ndtm::se3_mul(e_dp, e_p), pn);                                   // impl2:166
+}
+
 __device__ __forceinline__ int newton_update(PairState& S, mi355ndt_result* res, double step_max, double eps, int max_iterations, int mt,
-                                             volatile double* sol = nullptr /* non-null: the solve comes from newton_solve_side */) {
+                                             volatile double* sol = nullptr /* non-null: the solve comes from newton_solve_side */,
+                                             const bool rebased = false /* S.reb_pn / S.reb_inc hold the re-basing of this step already */) {
   const int lane = threadIdx.x & 63;
   // exp(delta_p) and exp(p) of impl2:163-166, side by side on two lanes (same bits as one after the other on one lane)
   ndtm::SE3 e_dp, e_p;
-  const bool pre = (mt == 0) && (S.phase == PH_STEP);                            // wave-uniform: nothing has been written yet
+  const bool pre = (mt == 0) && (S.phase == PH_STEP) && !rebased;                // wave-uniform: nothing has been written yet
   if (pre) {
     double in[6];
     for (int a = 0; a < 6; a++) in[a] = (lane & 1) ? S.p[a] : S.dir[a] * S.a_t;   // impl2:156
@@ -339,7 +360,10 @@ __device__ __forceinline__ int newton_update(PairState& S, mi355ndt_result* res,
   if (S.phase == PH_HESS) S.phase = PH_STEP;
   if (S.phase == PH_STEP) {
     double pn[6];
-    if (pre) {
+    if (rebased) {                                                               // computed after the previous update published its sweep (same operations)
+      for (int a = 0; a < 16; a++) S.inc_cm[a] = S.reb_inc[a];
+      for (int a = 0; a < 6; a++) pn[a] = S.reb_pn[a];
+    } else if (pre) {
       set_increment_se3(S, e_dp);                                                // impl2:163
       ndtm::se3_log(ndtm::se3_mul(e_dp, e_p), pn);                               // impl2:166
     } else {

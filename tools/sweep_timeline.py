@@ -31,9 +31,9 @@ for _ in range(R): eng.batch_align_raw(guesses, res)
 p = eng.profile_get()
 lib.mi355ndt_debug_timeline(out)
 v = np.array(list(out), dtype=np.float64)
-names = ["claim/loop", "setup+pt issue", "pt wait+transform", "bitmap issue", "bitmap wait+push", "drain(eval)", "reduce+write", "(items)", "row drain+arrive", "update: write-back + publish", "ticket wait", "-", "update: state + rows", "update: solve", "update: Newton step", "-"]
-tot = v[:7].sum() + v[8:11].sum() + v[12:15].sum()
+names = ["claim/loop", "setup+pt issue", "pt wait+transform", "bitmap issue", "bitmap wait+push", "drain(eval)", "reduce+write", "(items)", "row drain+arrive", "update: write-back + publish", "ticket wait", "-", "update: state + rows", "update: solve", "update: Newton step", "update: deferred re-basing"]
+tot = v[:7].sum() + v[8:11].sum() + v[12:16].sum()
 print(MODE, VAR, "items", int(v[7]), "sweep ms/align", p["sweep_ms"] / R, "launches", p["sweep_launches"] / R)
-for n, x in [(a, c) for k, (a, c) in enumerate(zip(names, v)) if k not in (7, 11, 15)]: print(f"  {n:22s} {x / v[7]:10.0f} cyc/item  {100 * x / tot:5.1f} %")
+for n, x in [(a, c) for k, (a, c) in enumerate(zip(names, v)) if k not in (7, 11)]: print(f"  {n:22s} {x / v[7]:10.0f} cyc/item  {100 * x / tot:5.1f} %")
 print("  total cyc/item", tot / v[7])
 eng.close()
