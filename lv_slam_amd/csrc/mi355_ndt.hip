@@ -40,6 +40,11 @@
 #include "ndt_prefilter.hpp"
 #include "ndt_sequence.hpp"
 #include "ndt_async.hpp"
+#ifndef NDT_SINGLE_TU      // the ORD = 1 instantiations come from mi355_ndt_ord1.hip (built side by side with this file)
+#include "ndt_ord1_list.hpp"
+#define NDT_DECLARE extern template
+NDT_ORD1_KERNELS(NDT_DECLARE)
+#endif
 
 
 // ------------------------------------------------------------------------------------ host side

@@ -42,7 +42,7 @@ struct AsyncCtl {
 #define ASYNC_SPIN_LIMIT (1u << 23)      // polls of ~1 us: a device that stopped making progress ends the launch after seconds, not never
 
 // ring / counters for pair b's first sweep (runs right after k_init_state, before the persistent launch: ordered by the stream)
-__global__ void k_async_begin(int n_pairs, int* ring, int ring_cap, AsyncCtl* ctl) {
+NDT_KERNEL void k_async_begin(int n_pairs, int* ring, int ring_cap, AsyncCtl* ctl) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b == 0) ctl->pub = (unsigned)n_pairs;
   if (b < n_pairs) ring[(size_t)(b & 7) * ring_cap + (b >> 3)] = b;

@@ -6,6 +6,14 @@
 #include <cstring>
 #include "mi355_ndt.h"
 
+// Non-template kernels defined in headers that both translation units include: the second unit (mi355_ndt_ord1.hip, kernel instantiations
+// only) sees them as unused internal functions and emits nothing for them.
+#ifdef NDT_SECOND_TU
+#define NDT_KERNEL static __global__
+#else
+#define NDT_KERNEL __global__
+#endif
+
 // ------------------------------------------------------------------------------------ constants
 #define CHUNK_PTS      2048          // source points per reduction chunk (fixed => results independent of launch geometry)
 #define SWEEP_THREADS  256

@@ -63,7 +63,7 @@ __device__ inline void init_pair_state(PairState& S, const float G[16] /* column
 }
 
 // p = SE3(R,t).log(); first sweep moves the cloud by the caller's f32 guess itself (impl2:102-129)
-__global__ void k_init_state(PairState* st, const float* __restrict__ guess_cm, const int* __restrict__ src_cnt,
+NDT_KERNEL void k_init_state(PairState* st, const float* __restrict__ guess_cm, const int* __restrict__ src_cnt,
                              const GridDesc* __restrict__ gd, int n_pairs, int* active_list, SweepCtl* ctl) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n_pairs) return;
@@ -73,7 +73,7 @@ __global__ void k_init_state(PairState* st, const float* __restrict__ guess_cm, 
 }
 
 // explicit sweep pose (parity hooks)
-__global__ void k_set_pose(PairState* st, int b, const float* __restrict__ T_cm, const float* __restrict__ Rj, const int* __restrict__ src_cnt,
+NDT_KERNEL void k_set_pose(PairState* st, int b, const float* __restrict__ T_cm, const float* __restrict__ Rj, const int* __restrict__ src_cnt,
                            const GridDesc* __restrict__ gd, int* active_list, SweepCtl* ctl) {
   PairState& S = st[b];
   active_list[0] = b; ctl->n_active = 1;
@@ -81,7 +81,7 @@ __global__ void k_set_pose(PairState* st, int b, const float* __restrict__ T_cm,
   for (int a = 0; a < 9; a++) S.Rj[a] = Rj[a];
   S.phase = PH_SWEEP0; S.n_src = src_cnt[b]; S.grid_status = gd[b].status; S.it = 0; S.sweeps = 1;
 }
-__global__ void k_set_pose_p(PairState* st, int b, const double* __restrict__ p, const int* __restrict__ src_cnt, const GridDesc* __restrict__ gd,
+NDT_KERNEL void k_set_pose_p(PairState* st, int b, const double* __restrict__ p, const int* __restrict__ src_cnt, const GridDesc* __restrict__ gd,
                              int* active_list, SweepCtl* ctl, int for_hessian) {
   PairState& S = st[b];
   active_list[0] = b; ctl->n_active = 1;
@@ -433,7 +433,7 @@ __device__ __forceinline__ int newton_update(PairState& S, mi355ndt_result* res,
 // One block (UPD_WAVES waves) per pair: fixed-order reduction of the pair's partial rows (reduce_pair_rows), then wave 0 runs the
 // Newton control (newton_update).  `rows_per_pair` = stored rows per pair (the row stride), `pts_per_chunk` = points covered by one
 // chunk = four consecutive rows (CHUNK_PTS in batch mode) or, with `chunk_rows`, by one stored row (latency mode).
-__global__ void __launch_bounds__(UPD_THREADS, 2)
+NDT_KERNEL void __launch_bounds__(UPD_THREADS, 2)
 k_update(PairState* st, const double* __restrict__ partials, int rows_per_pair, int pts_per_chunk, int chunk_rows, mi355ndt_result* results,
          int* active_counter, int* active_list, SweepCtl* ctl, unsigned long long* hits_total,
          double step_max, double eps, int max_iterations, int reduce_only, int mt) {
@@ -465,7 +465,7 @@ k_update(PairState* st, const double* __restrict__ partials, int rows_per_pair, 
 }
 
 // output cloud of align(): source moved by final_transformation_ (f32), written as packed x,y,z triples (what goes back over PCIe)
-__global__ void k_transform(const float* __restrict__ src, size_t pitch, const PairState* __restrict__ st, int b, float* out, int n) {
+NDT_KERNEL void k_transform(const float* __restrict__ src, size_t pitch, const PairState* __restrict__ st, int b, float* out, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float* X = src + (size_t)b * 3 * pitch;
@@ -476,7 +476,7 @@ __global__ void k_transform(const float* __restrict__ src, size_t pitch, const P
 
 // host clouds arrive as packed x,y,z triples (the engine drops the other fields of the caller's records while it stages them in
 // pinned memory); this turns one cloud into the SoA rows the kernels read, zero-filling the padding up to the row pitch
-__global__ void __launch_bounds__(256) k_deinterleave(const float* __restrict__ xyz, int n, float* rows, size_t pitch) {
+NDT_KERNEL void __launch_bounds__(256) k_deinterleave(const float* __restrict__ xyz, int n, float* rows, size_t pitch) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= pitch) return;
   float x = 0.f, y = 0.f, z = 0.f;
@@ -489,7 +489,7 @@ __global__ void __launch_bounds__(256) k_deinterleave(const float* __restrict__ 
 // int converged; int pair_id; int pad[4]} per pair, packed on the device straight from the results of the last batch align.
 // Rows past the batch (a rank that owns one pair fewer than its neighbours) carry pair_id = -1.
 struct PoseRecord { float final_cm[16]; float score; int iterations, converged, pair_id, pad[4]; };
-__global__ void k_pose_records(const mi355ndt_result* __restrict__ res, int n_pairs, int id_base, int id_stride, PoseRecord* out, int capacity) {
+NDT_KERNEL void k_pose_records(const mi355ndt_result* __restrict__ res, int n_pairs, int id_base, int id_stride, PoseRecord* out, int capacity) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= capacity) return;
   PoseRecord r;
