@@ -7,6 +7,8 @@
 //   align         : k_init_state -> k_sweep -> [k_update -> k_sweep]*      (computeTransformation +
 //                   computeDerivatives + computeStepLengthMT, include/ndt_omp/ndt_omp_impl2.hpp:87-188, 196-305, 841-1003;
 //                   step_size <= eps/2 only: [k_update -> k_hessian -> k_update -> k_sweep]*, impl2:622-714, 920-1000)
+// Build: __graft_entry__.build() compiles this file and mi355_ndt_ord1.hip (the kernel instantiations of the second f32 sum order) side by
+// side and links them; -DNDT_SINGLE_TU builds everything from this file alone.
 // Kernels live in ndt_build.hpp / ndt_sweep.hpp / ndt_update.hpp / ndt_hessian.hpp / ndt_fitness.hpp / ndt_prefilter.hpp; this file is
 // the host side of the C-ABI (one translation unit).  Data layout in HBM: DESIGN.md.  Built with -ffp-contract=off: every f32/f64 step of the
 // reference recipe is a separately rounded operation.
