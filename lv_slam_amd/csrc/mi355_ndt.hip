@@ -1,8 +1,8 @@
 // mi355_ndt.hip -- MI355X (gfx950) NDT scan-matching engine behind the C-ABI of include/mi355_ndt.h.
 //
 // What runs where (all on the GPU; the host only enqueues):
-//   target build  : k_minmax -> k_griddesc -> k_keys -> radix sort (cell, input order) -> k_mark
-//                   -> k_rank -> k_segstart -> k_leafsum -> k_voxels          (VoxelGridCovariance::applyFilter,
+//   target build  : k_minmax -> k_griddesc -> k_keys -> radix sort (cell, input order) -> k_mark (+ run heads)
+//                   -> k_rank (+ run starts by voxel id) -> k_leafsum -> k_voxels          (VoxelGridCovariance::applyFilter,
 //                   include/ndt_omp/voxel_grid_covariance_omp_impl.hpp:48-370)
 //   align         : k_init_state -> k_sweep -> [k_update -> k_sweep]*      (computeTransformation +
 //                   computeDerivatives + computeStepLengthMT, include/ndt_omp/ndt_omp_impl2.hpp:87-188, 196-305, 841-1003;
@@ -72,7 +72,7 @@ struct mi355ndt_handle {
   bool cent_built = false;                        // last target build also produced the f32 leaf centroids (KDTREE mode)
 
   // build workspace
-  int* d_minmax = nullptr;
+  unsigned* d_minmax = nullptr;                  // a slice of d_word_off's allocation (zeroed together before every build)
   GridDesc* d_grid = nullptr;
   unsigned *d_nwords = nullptr, *d_word_off = nullptr;
   unsigned *d_keys_a = nullptr, *d_keys_b = nullptr;      // cell key per target point: unsorted / sorted (segment-local radix sort)
@@ -80,7 +80,9 @@ struct mi355ndt_handle {
   size_t keys_cap = 0;
   BitWord* d_words = nullptr; size_t words_cap = 0;
   VoxelRec* d_recs = nullptr; int *d_vox_idx = nullptr, *d_vox_n = nullptr;
-  unsigned* d_seg_start = nullptr; double* d_sums = nullptr; float* d_cent = nullptr; double* d_icov64 = nullptr; size_t icov64_cap = 0;
+  unsigned* d_seg_start = nullptr; double* d_sums = nullptr;
+  unsigned *d_heads = nullptr, *d_head_cnt = nullptr; size_t heads_cap = 0, head_cnt_cap = 0;   // k_mark's run heads per slice
+  float* d_cent = nullptr; double* d_icov64 = nullptr; size_t icov64_cap = 0;
   int* d_kdw = nullptr; size_t kdw_cap = 0; bool kdw_built = false;   // per-leaf weights for ndt_pca + KDTREE (dead leaves included)
   unsigned* d_rs_hist = nullptr; unsigned* d_rs_offs = nullptr; size_t rs_cap = 0;   // segmented radix sort: tile histograms / offsets
   unsigned *d_cstart = nullptr, *d_cend = nullptr; size_t cell_cap = 0; bool cells_ready = false; int last_cb = 0;
@@ -346,9 +348,9 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->d_tgt_own, h->d_src_own, h->d_tgt_cnt, h->d_src_cnt, h->d_minmax, h->d_grid, h->d_nwords, h->d_word_off,
+  void* ptrs[] = {h->d_tgt_own, h->d_src_own, h->d_tgt_cnt, h->d_src_cnt, h->d_grid, h->d_nwords, h->d_word_off,
                   h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, h->d_words, h->d_recs, h->d_vox_idx, h->d_vox_n,
-                  h->d_state, h->d_partials, h->d_guess, h->d_results, h->d_active, h->d_hook, h->d_aligned, h->d_hits, h->d_seg_start, h->d_sums,
+                  h->d_state, h->d_partials, h->d_guess, h->d_results, h->d_active, h->d_hook, h->d_aligned, h->d_hits, h->d_seg_start, h->d_heads, h->d_head_cnt, h->d_sums,
                   h->d_cent, h->d_icov64, h->d_kdw, h->d_rs_hist, h->d_rs_offs, h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit, h->d_pf_in, h->d_pf_out, h->d_pf_keep, h->d_pf_keys,
                   h->d_pf_vals, h->d_pf_flag, h->d_pf_pos, h->d_pf_mm, h->d_pf_grid, h->d_pf_tmp, h->d_score_pts, h->d_score_part,
                   h->d_ring, h->d_arrived, h->d_actl};
@@ -426,10 +428,12 @@ static int ensure_pair_arrays(mi355ndt_handle* h, int n_pairs) {
   HIPCHK(h, re((void**)&h->d_tgt_cnt, n_pairs * sizeof(int)));
   HIPCHK(h, re((void**)&h->d_src_cnt, n_pairs * sizeof(int)));
   h->up_tgt_cnt.clear(); h->up_src_cnt.clear();       // fresh device arrays: nothing uploaded yet
-  HIPCHK(h, re((void**)&h->d_minmax, n_pairs * 6 * sizeof(int)));
   HIPCHK(h, re((void**)&h->d_grid, n_pairs * sizeof(GridDesc)));
   HIPCHK(h, re((void**)&h->d_nwords, (n_pairs + 2) * sizeof(unsigned)));
-  HIPCHK(h, re((void**)&h->d_word_off, (n_pairs + 1) * sizeof(unsigned)));
+  // build control words, zeroed by ONE memset per build: [0] total bitmap words, [1] largest grid, then per target six extremes
+  // (k_minmax's encoding makes zero "none yet")
+  HIPCHK(h, re((void**)&h->d_word_off, (2 + 6 * (size_t)n_pairs) * sizeof(unsigned)));
+  h->d_minmax = h->d_word_off + 2;
   HIPCHK(h, re((void**)&h->d_state, n_pairs * sizeof(PairState)));
   HIPCHK(h, re((void**)&h->d_guess, n_pairs * 16 * sizeof(float)));
   if (h->h_pin_guess) { HIPCHK(h, hipHostFree(h->h_pin_guess)); h->h_pin_guess = nullptr; }
@@ -772,9 +776,8 @@ static int build_targets_impl(mi355ndt_handle* h) {
   h->ev_last_fresh = false;
   if (h->prof) HIPCHK(h, ev_begin(h, h->ev_build));
   const int gx = (int)((pitch + 255) / 256);
-  k_minmax_init<<<(B * 6 + 255) / 256, 256, 0, s>>>(h->d_minmax, B);
+  HIPCHK(h, hipMemsetAsync(h->d_word_off, 0, (2 + 6 * (size_t)h->cap_pairs) * sizeof(unsigned), s));
   k_minmax<<<dim3(std::min(gx, 16), B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_minmax);
-  HIPCHK(h, hipMemsetAsync(h->d_word_off, 0, 2 * sizeof(unsigned), s));
   k_griddesc<<<(B + 63) / 64, 64, 0, s>>>(h->d_minmax, h->d_grid, h->d_nwords, h->prm.resolution, B, (unsigned)rpp);
   k_word_offsets<<<1, 1024, 0, s>>>(h->d_grid, h->d_nwords, B, h->d_word_off);   // d_word_off[0] = total words, [1] = largest grid
   HIPCHK(h, hipMemcpyAsync(h->h_pin_u, h->d_word_off, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
@@ -787,9 +790,6 @@ static int build_targets_impl(mi355ndt_handle* h) {
     h->words_cap = c;
   }
   if (total_words) HIPCHK(h, hipMemsetAsync(h->d_words, 0, total_words * sizeof(BitWord), s));
-  // leaf-sum workgroups per target: 64 keeps ~4 targets (3 MB of points) in flight per XCD, inside its 4 MB L2
-  const int lb = std::max(1, std::min((int)((rpp + LS_WAVES - 1) / LS_WAVES), 64));
-  const unsigned gx4 = (unsigned)((pitch + 256 * RUN_ILP - 1) / (256 * RUN_ILP));   // k_mark / k_segstart: RUN_ILP positions per thread
   const bool mt_live = mt_is_live(h->prm);
   const bool want_cent = h->prm.neighbor_mode == MI355NDT_KDTREE || mt_live;   // f32 leaf centroids: KDTREE probe, computeHessian
   h->cent_built = want_cent;
@@ -821,9 +821,14 @@ static int build_targets_impl(mi355ndt_handle* h) {
       rs_pass(s, plan.bits, kin, vin, kout, vout, pitch, p * plan.bits, h->d_rs_hist, h->d_rs_offs, tiles, B, p == 0);
       std::swap(kin, kout); std::swap(vin, vout);
     }
-    k_mark<unsigned><<<dim3(gx4, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, minpts, cb);
-    k_rank<<<B, 1024, 0, s>>>(h->d_grid, h->d_words);
-    k_segstart<unsigned><<<dim3(gx4, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, h->d_seg_start, minpts, cb);
+    // k_mark leaves the leaves' run starts in per-wave slices; k_rank strings them together by voxel id (d_seg_start)
+    const unsigned nsl = ls_slices(pitch), scap = ls_slice_cap(minpts);
+    HIPCHK(h, grow(h->d_heads, h->heads_cap, (size_t)B * nsl * scap));
+    HIPCHK(h, grow(h->d_head_cnt, h->head_cnt_cap, (size_t)B * nsl));
+    k_mark<unsigned><<<dim3((nsl + 3) / 4, B), 256, 0, s>>>(kb, pitch, h->d_grid, h->d_words, h->d_heads, h->d_head_cnt, nsl, scap, minpts, cb);
+    k_rank<<<B, 1024, 0, s>>>(h->d_grid, h->d_words, h->d_heads, h->d_head_cnt, nsl, scap, h->d_seg_start);
+    // leaf-sum workgroups per target: 64 keeps ~4 targets (3 MB of points) in flight per XCD, inside its 4 MB L2
+    const int lb = std::max(1, std::min((int)((rpp + LS_WAVES - 1) / LS_WAVES), 64));
     if (want_cent) k_leafsum<unsigned, true><<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start,
                                                                                     h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent, lb, B);
     else k_leafsum<unsigned, false><<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start,

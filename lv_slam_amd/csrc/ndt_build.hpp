@@ -5,13 +5,22 @@
 #include "ndt_math.hpp"
 
 // ------------------------------------------------------------------------------------ target build
+// (the prefilter's one-cloud extremes, ndt_prefilter.hpp, are plain ints with an init launch)
 __global__ void k_minmax_init(int* mm, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n * 6) mm[i] = (i % 6) < 3 ? INT_MAX : INT_MIN;
 }
 
+// The six extremes of a target live as unsigned "the larger wins" words whose all-zero state means "no finite point yet", so that the
+// workspace memset that precedes every build is their initialisation: a maximum as ord ^ 0x80000000 (order-preserving int -> unsigned),
+// a minimum as the complement of that.  No finite float maps to 0 in either form (f2ord of a finite float is neither INT_MIN nor INT_MAX).
+__device__ __forceinline__ unsigned mm_enc_max(int ord) { return (unsigned)ord ^ 0x80000000u; }
+__device__ __forceinline__ unsigned mm_enc_min(int ord) { return ~((unsigned)ord ^ 0x80000000u); }
+__device__ __forceinline__ int mm_dec_max(unsigned e) { return (int)(e ^ 0x80000000u); }
+__device__ __forceinline__ int mm_dec_min(unsigned e) { return (int)(~e ^ 0x80000000u); }
+
 // getMinMax3D over finite points (voxel_grid_covariance_omp_impl.hpp:72, 211-216)
-__global__ void __launch_bounds__(256) k_minmax(const float* __restrict__ tgt, size_t pitch, const int* __restrict__ cnt, int* mm) {
+__global__ void __launch_bounds__(256) k_minmax(const float* __restrict__ tgt, size_t pitch, const int* __restrict__ cnt, unsigned* mm) {
   const int b = blockIdx.y;
   const int n = cnt[b];
   const float* X = tgt + (size_t)b * 3 * pitch;
@@ -37,13 +46,13 @@ __global__ void __launch_bounds__(256) k_minmax(const float* __restrict__ tgt, s
     const bool is_min = threadIdx.x < 3;
     int v = red[0][threadIdx.x];
     for (int w = 1; w < 4; w++) v = is_min ? min(v, red[w][threadIdx.x]) : max(v, red[w][threadIdx.x]);
-    if (is_min) { if (v != INT_MAX) atomicMin(&mm[b * 6 + threadIdx.x], v); }
-    else if (v != INT_MIN) atomicMax(&mm[b * 6 + threadIdx.x], v);
+    if (is_min) { if (v != INT_MAX) atomicMax(&mm[b * 6 + threadIdx.x], mm_enc_min(v)); }
+    else if (v != INT_MIN) atomicMax(&mm[b * 6 + threadIdx.x], mm_enc_max(v));
   }
 }
 
 // min_b_/max_b_/div_b_/divb_mul_ (voxel_grid_covariance_omp_impl.hpp:75-103)
-__global__ void k_griddesc(const int* __restrict__ mm, GridDesc* gd, unsigned* nwords, float leaf, int n_pairs, unsigned recs_per_pair) {
+__global__ void k_griddesc(const unsigned* __restrict__ mm, GridDesc* gd, unsigned* nwords, float leaf, int n_pairs, unsigned recs_per_pair) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n_pairs) return;
   GridDesc g;
@@ -51,11 +60,11 @@ __global__ void k_griddesc(const int* __restrict__ mm, GridDesc* gd, unsigned* n
   g.leaf = leaf;
   g.inv_leaf = 1.0f / leaf;                      // pcl::VoxelGrid::setLeafSize
   g.rec_off = (unsigned)b * recs_per_pair;
-  if (mm[b * 6] == INT_MAX) {
+  if (mm[b * 6] == 0u) {
     g.status = GRID_EMPTY;
   } else {
     float mn[3], mx[3];
-    for (int a = 0; a < 3; a++) { mn[a] = ord2f(mm[b * 6 + a]); mx[a] = ord2f(mm[b * 6 + 3 + a]); }
+    for (int a = 0; a < 3; a++) { mn[a] = ord2f(mm_dec_min(mm[b * 6 + a])); mx[a] = ord2f(mm_dec_max(mm[b * 6 + 3 + a])); }
     if (grid_too_big((mx[0] - mn[0]) * g.inv_leaf, (mx[1] - mn[1]) * g.inv_leaf, (mx[2] - mn[2]) * g.inv_leaf)) {
       g.status = GRID_OVERFLOW;                  // impl:79-84: empty grid
     } else {
@@ -143,25 +152,47 @@ __device__ __forceinline__ void run_heads(const KeyT* __restrict__ K, size_t pit
     head[u] = i < pitch && cell[u] != cmask && (i == 0 || km[u] != k0[u]) && (i + span < pitch) && kl[u] == k0[u];
   }
 }
+// A head is also where the leaf's sums start (k_leafsum), so it is recorded here, once, instead of being found again after the ranking:
+// every wave tests LS_SLICE consecutive sorted positions and owns a slice of `heads` for the heads it finds, in position order, their
+// number in one word per slice.  No atomics, nothing to zero: a slice holds at most LS_SLICE / min_points + 1 heads.  Voxel ids are
+// ranks in ascending cell order and the order is sorted by cell, so the concatenation of a target's slices IS its list of run starts
+// by voxel id; k_rank, one workgroup per target anyway, closes the gaps.
+#define LS_SLICE (64 * RUN_ILP)
+static inline unsigned ls_slice_cap(int min_points) { return (unsigned)(LS_SLICE / (min_points > 0 ? min_points : 1) + 2); }
+static inline unsigned ls_slices(size_t pitch) { return (unsigned)((pitch + LS_SLICE - 1) / LS_SLICE); }
 template <typename KeyT>
 __global__ void __launch_bounds__(256) k_mark(const KeyT* __restrict__ keys, size_t pitch, const GridDesc* __restrict__ gd,
-                                               BitWord* words, int min_points, int cb) {
+                                               BitWord* words, unsigned* heads, unsigned* head_cnt, unsigned n_slices, unsigned slice_cap,
+                                               int min_points, int cb) {
   const int b = blockIdx.y;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const unsigned q = blockIdx.x * 4u + (threadIdx.x >> 6);      // the wave's slice
+  if (q >= n_slices) return;
+  const size_t i0 = (size_t)q * LS_SLICE + lane;
   bool head[RUN_ILP];
   unsigned cell[RUN_ILP];
-  run_heads<KeyT>(keys + (size_t)b * pitch, pitch, i0, stride, min_points, (1u << cb) - 1u, head, cell);
+  run_heads<KeyT>(keys + (size_t)b * pitch, pitch, i0, 64, min_points, (1u << cb) - 1u, head, cell);
+  unsigned* H = heads + ((size_t)b * n_slices + q) * slice_cap;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  unsigned n = 0;
 #pragma unroll
-  for (int u = 0; u < RUN_ILP; u++)
-    if (head[u]) atomicOr(&words[gd[b].word_off + (cell[u] >> 6)].bits, 1ull << (cell[u] & 63));
+  for (int u = 0; u < RUN_ILP; u++) {
+    const unsigned long long hm = __ballot(head[u]);
+    if (head[u]) {
+      atomicOr(&words[gd[b].word_off + (cell[u] >> 6)].bits, 1ull << (cell[u] & 63));
+      H[n + (unsigned)__popcll(hm & below)] = (unsigned)(i0 + (size_t)u * 64);
+    }
+    n += (unsigned)__popcll(hm);
+  }
+  if (lane == 0) head_cnt[(size_t)b * n_slices + q] = n;
 }
 // exclusive popcount prefix over the bitmap words of each target: voxel id = rank in ascending cell order.
 // One block of 16 waves per target; per round a wave owns 512 consecutive words as eight rows of 64 (lane = word: coalesced 16-byte
 // accesses), scans every row with shuffles and carries the row totals along; the 16 wave totals go through one small LDS scan.
 // A 0.5 m grid of ~21 k words takes 3 rounds.
 #define RANK_ROWS 8
-__global__ void __launch_bounds__(1024) k_rank(GridDesc* gd, BitWord* words) {
+__global__ void __launch_bounds__(1024) k_rank(GridDesc* gd, BitWord* words, const unsigned* __restrict__ heads, const unsigned* __restrict__ head_cnt,
+                                                 unsigned n_slices, unsigned slice_cap, unsigned* seg_start) {
   __shared__ unsigned wtot[17];
   const int b = blockIdx.x;
   BitWord* W = words + gd[b].word_off;
@@ -199,25 +230,18 @@ __global__ void __launch_bounds__(1024) k_rank(GridDesc* gd, BitWord* words) {
     __syncthreads();
   }
   if (threadIdx.x == 0) gd[b].n_voxels = (int)base;
-}
-
-// where does the point run of searchable leaf `id` start in the sorted order?
-template <typename KeyT>
-__global__ void __launch_bounds__(256) k_segstart(const KeyT* __restrict__ keys, size_t pitch, const GridDesc* __restrict__ gd,
-                                                   const BitWord* __restrict__ words, unsigned* seg_start, int min_points, int cb) {
-  const int b = blockIdx.y;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool head[RUN_ILP];
-  unsigned cell[RUN_ILP];
-  run_heads<KeyT>(keys + (size_t)b * pitch, pitch, i0, stride, min_points, (1u << cb) - 1u, head, cell);
-  const GridDesc& g = gd[b];
-#pragma unroll
-  for (int u = 0; u < RUN_ILP; u++) {
-    if (!head[u]) continue;
-    const BitWord bw = words[g.word_off + (cell[u] >> 6)];
-    const unsigned id = bw.prefix + (unsigned)__popcll(bw.bits & ((1ull << (cell[u] & 63)) - 1ull));
-    seg_start[g.rec_off + id] = (unsigned)(i0 + (size_t)u * stride);
+  // run start of voxel id = the id-th head of the target's slices (k_mark): exclusive scan of the slice counts, then every thread moves
+  // the few heads of its slice
+  unsigned hbase = 0;
+  for (unsigned q0 = 0; q0 < n_slices; q0 += 1024) {
+    const unsigned q = q0 + threadIdx.x;
+    const unsigned c = q < n_slices ? head_cnt[(size_t)b * n_slices + q] : 0u;
+    unsigned tot;
+    const unsigned ex = block_exscan<1024>(c, &tot, wtot);
+    const unsigned* H = heads + ((size_t)b * n_slices + q) * slice_cap;
+    unsigned* S = seg_start + gd[b].rec_off + hbase + ex;
+    for (unsigned k = 0; k < c; k++) S[k] = H[k];
+    hbase += tot;
   }
 }
 
