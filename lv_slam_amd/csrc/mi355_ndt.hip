@@ -1,7 +1,7 @@
 // mi355_ndt.hip -- MI355X (gfx950) NDT scan-matching engine behind the C-ABI of include/mi355_ndt.h.
 //
 // What runs where (all on the GPU; the host only enqueues):
-//   target build  : k_minmax -> k_griddesc -> k_keys -> radix sort (cell, input order) -> k_mark (+ run heads)
+//   target build  : k_minmax -> k_griddesc -> radix sort (cell from the points, input order) -> k_mark (+ run heads)
 //                   -> k_rank (+ run starts by voxel id) -> k_leafsum -> k_voxels          (VoxelGridCovariance::applyFilter,
 //                   include/ndt_omp/voxel_grid_covariance_omp_impl.hpp:48-370)
 //   align         : k_init_state -> k_sweep -> [k_update -> k_sweep]*      (computeTransformation +
@@ -816,9 +816,10 @@ static int build_targets_impl(mi355ndt_handle* h) {
     }
     unsigned *kin = (npass & 1) ? ka : kb, *kout = (npass & 1) ? kb : ka;      // an odd number of hops must end in kb
     unsigned *vin = (npass & 1) ? h->d_vals_a : h->d_vals_b, *vout = (npass & 1) ? h->d_vals_b : h->d_vals_a;
-    k_keys<unsigned><<<dim3(gx, B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_grid, kin, nullptr, cb);
+    // (no key kernel: the first pass's histogram computes the cell indices from the points and writes them, ndt_segsort.hpp)
+    const RsPoints points = {h->d_tgt, h->d_tgt_cnt, h->d_grid, cb, kin};
     for (int p = 0; p < npass; p++) {
-      rs_pass(s, plan.bits, kin, vin, kout, vout, pitch, p * plan.bits, h->d_rs_hist, h->d_rs_offs, tiles, B, p == 0);
+      rs_pass(s, plan.bits, kin, vin, kout, vout, pitch, p * plan.bits, h->d_rs_hist, h->d_rs_offs, tiles, B, p == 0, p == 0 ? &points : nullptr);
       std::swap(kin, kout); std::swap(vin, vout);
     }
     // k_mark leaves the leaves' run starts in per-wave slices; k_rank strings them together by voxel id (d_seg_start)

@@ -104,28 +104,7 @@ __global__ void __launch_bounds__(1024) k_word_offsets(GridDesc* gd, const unsig
   if (threadIdx.x == 0) out[0] = base;
 }
 
-// first pass of applyFilter: cell index per point (impl:218-223)
-template <typename KeyT>
-__global__ void __launch_bounds__(256) k_keys(const float* __restrict__ tgt, size_t pitch, const int* __restrict__ cnt,
-                                               const GridDesc* __restrict__ gd, KeyT* keys, unsigned* vals, int cb) {
-  const int b = blockIdx.y;
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= pitch) return;
-  const GridDesc& g = gd[b];
-  unsigned cell = (1u << cb) - 1u;               // "not binned": padding, non-finite point or unusable grid
-  if ((int)i < cnt[b] && g.status == GRID_OK) {
-    const float* X = tgt + (size_t)b * 3 * pitch;
-    float x = X[i], y = X[pitch + i], z = X[2 * pitch + i];
-    if (finite3(x, y, z)) {
-      int i0 = (int)(floorf(x * g.inv_leaf) - (float)g.min_b[0]);
-      int i1 = (int)(floorf(y * g.inv_leaf) - (float)g.min_b[1]);
-      int i2 = (int)(floorf(z * g.inv_leaf) - (float)g.min_b[2]);
-      cell = (unsigned)(i0 + i1 * g.mul1 + i2 * g.mul2);
-    }
-  }
-  keys[(size_t)b * pitch + i] = (KeyT)cell;      // the sort is segment-local: the pair index is no part of the key
-  if (vals) vals[(size_t)b * pitch + i] = (unsigned)i;      // the segmented sort derives the ids itself in its first pass
-}
+// (first pass of applyFilter -- the cell index per point, impl:218-223 -- is computed by the sort's first histogram kernel: ndt_segsort.hpp, rs_cell)
 
 // mark cells that hold >= min_points points (impl:297) in the occupancy bitmap
 // A sorted position i is the head of a searchable leaf's run iff its cell is binned, K[i-1] differs and K[i+min_points-1]

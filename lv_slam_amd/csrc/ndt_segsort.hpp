@@ -30,6 +30,26 @@ static inline RsPlan rs_plan(int field_bits) {
   return p;
 }
 
+// Where the keys of a target build come from: the points.  The cell index of a point (first pass of applyFilter,
+// voxel_grid_covariance_omp_impl.hpp:218-223) is a dozen instructions on three coalesced loads, so the first pass's histogram kernel
+// computes it, counts it and writes it (`keys`) for the scatter -- a key kernel of its own would write the keys and the histogram read
+// them back.  (Computing them a second time in the first scatter instead of writing them moves as many bytes as before -- 12 per point
+// read twice against 12 + 4 written + 4 + 4 read -- and measured 20 % slower: docs/experiments.md section 10c.)
+// "Not binned" (padding, non-finite point, unusable grid) is the all-ones cell, which sorts to the end.
+struct RsPoints { const float* tgt; const int* cnt; const GridDesc* gd; int cb; unsigned* keys; };
+__device__ __forceinline__ unsigned rs_cell(const GridDesc& g, const bool grid_ok, const int n, const float* __restrict__ X, const size_t pitch,
+                                            const size_t i, const unsigned none) {
+  // branch-free (the loads of a wave's sixteen rounds are to be in flight together): a position past the cloud reads the row's last
+  // entry and drops it
+  const size_t ii = i < pitch ? i : pitch - 1;
+  const float x = X[ii], y = X[pitch + ii], z = X[2 * pitch + ii];
+  const int i0 = (int)(floorf(x * g.inv_leaf) - (float)g.min_b[0]);
+  const int i1 = (int)(floorf(y * g.inv_leaf) - (float)g.min_b[1]);
+  const int i2 = (int)(floorf(z * g.inv_leaf) - (float)g.min_b[2]);
+  const unsigned cell = (unsigned)(i0 + i1 * g.mul1 + i2 * g.mul2);
+  return (grid_ok && (int)i < n && finite3(x, y, z)) ? cell : none;
+}
+
 // lanes of the wave holding the same digit as this lane (valid lanes only); BITS ballots
 template <int BITS>
 __device__ __forceinline__ unsigned long long rs_match(unsigned d, bool valid) {
@@ -44,9 +64,9 @@ __device__ __forceinline__ unsigned long long rs_match(unsigned d, bool valid) {
 }
 
 // digit histogram of every tile: hist[(b * tiles + tile) * RS_NB + d]
-template <int BITS>
+template <int BITS, bool POINTS = false>
 __global__ void __launch_bounds__(RS_THREADS) k_rs_hist(const unsigned* __restrict__ kin, size_t pitch, int shift, unsigned* hist, int tiles,
-                                                        int n_targets) {
+                                                        int n_targets, const RsPoints src = RsPoints()) {
   constexpr int RS_NB = 1 << BITS;
   __shared__ unsigned cnt[RS_THREADS / 64][RS_NB];
   int b, tile;
@@ -57,10 +77,24 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_hist(const unsigned* __restri
   const unsigned* K = kin + (size_t)b * pitch;
   const size_t wbase = (size_t)tile * RS_TILE + (size_t)w * (RS_TILE / 4);
   unsigned key[RS_ROUNDS];
+  if (POINTS) {
+    const GridDesc& g = src.gd[b];
+    const bool grid_ok = g.status == GRID_OK;
+    const int n = src.cnt[b];
+    const float* X = src.tgt + (size_t)b * 3 * pitch;
 #pragma unroll
-  for (int r = 0; r < RS_ROUNDS; r++) {
-    const size_t i = wbase + r * 64 + lane;
-    key[r] = i < pitch ? K[i] : 0u;
+    for (int r = 0; r < RS_ROUNDS; r++) {
+      const size_t i = wbase + r * 64 + lane;
+      const unsigned c = rs_cell(g, grid_ok, n, X, pitch, i, (1u << src.cb) - 1u);
+      key[r] = i < pitch ? c : 0u;
+      if (i < pitch) src.keys[(size_t)b * pitch + i] = c;      // the sort is segment-local: the target index is no part of the key
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {
+      const size_t i = wbase + r * 64 + lane;
+      key[r] = i < pitch ? K[i] : 0u;
+    }
   }
   // Counting needs no ranks, only totals: equal digits mostly come in runs (neighbouring points of a scan fall into the same
   // cell), so the head of each run adds the run's length with one LDS atomic -- a dozen instructions per round instead of the
@@ -192,16 +226,18 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_scatter(const unsigned* __res
 // One stable pass over `field` bits starting at bit `shift` of the keys of every segment: histogram, scan, scatter.
 template <int BITS>
 static inline void rs_pass_bits(hipStream_t s, const unsigned* kin, const unsigned* vin, unsigned* kout, unsigned* vout, size_t pitch, int shift,
-                                unsigned* hist, unsigned* offs, int tiles, int n_segments, bool first) {
-  k_rs_hist<BITS><<<xcd_grid(tiles, n_segments), RS_THREADS, 0, s>>>(kin, pitch, shift, hist, tiles, n_segments);
+                                unsigned* hist, unsigned* offs, int tiles, int n_segments, bool first, const RsPoints* points) {
+  if (points) k_rs_hist<BITS, true><<<xcd_grid(tiles, n_segments), RS_THREADS, 0, s>>>(nullptr, pitch, shift, hist, tiles, n_segments, *points);   // writes kin
+  else k_rs_hist<BITS><<<xcd_grid(tiles, n_segments), RS_THREADS, 0, s>>>(kin, pitch, shift, hist, tiles, n_segments);
   k_rs_scan<BITS><<<n_segments, (1 << BITS) > 1024 ? 1024 : (1 << BITS), 0, s>>>(hist, offs, tiles);
   if (first) k_rs_scatter<BITS, true><<<xcd_grid(tiles, n_segments), RS_THREADS, 0, s>>>(kin, vin, kout, vout, pitch, shift, offs, tiles, n_segments);
   else k_rs_scatter<BITS, false><<<xcd_grid(tiles, n_segments), RS_THREADS, 0, s>>>(kin, vin, kout, vout, pitch, shift, offs, tiles, n_segments);
 }
 // `first`: the point id of position i is i itself (no id array to read yet)
+// `points`: (first pass of a target build) the histogram kernel computes the keys from the points and writes them to points->keys = kin
 static inline void rs_pass(hipStream_t s, int bits, const unsigned* kin, const unsigned* vin, unsigned* kout, unsigned* vout, size_t pitch, int shift,
-                           unsigned* hist, unsigned* offs, int tiles, int n_segments, bool first) {
-  if (bits == 8) rs_pass_bits<8>(s, kin, vin, kout, vout, pitch, shift, hist, offs, tiles, n_segments, first);
-  else if (bits == 10) rs_pass_bits<10>(s, kin, vin, kout, vout, pitch, shift, hist, offs, tiles, n_segments, first);
-  else rs_pass_bits<11>(s, kin, vin, kout, vout, pitch, shift, hist, offs, tiles, n_segments, first);
+                           unsigned* hist, unsigned* offs, int tiles, int n_segments, bool first, const RsPoints* points = nullptr) {
+  if (bits == 8) rs_pass_bits<8>(s, kin, vin, kout, vout, pitch, shift, hist, offs, tiles, n_segments, first, points);
+  else if (bits == 10) rs_pass_bits<10>(s, kin, vin, kout, vout, pitch, shift, hist, offs, tiles, n_segments, first, points);
+  else rs_pass_bits<11>(s, kin, vin, kout, vout, pitch, shift, hist, offs, tiles, n_segments, first, points);
 }
