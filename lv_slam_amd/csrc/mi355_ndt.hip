@@ -777,7 +777,7 @@ static int build_targets_impl(mi355ndt_handle* h) {
   if (h->prof) HIPCHK(h, ev_begin(h, h->ev_build));
   const int gx = (int)((pitch + 255) / 256);
   HIPCHK(h, hipMemsetAsync(h->d_word_off, 0, (2 + 6 * (size_t)h->cap_pairs) * sizeof(unsigned), s));
-  k_minmax<<<dim3(std::min(gx, 16), B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_minmax);
+  k_minmax<<<dim3(std::max(1, std::min((gx + 3) / 4 / MM_ILP, 64)), B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_minmax);
   k_griddesc<<<(B + 63) / 64, 64, 0, s>>>(h->d_minmax, h->d_grid, h->d_nwords, h->prm.resolution, B, (unsigned)rpp);
   k_word_offsets<<<1, 1024, 0, s>>>(h->d_grid, h->d_nwords, B, h->d_word_off);   // d_word_off[0] = total words, [1] = largest grid
   HIPCHK(h, hipMemcpyAsync(h->h_pin_u, h->d_word_off, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));

@@ -20,18 +20,43 @@ __device__ __forceinline__ int mm_dec_max(unsigned e) { return (int)(e ^ 0x80000
 __device__ __forceinline__ int mm_dec_min(unsigned e) { return (int)(~e ^ 0x80000000u); }
 
 // getMinMax3D over finite points (voxel_grid_covariance_omp_impl.hpp:72, 211-216)
+#define MM_ILP 4
+struct __attribute__((packed, aligned(4))) MmQuad { float v[4]; };
 __global__ void __launch_bounds__(256) k_minmax(const float* __restrict__ tgt, size_t pitch, const int* __restrict__ cnt, unsigned* mm) {
   const int b = blockIdx.y;
   const int n = cnt[b];
   const float* X = tgt + (size_t)b * 3 * pitch;
   int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float x = X[i], y = X[pitch + i], z = X[2 * pitch + i];
-    if (!finite3(x, y, z)) continue;
-    int ox = f2ord(x), oy = f2ord(y), oz = f2ord(z);
+  auto take = [&](const float x, const float y, const float z) {
+    if (!finite3(x, y, z)) return;
+    const int ox = f2ord(x), oy = f2ord(y), oz = f2ord(z);
     mn[0] = min(mn[0], ox); mx[0] = max(mx[0], ox);
     mn[1] = min(mn[1], oy); mx[1] = max(mx[1], oy);
     mn[2] = min(mn[2], oz); mx[2] = max(mx[2], oz);
+  };
+  // A thread reads four consecutive points of each row with one 16-byte load (the rows need no alignment beyond a float's), and
+  // MM_ILP such groups a block stride apart before it looks at any of them: the pass is a pure stream, and what it needs is bytes in flight.
+  const int stride = (int)(gridDim.x * blockDim.x) * 4;
+  for (int i0 = (int)(blockIdx.x * blockDim.x + threadIdx.x) * 4; i0 < n; i0 += stride * MM_ILP) {
+    MmQuad qx[MM_ILP], qy[MM_ILP], qz[MM_ILP];
+#pragma unroll
+    for (int u = 0; u < MM_ILP; u++) {
+      const int i = i0 + u * stride;
+      if (i + 4 <= n) {
+        qx[u] = *reinterpret_cast<const MmQuad*>(X + i); qy[u] = *reinterpret_cast<const MmQuad*>(X + pitch + i);
+        qz[u] = *reinterpret_cast<const MmQuad*>(X + 2 * pitch + i);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const bool in = i + k < n;
+          qx[u].v[k] = in ? X[i + k] : NAN; qy[u].v[k] = in ? X[pitch + i + k] : NAN; qz[u].v[k] = in ? X[2 * pitch + i + k] : NAN;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < MM_ILP; u++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) take(qx[u].v[k], qy[u].v[k], qz[u].v[k]);
   }
   __shared__ int red[4][6];
   for (int a = 0; a < 3; a++) {
