@@ -28,7 +28,7 @@ pmc)
   timeout 500 tools/pmc_kernel.sh 'k_sweep|k_align_async' sq_direct7 > $O/pmc_sq_direct7.txt 2>&1
   timeout 500 tools/pmc_kernel.sh 'k_sweep|k_align_async' sq_pca_direct1 --variant pca --mode direct1 > $O/pmc_sq_pca_direct1.txt 2>&1
   timeout 500 tools/pmc_kernel.sh 'k_sweep|k_align_async' sq_cfg5_d1 --variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128 > $O/pmc_sq_cfg5_d1.txt 2>&1
-  timeout 500 tools/pmc_kernel.sh 'k_leafsum|k_rs_|k_keys|k_voxels|k_mark|k_rank|k_minmax' sq_build > $O/pmc_build.txt 2>&1
+  timeout 500 tools/pmc_kernel.sh 'k_leafsum|k_rs_|k_voxels|k_mark|k_rank|k_minmax|k_griddesc|k_word_offsets' sq_build > $O/pmc_build.txt 2>&1
   timeout 500 tools/pmc_kernel.sh 'k_seq_update|k_update' sq_update --seq-frames 65 > $O/pmc_update.txt 2>&1
   timeout 300 tools/pmc_calib.sh > $O/pmc_valu_calib.log 2>&1; cp $R/gpurun_out/pmc_calib/calib.json $O/pmc_valu_calib.json
   ;;

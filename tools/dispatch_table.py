@@ -5,8 +5,8 @@ f = glob.glob(sys.argv[1] + "/**/*_kernel_trace.csv", recursive=True)
 rows = sorted(csv.DictReader(open(f[0])), key=lambda r: int(r["Start_Timestamp"]))
 pat = re.compile(sys.argv[2])
 sel = [r for r in rows if pat.search(r["Kernel_Name"])]
-# the last step = everything after the last k_minmax_init
-last = max((i for i, r in enumerate(rows) if "k_minmax_init" in r["Kernel_Name"]), default=0)
+# the last step = everything after the last k_minmax (the first kernel of a target build)
+last = max((i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_minmax(")), default=0)
 t0 = int(rows[last]["Start_Timestamp"])
 print(f"{'kernel':40s} {'start_us':>10s} {'dur_us':>9s} {'gap_us':>8s}")
 prev_end = t0

@@ -10,7 +10,7 @@ for stage in "$@"; do
     bench)      (time timeout 900 python bench.py) > $O/bench.json 2> $O/bench.log; tail -c 3000 $O/bench.json; tail -5 $O/bench.log ;;
     bench20)    (time timeout 900 python bench.py --steps 20 --warmup 3) > $O/bench.json 2> $O/bench.log; tail -c 3000 $O/bench.json; tail -5 $O/bench.log ;;
     pmc_cfg5d1) timeout 900 tools/pmc_kernel.sh k_sweep run_cfg5_d1 --variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128 > $O/pmc.txt 2>&1; cat $O/pmc.txt ;;
-    pmc_build)  timeout 900 tools/pmc_kernel.sh 'k_leafsum|k_rs_scatter|k_rs_hist|k_keys|k_voxels|k_mark|k_minmax' run_build > $O/pmc.txt 2>&1; cat $O/pmc.txt ;;
+    pmc_build)  timeout 900 tools/pmc_kernel.sh 'k_leafsum|k_rs_scatter|k_rs_hist|k_voxels|k_mark|k_minmax' run_build > $O/pmc.txt 2>&1; cat $O/pmc.txt ;;
     pmc_update) timeout 900 tools/pmc_kernel.sh 'k_update' run_update --variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128 > $O/pmc.txt 2>&1; cat $O/pmc.txt ;;
     kstats_cfg5d1) timeout 600 tools/kstats.sh kstats_cfg5d1_run --no-host-clouds --variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128 --steps 10 --warmup 2 > $O/out.txt 2>&1; cat $O/out.txt ;;
     kstats)     timeout 600 tools/kstats.sh kstats_run --no-host-clouds --steps 20 --warmup 3 > $O/out.txt 2>&1; cat $O/out.txt ;;
