@@ -381,6 +381,36 @@ def test_non_default_parameters_vs_oracle():
     assert abs(r["trans_probability"] - ro["trans_probability"]) <= 1e-9 * max(1.0, abs(ro["trans_probability"]))
 
 
+@pytest.mark.parametrize("min_points,resolution", [(1, 0.4), (2, 0.5), (12, 1.0)])
+def test_voxel_grids_at_other_min_points(min_points, resolution):
+    """The build records a leaf's run start where it marks its cell (k_mark: per-wave slices of LS_SLICE / min_points + 2 entries, strung
+    together by voxel id in k_rank): with min_points 1 and small cells every occupied cell is a leaf and a slice of 256 sorted
+    positions holds far more than 64 of them; the grids stay bit-exact (voxel_grid_covariance_omp.h:204, impl:297), in a single build
+    and in a ragged batch."""
+    clouds = [synth.make_pair(k, 256, n_beams=32)[0].numpy() for k in (11, 12, 13)]
+    clouds[1] = clouds[1][:5000]
+    clouds[2] = clouds[2][:777]
+    kw = dict(resolution=resolution, neighbor_mode=ndt.DIRECT7, min_points_per_voxel=min_points)
+    gp, op = both_params(**kw)
+    eng = ndt.Engine(gp)
+    for c in clouds:
+        eng.set_target(c)
+        check_voxels(eng, O.Grid(c, op))
+    eng.batch_reserve(len(clouds), max(len(c) for c in clouds), 64)
+    for b, c in enumerate(clouds):
+        eng.batch_set_target(b, c)
+        eng.batch_set_source(b, clouds[0][:64])
+    eng.batch_build_targets()
+    for b, c in enumerate(clouds):
+        lv = O.Grid(c, op).leaves()
+        sel = lv[(lv["n"] >= min_points) | (lv["n"] == -1)]
+        v = eng.get_voxels(b)
+        assert np.array_equal(v["idx"], sel["idx"]) and np.array_equal(v["n"], sel["n"])
+        assert np.array_equal(v["mean"], sel["mean"])
+        live = sel["n"] >= min_points
+        assert np.array_equal(v["icov"][live], sel["icov"][live].astype(np.float32))
+
+
 def test_identity_alignment_property():
     """identical clouds + identity guess => nothing to do: |delta| -> 0 within the 3-sweep minimum."""
     tgt, _, _ = synth.make_pair(2, 256)
