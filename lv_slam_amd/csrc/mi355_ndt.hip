@@ -1031,11 +1031,13 @@ static int align_async(mi355ndt_handle* h, const SweepConst& sc, int B, mi355ndt
   HIPCHK(h, grow(h->d_arrived, h->arrived_cap, (size_t)B * ASYNC_ARR_STRIDE));
   if (!h->d_actl) HIPCHK(h, hipMalloc((void**)&h->d_actl, sizeof(AsyncCtl)));
   if (!h->h_pin_actl) HIPCHK(h, hipHostMalloc((void**)&h->h_pin_actl, sizeof(AsyncCtl)));
-  // everything the launch polls is reset on the stream before it (never inside the kernel, never by a previous launch)
-  HIPCHK(h, hipMemsetAsync(h->d_ring, 0xFF, (size_t)8 * ring_cap * sizeof(int), s));
-  HIPCHK(h, hipMemsetAsync(h->d_arrived, 0, (size_t)B * ASYNC_ARR_STRIDE * sizeof(unsigned), s));
-  HIPCHK(h, hipMemsetAsync(h->d_actl, 0, sizeof(AsyncCtl), s));
-  k_async_begin<<<(B + 255) / 256, 256, 0, s>>>(B, h->d_ring, ring_cap, h->d_actl);
+  // everything the launch polls is reset on the stream before it (never inside the kernel, never by a previous launch), together with
+  // the pairs' initial states
+  {
+    const size_t n = std::max(std::max((size_t)8 * ring_cap, (size_t)B * ASYNC_ARR_STRIDE), sizeof(AsyncCtl) / sizeof(unsigned));
+    k_async_prepare<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(h->d_state, h->d_guess, h->d_src_cnt, h->d_grid, B, h->d_active_list, h->d_ctl,
+                                                               h->d_ring, ring_cap, h->d_arrived, h->d_actl);
+  }
   if (h->prof) HIPCHK(h, ev_begin(h, h->ev_sweep));
   int rc;
   if (sc.pca) rc = sc.K == 1 ? launch_async_o<true, 1>(h, sc, B, ring_cap) : sc.K == 7 ? launch_async_o<true, 7>(h, sc, B, ring_cap) : launch_async_o<true, 26>(h, sc, B, ring_cap);
@@ -1076,18 +1078,18 @@ static int batch_align_impl(mi355ndt_handle* h, const float* guesses, mi355ndt_r
   h->ev_last_fresh = false;
   memcpy(h->h_pin_guess, guesses, (size_t)B * 16 * sizeof(float));
   HIPCHK(h, hipMemcpyAsync(h->d_guess, h->h_pin_guess, (size_t)B * 16 * sizeof(float), hipMemcpyHostToDevice, s));
-  HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, 2 * sizeof(SweepCtl), s));
   h->ctl_idx = 0;
-  k_init_state<<<(B + 63) / 64, 64, 0, s>>>(h->d_state, h->d_guess, h->d_src_cnt, h->d_grid, B, h->d_active_list, h->d_ctl);
   // One launch for the whole align (ndt_async.hpp) when the batch offers more work items than the GPU has resident waves.  A smaller batch
   // -- a single registration above all -- keeps the round-based kernels, whose flat dealing spreads a pair's items over every XCD: a ticket
   // is served by ONE ring (an eighth of the waves), which costs a lone 65,536-point pair 0.39 ms against 0.31 ms per align.
   const bool big_batch = (long long)B * h->items_per_pair > (long long)h->n_cu * sweep_wpe(sc.pca != 0, sc.K) * WAVES;
   if (h->async_align && (big_batch || h->async_force) && !h->fine_it && !mt_live && !pca_kd) {
-    rc = align_async(h, sc, B, out);
+    rc = align_async(h, sc, B, out);                                // (prepares the pair states itself: k_async_prepare)
     if (rc == MI355NDT_OK) { h->aligned_once = true; return MI355NDT_OK; }
     if (rc != MI355NDT_ERR_UNSUPPORTED) return rc;                  // (not resident: the lockstep rounds below)
   }
+  HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, 2 * sizeof(SweepCtl), s));
+  k_init_state<<<(B + 63) / 64, 64, 0, s>>>(h->d_state, h->d_guess, h->d_src_cnt, h->d_grid, B, h->d_active_list, h->d_ctl);
   if (h->fine_it) {                                // latency mode: the pump (no bursts, no counter copies, no event waits)
     rc = align_pump(h, sc, B);
     if (rc) return rc;

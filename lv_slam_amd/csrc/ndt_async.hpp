@@ -41,11 +41,25 @@ struct AsyncCtl {
 #endif
 #define ASYNC_SPIN_LIMIT (1u << 23)      // polls of ~1 us: a device that stopped making progress ends the launch after seconds, not never
 
-// ring / counters for pair b's first sweep (runs right after k_init_state, before the persistent launch: ordered by the stream)
-NDT_KERNEL void k_async_begin(int n_pairs, int* ring, int ring_cap, AsyncCtl* ctl) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b == 0) ctl->pub = (unsigned)n_pairs;
-  if (b < n_pairs) ring[(size_t)(b & 7) * ring_cap + (b >> 3)] = b;
+// Everything the launch reads before it has written it, set by ONE kernel on the stream in front of it (never inside the launch, never by
+// a previous launch): the pairs' initial states (k_init_state's job), ticket g = pair g of the first sweeps in ring g & 7 / slot g >> 3 and
+// "no ticket yet" everywhere else, the arrival counters, the control words.  (Six small launches -- two kernels and four fills -- until the
+// end of round 4: ~25 us per align.)
+NDT_KERNEL void k_async_prepare(PairState* st, const float* __restrict__ guess_cm, const int* __restrict__ src_cnt, const GridDesc* __restrict__ gd,
+                                int n_pairs, int* active_list, SweepCtl* sweep_ctl /* two of them */, int* ring, int ring_cap, unsigned* arrived,
+                                AsyncCtl* ctl) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)8 * ring_cap) {
+    const size_t g = (i % (size_t)ring_cap) * 8 + i / (size_t)ring_cap;
+    ring[i] = g < (size_t)n_pairs ? (int)g : -1;
+  }
+  if (i < (size_t)n_pairs * ASYNC_ARR_STRIDE) arrived[i] = 0u;
+  if (i < sizeof(AsyncCtl) / sizeof(unsigned)) reinterpret_cast<unsigned*>(ctl)[i] = i == 0 ? (unsigned)n_pairs : 0u;   // pub = n_pairs
+  if (i < 2 * sizeof(SweepCtl) / sizeof(int)) reinterpret_cast<int*>(sweep_ctl)[i] = i == 0 ? n_pairs : 0;              // n_active of the first
+  if (i < (size_t)n_pairs) {
+    active_list[i] = (int)i;
+    init_pair_state(st[i], guess_cm + i * 16, src_cnt[i], gd[i].status);
+  }
 }
 
 // The pair's rows -> (score, g, H, hits), Newton step, publication.  Called by every lane of ONE wave; `Ssh` / `sol` are that wave's LDS.
