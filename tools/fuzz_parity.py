@@ -187,7 +187,28 @@ def run_aux(case, rng, kw, fails, oracle_only):
             STATS["aux_align_checks"] = STATS.get("aux_align_checks", 0) + 1
             a, b = eng.get_incremental()
             if not (np.array_equal(a, ro["transformation"], equal_nan=True) and np.array_equal(b, ro["previous_transformation"], equal_nan=True)):
-                fails.append(dict(ctx, what="incremental transforms"))
+                # exp(delta_p) of the last two steps in f32: the oracle's own Newton-solve variants (LU, two-sided SVD) move delta_p by
+                # ~1e-8 relative when H is ill-conditioned, which is a last f32 bit in a few entries -- replay them before calling it a defect
+                import ctypes as C
+                L = O.lib()
+                L.ora_set_variant.argtypes = [C.c_uint, C.c_int]
+                var, sens, same = {}, False, []
+                try:
+                    for name, flags, chunk in ORA_VARIANTS:
+                        L.ora_set_variant(flags, chunk)
+                        rv = ora_align(O.Grid(tgt, op), src, G)
+                        ta, tb = np.asarray(rv["transformation"]), np.asarray(rv["previous_transformation"])
+                        d_can = not (np.array_equal(ta, ro["transformation"], equal_nan=True) and np.array_equal(tb, ro["previous_transformation"], equal_nan=True))
+                        d_hip = not (np.array_equal(ta, a, equal_nan=True) and np.array_equal(tb, b, equal_nan=True))
+                        var[name] = dict(differs_from_canonical=bool(d_can), differs_from_hip=bool(d_hip))
+                        sens = sens or d_can
+                        if not d_hip:
+                            same.append(name)
+                finally:
+                    L.ora_set_variant(0, 256)
+                ulp = float(np.nanmax(np.abs(a.astype(np.float64) - np.asarray(ro["transformation"], np.float64)) / np.maximum(np.spacing(np.abs(np.asarray(ro["transformation"], np.float32))).astype(np.float64), 1e-45)))
+                fails.append(dict(ctx, what="incremental transforms", max_f32_ulps=ulp,
+                                  classification=dict(order_sensitive=bool(sens), hip_equals_oracle_variant=same, variants=var)))
             out = eng.get_aligned()
             F = np.asarray(ro["final"], np.float32)
             s32 = src.astype(np.float32)
@@ -326,7 +347,8 @@ def summarize(paths, out_path):
                           "resolution": f.get("resolution"), "max_iterations": f.get("max_iterations"), "iterations_hip_oracle": f.get("it"),
                           "dtrans_m": f.get("dtrans"), "drot_rad": f.get("drot"), "hits_last": f.get("hits_last"), "detail": f.get("detail"),
                           "oracle_variant_moves_the_oracle": c.get("order_sensitive"), "hip_equals_oracle_variant": c.get("hip_equals_oracle_variant"),
-                          "oracle_variants": {k: {"iterations": v["it"], "d_vs_canonical": v["d_vs_canonical"]} for k, v in c.get("variants", {}).items()}})
+                          "max_f32_ulps": f.get("max_f32_ulps"),
+                          "oracle_variants": {k: ({"iterations": v["it"], "d_vs_canonical": v["d_vs_canonical"]} if "it" in v else v) for k, v in c.get("variants", {}).items()}})
     out = {"what": "tools/fuzz_parity.py: randomised differential test, HIP path (C-ABI) vs oracle; same bars as tests/test_gpu_parity.py (voxels exact, sweep rtol 1e-11, "
                    "align: iterations / converged / sweeps equal, pose inside 1e-4 m and 1e-5 rad)",
            "seeds": [r["seed"] for r in runs], "cases": sum(r["cases_run"] for r in runs), "totals": tot, "entry_paths": paths_n,
