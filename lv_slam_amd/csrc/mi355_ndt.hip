@@ -1009,8 +1009,10 @@ static int align_pump(mi355ndt_handle* h, SweepConst sc, int B) {
 template <bool PCA, int K, int ORD>
 static int launch_async_t(mi355ndt_handle* h, const SweepConst& sc, int B, int ring_cap) {
   auto kern = k_align_async<PCA, K, ORD>;
-  int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SWEEP_THREADS, 0) != hipSuccess) { (void)hipGetLastError(); return MI355NDT_ERR_UNSUPPORTED; }
+  // (asked once per instantiation and device: the query sits between the prepare kernel and the launch, on the host's critical path)
+  static int per_cu_of_device[64] = {0};
+  int& per_cu = per_cu_of_device[h->device & 63];
+  if (per_cu == 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SWEEP_THREADS, 0) != hipSuccess) { per_cu = 0; (void)hipGetLastError(); return MI355NDT_ERR_UNSUPPORTED; }
   const int wpe = sweep_wpe(PCA, K);
   if (per_cu < wpe) return MI355NDT_ERR_UNSUPPORTED;              // every workgroup must be resident: waves wait for each other's tickets
   dim3 grid((unsigned)(h->n_cu * wpe));
