@@ -93,6 +93,11 @@ typedef struct mi355ndt_profile {
   double    build_alg_bytes; /* algorithmic bytes of the builds (DESIGN.md B_build) */
   double    update_ms;       /* sum of Newton-update kernel durations */
   long long update_launches;
+  long long async_fallbacks; /* one-launch aligns that gave up (a wave's ticket never came within its poll budget) and were re-run by the
+                                round-based path: same results, never an error */
+  long long stream_launches; /* stream mode: persistent launches (one per submitted batch + flushes) */
+  long long stream_carried;  /* stream mode: pairs handed over from one launch to the next (stragglers that finished under a later batch) */
+  long long stream_redone;   /* stream mode: batches re-run synchronously (build plan exceeded, or a launch gave up) */
 } mi355ndt_profile;
 
 typedef struct mi355ndt_handle mi355ndt_handle;
@@ -180,7 +185,15 @@ enum mi355ndt_option {
    * MI355NDT_ASYNC=0 sets the default to 0 for engines created afterwards.  The one launch is used when the batch offers more work items
    * than the GPU has resident waves (smaller batches are faster in rounds); 2 = use it for every batch size (testing).  The latency mode and the live More-Thuente configuration
    * always take the round-based path. */
-  MI355NDT_OPT_ASYNC_ALIGN = 2
+  MI355NDT_OPT_ASYNC_ALIGN = 2,
+  /* Test hook, default -1 (off).  n >= 0: inside a one-launch align the wave that claims position n of ring 0 gives up exactly as a wave whose
+   * ticket never came within its poll budget does: the launch ends early and mi355ndt_batch_align re-runs the batch through the round-based path
+   * (mi355ndt_profile.async_fallbacks counts it).  Lets the test-suite exercise the fallback, which a healthy device never takes. */
+  MI355NDT_OPT_DEBUG_ASYNC_ABORT = 3,
+  /* Stream mode (mi355ndt_stream_*): a launch hands its last `value` unfinished pairs over to the next launch instead of iterating them alone
+   * on an otherwise idle GPU.  -1 (default): as many as it takes to keep every resident wave busy (resident waves / work items per sweep);
+   * 0: never (every launch runs its own pairs to the end: pipelining of the host side only).  No result bit depends on it. */
+  MI355NDT_OPT_STREAM_THRESHOLD = 4
 };
 int mi355ndt_set_option(mi355ndt_handle* h, int option, int value);
 int mi355ndt_get_option(const mi355ndt_handle* h, int option, int* value);
@@ -234,6 +247,36 @@ int mi355ndt_batch_size(const mi355ndt_handle* h);
  * sharding: base = rank, stride = world size); records k >= batch size carry pair_id = -1.  The buffer can go straight into
  * an RCCL all-gather: no host hop.  Returns after the records are complete (the engine's stream is synchronised). */
 int mi355ndt_batch_pose_records(mi355ndt_handle* h, int id_base, int id_stride, void* d_records, size_t capacity);
+
+/* ---- stream mode: batches arrive one after the other and overlap on the GPU --------------------------------------------------- */
+/* The reference's odometry node consumes a continuous stream of frames (scan_matching_odom_nodelet.cpp:144-183: one cloud_callback per
+ * scan); BASELINE config 3 streams batches of independent scan pairs through one GPU.  mi355ndt_batch_align is synchronous: build, ONE
+ * persistent launch, results on the host, and only then the next batch -- the last pairs of a batch iterate alone on an idle GPU (the
+ * tail), and the host's own work between two batches is dead time.  In stream mode the engine keeps `n_contexts` batches resident:
+ *   submit(k)  enqueues batch k's target build, its persistent launch and the result copies, and returns at once;
+ *   a launch ends as soon as its unfinished pairs can no longer keep the GPU busy; those pairs are SUSPENDED and become the first tickets of
+ *              the next launch, where they finish under batch k+1's bulk (a pair runs the same code on the same operands whichever launch
+ *              serves it: results are bit-identical to mi355ndt_batch_align's);
+ *   collect(k) blocks until every pair of batch k is finalised -- normally a launch or two after its own; if nothing newer has been
+ *              submitted it flushes the stragglers itself.
+ * Batch k's context is recycled by submit(k + n_contexts), so at most n_contexts batches may be uncollected, and a pair is carried
+ * through at most n_contexts - 1 further launches (the last of them runs it to its end).
+ * Inputs are device-resident SoA buffers as in mi355ndt_batch_bind_device (zero-copy); batch k's buffers must stay valid and unchanged
+ * until collect(k) has returned.  Parameters and options are those of the handle at mi355ndt_stream_begin; the handle's single-registration
+ * and batch calls are unavailable (MI355NDT_ERR_STATE) between begin and end.  Served for every configuration the one-launch align
+ * serves (DIRECT1/7/26 and ndt_omp KDTREE, dead More-Thuente loop: everything lv_slam ships); others are processed synchronously
+ * inside submit. */
+int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts /* 2..4 */, int max_pairs, size_t max_target_pts, size_t max_source_pts);
+int mi355ndt_stream_submit(mi355ndt_handle* h, int n_pairs, const float* d_targets, const int* target_counts, size_t target_pitch,
+                           const float* d_sources, const int* source_counts, size_t source_pitch, const float* guesses_colmajor,
+                           long long* batch_id);
+int mi355ndt_stream_collect(mi355ndt_handle* h, long long batch_id, mi355ndt_result* out);
+/* Pose records (the 96-byte layout of mi355ndt_batch_pose_records) of a COLLECTED batch, packed on the host from its results into
+ * `records` (host memory, `capacity` records; rows >= n carry pair_id = -1).  In stream mode the GPU is busy with the next batch's launch when
+ * a batch is collected -- a packing kernel would wait for that launch -- so the 26 KB of a 271-pair batch are packed here and go to the device
+ * with the caller's own copy.  Plain host arithmetic, no device needed. */
+int mi355ndt_pack_pose_records(const mi355ndt_result* results, int n, int id_base, int id_stride, void* records, size_t capacity);
+int mi355ndt_stream_end(mi355ndt_handle* h);      /* collects nothing: outstanding batches are dropped after the device has drained */
 
 /* ---- latency mode: one frame at a time, as the live nodelet runs ---------------------------------------- */
 /* Opt-in fine-grained derivative sweep for SMALL batches (a single registration above all): work items of 128 points dealt over

@@ -105,6 +105,8 @@ struct mi355ndt_handle {
   bool async_align = true;                        // MI355NDT_OPT_ASYNC_ALIGN: batch aligns as ONE persistent launch (ndt_async.hpp); MI355NDT_ASYNC=0 turns it off
   int* d_ring = nullptr; size_t ring_cap_total = 0; unsigned* d_arrived = nullptr; size_t arrived_cap = 0; AsyncCtl* d_actl = nullptr;
   AsyncCtl* h_pin_actl = nullptr;
+  AsyncTab* d_atab = nullptr;                     // the launch's context table (ndt_async.hpp)
+  unsigned debug_abort_pos = 0xFFFFFFFFu;         // MI355NDT_OPT_DEBUG_ASYNC_ABORT (test hook): the wave that claims this position of ring 0 gives up
   int f32_sum_order = 0;                          // MI355NDT_OPT_F32_SUM_ORDER: 0 = (t0 + t1) + t2 (canonical), 1 = (t0 + t2) + t1 (Eigen 3.3 SSE predux pairing)
   double gauss_last[3] = {0, 0, 0};               // gauss_d1_/d2_/d3_ as the constructor / the last computeTransformation left them (calculateScore reads them)
   float* d_score_pts = nullptr; size_t score_pts_cap = 0; double* d_score_part = nullptr; size_t score_part_cap = 0;   // calculateScore workspace
@@ -145,6 +147,42 @@ struct mi355ndt_handle {
   bool uploads_pending = false;
   std::mutex up_mtx;                              // batch_set_target / batch_set_source may be called from several threads (distinct pairs)
 
+  // asynchronous target build (stream mode: the engine is one batch context of a parent handle).  A build normally waits for two words
+  // from the device -- the bitmap words of all grids (pool size) and the largest grid (sort key width); with a PLAN from earlier builds of
+  // the stream it does not: it sorts plan_cb key bits, clears plan_words pool words, and k_build_check turns every grid of the batch into
+  // "no grid" (and raises d_bflag) should the batch not fit the plan -- the parent then re-runs that batch synchronously and learns.
+  bool async_build = false;
+  int plan_cb = 0; size_t plan_words = 0;
+  unsigned* d_bflag = nullptr;                    // [0] plan exceeded
+  unsigned* h_pin_binfo = nullptr;                // pinned: [0] total bitmap words, [1] cells of the largest grid, [2] plan exceeded (last planned build)
+  int* h_pin_cnt = nullptr; size_t pin_cnt_cap = 0;   // pinned staging of the point counts (target counts, then source counts)
+  size_t last_total_words = 0;                    // of the last synchronous build
+
+  // ---- stream mode (mi355ndt_stream_*, the parent handle): n_contexts batches resident, one persistent launch per submitted batch,
+  // the stragglers of a launch carried into the next one (ndt_async.hpp)
+  struct StreamCtx {
+    mi355ndt_handle* e = nullptr;                 // the context's own engine: bound clouds, grids, pair states (runs on the parent's stream)
+    long long batch_id = -1; int n_pairs = 0;
+    bool busy = false;                            // submitted, not yet collected
+    bool redo = false;                            // collect re-runs it synchronously (its launch gave up)
+    bool done_sync = false;                       // processed synchronously inside submit (configuration the one-launch align does not serve)
+    long long launch = -1;                        // the launch that started it
+    unsigned* d_done = nullptr;                   // pairs finalised so far
+    mi355ndt_result* h_res = nullptr;             // pinned snapshot of the context's results (after every launch)
+    unsigned* h_flags = nullptr;                  // pinned: [0] pairs finalised, [1] build plan exceeded
+  };
+  bool stream_on = false, s_sync_only = false, s_drop_carry = true;
+  int s_nctx = 0, s_max_pairs = 0, s_items = 0, s_ring_cap = 0, s_thresh = 0;
+  int s_thresh_opt = -1;                          // MI355NDT_OPT_STREAM_THRESHOLD
+  int s_plan_cb = 0; size_t s_plan_words = 0;
+  StreamCtx sctx[ASYNC_MAX_CTX];
+  long long s_next_id = 0, s_launches = 0, s_counted = 0;
+  AsyncCtl* d_sctl = nullptr;                     // two control blocks: a launch reads the hand-over list of the previous one
+  int* d_sring = nullptr;
+  static constexpr int S_EV = 16;
+  hipEvent_t s_ev[S_EV] = {};                     // one per launch (ring)
+  unsigned* h_pin_sinfo = nullptr;                // pinned: per launch slot {abort_, susp, fin, n_live}
+
   // profiling
   bool prof = false;
   mi355ndt_profile P{};
@@ -153,6 +191,7 @@ struct mi355ndt_handle {
   hipEvent_t ev_last = nullptr;                   // end event of the span just closed, reusable as the next span's begin while
   bool ev_last_fresh = false;                     // nothing else has been enqueued on the stream since
   std::vector<hipEvent_t> ev_pool;                // idle timing events (filled by mi355ndt_profile_enable)
+  size_t ev_pool_target = 4096;
 };
 
 #define HIPCHK(h, call)                                                                          \
@@ -166,6 +205,15 @@ struct mi355ndt_handle {
 
 // several kernels carry the pair index in grid.y (HIP limit 65535)
 #define MAX_PAIRS 65535
+// between mi355ndt_stream_begin and mi355ndt_stream_end the handle's batches belong to the stream: the other entry points refuse
+#define NOT_IN_STREAM(h) do { if ((h)->stream_on) { (h)->err = "the handle is in stream mode (mi355ndt_stream_begin): call mi355ndt_stream_end first"; return MI355NDT_ERR_STATE; } } while (0)
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield");
+#endif
+}
 static int ceil_log2(unsigned v) { int b = 0; while ((1u << b) < v) b++; return b; }
 
 template <typename T>
@@ -344,16 +392,18 @@ int mi355ndt_create(const mi355ndt_params* params, int device, mi355ndt_handle**
   return MI355NDT_OK;
 }
 
+int mi355ndt_stream_end(mi355ndt_handle* h);
 int mi355ndt_destroy(mi355ndt_handle* h) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
+  if (h->stream_on) (void)mi355ndt_stream_end(h);
   void* ptrs[] = {h->d_tgt_own, h->d_src_own, h->d_tgt_cnt, h->d_src_cnt, h->d_grid, h->d_nwords, h->d_word_off,
                   h->d_keys_a, h->d_keys_b, h->d_vals_a, h->d_vals_b, h->d_words, h->d_recs, h->d_vox_idx, h->d_vox_n,
                   h->d_state, h->d_partials, h->d_guess, h->d_results, h->d_active, h->d_hook, h->d_aligned, h->d_hits, h->d_seg_start, h->d_heads, h->d_head_cnt, h->d_sums,
                   h->d_cent, h->d_icov64, h->d_kdw, h->d_rs_hist, h->d_rs_offs, h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit, h->d_pf_in, h->d_pf_out, h->d_pf_keep, h->d_pf_keys,
                   h->d_pf_vals, h->d_pf_flag, h->d_pf_pos, h->d_pf_mm, h->d_pf_grid, h->d_pf_tmp, h->d_score_pts, h->d_score_part,
-                  h->d_ring, h->d_arrived, h->d_actl};
+                  h->d_ring, h->d_arrived, h->d_actl, h->d_atab};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : {(void*)h->d_grid_of, (void*)h->d_seq, (void*)h->d_seq_out, (void*)h->d_stamps}) if (p) (void)hipFree(p);
   if (h->h_seq_flags) (void)hipHostFree((void*)h->h_seq_flags);
@@ -364,6 +414,9 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
   if (h->ev_compute) (void)hipEventDestroy(h->ev_compute);
   for (hipStream_t cs : h->copy_stream) if (cs) (void)hipStreamDestroy(cs);
   if (h->h_pin_actl) (void)hipHostFree(h->h_pin_actl);
+  if (h->d_bflag) (void)hipFree(h->d_bflag);
+  if (h->h_pin_binfo) (void)hipHostFree(h->h_pin_binfo);
+  if (h->h_pin_cnt) (void)hipHostFree(h->h_pin_cnt);
   if (h->h_pin_u) (void)hipHostFree(h->h_pin_u);
   if (h->h_pin_active) (void)hipHostFree(h->h_pin_active);
   if (h->h_pin_guess) (void)hipHostFree(h->h_pin_guess);
@@ -385,6 +438,7 @@ int mi355ndt_get_params(const mi355ndt_handle* h, mi355ndt_params* out) {
 
 int mi355ndt_set_stream(mi355ndt_handle* h, void* s) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  NOT_IN_STREAM(h);
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   if (s) {
@@ -466,6 +520,7 @@ static int alloc_side(mi355ndt_handle* h, bool tgt, int n_pairs, size_t pitch) {
 
 int mi355ndt_batch_reserve(mi355ndt_handle* h, int n_pairs, size_t max_tgt, size_t max_src) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  NOT_IN_STREAM(h);
   if (n_pairs <= 0 || max_tgt == 0 || max_src == 0 || n_pairs > MAX_PAIRS) return MI355NDT_ERR_BAD_ARG;
   if (max_tgt >= (1u << 31) || max_src >= (1u << 31)) return MI355NDT_ERR_BAD_ARG;
   HIPCHK(h, hipSetDevice(h->device));
@@ -634,6 +689,7 @@ int mi355ndt_batch_set_clouds(mi355ndt_handle* h, int first_pair, int n, const v
 int mi355ndt_batch_bind_device(mi355ndt_handle* h, int n_pairs, const float* d_t, const int* tc, size_t tp,
                                const float* d_s, const int* scnt, size_t sp) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  NOT_IN_STREAM(h);
   if (n_pairs <= 0 || !d_t || !d_s || !tc || !scnt || tp == 0 || sp == 0 || n_pairs > MAX_PAIRS) return MI355NDT_ERR_BAD_ARG;
   if (tp >= (1u << 31) || sp >= (1u << 31)) return MI355NDT_ERR_BAD_ARG;
   for (int b = 0; b < n_pairs; b++) if (tc[b] < 0 || (size_t)tc[b] > tp || scnt[b] < 0 || (size_t)scnt[b] > sp) return MI355NDT_ERR_BAD_ARG;
@@ -690,9 +746,10 @@ static void ev_collect(mi355ndt_handle* h, std::vector<mi355ndt_handle::EvSpan>&
 int mi355ndt_profile_enable(mi355ndt_handle* h, int on) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   h->prof = on != 0;
+  if (h->stream_on) for (int c = 0; c < h->s_nctx; c++) if (h->sctx[c].e) { h->sctx[c].e->ev_pool_target = 128; (void)mi355ndt_profile_enable(h->sctx[c].e, on); }
   if (h->prof) {
     HIPCHK(h, hipSetDevice(h->device));
-    while (h->ev_pool.size() < 4096) {             // ~40 profiled steps of a 10-round batch align before the pool has to grow
+    while (h->ev_pool.size() < h->ev_pool_target) { // ~40 profiled steps of a 10-round batch align before the pool has to grow
       hipEvent_t e;
       HIPCHK(h, hipEventCreate(&e));
       h->ev_pool.push_back(e);
@@ -706,6 +763,10 @@ int mi355ndt_profile_reset(mi355ndt_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   double d; long long n;
   ev_collect(h, h->ev_sweep, d, n); ev_collect(h, h->ev_update, d, n); ev_collect(h, h->ev_build, d, n);
+  if (h->stream_on) for (int c = 0; c < h->s_nctx; c++) if (mi355ndt_handle* e = h->sctx[c].e) {
+    ev_collect(e, e->ev_sweep, d, n); ev_collect(e, e->ev_update, d, n); ev_collect(e, e->ev_build, d, n);
+    e->P = mi355ndt_profile{};
+  }
   h->P = mi355ndt_profile{};
   (void)hipMemsetAsync(h->d_hits, 0, sizeof(unsigned long long), h->stream);
   (void)hipStreamSynchronize(h->stream);
@@ -719,6 +780,12 @@ int mi355ndt_profile_get(mi355ndt_handle* h, mi355ndt_profile* out) {
   ev_collect(h, h->ev_sweep, h->P.sweep_ms, h->P.sweep_launches);
   ev_collect(h, h->ev_update, h->P.update_ms, h->P.update_launches);
   ev_collect(h, h->ev_build, h->P.build_ms, h->P.build_launches);
+  if (h->stream_on) for (int c = 0; c < h->s_nctx; c++) if (mi355ndt_handle* e = h->sctx[c].e) {   // the contexts' builds (and synchronous re-runs) are this handle's work
+    ev_collect(e, e->ev_sweep, h->P.sweep_ms, h->P.sweep_launches);
+    ev_collect(e, e->ev_update, h->P.update_ms, h->P.update_launches);
+    ev_collect(e, e->ev_build, h->P.build_ms, h->P.build_launches);
+    h->P.build_alg_bytes += e->P.build_alg_bytes; e->P.build_alg_bytes = 0;
+  }
   unsigned long long hh = 0;                      // (point, voxel) evaluations since the last reset, summed on the device
   HIPCHK(h, hipMemcpy(&hh, h->d_hits, sizeof hh, hipMemcpyDeviceToHost));
   *out = h->P;
@@ -731,6 +798,7 @@ int mi355ndt_profile_get(mi355ndt_handle* h, mi355ndt_profile* out) {
 static int build_targets_impl(mi355ndt_handle* h);
 int mi355ndt_batch_build_targets(mi355ndt_handle* h) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  NOT_IN_STREAM(h);
   const int rc = build_targets_impl(h);
   // an error exit may leave kernels queued that still read the cloud rows: later uploads have to wait for them all the same
   if (rc != MI355NDT_OK && h->ev_compute) (void)compute_enqueued(h);
@@ -744,7 +812,13 @@ static int build_targets_impl(mi355ndt_handle* h) {
   const size_t pitch = h->tgt_pitch;
   const size_t total = (size_t)B * pitch;
   hipStream_t s = h->stream;
-  if (h->up_tgt_cnt.size() != (size_t)B || !std::equal(h->up_tgt_cnt.begin(), h->up_tgt_cnt.end(), h->h_tgt_cnt.begin())) {
+  if (h->async_build && h->h_pin_cnt && h->pin_cnt_cap >= (size_t)B) {
+    // stream mode: the counts travel through pinned memory, nothing waits (the context's previous batch, which used the staging
+    // copy last, is long finished)
+    memcpy(h->h_pin_cnt, h->h_tgt_cnt.data(), B * sizeof(int));
+    HIPCHK(h, hipMemcpyAsync(h->d_tgt_cnt, h->h_pin_cnt, B * sizeof(int), hipMemcpyHostToDevice, s));
+    h->up_tgt_cnt.clear();
+  } else if (h->up_tgt_cnt.size() != (size_t)B || !std::equal(h->up_tgt_cnt.begin(), h->up_tgt_cnt.end(), h->h_tgt_cnt.begin())) {
     HIPCHK(h, hipMemcpyAsync(h->d_tgt_cnt, h->h_tgt_cnt.data(), B * sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHK(h, hipStreamSynchronize(s));   // h_tgt_cnt is pageable
     h->up_tgt_cnt.assign(h->h_tgt_cnt.begin(), h->h_tgt_cnt.begin() + B);   // exactly what the device now holds
@@ -780,10 +854,25 @@ static int build_targets_impl(mi355ndt_handle* h) {
   k_minmax<<<dim3(std::max(1, std::min((gx + 3) / 4 / MM_ILP, 64)), B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_minmax);
   k_griddesc<<<(B + 63) / 64, 64, 0, s>>>(h->d_minmax, h->d_grid, h->d_nwords, h->prm.resolution, B, (unsigned)rpp);
   k_word_offsets<<<1, 1024, 0, s>>>(h->d_grid, h->d_nwords, B, h->d_word_off);   // d_word_off[0] = total words, [1] = largest grid
-  HIPCHK(h, hipMemcpyAsync(h->h_pin_u, h->d_word_off, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
-  HIPCHK(h, hipStreamSynchronize(s));           // total bitmap words -> size the pool; largest grid -> key width
-  const size_t total_words = h->h_pin_u[0];
-  const int cb = std::max(1, ceil_log2(h->h_pin_u[1] + 1u));   // cell field: every cell index + the all-ones "not binned" value
+  size_t total_words;
+  int cb;
+  const bool planned = h->async_build && h->plan_cb > 0 && h->plan_words > 0 && h->plan_words <= h->words_cap && h->d_bflag && h->h_pin_binfo;
+  if (planned) {
+    // no wait: the plan's key width and pool size, checked on the device (a batch that does not fit loses its grids and is flagged)
+    k_build_check<<<(B + 255) / 256, 256, 0, s>>>(h->d_word_off, h->d_grid, h->d_nwords, B, (unsigned)std::min(h->plan_words, (size_t)0xFFFFFFFFu), h->plan_cb, h->d_bflag);
+    HIPCHK(h, hipMemcpyAsync(h->h_pin_binfo, h->d_word_off, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->h_pin_binfo + 2, h->d_bflag, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    total_words = h->plan_words;
+    cb = h->plan_cb;
+  } else {
+    HIPCHK(h, hipMemcpyAsync(h->h_pin_u, h->d_word_off, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));           // total bitmap words -> size the pool; largest grid -> key width
+    total_words = h->h_pin_u[0];
+    cb = std::max(1, ceil_log2(h->h_pin_u[1] + 1u));   // cell field: every cell index + the all-ones "not binned" value
+    if (h->async_build) cb = std::max(cb, h->plan_cb);        // (a wider field sorts the same order: the plan only ever grows)
+    h->last_total_words = total_words;
+    if (h->d_bflag) HIPCHK(h, hipMemsetAsync(h->d_bflag, 0, sizeof(unsigned), s));
+  }
   if (total_words > h->words_cap) {
     size_t c = h->words_cap;
     HIPCHK(h, grow(h->d_words, c, std::max(total_words, (size_t)1024)));
@@ -947,6 +1036,7 @@ static void launch_hessian(mi355ndt_handle* h, const SweepConst& sc) {
 static int batch_align_impl(mi355ndt_handle* h, const float* guesses, mi355ndt_result* out);
 int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_result* out) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  NOT_IN_STREAM(h);
   const int rc = batch_align_impl(h, guesses, out);
   if (rc != MI355NDT_OK) {
     // an error exit may leave (update, sweep) rounds queued: drain them, so that no sweep of THIS align can post its progress words
@@ -988,7 +1078,7 @@ static int align_pump(mi355ndt_handle* h, SweepConst sc, int B) {
     if (seen != seen_last) { seen_last = seen; t_progress = std::chrono::steady_clock::now(); }
     if (enq >= max_rounds || enq + 1 - seen >= depth) {
       if (std::chrono::steady_clock::now() - t_progress > std::chrono::seconds(20)) { h->err = "align: the device stopped making progress"; return MI355NDT_ERR_STATE; }
-      __builtin_ia32_pause();                    // (busy-wait: a round is ~20 us, a yield costs more than it gives; pause frees the sibling hyperthread)
+      cpu_relax();                               // (busy-wait: a round is ~20 us, a yield costs more than it gives; pause frees the sibling hyperthread)
       continue;
     }
     k_update<<<B, UPD_THREADS, 0, s>>>(h->d_state, h->d_partials, h->rows_per_pair, h->pts_per_chunk, 1, h->d_results, h->d_active,
@@ -1006,52 +1096,97 @@ static int align_pump(mi355ndt_handle* h, SweepConst sc, int B) {
 // More-Thuente loop -- every configuration lv_slam ships.  Returns MI355NDT_ERR_UNSUPPORTED when the launch cannot be made resident
 // (the caller then takes the lockstep path).
 }  // extern "C" (templates need C++ linkage)
+// What one persistent launch needs besides the engine's parameters: the context table (one context: the synchronous batch align; several:
+// the stream mode), the NEW context's arrays for the prepare kernel, the rings and the control blocks.
+struct AsyncLaunch {
+  AsyncTab tab;
+  int new_ci = 0, n_new = 0;                       // context and number of the pairs that START in this launch (0: only carried pairs)
+  PairState* st_new = nullptr; const float* guess_new = nullptr; const int* src_cnt_new = nullptr; const GridDesc* gd_new = nullptr; unsigned* arrived_new = nullptr;
+  int* active_list = nullptr; SweepCtl* sweep_ctl = nullptr;
+  AsyncTab* tab_dev = nullptr; int* ring = nullptr; int ring_cap = 0; AsyncCtl* ctl = nullptr; const AsyncCtl* prev = nullptr;
+  int items_per_pair = 0, stop_thresh = 0; unsigned debug_abort_pos = 0xFFFFFFFFu;
+};
 template <bool PCA, int K, int ORD>
-static int launch_async_t(mi355ndt_handle* h, const SweepConst& sc, int B, int ring_cap) {
+static int launch_async_t(mi355ndt_handle* h, const SweepConst& sc, const AsyncLaunch& L) {
   auto kern = k_align_async<PCA, K, ORD>;
   // (asked once per instantiation and device: the query sits between the prepare kernel and the launch, on the host's critical path)
   static int per_cu_of_device[64] = {0};
   int& per_cu = per_cu_of_device[h->device & 63];
   if (per_cu == 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SWEEP_THREADS, 0) != hipSuccess) { per_cu = 0; (void)hipGetLastError(); return MI355NDT_ERR_UNSUPPORTED; }
   const int wpe = sweep_wpe(PCA, K);
-  if (per_cu < wpe) return MI355NDT_ERR_UNSUPPORTED;              // every workgroup must be resident: waves wait for each other's tickets
+  // Every ring needs waves of its own (workgroup L serves ring L % 8), and the launch is sized to be resident as a whole.  Residency is
+  // no condition of correctness: positions are claimed, so the resident waves of a ring do all of its work and a workgroup that starts
+  // late -- another engine's launch holds its CU -- finds the launch over or joins in; a launch that cannot progress ends itself
+  // (bounded polls) and the caller falls back to the rounds.
+  if (per_cu < wpe || h->n_cu * wpe < 8) return MI355NDT_ERR_UNSUPPORTED;
   dim3 grid((unsigned)(h->n_cu * wpe));
-  kern<<<grid, SWEEP_THREADS, 0, h->stream>>>(h->d_src, h->src_pitch, h->d_state, h->d_grid, h->d_words, h->d_recs, h->d_partials, h->items_per_pair, B, h->d_src_cnt,
-                                             h->d_ring, ring_cap, h->d_actl, h->d_arrived, sc, h->d_cent, h->d_results, h->prof ? h->d_hits : nullptr,
-                                             h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations);
+  kern<<<grid, SWEEP_THREADS, 0, h->stream>>>(L.tab_dev, L.items_per_pair, L.ring, L.ring_cap, L.ctl, sc, h->prof ? h->d_hits : nullptr,
+                                             h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations, L.stop_thresh, L.debug_abort_pos);
   return MI355NDT_OK;
 }
 template <bool PCA, int K>
-static int launch_async_o(mi355ndt_handle* h, const SweepConst& sc, int B, int ring_cap) {
-  return h->f32_sum_order == 1 ? launch_async_t<PCA, K, 1>(h, sc, B, ring_cap) : launch_async_t<PCA, K, 0>(h, sc, B, ring_cap);
+static int launch_async_o(mi355ndt_handle* h, const SweepConst& sc, const AsyncLaunch& L) {
+  return h->f32_sum_order == 1 ? launch_async_t<PCA, K, 1>(h, sc, L) : launch_async_t<PCA, K, 0>(h, sc, L);
+}
+// prepare kernel + the persistent launch on the engine's stream (HIP events around the launch when profiling)
+static int launch_async(mi355ndt_handle* h, const SweepConst& sc, const AsyncLaunch& L) {
+  hipStream_t s = h->stream;
+  {
+    const size_t n = std::max(std::max((size_t)8 * L.ring_cap, (size_t)L.n_new * ASYNC_ARR_STRIDE), sizeof(AsyncCtl) / sizeof(unsigned));
+    k_async_prepare<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(L.tab, L.tab_dev, L.new_ci, L.n_new, L.st_new, L.guess_new, L.src_cnt_new, L.gd_new, L.arrived_new,
+                                                               L.active_list, L.sweep_ctl, L.ring, L.ring_cap, L.ctl, L.prev);
+  }
+  if (h->prof) HIPCHK(h, ev_begin(h, h->ev_sweep));
+  int rc;
+  if (sc.pca) rc = sc.K == 1 ? launch_async_o<true, 1>(h, sc, L) : sc.K == 7 ? launch_async_o<true, 7>(h, sc, L) : launch_async_o<true, 26>(h, sc, L);
+  else rc = sc.K == 1 ? launch_async_o<false, 1>(h, sc, L) : sc.K == 7 ? launch_async_o<false, 7>(h, sc, L)
+          : sc.K == 26 ? launch_async_o<false, 26>(h, sc, L) : launch_async_o<false, 27>(h, sc, L);
+  if (h->prof) HIPCHK(h, ev_end(h, h->ev_sweep));
+  return rc;
+}
+// ring slots a launch over at most `pairs` pairs can need: every pair publishes at most max_iterations + 3 tickets.
+// 0: too many for a sane allocation (the caller takes the round-based path, which needs no ring)
+static int async_ring_cap(const mi355ndt_handle* h, long long pairs) {
+  const long long cap = (pairs * ((long long)h->prm.max_iterations + 4) + 7) / 8 + 1;
+  return cap > (1LL << 26) ? 0 : (int)cap;        // 8 rings x 2^26 words = 2 GB: beyond that the rounds are the right tool anyway
+}
+static void fill_async_ctx(const mi355ndt_handle* e, AsyncCtx& c) {
+  c.src = e->d_src; c.pitch = e->src_pitch; c.st = e->d_state; c.gd = e->d_grid; c.words = e->d_words; c.recs = e->d_recs; c.cent = e->d_cent;
+  c.partials = e->d_partials; c.src_cnt = e->d_src_cnt; c.arrived = e->d_arrived; c.results = e->d_results; c.n_done = nullptr; c.must_finish = 1; c.pad_ = 0;
 }
 extern "C" {
 static int align_async(mi355ndt_handle* h, const SweepConst& sc, int B, mi355ndt_result* out) {
   hipStream_t s = h->stream;
-  const int ring_cap = (int)(((long long)B * (h->prm.max_iterations + 4) + 7) / 8 + 1);
-  HIPCHK(h, grow(h->d_ring, h->ring_cap_total, (size_t)8 * ring_cap));
+  const int ring_cap = async_ring_cap(h, B);
+  if (ring_cap == 0) return MI355NDT_ERR_UNSUPPORTED;
+  // (a ring that cannot be allocated is no error of the align: the round-based path needs none)
+  if (grow(h->d_ring, h->ring_cap_total, (size_t)8 * ring_cap) != hipSuccess) { (void)hipGetLastError(); return MI355NDT_ERR_UNSUPPORTED; }
   HIPCHK(h, grow(h->d_arrived, h->arrived_cap, (size_t)B * ASYNC_ARR_STRIDE));
   if (!h->d_actl) HIPCHK(h, hipMalloc((void**)&h->d_actl, sizeof(AsyncCtl)));
+  if (!h->d_atab) HIPCHK(h, hipMalloc((void**)&h->d_atab, sizeof(AsyncTab)));
   if (!h->h_pin_actl) HIPCHK(h, hipHostMalloc((void**)&h->h_pin_actl, sizeof(AsyncCtl)));
   // everything the launch polls is reset on the stream before it (never inside the kernel, never by a previous launch), together with
   // the pairs' initial states
-  {
-    const size_t n = std::max(std::max((size_t)8 * ring_cap, (size_t)B * ASYNC_ARR_STRIDE), sizeof(AsyncCtl) / sizeof(unsigned));
-    k_async_prepare<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(h->d_state, h->d_guess, h->d_src_cnt, h->d_grid, B, h->d_active_list, h->d_ctl,
-                                                               h->d_ring, ring_cap, h->d_arrived, h->d_actl);
-  }
-  if (h->prof) HIPCHK(h, ev_begin(h, h->ev_sweep));
-  int rc;
-  if (sc.pca) rc = sc.K == 1 ? launch_async_o<true, 1>(h, sc, B, ring_cap) : sc.K == 7 ? launch_async_o<true, 7>(h, sc, B, ring_cap) : launch_async_o<true, 26>(h, sc, B, ring_cap);
-  else rc = sc.K == 1 ? launch_async_o<false, 1>(h, sc, B, ring_cap) : sc.K == 7 ? launch_async_o<false, 7>(h, sc, B, ring_cap)
-          : sc.K == 26 ? launch_async_o<false, 26>(h, sc, B, ring_cap) : launch_async_o<false, 27>(h, sc, B, ring_cap);
-  if (rc) { if (h->prof) { HIPCHK(h, ev_end(h, h->ev_sweep)); } return rc; }
-  if (h->prof) HIPCHK(h, ev_end(h, h->ev_sweep));
-  HIPCHK(h, hipMemcpyAsync(h->h_pin_actl, h->d_actl, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s));   // pub, done, abort_
+  AsyncLaunch L;
+  memset(&L.tab, 0, sizeof L.tab);
+  fill_async_ctx(h, L.tab.c[0]);
+  L.new_ci = 0; L.n_new = B;
+  L.st_new = h->d_state; L.guess_new = h->d_guess; L.src_cnt_new = h->d_src_cnt; L.gd_new = h->d_grid; L.arrived_new = h->d_arrived;
+  L.active_list = h->d_active_list; L.sweep_ctl = h->d_ctl;
+  L.tab_dev = h->d_atab; L.ring = h->d_ring; L.ring_cap = ring_cap; L.ctl = h->d_actl; L.prev = nullptr;
+  L.items_per_pair = h->items_per_pair; L.stop_thresh = 0; L.debug_abort_pos = h->debug_abort_pos;
+  int rc = launch_async(h, sc, L);
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpyAsync(h->h_pin_actl, h->d_actl, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, s));   // pub, fin, abort_, n_live, susp
   HIPCHK(h, hipMemcpyAsync(out, h->d_results, (size_t)B * sizeof(mi355ndt_result), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
   HIPCHK(h, hipGetLastError());
-  if (h->h_pin_actl->abort_ || h->h_pin_actl->done != (unsigned)B) { h->err = "align: the device stopped making progress"; return MI355NDT_ERR_STATE; }
+  if (h->h_pin_actl->abort_ || h->h_pin_actl->fin != (unsigned)B) {
+    // a wave gave up (its ticket never came within the poll budget: a device shared with something that starves the launch, or the
+    // test hook): nothing is lost -- the round-based path below produces the same bits from the same guesses
+    h->P.async_fallbacks++;
+    return MI355NDT_ERR_UNSUPPORTED;
+  }
   if (h->prof) {                                   // every sweep a pair took part in streamed its points + K table probes
     for (int b = 0; b < B; b++) {
       h->P.sweep_alg_bytes += (double)out[b].sweeps * h->h_src_cnt[b] * (12.0 + 4.0 * sc.K);
@@ -1088,7 +1223,7 @@ static int batch_align_impl(mi355ndt_handle* h, const float* guesses, mi355ndt_r
   if (h->async_align && (big_batch || h->async_force) && !h->fine_it && !mt_live && !pca_kd) {
     rc = align_async(h, sc, B, out);                                // (prepares the pair states itself: k_async_prepare)
     if (rc == MI355NDT_OK) { h->aligned_once = true; return MI355NDT_OK; }
-    if (rc != MI355NDT_ERR_UNSUPPORTED) return rc;                  // (not resident: the lockstep rounds below)
+    if (rc != MI355NDT_ERR_UNSUPPORTED) return rc;                  // (not resident, no ring, or the launch gave up: the lockstep rounds below)
   }
   HIPCHK(h, hipMemsetAsync(h->d_ctl, 0, 2 * sizeof(SweepCtl), s));
   k_init_state<<<(B + 63) / 64, 64, 0, s>>>(h->d_state, h->d_guess, h->d_src_cnt, h->d_grid, B, h->d_active_list, h->d_ctl);
@@ -1209,6 +1344,7 @@ static int ensure_single(mi355ndt_handle* h, bool tgt, size_t n) {
 
 int mi355ndt_set_target(mi355ndt_handle* h, const void* pts, size_t n, size_t stride) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  NOT_IN_STREAM(h);
   if ((!pts && n) || (n && stride < 12) || n >= (1u << 31)) return MI355NDT_ERR_BAD_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   int rc = ensure_single(h, true, n);
@@ -1221,6 +1357,7 @@ int mi355ndt_set_target(mi355ndt_handle* h, const void* pts, size_t n, size_t st
 
 int mi355ndt_set_source(mi355ndt_handle* h, const void* pts, size_t n, size_t stride) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  NOT_IN_STREAM(h);
   if ((!pts && n) || (n && stride < 12) || n >= (1u << 31)) return MI355NDT_ERR_BAD_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   int rc = ensure_single(h, false, n);
@@ -1233,6 +1370,7 @@ int mi355ndt_set_source(mi355ndt_handle* h, const void* pts, size_t n, size_t st
 
 int mi355ndt_set_params(mi355ndt_handle* h, const mi355ndt_params* p) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  NOT_IN_STREAM(h);
   if (!p) return MI355NDT_ERR_BAD_ARG;
   int rc = check_params(*p);
   if (rc) return rc;
@@ -1586,6 +1724,15 @@ int mi355ndt_set_option(mi355ndt_handle* h, int option, int value) {
     h->async_force = value == 2;                 // 2: also for batches smaller than the GPU's resident waves (testing)
     return MI355NDT_OK;
   }
+  if (option == MI355NDT_OPT_DEBUG_ASYNC_ABORT) {
+    h->debug_abort_pos = value < 0 ? 0xFFFFFFFFu : (unsigned)value;
+    return MI355NDT_OK;
+  }
+  if (option == MI355NDT_OPT_STREAM_THRESHOLD) {
+    if (value < -1 || value > ASYNC_MAX_CARRY) return MI355NDT_ERR_BAD_ARG;
+    h->s_thresh_opt = value;
+    return MI355NDT_OK;
+  }
   return MI355NDT_ERR_BAD_ARG;
 }
 int mi355ndt_get_option(const mi355ndt_handle* h, int option, int* value) {
@@ -1593,6 +1740,8 @@ int mi355ndt_get_option(const mi355ndt_handle* h, int option, int* value) {
   if (!value) return MI355NDT_ERR_BAD_ARG;
   if (option == MI355NDT_OPT_F32_SUM_ORDER) { *value = h->f32_sum_order; return MI355NDT_OK; }
   if (option == MI355NDT_OPT_ASYNC_ALIGN) { *value = h->async_force ? 2 : (h->async_align ? 1 : 0); return MI355NDT_OK; }
+  if (option == MI355NDT_OPT_DEBUG_ASYNC_ABORT) { *value = h->debug_abort_pos == 0xFFFFFFFFu ? -1 : (int)h->debug_abort_pos; return MI355NDT_OK; }
+  if (option == MI355NDT_OPT_STREAM_THRESHOLD) { *value = h->s_thresh_opt; return MI355NDT_OK; }
   return MI355NDT_ERR_BAD_ARG;
 }
 
@@ -1720,6 +1869,300 @@ int mi355ndt_use_prefiltered(mi355ndt_handle* h, int role) {
   return compute_enqueued(h);
 }
 
+// ---- stream mode ----------------------------------------------------------------------------------------------------------
+// (include/mi355_ndt.h: mi355ndt_stream_*; kernels: ndt_async.hpp.  Replaces a run of batch_bind_device + batch_build_targets +
+//  batch_align triples for batches that arrive one after the other -- scan_matching_odom_nodelet.cpp:144-183 is a stream of frames.)
+static bool stream_async_ok(const mi355ndt_handle* h) {
+  const bool pca_kd = h->prm.neighbor_mode == MI355NDT_KDTREE && h->prm.variant == MI355NDT_VARIANT_PCA;
+  return h->async_align && !mt_is_live(h->prm) && !pca_kd;
+}
+static int stream_free(mi355ndt_handle* h) {
+  for (auto& c : h->sctx) {
+    if (c.e) (void)mi355ndt_destroy(c.e);
+    if (c.d_done) (void)hipFree(c.d_done);
+    if (c.h_res) (void)hipHostFree(c.h_res);
+    if (c.h_flags) (void)hipHostFree(c.h_flags);
+    c = mi355ndt_handle::StreamCtx();
+  }
+  if (h->d_sctl) { (void)hipFree(h->d_sctl); h->d_sctl = nullptr; }
+  if (h->d_sring) { (void)hipFree(h->d_sring); h->d_sring = nullptr; }
+  if (h->h_pin_sinfo) { (void)hipHostFree(h->h_pin_sinfo); h->h_pin_sinfo = nullptr; }
+  for (auto& e : h->s_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  h->stream_on = false; h->s_nctx = 0;
+  return MI355NDT_OK;
+}
+
+int mi355ndt_stream_end(mi355ndt_handle* h) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (!h->stream_on) return MI355NDT_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  // the contexts' build timings and byte counts belong to this handle's profile
+  for (int c = 0; c < h->s_nctx; c++) {
+    mi355ndt_handle* e = h->sctx[c].e;
+    if (!e) continue;
+    ev_collect(e, e->ev_build, h->P.build_ms, h->P.build_launches);
+    h->P.build_alg_bytes += e->P.build_alg_bytes; e->P.build_alg_bytes = 0;
+  }
+  return stream_free(h);
+}
+
+int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts, int max_pairs, size_t max_tgt, size_t max_src) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (n_contexts < 2 || n_contexts > ASYNC_MAX_CTX || max_pairs < 1 || max_pairs > MAX_PAIRS || max_pairs >= (1 << ASYNC_CTX_SHIFT) ||
+      max_tgt == 0 || max_src == 0 || max_tgt >= (1u << 31) || max_src >= (1u << 31)) return MI355NDT_ERR_BAD_ARG;
+  if (h->stream_on) return MI355NDT_ERR_STATE;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->s_nctx = n_contexts; h->s_max_pairs = max_pairs;
+  h->s_items = std::max(1, (int)((max_src + CHUNK_PTS - 1) / CHUNK_PTS)) * QUARTERS;
+  h->s_sync_only = !stream_async_ok(h);
+  h->s_next_id = 0; h->s_launches = 0; h->s_counted = 0; h->s_drop_carry = true;
+  h->s_plan_cb = 0; h->s_plan_words = 0;
+  SweepConst sc;
+  make_sweep_const(h, sc);
+  {
+    const int iu = h->s_items / ASYNC_CLAIM(sc.K == 1 ? 1 : 7);
+    const int waves = h->n_cu * sweep_wpe(sc.pca != 0, sc.K) * WAVES;
+    int t = h->s_thresh_opt >= 0 ? h->s_thresh_opt : (waves + iu - 1) / std::max(1, iu);
+    if (const char* e = std::getenv("MI355NDT_STREAM_THRESH")) t = std::atoi(e);
+    h->s_thresh = std::max(0, std::min(t, ASYNC_MAX_CARRY));
+  }
+  h->s_ring_cap = async_ring_cap(h, (long long)max_pairs + ASYNC_MAX_CARRY);
+  if (h->s_ring_cap == 0) h->s_sync_only = true;
+  auto fail = [&](int rc) { (void)stream_free(h); return rc; };
+  for (int c = 0; c < n_contexts; c++) {
+    mi355ndt_handle::StreamCtx& S = h->sctx[c];
+    int rc = mi355ndt_create(&h->prm, h->device, &S.e);
+    if (rc) return fail(rc);
+    mi355ndt_handle* e = S.e;
+    rc = mi355ndt_set_stream(e, h->stream);
+    if (rc) return fail(rc);
+    e->f32_sum_order = h->f32_sum_order; e->async_align = h->async_align; e->dyn_shift = h->dyn_shift;
+    e->async_build = true;
+    rc = ensure_pair_arrays(e, max_pairs);          // every per-pair array at its final size: no allocation, no wait inside submit
+    if (rc) { h->err = e->err; return fail(rc); }
+    if (hipMalloc((void**)&e->d_bflag, 64) != hipSuccess || hipHostMalloc((void**)&e->h_pin_binfo, 64) != hipSuccess ||
+        hipHostMalloc((void**)&e->h_pin_cnt, 2 * (size_t)max_pairs * sizeof(int)) != hipSuccess ||
+        hipMalloc((void**)&S.d_done, 64) != hipSuccess || hipHostMalloc((void**)&S.h_res, (size_t)max_pairs * sizeof(mi355ndt_result)) != hipSuccess ||
+        hipHostMalloc((void**)&S.h_flags, 64) != hipSuccess) { h->err = "stream_begin: allocation failed"; return fail(MI355NDT_ERR_HIP); }
+    e->pin_cnt_cap = (size_t)max_pairs;
+    memset(e->h_pin_binfo, 0, 64); memset(S.h_flags, 0, 64);
+    if (hipMemsetAsync(e->d_bflag, 0, 64, h->stream) != hipSuccess || hipMemsetAsync(S.d_done, 0, 64, h->stream) != hipSuccess) return fail(MI355NDT_ERR_HIP);
+    size_t need = (size_t)max_pairs * h->s_items * NACC;
+    if (grow(e->d_partials, e->partials_cap, need) != hipSuccess || grow(e->d_arrived, e->arrived_cap, (size_t)max_pairs * ASYNC_ARR_STRIDE) != hipSuccess)
+      { h->err = "stream_begin: allocation failed"; return fail(MI355NDT_ERR_HIP); }
+    e->ev_pool_target = 128;
+    if (h->prof) (void)mi355ndt_profile_enable(e, 1);
+  }
+  if (hipMalloc((void**)&h->d_sctl, 2 * sizeof(AsyncCtl)) != hipSuccess || hipMemsetAsync(h->d_sctl, 0, 2 * sizeof(AsyncCtl), h->stream) != hipSuccess ||
+      hipHostMalloc((void**)&h->h_pin_sinfo, mi355ndt_handle::S_EV * 4 * sizeof(unsigned)) != hipSuccess) return fail(MI355NDT_ERR_HIP);
+  if (!h->d_atab && hipMalloc((void**)&h->d_atab, sizeof(AsyncTab)) != hipSuccess) return fail(MI355NDT_ERR_HIP);
+  if (!h->s_sync_only && hipMalloc((void**)&h->d_sring, (size_t)8 * h->s_ring_cap * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); h->s_sync_only = true; }
+  for (auto& e : h->s_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(MI355NDT_ERR_HIP);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  (void)max_tgt;
+  h->stream_on = true;
+  return MI355NDT_OK;
+}
+
+// one persistent launch of the stream: the pairs the previous launch suspended + the `n_new` pairs of context `new_ci` (-1: a flush --
+// nothing new, everything runs to its end), then a snapshot of every busy context's results and counters into pinned memory
+static int stream_launch(mi355ndt_handle* h, int new_ci, int n_new) {
+  hipStream_t s = h->stream;
+  SweepConst sc;
+  make_sweep_const(h, sc);
+  AsyncLaunch L;
+  memset(&L.tab, 0, sizeof L.tab);
+  const bool flush = new_ci < 0;
+  for (int c = 0; c < h->s_nctx; c++) {
+    mi355ndt_handle* e = h->sctx[c].e;
+    if (!e->d_src) continue;                         // never bound: no ticket can name it
+    fill_async_ctx(e, L.tab.c[c]);
+    L.tab.c[c].n_done = h->sctx[c].d_done;
+    // the context the NEXT submit recycles must be finished by this launch; the others may hand their last pairs over
+    L.tab.c[c].must_finish = (flush || c == (new_ci + 1) % h->s_nctx) ? 1 : 0;
+  }
+  const long long j = h->s_launches;
+  L.new_ci = flush ? 0 : new_ci; L.n_new = flush ? 0 : n_new;
+  if (!flush) {
+    mi355ndt_handle* e = h->sctx[new_ci].e;
+    L.st_new = e->d_state; L.guess_new = e->d_guess; L.src_cnt_new = e->d_src_cnt; L.gd_new = e->d_grid; L.arrived_new = e->d_arrived;
+    L.active_list = e->d_active_list; L.sweep_ctl = nullptr;
+  }
+  L.tab_dev = h->d_atab; L.ring = h->d_sring; L.ring_cap = h->s_ring_cap;
+  L.ctl = h->d_sctl + (j & 1); L.prev = h->s_drop_carry ? nullptr : h->d_sctl + ((j + 1) & 1);
+  L.items_per_pair = h->s_items; L.stop_thresh = flush ? 0 : h->s_thresh; L.debug_abort_pos = h->debug_abort_pos;
+  h->ev_last_fresh = false;                          // (the contexts' builds sit between two launches on this stream)
+  int rc = launch_async(h, sc, L);
+  if (rc) return rc;
+  h->s_drop_carry = false;
+  for (int c = 0; c < h->s_nctx; c++) {
+    mi355ndt_handle::StreamCtx& S = h->sctx[c];
+    if (!S.busy || S.done_sync) continue;
+    HIPCHK(h, hipMemcpyAsync(S.h_res, S.e->d_results, (size_t)S.n_pairs * sizeof(mi355ndt_result), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(S.h_flags, S.d_done, sizeof(unsigned), hipMemcpyDeviceToHost, s));        // (after the results: a full count vouches for them)
+    HIPCHK(h, hipMemcpyAsync(S.h_flags + 1, S.e->d_bflag, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  }
+  const int slot = (int)(j % mi355ndt_handle::S_EV);
+  static_assert(offsetof(AsyncCtl, abort_) == 8 && offsetof(AsyncCtl, susp) == 16, "launch status words");
+  HIPCHK(h, hipMemcpyAsync(h->h_pin_sinfo + 4 * slot, &L.ctl->fin, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s));   // fin, abort_, n_live, susp
+  HIPCHK(h, hipEventRecord(h->s_ev[slot], s));
+  h->s_launches++;
+  h->P.stream_launches++;
+  return MI355NDT_OK;
+}
+
+int mi355ndt_stream_submit(mi355ndt_handle* h, int n_pairs, const float* d_t, const int* tc, size_t tp, const float* d_s, const int* scnt, size_t sp,
+                           const float* guesses, long long* batch_id) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (!h->stream_on) return MI355NDT_ERR_STATE;
+  if (n_pairs < 1 || n_pairs > h->s_max_pairs || !guesses || !batch_id) return MI355NDT_ERR_BAD_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  const long long id = h->s_next_id;
+  const int ci = (int)(id % h->s_nctx);
+  mi355ndt_handle::StreamCtx& S = h->sctx[ci];
+  if (S.busy) { h->err = "stream_submit: collect batch " + std::to_string(S.batch_id) + " first (its context is the one this batch needs)"; return MI355NDT_ERR_STATE; }
+  mi355ndt_handle* e = S.e;
+  for (int b = 0; b < n_pairs; b++) if (scnt && (size_t)scnt[b] > (size_t)(h->s_items / QUARTERS) * CHUNK_PTS) return MI355NDT_ERR_BAD_ARG;   // more source points than stream_begin was told
+  int rc = mi355ndt_batch_bind_device(e, n_pairs, d_t, tc, tp, d_s, scnt, sp);
+  if (rc) { h->err = e->err; return rc; }
+  e->prm = h->prm;
+  S.batch_id = id; S.n_pairs = n_pairs; S.redo = false; S.done_sync = false; S.launch = -1;
+  S.h_flags[0] = 0; S.h_flags[1] = 0;
+  memcpy(e->h_pin_guess, guesses, (size_t)n_pairs * 16 * sizeof(float));
+  if (h->s_sync_only) {                              // a configuration the one-launch align does not serve: processed here and now
+    e->async_build = false;
+    rc = mi355ndt_batch_build_targets(e);
+    if (rc == MI355NDT_OK) rc = mi355ndt_batch_align(e, guesses, S.h_res);
+    if (rc) { h->err = e->err; return rc; }
+    S.done_sync = true; S.busy = true;
+    *batch_id = id; h->s_next_id++;
+    return MI355NDT_OK;
+  }
+  // target build: against the stream's plan when there is one (no wait), else synchronously -- which makes the plan
+  e->async_build = true;
+  e->plan_cb = h->s_plan_cb; e->plan_words = h->s_plan_words;
+  if (e->plan_words > e->words_cap) {
+    size_t c = e->words_cap;
+    HIPCHK(h, grow(e->d_words, c, e->plan_words));
+    e->words_cap = c;
+  }
+  rc = mi355ndt_batch_build_targets(e);
+  if (rc) { h->err = e->err; return rc; }
+  if (!(e->plan_cb > 0 && e->plan_words > 0)) {      // that build waited for its sizes: learn from it (with headroom: scans of one drive vary by a few per cent)
+    h->s_plan_cb = std::max(h->s_plan_cb, e->last_cb);
+    h->s_plan_words = std::max(h->s_plan_words, e->last_total_words + e->last_total_words / 4 + 1024);
+  }
+  // align workspace of this context: fixed row geometry for the whole stream (a pair's rows do not depend on it), counts and guesses
+  // through pinned memory
+  e->chunks_per_pair = h->s_items / QUARTERS; e->rows_per_pair = e->items_per_pair = h->s_items; e->pts_per_chunk = CHUNK_PTS; e->fine_it = 0;
+  memcpy(e->h_pin_cnt + h->s_max_pairs, e->h_src_cnt.data(), (size_t)n_pairs * sizeof(int));
+  HIPCHK(h, hipMemcpyAsync(e->d_src_cnt, e->h_pin_cnt + h->s_max_pairs, (size_t)n_pairs * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  e->up_src_cnt.clear();
+  HIPCHK(h, hipMemcpyAsync(e->d_guess, e->h_pin_guess, (size_t)n_pairs * 16 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemsetAsync(S.d_done, 0, sizeof(unsigned), h->stream));
+  gauss_constants3(h->prm.outlier_ratio, h->prm.resolution, h->gauss_last);
+  S.busy = true;
+  S.launch = h->s_launches;
+  rc = stream_launch(h, ci, n_pairs);
+  if (rc) {                                          // the launch cannot be made (not resident): this and every later batch synchronously
+    h->s_sync_only = true;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    e->async_build = false;
+    rc = mi355ndt_batch_build_targets(e);
+    if (rc == MI355NDT_OK) rc = mi355ndt_batch_align(e, guesses, S.h_res);
+    if (rc) { S.busy = false; h->err = e->err; return rc; }
+    S.done_sync = true;
+  }
+  e->aligned_once = true;
+  *batch_id = id; h->s_next_id++;
+  return MI355NDT_OK;
+}
+
+// a launch gave up (ctl->abort_): nothing it left behind can be trusted to continue from -- every unfinished batch is re-run synchronously
+// by its collect, and the next launch starts without a hand-over list
+static void stream_recover(mi355ndt_handle* h) {
+  (void)hipStreamSynchronize(h->stream);
+  for (int c = 0; c < h->s_nctx; c++) {
+    mi355ndt_handle::StreamCtx& S = h->sctx[c];
+    if (S.busy && !S.done_sync && S.h_flags[0] != (unsigned)S.n_pairs) S.redo = true;
+  }
+  h->s_drop_carry = true;
+  h->P.async_fallbacks++;
+}
+
+int mi355ndt_stream_collect(mi355ndt_handle* h, long long batch_id, mi355ndt_result* out) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (!h->stream_on) return MI355NDT_ERR_STATE;
+  if (batch_id < 0 || batch_id >= h->s_next_id || !out) return MI355NDT_ERR_BAD_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  mi355ndt_handle::StreamCtx& S = h->sctx[batch_id % h->s_nctx];
+  if (!S.busy || S.batch_id != batch_id) return MI355NDT_ERR_BAD_ARG;       // collected already (or its context has been recycled)
+  mi355ndt_handle* e = S.e;
+  if (!S.done_sync) {
+    long long j = S.launch;
+    for (;;) {
+      const int slot = (int)(j % mi355ndt_handle::S_EV);
+      HIPCHK(h, hipEventSynchronize(h->s_ev[slot]));
+      for (; h->s_counted <= j; h->s_counted++) h->P.stream_carried += h->h_pin_sinfo[4 * (h->s_counted % mi355ndt_handle::S_EV) + 3];   // (launches finish in order)
+      if (h->h_pin_sinfo[4 * slot + 1]) { h->h_pin_sinfo[4 * slot + 1] = 0; stream_recover(h); }
+      if (S.redo || S.h_flags[1]) break;
+      if (S.h_flags[0] == (unsigned)S.n_pairs) break;
+      if (j + 1 < h->s_launches) { j++; continue; }  // its stragglers ride in a later launch that is already queued
+      int rc = stream_launch(h, -1, 0);              // nothing newer: flush them
+      if (rc) { stream_recover(h); S.redo = true; break; }
+      j = h->s_launches - 1;
+    }
+    if (S.redo || S.h_flags[1]) {
+      // the batch did not fit the build plan (its grids were withheld), or its launch gave up: the synchronous path, which also re-makes the plan
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      e->async_build = false;
+      const std::vector<float> gs(e->h_pin_guess, e->h_pin_guess + (size_t)S.n_pairs * 16);    // (batch_align stages its guesses in that very buffer)
+      int rc = mi355ndt_batch_build_targets(e);
+      if (rc == MI355NDT_OK) rc = mi355ndt_batch_align(e, gs.data(), S.h_res);
+      e->async_build = true;
+      if (rc) { h->err = e->err; S.busy = false; return rc; }
+      h->s_plan_cb = std::max(h->s_plan_cb, e->last_cb);
+      h->s_plan_words = std::max(h->s_plan_words, e->last_total_words + e->last_total_words / 4 + 1024);
+      // the synchronous align re-computed its own row geometry: back to the stream's for this context's next batch
+      e->chunks_per_pair = h->s_items / QUARTERS; e->rows_per_pair = e->items_per_pair = h->s_items; e->pts_per_chunk = CHUNK_PTS; e->fine_it = 0;
+      if (grow(e->d_partials, e->partials_cap, (size_t)h->s_max_pairs * h->s_items * NACC) != hipSuccess) return MI355NDT_ERR_HIP;
+      S.h_flags[1] = 0;
+      h->P.stream_redone++;
+    }
+  }
+  memcpy(out, S.h_res, (size_t)S.n_pairs * sizeof(mi355ndt_result));
+  if (h->prof) {
+    const int K = h->prm.neighbor_mode == MI355NDT_DIRECT1 ? 1 : h->prm.neighbor_mode == MI355NDT_DIRECT7 ? 7 : h->prm.neighbor_mode == MI355NDT_DIRECT26 ? 26 : 27;
+    for (int b = 0; b < S.n_pairs; b++) {
+      h->P.sweep_alg_bytes += (double)out[b].sweeps * e->h_src_cnt[b] * (12.0 + 4.0 * K);
+      h->P.sweep_points += (long long)out[b].sweeps * e->h_src_cnt[b];
+    }
+  }
+  S.busy = false;
+  return MI355NDT_OK;
+}
+
+int mi355ndt_pack_pose_records(const mi355ndt_result* results, int n, int id_base, int id_stride, void* records, size_t capacity) {
+  if (!results || !records || n < 0 || (size_t)n > capacity) return MI355NDT_ERR_BAD_ARG;
+  PoseRecord* out = (PoseRecord*)records;
+  for (size_t k = 0; k < capacity; k++) {
+    PoseRecord r;
+    memset(&r, 0, sizeof r);
+    r.pair_id = -1;
+    if (k < (size_t)n) {
+      for (int a = 0; a < 16; a++) r.final_cm[a] = results[k].final_colmajor[a];
+      r.score = (float)results[k].score;
+      r.iterations = results[k].iterations;
+      r.converged = results[k].converged;
+      r.pair_id = id_base + (int)k * id_stride;
+    }
+    out[k] = r;
+  }
+  return MI355NDT_OK;
+}
+
 // ---- latency mode ---------------------------------------------------------------------------------------------------------
 int mi355ndt_set_latency_mode(mi355ndt_handle* h, int on) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
@@ -1731,6 +2174,7 @@ int mi355ndt_sequence_run(mi355ndt_handle* h, int n_frames, const void* const* c
                           const double* stamps, const mi355ndt_seq_params* policy,
                           mi355ndt_seq_frame* out_frames, mi355ndt_result* out_results, mi355ndt_seq_stats* stats) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  NOT_IN_STREAM(h);
   if (n_frames < 1 || n_frames > MAX_PAIRS || !clouds || !counts || !stamps || !out_frames || stride < 12) return MI355NDT_ERR_BAD_ARG;
   if (mt_is_live(h->prm) || (h->prm.neighbor_mode != MI355NDT_DIRECT1 && h->prm.neighbor_mode != MI355NDT_DIRECT7)) {
     h->err = "sequence mode serves DIRECT1 / DIRECT7 with step_size > transformation_epsilon / 2 (every configuration lv_slam ships)";

@@ -28,12 +28,31 @@
 
 #define ASYNC_POS_STRIDE 32      // unsigned words between the rings' position counters (one 128-B line each: eight hot atomics, eight lines)
 #define ASYNC_ARR_STRIDE 16      // ... between the pairs' arrival counters (64 B: pairs in flight together do not share an atomic's line)
+#define ASYNC_MAX_CTX    4       // batch contexts one launch can serve (the synchronous batch align: one; the stream mode: 2..4)
+#define ASYNC_MAX_CARRY  128     // pairs one launch may hand over to the next (stream mode)
+#define ASYNC_CTX_SHIFT  24      // ticket word = context << 24 | pair slot of that context; -1 = no ticket yet
+
+// One batch context: everything a work item or an update of one of ITS pairs touches.  The synchronous mi355ndt_batch_align has one;
+// the stream mode (mi355ndt_stream_*) keeps several batches resident and a launch serves the pairs of all of them.
+struct AsyncCtx {
+  const float* src; size_t pitch;
+  PairState* st; const GridDesc* gd; const BitWord* words; const VoxelRec* recs; const float* cent;
+  double* partials; const int* src_cnt; unsigned* arrived; mi355ndt_result* results;
+  unsigned* n_done;             // (may be null) pairs of this context finalised so far, over all launches: the host's "batch complete" test
+  int must_finish;              // the context's buffers are recycled after this launch: its pairs are never handed over
+  int pad_;
+};
+struct AsyncTab { AsyncCtx c[ASYNC_MAX_CTX]; };
+
 struct AsyncCtl {
   unsigned pub;                 // tickets published so far (ticket numbers are handed out by fetch-add)
-  unsigned done;                // pairs finalised; n_pairs = the launch is over
-  unsigned abort_;              // a wave gave up waiting (bounded spins): the host reports an error
-  unsigned pad_[29];
+  unsigned fin;                 // pairs that left the launch -- finalised, or suspended for the next launch; n_live = the launch is over
+  unsigned abort_;              // a wave gave up waiting (bounded spins): the host falls back to the round-based align
+  unsigned n_live;              // pairs that entered the launch (k_async_prepare: carried over + new)
+  unsigned susp;                // pairs suspended by this launch = entries of `carry`
+  unsigned pad_[27];
   unsigned pos[8 * ASYNC_POS_STRIDE];   // per ring: positions of its item stream handed out so far
+  unsigned carry[ASYNC_MAX_CARRY];      // ticket words of the suspended pairs: the next launch's first tickets
 };
 
 #ifndef ASYNC_CLAIM
@@ -41,35 +60,52 @@ struct AsyncCtl {
 #endif
 #define ASYNC_SPIN_LIMIT (1u << 23)      // polls of ~1 us: a device that stopped making progress ends the launch after seconds, not never
 
-// Everything the launch reads before it has written it, set by ONE kernel on the stream in front of it (never inside the launch, never by
-// a previous launch): the pairs' initial states (k_init_state's job), ticket g = pair g of the first sweeps in ring g & 7 / slot g >> 3 and
-// "no ticket yet" everywhere else, the arrival counters, the control words.  (Six small launches -- two kernels and four fills -- until the
-// end of round 4: ~25 us per align.)
-NDT_KERNEL void k_async_prepare(PairState* st, const float* __restrict__ guess_cm, const int* __restrict__ src_cnt, const GridDesc* __restrict__ gd,
-                                int n_pairs, int* active_list, SweepCtl* sweep_ctl /* two of them */, int* ring, int ring_cap, unsigned* arrived,
-                                AsyncCtl* ctl) {
+// Everything the launch reads before it has written it, set by ONE kernel on the stream in front of it (never inside the launch): the
+// context table, the NEW pairs' initial states (k_init_state's job) and arrival counters, the first tickets -- the pairs the previous
+// launch suspended (`prev->carry`, stream mode), then the new pairs in slot order; ticket g sits in ring g & 7 / slot g >> 3, "no ticket
+// yet" everywhere else -- and the control words.  `prev` is a different block than `ctl` (the stream mode alternates two).
+NDT_KERNEL void k_async_prepare(const AsyncTab tab, AsyncTab* tab_dev, const int new_ci, const int n_new, PairState* st, const float* __restrict__ guess_cm,
+                                const int* __restrict__ src_cnt, const GridDesc* __restrict__ gd, unsigned* arrived, int* active_list, SweepCtl* sweep_ctl /* two of them */,
+                                int* ring, const int ring_cap, AsyncCtl* ctl, const AsyncCtl* prev) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned nc = prev ? min(prev->susp, (unsigned)ASYNC_MAX_CARRY) : 0u;
+  const unsigned n_live = nc + (unsigned)n_new;
   if (i < (size_t)8 * ring_cap) {
     const size_t g = (i % (size_t)ring_cap) * 8 + i / (size_t)ring_cap;
-    ring[i] = g < (size_t)n_pairs ? (int)g : -1;
+    int w = -1;
+    if (g < nc) w = (int)prev->carry[g];
+    else if (g < n_live) w = (new_ci << ASYNC_CTX_SHIFT) | (int)(g - nc);
+    ring[i] = w;
   }
-  if (i < (size_t)n_pairs * ASYNC_ARR_STRIDE) arrived[i] = 0u;
-  if (i < sizeof(AsyncCtl) / sizeof(unsigned)) reinterpret_cast<unsigned*>(ctl)[i] = i == 0 ? (unsigned)n_pairs : 0u;   // pub = n_pairs
-  if (i < 2 * sizeof(SweepCtl) / sizeof(int)) reinterpret_cast<int*>(sweep_ctl)[i] = i == 0 ? n_pairs : 0;              // n_active of the first
-  if (i < (size_t)n_pairs) {
-    active_list[i] = (int)i;
+  if (i < (size_t)n_new * ASYNC_ARR_STRIDE) arrived[i] = 0u;
+  if (i < offsetof(AsyncCtl, carry) / sizeof(unsigned)) reinterpret_cast<unsigned*>(ctl)[i] = (i == 0 || i == 3) ? n_live : 0u;   // pub = n_live = tickets out
+  if (sweep_ctl && i < 2 * sizeof(SweepCtl) / sizeof(int)) reinterpret_cast<int*>(sweep_ctl)[i] = i == 0 ? n_new : 0;           // n_active of the first
+  if (i == 0) tab_dev->c[0] = tab.c[0];
+  if (i == 1) tab_dev->c[1] = tab.c[1];
+  if (i == 2) tab_dev->c[2] = tab.c[2];
+  if (i == 3) tab_dev->c[3] = tab.c[3];
+  static_assert(ASYNC_MAX_CTX == 4, "the table is copied entry by entry");
+  if (i < (size_t)n_new) {
+    if (active_list) active_list[i] = (int)i;
     init_pair_state(st[i], guess_cm + i * 16, src_cnt[i], gd[i].status);
   }
 }
 
 // The pair's rows -> (score, g, H, hits), Newton step, publication.  Called by every lane of ONE wave; `Ssh` / `sol` are that wave's LDS.
-__device__ __forceinline__ void async_update(const int b, const int n_pts, PairState* st, const double* partials, const int rows_per_pair, PairState& Ssh, volatile double* sol,
-                                             mi355ndt_result* results, int* ring, const int ring_cap, AsyncCtl* ctl, unsigned long long* hits_total,
+// `tw` = the pair's ticket word (what is published again, or handed over); `stop_thresh` > 0 (stream mode): once no more than that many pairs
+// are still in the launch, a pair that wants another sweep is SUSPENDED instead -- its state is complete in memory, its ticket word goes
+// into ctl->carry, and the next launch's prepare kernel turns it into one of that launch's first tickets.  The count only ever falls, so
+// at most `stop_thresh` pairs are suspended; which ones is a matter of timing, what they compute is not (a pair's bits depend on the pair alone).
+__device__ __forceinline__ void async_update(const AsyncCtx& C, const int b, const int tw, const int n_pts, const int rows_per_pair, PairState& Ssh, volatile double* sol,
+                                             int* ring, const int ring_cap, AsyncCtl* ctl, const unsigned n_live, const int stop_thresh, unsigned long long* hits_total,
                                              const double step_max, const double eps, const int max_iterations
 #ifdef NDT_TIMELINE
                                              , unsigned long long* tl, unsigned long long& tl_last
 #endif
                                              ) {
+  PairState* st = C.st;
+  const double* partials = C.partials;
+  mi355ndt_result* results = C.results;
   const int lane = threadIdx.x & 63;
   // the update is a chain of dependent instructions on the critical path of its pair (and of the whole batch once few pairs are left):
   // it goes first at the SIMD's issue arbiter while it runs next to a wave that streams independent evaluation work
@@ -181,12 +217,21 @@ __device__ __forceinline__ void async_update(const int b, const int n_pts, PairS
   for (int i = lane; i < NW; i += 64) __hip_atomic_store(sg + i, sl[i], RLX_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0) {
-    if (rc == NEWTON_SWEEP) {
+    bool suspend = false;
+    if (rc == NEWTON_SWEEP && stop_thresh > 0 && !C.must_finish)
+      suspend = n_live - __hip_atomic_load((const gu32*)&ctl->fin, RLX_AGENT) <= (unsigned)stop_thresh;
+    if (rc == NEWTON_SWEEP && !suspend) {
       const unsigned g = __hip_atomic_fetch_add((gu32*)&ctl->pub, 1u, RLX_AGENT);
-      __hip_atomic_store((gu32*)reinterpret_cast<unsigned*>(ring + (size_t)(g & 7u) * ring_cap + (g >> 3)), (unsigned)b, RLX_AGENT);
+      __hip_atomic_store((gu32*)reinterpret_cast<unsigned*>(ring + (size_t)(g & 7u) * ring_cap + (g >> 3)), (unsigned)tw, RLX_AGENT);
+    } else if (rc == NEWTON_SWEEP) {
+      const unsigned k = __hip_atomic_fetch_add((gu32*)&ctl->susp, 1u, RLX_AGENT);
+      if (k < (unsigned)ASYNC_MAX_CARRY) __hip_atomic_store((gu32*)&ctl->carry[k], (unsigned)tw, RLX_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add((gu32*)&ctl->fin, 1u, RLX_AGENT);
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (finalize_pair's result record)
-      __hip_atomic_fetch_add((gu32*)&ctl->done, 1u, RLX_AGENT);
+      if (C.n_done) __hip_atomic_fetch_add((gu32*)C.n_done, 1u, RLX_AGENT);
+      __hip_atomic_fetch_add((gu32*)&ctl->fin, 1u, RLX_AGENT);
     }
   }
   TL_STAMP(9);
@@ -209,10 +254,8 @@ __device__ __forceinline__ void async_update(const int b, const int n_pts, PairS
 
 template <bool PCA, int K, int ORD>
 __global__ void __launch_bounds__(SWEEP_THREADS, (SweepTune<PCA, K>::WPE))
-k_align_async(const float* __restrict__ src, size_t pitch, PairState* st, const GridDesc* __restrict__ gd, const BitWord* __restrict__ words,
-              const VoxelRec* __restrict__ recs, double* partials, int items_per_pair, int n_pairs, const int* __restrict__ src_cnt, int* ring, int ring_cap,
-              AsyncCtl* ctl, unsigned* arrived, SweepConst sc, const float* __restrict__ cent, mi355ndt_result* results, unsigned long long* hits_total,
-              double step_max, double eps, int max_iterations) {
+k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, int ring_cap, AsyncCtl* ctl, SweepConst sc, unsigned long long* hits_total,
+              double step_max, double eps, int max_iterations, int stop_thresh, unsigned debug_abort_pos) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   __shared__ double exp_tab[64];
   __shared__ PairState Ssh[WAVES];
@@ -221,8 +264,9 @@ k_align_async(const float* __restrict__ src, size_t pitch, PairState* st, const 
   __syncthreads();                                 // (the only block barrier: the four waves are independent from here on)
   const int x = blockIdx.x & 7;                    // the ring this workgroup serves
   const gu32* ringx = (const gu32*)reinterpret_cast<const unsigned*>(ring + (size_t)x * ring_cap);
-  const gu32* done_p = (const gu32*)&ctl->done;
+  const gu32* fin_p = (const gu32*)&ctl->fin;
   gu32* pos_p = (gu32*)&ctl->pos[x * ASYNC_POS_STRIDE];
+  const unsigned n_live = ctl->n_live;             // (written by k_async_prepare, the kernel in front of this one; constant during the launch)
   const int I = items_per_pair;
   // DIRECT1 items are short (one probe per point, ~0.85 hits): two consecutive items of a pair per claim / arrival halve the hand-overs
   constexpr int CLAIM = ASYNC_CLAIM(K);
@@ -231,23 +275,23 @@ k_align_async(const float* __restrict__ src, size_t pitch, PairState* st, const 
   unsigned long long tl[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tl_last = __builtin_readcyclecounter();
 #endif
+  auto give_up = [&]() {                           // never hang: end the launch for everybody and tell the host (which takes the round-based path)
+    __hip_atomic_store((gu32*)&ctl->abort_, 1u, RLX_AGENT);
+    __hip_atomic_store((gu32*)&ctl->fin, n_live, RLX_AGENT);
+  };
   // wait (one lane, relaxed polls with sleeps) until ticket `t` of this ring exists; -2: the launch is over
   auto wait_ticket = [&](const int t, int have) -> int {
-    int b = have;
+    int w = have;
     if (lane == 0) {
       unsigned spins = 0;
-      while (b < 0) {
-        if (__hip_atomic_load(done_p, RLX_AGENT) >= (unsigned)n_pairs) { b = -2; break; }
+      while (w < 0) {
+        if (__hip_atomic_load(fin_p, RLX_AGENT) >= n_live) { w = -2; break; }
         __builtin_amdgcn_s_sleep(32);
-        if (t < ring_cap) b = (int)__hip_atomic_load(ringx + t, RLX_AGENT);
-        if (++spins > ASYNC_SPIN_LIMIT) {          // never hang: end the launch for everybody and tell the host
-          __hip_atomic_store((gu32*)&ctl->abort_, 1u, RLX_AGENT);
-          __hip_atomic_store((gu32*)&ctl->done, (unsigned)n_pairs, RLX_AGENT);
-          b = -2; break;
-        }
+        if (t < ring_cap) w = (int)__hip_atomic_load(ringx + t, RLX_AGENT);
+        if (++spins > ASYNC_SPIN_LIMIT) { give_up(); w = -2; break; }
       }
     }
-    return __builtin_amdgcn_readfirstlane(b);
+    return __builtin_amdgcn_readfirstlane(w);
   };
   // Positions of the ring's item stream (ticket 0's items, ticket 1's, ...) are CLAIMED, one returning fetch-add per item.  Static dealing
   // (wave w takes positions w, w + W, ...) was built and measured first: every update makes its wave late for good, a ticket completes when
@@ -255,19 +299,21 @@ k_align_async(const float* __restrict__ src, size_t pitch, PairState* st, const 
   unsigned pos = 0;
   if (lane == 0) pos = __hip_atomic_fetch_add(pos_p, 1u, RLX_AGENT);
   pos = __builtin_amdgcn_readfirstlane(pos);
-  int b = -1;
-  if (lane == 0 && (int)(pos / (unsigned)Iu) < ring_cap) b = (int)__hip_atomic_load(ringx + pos / (unsigned)Iu, RLX_AGENT);
-  b = wait_ticket((int)(pos / (unsigned)Iu), b);
-  if (b < 0) return;
-  unsigned pose_w = sweep_pose_words(st + b);
+  int tw = -1;                                     // ticket word: context << 24 | pair slot
+  if (lane == 0 && (int)(pos / (unsigned)Iu) < ring_cap) tw = (int)__hip_atomic_load(ringx + pos / (unsigned)Iu, RLX_AGENT);
+  tw = wait_ticket((int)(pos / (unsigned)Iu), tw);
+  if (tw < 0) return;
+  unsigned pose_w = sweep_pose_words(tab->c[tw >> ASYNC_CTX_SHIFT].st + (tw & ((1 << ASYNC_CTX_SHIFT) - 1)));
 #pragma unroll 1
   for (;;) {
     const int rem = (int)(pos % (unsigned)Iu) * CLAIM;
     TL_STAMP(10);                                  // hand-over: claim, ticket, (update)
-    const int n_b = src_cnt[b];
+    const AsyncCtx C = tab->c[tw >> ASYNC_CTX_SHIFT];   // (wave-uniform: scalar loads of a table nobody writes during the launch)
+    const int b = tw & ((1 << ASYNC_CTX_SHIFT) - 1);
+    const int n_b = C.src_cnt[b];
 #pragma unroll 1
     for (int k = 0; k < CLAIM; k++)
-      sweep_item<PCA, K, 8, false, ORD, true>(b, rem + k, src, pitch, st, gd, words, recs, partials, I, sc, cent, nullptr, exp_tab, pose_w, n_b, b
+      sweep_item<PCA, K, 8, false, ORD, true>(b, rem + k, C.src, C.pitch, C.st, C.gd, C.words, C.recs, C.partials, I, sc, C.cent, nullptr, exp_tab, pose_w, n_b, b
 #ifdef NDT_TIMELINE
                                               , tl, tl_last
 #endif
@@ -282,31 +328,33 @@ k_align_async(const float* __restrict__ src, size_t pitch, PairState* st, const 
     const int tn = (int)(npos / (unsigned)Iu);
     //  2. the arrival, and the ticket word of the next position;
     unsigned old = 0;
-    int nb = -1;
+    int ntw = -1;
     if (lane == 0) {
-      old = __hip_atomic_fetch_add((gu32*)(arrived + (size_t)b * ASYNC_ARR_STRIDE), (unsigned)CLAIM, RLX_AGENT);
-      if (tn < ring_cap) nb = (int)__hip_atomic_load(ringx + tn, RLX_AGENT);
+      old = __hip_atomic_fetch_add((gu32*)(C.arrived + (size_t)b * ASYNC_ARR_STRIDE), (unsigned)CLAIM, RLX_AGENT);
+      if (tn < ring_cap) ntw = (int)__hip_atomic_load(ringx + tn, RLX_AGENT);
     }
     old = __builtin_amdgcn_readfirstlane(old);
-    nb = __builtin_amdgcn_readfirstlane(nb);
+    ntw = __builtin_amdgcn_readfirstlane(ntw);
     //  3. the next pair's pose -- in flight while this wave updates (if it has to), then together with the next item's point loads.
     unsigned npose = 0;
-    if (nb >= 0) npose = sweep_pose_words(st + nb);
+    if (ntw >= 0) npose = sweep_pose_words(tab->c[ntw >> ASYNC_CTX_SHIFT].st + (ntw & ((1 << ASYNC_CTX_SHIFT) - 1)));
     TL_STAMP(8);                                   // row drain + claim, arrival + ticket
     if ((old + (unsigned)CLAIM) % (unsigned)I == 0u) {   // this was the sweep's last item: this wave is the pair's updater
-      async_update(b, n_b, st, partials, I, Ssh[wv], sol[wv], results, ring, ring_cap, ctl, hits_total, step_max, eps, max_iterations
+      async_update(C, b, tw, n_b, I, Ssh[wv], sol[wv], ring, ring_cap, ctl, n_live, stop_thresh, hits_total, step_max, eps, max_iterations
 #ifdef NDT_TIMELINE
                    , tl, tl_last
 #endif
                    );
       TL_STAMP(15);                                // the deferred re-basing (off the pair's critical path)
     }
-    if (nb < 0) {                                  // the next position's ticket does not exist yet
-      nb = wait_ticket(tn, nb);
-      if (nb < 0) break;
-      npose = sweep_pose_words(st + nb);
+    // (test hook, MI355NDT_OPT_DEBUG_ASYNC_ABORT: the wave that claimed this position of ring 0 gives up as a wave whose ticket never came would)
+    if (x == 0 && npos == debug_abort_pos) { if (lane == 0) give_up(); break; }
+    if (ntw < 0) {                                 // the next position's ticket does not exist yet
+      ntw = wait_ticket(tn, ntw);
+      if (ntw < 0) break;
+      npose = sweep_pose_words(tab->c[ntw >> ASYNC_CTX_SHIFT].st + (ntw & ((1 << ASYNC_CTX_SHIFT) - 1)));
     }
-    b = nb; pos = npos; pose_w = npose;
+    tw = ntw; pos = npos; pose_w = npose;
   }
 #ifdef NDT_TIMELINE
   if (lane == 0) for (int k = 0; k < 16; k++) atomicAdd(&g_tl[k], tl[k]);

@@ -54,7 +54,8 @@ class Profile(C.Structure):
     _fields_ = [("sweep_ms", C.c_double), ("sweep_launches", C.c_longlong), ("sweep_alg_bytes", C.c_double),
                 ("sweep_hits", C.c_longlong), ("sweep_points", C.c_longlong), ("build_ms", C.c_double),
                 ("build_launches", C.c_longlong), ("build_alg_bytes", C.c_double), ("update_ms", C.c_double),
-                ("update_launches", C.c_longlong)]
+                ("update_launches", C.c_longlong), ("async_fallbacks", C.c_longlong), ("stream_launches", C.c_longlong),
+                ("stream_carried", C.c_longlong), ("stream_redone", C.c_longlong)]
 
 
 class SeqParams(C.Structure):
@@ -83,8 +84,11 @@ SYMBOLS = [
     "mi355ndt_profile_enable", "mi355ndt_profile_reset", "mi355ndt_profile_get", "mi355ndt_synchronize",
     "mi355ndt_set_latency_mode", "mi355ndt_sequence_run",
     "mi355ndt_calculate_score", "mi355ndt_convert_transform", "mi355ndt_set_option", "mi355ndt_get_option",
+    "mi355ndt_stream_begin", "mi355ndt_stream_submit", "mi355ndt_stream_collect", "mi355ndt_stream_end", "mi355ndt_pack_pose_records",
 ]
 OPT_ASYNC_ALIGN = 2            # mi355ndt_option: 1 (default) = one persistent launch per batch align, 0 = lockstep (update, sweep) rounds; same bits
+OPT_DEBUG_ASYNC_ABORT = 3      # mi355ndt_option (test hook): the wave that claims this position of ring 0 gives up -> the batch is re-run in rounds
+OPT_STREAM_THRESHOLD = 4       # mi355ndt_option: pairs a stream launch hands over to the next one (-1 = auto, 0 = none)
 OPT_F32_SUM_ORDER = 1          # mi355ndt_option: 0 = (t0 + t1) + t2 (canonical), 1 = (t0 + t2) + t1 (Eigen 3.3 SSE predux pairing)
 
 _LIB = None
@@ -143,6 +147,11 @@ def load_library(path: str = LIB_PATH):
     L.mi355ndt_convert_transform.argtypes = [vp, vp]
     L.mi355ndt_set_option.argtypes = [vp, i, i]
     L.mi355ndt_get_option.argtypes = [vp, i, C.POINTER(i)]
+    L.mi355ndt_stream_begin.argtypes = [vp, i, i, sz, sz]
+    L.mi355ndt_stream_submit.argtypes = [vp, i, vp, vp, sz, vp, vp, sz, vp, C.POINTER(C.c_longlong)]
+    L.mi355ndt_stream_collect.argtypes = [vp, C.c_longlong, vp]
+    L.mi355ndt_stream_end.argtypes = [vp]
+    L.mi355ndt_pack_pose_records.argtypes = [vp, i, i, i, vp, sz]
     _LIB = L
     return L
 
@@ -384,6 +393,36 @@ class Engine:
 
     def synchronize(self):
         self._chk(self.lib.mi355ndt_synchronize(self.h), "synchronize")
+
+    # -- stream mode: batches overlap on the GPU (mi355ndt_stream_*)
+    def stream_begin(self, n_contexts: int, max_pairs: int, max_target_pts: int, max_source_pts: int):
+        self._chk(self.lib.mi355ndt_stream_begin(self.h, n_contexts, max_pairs, max_target_pts, max_source_pts), "stream_begin")
+
+    def stream_submit(self, d_targets_ptr: int, target_counts, target_pitch: int, d_sources_ptr: int, source_counts, source_pitch: int,
+                      guesses_colmajor: np.ndarray) -> int:
+        """Enqueue one batch (device-resident SoA buffers as in batch_bind_device; they must stay unchanged until the batch is collected).
+        Returns the batch id at once."""
+        tc = np.ascontiguousarray(target_counts, np.int32)
+        sc = np.ascontiguousarray(source_counts, np.int32)
+        g = np.ascontiguousarray(guesses_colmajor, np.float32)
+        assert len(tc) == len(sc) and g.size == 16 * len(tc)
+        bid = C.c_longlong(-1)
+        self._chk(self.lib.mi355ndt_stream_submit(self.h, len(tc), C.c_void_p(d_targets_ptr), tc.ctypes.data_as(C.c_void_p), target_pitch,
+                                                  C.c_void_p(d_sources_ptr), sc.ctypes.data_as(C.c_void_p), source_pitch,
+                                                  g.ctypes.data_as(C.c_void_p), C.byref(bid)), "stream_submit")
+        return bid.value
+
+    def stream_collect_raw(self, batch_id: int, res_array):
+        """Block until every pair of the batch is finalised; res_array = (Result * n_pairs)()."""
+        self._chk(self.lib.mi355ndt_stream_collect(self.h, batch_id, C.cast(res_array, C.c_void_p)), "stream_collect")
+
+    def stream_collect(self, batch_id: int, n_pairs: int) -> list[dict]:
+        res = (Result * n_pairs)()
+        self.stream_collect_raw(batch_id, res)
+        return [_result_dict(r) for r in res]
+
+    def stream_end(self):
+        self._chk(self.lib.mi355ndt_stream_end(self.h), "stream_end")
 
     # -- latency mode
     def set_latency_mode(self, on: bool = True):

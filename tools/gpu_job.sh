@@ -33,6 +33,8 @@ for stage in "$@"; do
     fuzz_async) MI355NDT_ASYNC=2 timeout 900 python tools/fuzz_parity.py --cases 100000 --seed 41 --seconds 420 > $O/fuzz.txt 2>&1; tail -15 $O/fuzz.txt ;;
     bench_d1)   for c in "--variant pca --mode direct1" "--variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128" ""; do timeout 600 python bench.py $c --cpu-seconds 6 --no-host-clouds --seq-frames 0 --config4-pairs 0 --no-other-configs 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d[\"config\"][\"workload\"][:60], d[\"value\"], d[\"ms_per_step\"], d[\"roofline\"][\"frac\"], d[\"parity\"][\"pairs_checked\"], d[\"parity\"][\"iterations_equal\"])"; done > $O/out.txt 2>&1; cat $O/out.txt ;;
     timeline_d1) (MODE=direct1 VARIANT=pca MAXIT=64 MI355NDT_LIB=$R/lv_slam_amd/libexp_tl.so timeout 300 python tools/sweep_timeline.py; MODE=direct1 VARIANT=pca RESOLUTION=0.5 AZIMUTH=2048 PAIRS=128 MAXIT=64 MI355NDT_LIB=$R/lv_slam_amd/libexp_tl.so timeout 300 python tools/sweep_timeline.py) 2>&1 | grep -v amdgpu.ids > $O/tl.txt; cat $O/tl.txt ;;
+    tests_stream) timeout 1800 python -m pytest tests/test_stream_gpu.py -x -q 2>&1 | tail -30 > $O/pytest.txt; cat $O/pytest.txt ;;
+    tests_async_all) timeout 1800 python -m pytest tests/test_gpu_configs.py -m gpu -x -q 2>&1 | tail -25 > $O/pytest.txt; cat $O/pytest.txt ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
