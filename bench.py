@@ -78,6 +78,9 @@ def parse():
                     help="skip the `other_configs` block of the single-GPU line (the nodelet's ndt_pca / DIRECT1 and BASELINE config 5 with DIRECT7 and "
                          "DIRECT1, each timed for --other-seconds with its own roofline and oracle parity sample)")
     ap.add_argument("--other-seconds", type=float, default=0.35, help="timed region of every `other_configs` entry")
+    ap.add_argument("--no-stream", action="store_true", help="skip the streamed job: `value` is then the synchronous job's rate (as in rounds 1-4)")
+    ap.add_argument("--stream-contexts", type=int, default=3, help="batches resident in the engine's stream mode (2..4)")
+    ap.add_argument("--stream-batches", type=int, default=3, help="distinct batches the streamed job rotates through")
     ap.add_argument("--kitti-dir", default=None,
                     help="a KITTI odometry sequence's velodyne directory (<seq>/velodyne/*.bin, N x 4 f32): consecutive frames (k, k+1) become the "
                          "pairs of the run instead of the synthetic scans (scripts/lidar_odom_kitti.sh:6); clouds are ragged, `data` says \"kitti\"")
@@ -730,6 +733,143 @@ def timed_job(ctx, eng, W, nb, job_total, steps, warmup, min_seconds=0.5):
             "gather_ms_per_step": None if gather_ms is None else round(gather_ms, 4), "gather_check": gather_check, "B": nb}
 
 
+def timed_stream_job(ctx, eng, W, nb, job_total, steps, warmup, n_batches=3, n_contexts=3, ref=None):
+    """The same job as timed_job, STREAMED (mi355ndt_stream_*): step i is batch i mod `n_batches` -- distinct batches of `nb` pair slots of W --
+    submitted without waiting for the one before; a launch hands its last unfinished pairs to the next, results are collected `n_contexts`
+    steps later (scan_matching_odom_nodelet.cpp:144-183: the node consumes a stream of frames; BASELINE config 3: "streamed through 1 GPU").
+    Timed like timed_job: barrier + synchronize on both sides of EXACTLY `steps` steps, every step's results on the host inside the region
+    (the last ones through the flush).  `ref`: per distinct batch the synchronous results, compared word for word after the clock stops."""
+    ndt, shard, dist, dev, on_dev, use_dist = ctx.ndt, ctx.shard, ctx.dist, ctx.dev, ctx.on_dev, ctx.use_dist
+    avail = len(W["ids"]) // nb
+    n_batches = max(1, min(n_batches, avail))
+    cap = shard.shard_capacity(job_total, ctx.world)
+    fsz = 4 * 3 * W["pitch"]                                  # bytes per pair slot of a cloud buffer
+    slots = [(W["T"].data_ptr() + k * nb * fsz, W["tcnt"][k * nb:(k + 1) * nb], W["S"].data_ptr() + k * nb * fsz, W["scnt"][k * nb:(k + 1) * nb]) for k in range(n_batches)]
+    guesses = np.ascontiguousarray(np.broadcast_to(ctx.G.T.reshape(1, 16), (nb, 16)), dtype=np.float32)
+    res = [(ndt.Result * nb)() for _ in range(n_batches)]
+    rec_host = torch.empty(cap, shard.REC_WORDS, dtype=torch.int32).pin_memory() if use_dist else None
+    rec_dev = torch.empty(cap, shard.REC_WORDS, device=dev, dtype=torch.int32) if use_dist else None
+    gathered = torch.empty(ctx.world * cap, shard.REC_WORDS, device=dev if on_dev else "cpu", dtype=torch.int32) if use_dist else None
+    gather_ev, gather_host_s = [], [0.0]
+    lib = ndt.load_library()
+    import ctypes as C
+    eng.stream_begin(n_contexts, nb, W["pitch"], W["pitch"])
+    state = {"sub": 0, "col": 0, "ids": []}
+
+    def gather(k, timed):
+        # the pose records of a collected batch: packed on the host from its results (the GPU is busy with the next launch), then the
+        # same all-gather as the synchronous job
+        lib.mi355ndt_pack_pose_records(C.cast(res[k], C.c_void_p), nb, ctx.rank, ctx.world, C.c_void_p(rec_host.data_ptr()), cap)
+        h0 = time.perf_counter()
+        if on_dev:
+            if gather_ev:
+                gather_ev[-1][1].synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            rec_dev.copy_(rec_host, non_blocking=True)
+            e0.record()
+            shard.gather_records(rec_dev, gathered)
+            e1.record()
+            if timed:
+                gather_ev.append((e0, e1))
+        else:
+            shard.gather_records(rec_host, gathered)
+            if timed:
+                gather_host_s[0] += time.perf_counter() - h0
+
+    def collect_one(timed):
+        k = state["col"] % n_batches
+        eng.stream_collect_raw(state["ids"][state["col"]], res[k])
+        state["col"] += 1
+        if use_dist:
+            gather(k, timed)
+
+    def step(timed=False):
+        if state["sub"] - state["col"] >= n_contexts:
+            collect_one(timed)
+        k = state["sub"] % n_batches
+        T, tc, S, sc = slots[k]
+        state["ids"].append(eng.stream_submit(T, tc, W["pitch"], S, sc, W["pitch"], guesses))
+        state["sub"] += 1
+
+    def drain(timed=False):
+        while state["col"] < state["sub"]:
+            collect_one(timed)
+
+    eng.profile_enable(True)
+    gc.collect()
+    gc.disable()
+    for _ in range(max(warmup, n_contexts)):           # (the first submits build synchronously: they make the stream's build plan)
+        step()
+    drain()
+    eng.profile_reset()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step_ms, tp = [], t0
+    for _ in range(steps):
+        step(True)
+        tn = time.perf_counter()
+        step_ms.append(1e3 * (tn - tp))
+        tp = tn
+    drain(True)                                        # every step's results are on the host before the clock stops
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    prof = eng.profile_get()
+    eng.profile_enable(False)
+    eng.stream_end()
+    gather_ms = None
+    if use_dist:
+        gather_ms = (sum(e0.elapsed_time(e1) for e0, e1 in gather_ev) if on_dev else 1e3 * gather_host_s[0]) / max(1, steps)
+    if dist is not None:
+        tt = torch.tensor([dt, gather_ms], device=dev if on_dev else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, gather_ms = float(tt[0].item()), float(tt[1].item())
+    gather_check = None
+    if dist is not None:
+        k_last = (state["col"] - 1) % n_batches
+        got = shard.unpack_records(gathered)
+        mine = np.frombuffer(res[k_last], dtype=RES_DT)
+        perm = sorted(got) == list(range(job_total))
+        own = all(np.array_equal(got[ctx.rank + j * ctx.world]["final"], mine["final"][j].reshape(4, 4).T) and got[ctx.rank + j * ctx.world]["iterations"] == int(mine["it"][j])
+                  for j in range(nb)) if perm else False
+        assert perm and own, "pose gather of the streamed job lost, duplicated or changed records"
+        ok = torch.tensor([int(perm and own)], dtype=torch.int32, device=dev if on_dev else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        gather_check = {"pairs_gathered": len(got), "permutation_of_all_pair_ids": bool(perm), "own_records_bit_identical_on_every_rank": bool(ok.item()),
+                        "record_bytes": 96, "records_per_rank": cap, "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                        "packed_on_device": False, "host_hop": True,
+                        "why_packed_on_the_host": "a collected batch's results are on the host anyway and the GPU is inside the next batch's launch (mi355ndt_pack_pose_records)"}
+    same = None
+    if ref is not None:                                # word for word against the synchronous align of the same batches
+        same = all(bytes(res[k]) == bytes(ref[k]) for k in range(min(n_batches, len(ref))))
+        assert same, "streamed results differ from the synchronous results of the same pairs"
+    return {"dt": dt, "steps": steps, "step_ms": step_ms, "prof": prof, "res": res[0], "res_np": np.frombuffer(res[0], dtype=RES_DT), "guesses": guesses,
+            "gather_ms_per_step": None if gather_ms is None else round(gather_ms, 4), "gather_check": gather_check, "B": nb, "n_batches": n_batches, "n_contexts": n_contexts,
+            "bit_identical_to_synchronous": same,
+            "launches": int(prof["stream_launches"]), "pairs_handed_over": int(prof["stream_carried"]), "batches_rerun": int(prof["stream_redone"]),
+            "launches_that_gave_up": int(prof["async_fallbacks"])}
+
+
+def sync_reference(ctx, eng, W, nb, n_batches):
+    """synchronous results (build + batch_align) of the first `n_batches` distinct batches of `nb` pair slots: what the stream must reproduce"""
+    ndt = ctx.ndt
+    n_batches = max(1, min(n_batches, len(W["ids"]) // nb))
+    fsz = 4 * 3 * W["pitch"]
+    guesses = np.ascontiguousarray(np.broadcast_to(ctx.G.T.reshape(1, 16), (nb, 16)), dtype=np.float32)
+    out = []
+    for k in range(n_batches):
+        eng.batch_bind_device(W["T"].data_ptr() + k * nb * fsz, W["tcnt"][k * nb:(k + 1) * nb], W["pitch"], W["S"].data_ptr() + k * nb * fsz, W["scnt"][k * nb:(k + 1) * nb], W["pitch"])
+        eng.batch_build_targets()
+        r = (ndt.Result * nb)()
+        eng.batch_align_raw(guesses, r)
+        out.append(r)
+    return out
+
+
 F32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: vector f32 peak (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz, x2 for packed)
 FLOP_PER_HIT = 450.0          # SURVEY.md 8(d): ~450 flop per (point, voxel) evaluation
 
@@ -739,7 +879,7 @@ def sweep_roofline(J):
     sw_s = prof["sweep_ms"] * 1e-3
     ach = (prof["sweep_alg_bytes"] / sw_s / 1e9) if sw_s > 0 else 0.0
     tfl = (FLOP_PER_HIT * prof["sweep_hits"] / sw_s / 1e12) if sw_s > 0 else 0.0
-    one_launch = prof["sweep_launches"] == steps and prof["update_launches"] == 0     # ndt_async.hpp: the whole batch align is one launch
+    one_launch = prof["update_launches"] == 0 and (prof["sweep_launches"] == steps or prof.get("stream_launches", 0) > 0)   # ndt_async.hpp: the whole batch align is one launch
     return {"bound": "hbm", "kernel": "k_align_async (one launch per batch align: every derivative sweep and Newton update of every pair)" if one_launch else "k_sweep",
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4),
@@ -768,8 +908,9 @@ def other_configs_block(ctx, a, synth, W_head):
     ndt = ctx.ndt
     p5, az5 = max(1, a.pairs * 128 // 271), 2 * a.azimuth
     t0 = time.perf_counter()
-    W5, gen5 = generate_synthetic(ctx, synth, list(range(p5)), az5)
-    specs = [("ndt_pca_direct1", dict(variant="pca", mode="direct1", resolution=1.0), W_head, min(a.pairs, len(W_head["ids"])), a.azimuth),
+    nb5 = max(1, a.stream_batches) if not a.no_stream else 1
+    W5, gen5 = generate_synthetic(ctx, synth, list(range(p5 * nb5)), az5)
+    specs = [("ndt_pca_direct1", dict(variant="pca", mode="direct1", resolution=1.0), W_head, min(a.pairs, len(W_head["ids"])), a.azimuth),   # (W_head holds the headline's distinct batches)
              ("config5_direct7", dict(variant="pca", mode="direct7", resolution=0.5), W5, p5, az5),
              ("config5_direct1", dict(variant="pca", mode="direct1", resolution=0.5), W5, p5, az5)]
     out = {}
@@ -779,8 +920,13 @@ def other_configs_block(ctx, a, synth, W_head):
         eng = ndt.Engine(prm, device=ctx.local)
         eng.set_option(ndt.OPT_F32_SUM_ORDER, a.f32_sum_order)
         J = timed_job(ctx, eng, W, nb, nb, None, 2, min_seconds=a.other_seconds)
-        r = sweep_roofline(J)
+        r_sync = sweep_roofline(J)
         res_np = np.frombuffer(np.frombuffer(J["res"], dtype=np.uint8).copy(), dtype=RES_DT)
+        JS = None
+        if not a.no_stream and len(W["ids"]) >= 2 * nb:       # the same steps streamed (distinct batches back to back, stragglers handed over)
+            ref_sync = sync_reference(ctx, eng, W, nb, a.stream_batches)
+            JS = timed_stream_job(ctx, eng, W, nb, nb, J["steps"], 2, a.stream_batches, a.stream_contexts, ref_sync)
+        r = sweep_roofline(JS) if JS is not None else r_sync
         eng.close()
         parity = None
         if a.cpu_seconds > 0:
@@ -788,8 +934,12 @@ def other_configs_block(ctx, a, synth, W_head):
         N = az * 64
         out[name] = {"workload": f"{baseline_config_name(b, N)}: {nb} synthetic HDL-64E scan pairs ({N} pts per cloud), ndt_pca, {b.resolution} m voxels, {b.mode.upper()}, "
                                  "eps 0.01, max_iter 64; one step = voxelise every target + align every pair",
-                     "value": round(nb * J["steps"] / J["dt"], 2), "unit": "registrations/s", "steps": J["steps"], "warmup": 2,
-                     "ms_per_step": round(1e3 * J["dt"] / J["steps"], 3), "timed_s": round(J["dt"], 3),
+                     "value": round(nb * J["steps"] / (JS or J)["dt"], 2), "unit": "registrations/s", "steps": J["steps"], "warmup": 2,
+                     "ms_per_step": round(1e3 * (JS or J)["dt"] / J["steps"], 3), "timed_s": round((JS or J)["dt"], 3),
+                     "mode": "streamed" if JS is not None else "synchronous",
+                     "value_synchronous": round(nb * J["steps"] / J["dt"], 2), "ms_per_step_synchronous": round(1e3 * J["dt"] / J["steps"], 3),
+                     "roofline_frac_synchronous": r_sync["frac"], "avg_launch_us_synchronous": r_sync["avg_launch_us"],
+                     "stream": None if JS is None else {k: JS[k] for k in ("n_batches", "n_contexts", "bit_identical_to_synchronous", "launches", "pairs_handed_over", "batches_rerun", "launches_that_gave_up")},
                      "mean_iterations": round(float(res_np["it"].mean()), 2), "converged": int(res_np["conv"].sum()),
                      "roofline": {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us", "alg_bytes_per_launch",
                                                    "hits_per_point", "flops", "build_ms_per_step", "update_ms_per_step", "sweep_ms_per_step", "build_frac")},
@@ -867,8 +1017,11 @@ def main():
     c4_total = 0 if (strong or a.config4_pairs <= 0 or a.config4_pairs < world) else a.config4_pairs
     pair_ids = shard.shard_pairs(total, rank, world)           # round-robin shard of the global pair index space
     c4_ids = shard.shard_pairs(c4_total, rank, world) if c4_total else []
-    all_ids = pair_ids if len(pair_ids) >= len(c4_ids) else c4_ids
-    assert all_ids[:len(pair_ids)] == pair_ids and all_ids[:len(c4_ids)] == c4_ids
+    # the streamed job rotates through --stream-batches DISTINCT batches of the same size: more of the same sequence
+    want_stream = not a.no_stream and not a.prefiltered
+    st_ids = shard.shard_pairs(total * max(1, a.stream_batches), rank, world)[:len(pair_ids) * max(1, a.stream_batches)] if (want_stream and not a.kitti_dir) else pair_ids
+    all_ids = max((pair_ids, c4_ids, st_ids), key=len)
+    assert all_ids[:len(pair_ids)] == pair_ids and all_ids[:len(c4_ids)] == c4_ids and all_ids[:len(st_ids)] == st_ids
     B = len(pair_ids)
     # ---- inputs, resident in HBM before any timed region: [pair][3][pitch] SoA
     if a.kitti_dir:
@@ -899,6 +1052,13 @@ def main():
                   "largest_leaf_points": int(max(v["n"].max() for v in lv))}
     head_res = np.frombuffer(res, dtype=np.uint8).copy()       # (the config-4 block below re-binds the engine)
     res_np = np.frombuffer(head_res, dtype=RES_DT)
+
+    # ---- the same job streamed: distinct batches submitted back to back, a launch's stragglers finishing under the next batch
+    JS = None
+    if want_stream and len(W["ids"]) >= 2 * B:
+        ref_sync = sync_reference(ctx, eng, W, B, a.stream_batches)
+        assert bytes(ref_sync[0]) == bytes(head_res), "the synchronous align is not deterministic"
+        JS = timed_stream_job(ctx, eng, W, B, total, steps, a.warmup, a.stream_batches, a.stream_contexts, ref_sync)
 
     # ---- the drop-in path: host AoS clouds (pcl::PointXYZI records) in, PCIe inclusive -- rank 0's pairs
     host_path = None
@@ -943,12 +1103,14 @@ def main():
             dist.destroy_process_group()
         return
 
-    value = total * steps / dt
+    value_sync = total * steps / dt
+    value = total * JS["steps"] / JS["dt"] if JS is not None else value_sync
     its = res_np["it"].astype(np.float64)
     sweeps = res_np["sweeps"].astype(np.float64)
     # ---- roofline of the dominant kernel (derivative sweep): algorithmic bytes / HIP-event time
     wkey = f"{a.pairs if not strong else B}x{N}:{a.variant}:{a.mode}:{a.resolution}"
-    roof = sweep_roofline(J)
+    roof_sync = sweep_roofline(J)
+    roof = sweep_roofline(JS) if JS is not None else roof_sync
     traffic, traffic_source = a.traffic, "command line" if a.traffic is not None else None
     if traffic is None:       # PMC counters cannot be read from inside the timed run: the committed separate-pass measurement of this workload
         tp_ = None
@@ -986,7 +1148,8 @@ def main():
     kind = "KITTI" if W["data"] == "kitti" else "synthetic HDL-64E"
     out = {
         "metric": "NDT registrations/sec (64k-pt Velodyne pairs)", "value": round(value, 2), "unit": "registrations/s",
-        "n_gpus": world, "steps": steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / steps, 3),
+        "n_gpus": world, "steps": steps, "warmup": a.warmup, "ms_per_step": round(1e3 * (JS["dt"] if JS is not None else dt) / steps, 3),
+        "value_synchronous": round(value_sync, 2), "ms_per_step_synchronous": round(1e3 * dt / steps, 3),
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32 terms, f64 accumulation",
         "data": W["data"],
         "config": {"workload": (f"BASELINE config 4: {total} {kind} scan pairs sharded round-robin over {world} GPU(s) " if strong else
@@ -994,6 +1157,11 @@ def main():
                                 f"batch of {a.pairs} {kind} scan pairs per GPU ") +
                                f"({N} pts per cloud{' at most' if W['data'] == 'kitti' else ''}), ndt_{a.variant}, {a.resolution} m voxels, {a.mode.upper()}, eps 0.01, max_iter 64; "
                                "one step = voxelise every target + align every pair (+ RCCL pose all-gather when N>1)",
+                   "mode": (f"streamed: {JS['n_batches']} distinct batches of {B} pairs submitted back to back through mi355ndt_stream_* ({JS['n_contexts']} batches resident; a launch hands "
+                            "its last unfinished pairs to the next launch; every step's results on the host inside the timed region; bit-identical to the synchronous align); "
+                            "`value_synchronous` = the same steps through batch_build_targets + batch_align, one batch at a time") if JS is not None else
+                           "synchronous: batch_build_targets + batch_align, one batch at a time",
+                   "stream": None if JS is None else {k: JS[k] for k in ("n_batches", "n_contexts", "bit_identical_to_synchronous", "launches", "pairs_handed_over", "batches_rerun", "launches_that_gave_up")},
                    "pairs_total": total, "pairs_rank0": B, "points_per_cloud": N, "neighbor_mode": a.mode, "variant": a.variant,
                    "resolution_m": a.resolution, "f32_sum_order": a.f32_sum_order, "sharding": "pair i -> rank i mod N (round-robin)",
                    "mean_iterations": round(float(its.mean()), 2), "max_iterations_seen": int(its.max()),
@@ -1005,8 +1173,9 @@ def main():
                    "input_generation_s": round(t_gen, 2), "inputs": W["generated_on"],
                    "mean_points_per_source": round(float(np.mean(W["scnt"][:B])), 1)},
         "world_size": pg["world_size"], "process_group": pg,
-        "gather_ms_per_step": J["gather_ms_per_step"],
-        "roofline": roof, "roofline_valu": roof_valu, "cpu_baseline": cpu, "parity": parity, "gather_check": J["gather_check"],
+        "gather_ms_per_step": (JS if JS is not None else J)["gather_ms_per_step"],
+        "roofline_synchronous": None if JS is None else {k: roof_sync[k] for k in ("achieved", "frac", "launches", "avg_launch_us", "alg_bytes_per_launch", "build_ms_per_step", "sweep_ms_per_step")},
+        "roofline": roof, "roofline_valu": roof_valu, "cpu_baseline": cpu, "parity": parity, "gather_check": (JS if JS is not None and JS["gather_check"] is not None else J)["gather_check"],
         "config4": cfg4, "other_configs": others,
     }
     if seq_leg is not None:

@@ -1992,7 +1992,9 @@ static int stream_launch(mi355ndt_handle* h, int new_ci, int n_new) {
   }
   L.tab_dev = h->d_atab; L.ring = h->d_sring; L.ring_cap = h->s_ring_cap;
   L.ctl = h->d_sctl + (j & 1); L.prev = h->s_drop_carry ? nullptr : h->d_sctl + ((j + 1) & 1);
-  L.items_per_pair = h->s_items; L.stop_thresh = flush ? 0 : h->s_thresh; L.debug_abort_pos = h->debug_abort_pos;
+  // (the automatic threshold never hands over more than a quarter of the batch: a batch too small to fill the GPU has no bulk to hide stragglers under)
+  const bool thresh_given = h->s_thresh_opt >= 0 || std::getenv("MI355NDT_STREAM_THRESH");
+  L.items_per_pair = h->s_items; L.stop_thresh = flush ? 0 : (thresh_given ? h->s_thresh : std::min(h->s_thresh, n_new / 4)); L.debug_abort_pos = h->debug_abort_pos;
   h->ev_last_fresh = false;                          // (the contexts' builds sit between two launches on this stream)
   int rc = launch_async(h, sc, L);
   if (rc) return rc;

@@ -306,6 +306,8 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
   unsigned pose_w = sweep_pose_words(tab->c[tw >> ASYNC_CTX_SHIFT].st + (tw & ((1 << ASYNC_CTX_SHIFT) - 1)));
 #pragma unroll 1
   for (;;) {
+    // (test hook, MI355NDT_OPT_DEBUG_ASYNC_ABORT: the wave that claimed this position of ring 0 gives up as a wave whose ticket never came would)
+    if (x == 0 && pos == debug_abort_pos) { if (lane == 0) give_up(); break; }
     const int rem = (int)(pos % (unsigned)Iu) * CLAIM;
     TL_STAMP(10);                                  // hand-over: claim, ticket, (update)
     const AsyncCtx C = tab->c[tw >> ASYNC_CTX_SHIFT];   // (wave-uniform: scalar loads of a table nobody writes during the launch)
@@ -347,8 +349,6 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
                    );
       TL_STAMP(15);                                // the deferred re-basing (off the pair's critical path)
     }
-    // (test hook, MI355NDT_OPT_DEBUG_ASYNC_ABORT: the wave that claimed this position of ring 0 gives up as a wave whose ticket never came would)
-    if (x == 0 && npos == debug_abort_pos) { if (lane == 0) give_up(); break; }
     if (ntw < 0) {                                 // the next position's ticket does not exist yet
       ntw = wait_ticket(tn, ntw);
       if (ntw < 0) break;

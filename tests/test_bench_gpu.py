@@ -106,6 +106,43 @@ def test_plain_gpus_2_launches_two_ranks_by_itself():
         assert bad.returncode != 0 and "GPU(s) visible" in bad.stderr and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
 
 
+def test_eight_ranks_on_one_device_gloo():
+    """The scaling run's largest shape, as far as one GPU allows: `bench.py --gpus 8` as EIGHT ranks (gloo; all on cuda:0), the weak-scaling job
+    (2 pairs per rank, streamed) and the config-4-style fixed job of 13 pairs (uneven: five ranks own 2, three own 1 + a padding row)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["LV_SLAM_BENCH_BACKEND"] = "gloo"
+    args = ["--gpus", "8", "--pairs", "2", "--azimuth", "128", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--config4-pairs", "13"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["world_size"] == 8 and d["process_group"]["world_size"] == 8 and d["process_group"]["backend"] == "gloo"
+    assert d["config"]["pairs_total"] == 16 and d["config"]["pairs_rank0"] == 2
+    g = d["gather_check"]
+    assert g["pairs_gathered"] == 16 and g["permutation_of_all_pair_ids"] and g["own_records_bit_identical_on_every_rank"] and g["world_size"] == 8
+    c4 = d["config4"]
+    assert c4["pairs_total"] == 13 and c4["pairs_rank0"] == 2 and c4["n_gpus"] == 8
+    g4 = c4["gather_check"]
+    assert g4["pairs_gathered"] == 13 and g4["records_per_rank"] == 2 and g4["permutation_of_all_pair_ids"] and g4["own_records_bit_identical_on_every_rank"]
+    assert d["config"]["stream"]["bit_identical_to_synchronous"] is True and d["value_synchronous"] > 0
+
+
+def test_streamed_headline_carries_both_rates():
+    """The N = 1 line: `value` is the streamed job (distinct batches back to back through mi355ndt_stream_*), `value_synchronous` the same steps one
+    batch at a time; the streamed results are bit-identical to the synchronous ones, pairs really were handed from launch to launch."""
+    d = run_bench(["--pairs", "24", "--azimuth", "512", "--steps", "6", "--warmup", "1", "--cpu-seconds", "0", "--no-host-clouds", "--config4-pairs", "0", "--seq-frames", "0",
+                   "--no-other-configs"])
+    st = d["config"]["stream"]
+    assert st["n_batches"] == 3 and st["n_contexts"] == 3 and st["bit_identical_to_synchronous"] is True and st["batches_rerun"] == 0 and st["launches_that_gave_up"] == 0
+    assert st["launches"] >= 6 and st["pairs_handed_over"] > 0
+    assert d["value"] > 0 and d["value_synchronous"] > 0 and "streamed" in d["config"]["mode"]
+    assert d["roofline"]["launches"] >= 6 and d["roofline_synchronous"]["launches"] == 6
+    d0 = run_bench(["--pairs", "8", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-host-clouds", "--config4-pairs", "0", "--seq-frames", "0",
+                    "--no-other-configs", "--no-stream"])
+    assert d0["config"]["stream"] is None and d0["value"] == d0["value_synchronous"] and d0["config"]["mode"].startswith("synchronous")
+
+
 def test_kitti_directory_as_input(tmp_path):
     """--kitti-dir: a KITTI-shaped sequence (here five synthetic scans written as velodyne/%06d.bin, one of them cut short so the
     clouds are ragged) -> consecutive frame pairs -> the same timed step, `data` = "kitti", parity against the oracle on the same clouds."""

@@ -49,22 +49,36 @@ def _worker(rank, world, port, n_total, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [6, 7, 4541])      # 4541 = BASELINE config 4 (uneven shards: 2271 + 2270)
-def test_gather_world2_gloo(n_total):
+def _run_world(world, n_total):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = [q.get(timeout=120) for _ in procs]
+    out = [q.get(timeout=240) for _ in procs]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
-    assert sorted(out) == [(0, True), (1, True)]
+    assert sorted(out) == [(r, True) for r in range(world)]
+
+
+@pytest.mark.parametrize("n_total", [6, 7, 4541])      # 4541 = BASELINE config 4 (uneven shards: 2271 + 2270)
+def test_gather_world2_gloo(n_total):
+    _run_world(2, n_total)
+
+
+@pytest.mark.parametrize("n_total", [13, 4541])        # 4541 over eight ranks: five shards of 568, three of 567 with a padding row each
+def test_gather_world8_gloo(n_total):
+    """The node the scaling run uses has eight GPUs (BASELINE config 4: 4,541 pairs round-robin over 8): eight ranks, uneven shards, padding
+    rows on three of them, every record back bit-identical on every rank (independence anchor: scan_matching_odom_nodelet.cpp:240-250)."""
+    cap = D.shard_capacity(n_total, 8)
+    sizes = [len(D.shard_pairs(n_total, r, 8)) for r in range(8)]
+    assert sum(sizes) == n_total and max(sizes) == cap and (n_total != 4541 or (sizes.count(568) == 5 and sizes.count(567) == 3))
+    _run_world(8, n_total)
 
 
 def test_records_roundtrip_single_process():

@@ -32,17 +32,24 @@ def resident_batch(pair_ids, naz):
     return T, S, host, n
 
 
-def run_and_check(pair_ids, naz, kw, check_motion=True):
+def run_and_check(pair_ids, naz, kw, check_motion=True, oracle_pairs=None, one_launch=None):
+    """oracle_pairs: batch slots held against the oracle (default: all); one_launch: assert that the align took (True) / did not take (False)
+    the one-launch path of ndt_async.hpp -- the DEFAULT choice of the engine for that batch, nothing forced."""
     T, S, host, n = resident_batch(pair_ids, naz)
     B = len(pair_ids)
     eng = ndt.Engine(ndt.default_params(**kw))
     eng.batch_bind_device(T.data_ptr(), [n] * B, n, S.data_ptr(), [n] * B, n)
     eng.batch_build_targets()
     G = synth.default_guess()
+    eng.profile_enable(True); eng.profile_reset()
     res = eng.batch_align(G)
+    pr = eng.profile_get()
+    eng.profile_enable(False)
+    if one_launch is not None:
+        assert (pr["sweep_launches"] == 1 and pr["update_launches"] == 0 and pr["async_fallbacks"] == 0) == one_launch, pr
     op = O.default_params(**kw)
     worst = [0.0, 0.0]
-    for k in range(B):
+    for k in (range(B) if oracle_pairs is None else oracle_pairs):
         tgt, src, dT = host[k]
         grid = O.Grid(tgt, op)
         # voxel grid of this pair: bounds, cells, counts, f64 means, f32 inverse covariances, pca weights -- bit-exact
@@ -78,13 +85,28 @@ def run_and_check(pair_ids, naz, kw, check_motion=True):
 
 def test_config3_shaped_batch_vs_oracle():
     """16 consecutive 65,536-pt pairs (pairs 0..15 of config 3), ndt_omp, 1 m, DIRECT7."""
-    run_and_check(list(range(16)), 1024, dict(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=ndt.DIRECT7, variant=0))
+    run_and_check(list(range(16)), 1024, dict(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=ndt.DIRECT7, variant=0), one_launch=False)
 
 
 @pytest.mark.parametrize("mode", [ndt.DIRECT7, ndt.DIRECT1])
 def test_config5_full_size_vs_oracle(mode):
     """config 5: 131,072-pt clouds, ndt_pca, 0.5 m voxels; three pairs in one device-resident batch."""
     run_and_check([0, 1, 7], 2048, dict(resolution=0.5, trans_epsilon=0.01, max_iterations=64, neighbor_mode=mode, variant=1))
+
+
+def test_config3_batch_just_above_the_one_launch_threshold_vs_oracle():
+    """17 pairs x 128 work items = 2,176 > 2,048 resident waves: the first batch size of config 3's shape that the engine aligns as ONE
+    persistent launch by default (16 pairs, the test above, still take the rounds).  Every pair against the oracle."""
+    run_and_check(list(range(16, 33)), 1024, dict(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=ndt.DIRECT7, variant=0), one_launch=True)
+
+
+@pytest.mark.parametrize("mode", [ndt.DIRECT7, ndt.DIRECT1])
+def test_config5_per_gpu_share_default_path_vs_oracle(mode):
+    """BASELINE config 5's per-GPU share as bench.py's `other_configs` runs it: 128 pairs x 131,072 points, ndt_pca, 0.5 m -- through the
+    engine's DEFAULT path, asserted to be the one-launch align (profile: one sweep launch, no update launch) --, 16 pairs spread over the
+    batch against the oracle: grids bit-exact, equal iterations / hits, SE(3) inside the tolerance."""
+    run_and_check(list(range(128)), 2048, dict(resolution=0.5, trans_epsilon=0.01, max_iterations=64, neighbor_mode=mode, variant=1),
+                  oracle_pairs=list(range(0, 128, 8)), one_launch=True)
 
 
 def test_nodelet_configuration_batch_vs_oracle():
