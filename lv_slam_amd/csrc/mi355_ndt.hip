@@ -150,12 +150,11 @@ struct mi355ndt_handle {
   // asynchronous target build (stream mode: the engine is one batch context of a parent handle).  A build normally waits for two words
   // from the device -- the bitmap words of all grids (pool size) and the largest grid (sort key width); with a PLAN from earlier builds of
   // the stream it does not: it sorts plan_cb key bits, clears plan_words pool words, and k_build_check turns every grid of the batch into
-  // "no grid" (and raises d_bflag) should the batch not fit the plan -- the parent then re-runs that batch synchronously and learns.
+  // "no grid" (and raises its flag in d_bstat) should the batch not fit the plan -- the parent then re-runs that batch synchronously and learns.
   bool async_build = false;
   int plan_cb = 0; size_t plan_words = 0;
-  unsigned* d_bflag = nullptr;                    // [0] plan exceeded
-  unsigned* h_pin_binfo = nullptr;                // pinned: [0] total bitmap words, [1] cells of the largest grid, [2] plan exceeded (last planned build)
-  int* h_pin_cnt = nullptr; size_t pin_cnt_cap = 0;   // pinned staging of the point counts (target counts, then source counts)
+  unsigned* d_bstat = nullptr;                    // (not owned: the parent's CtxStat of this context) [1] total words, [2] largest grid, [3] plan exceeded
+  bool counts_preloaded = false;                  // the parent has put this batch's point counts (and guesses) on the device already
   size_t last_total_words = 0;                    // of the last synchronous build
 
   // ---- stream mode (mi355ndt_stream_*, the parent handle): n_contexts batches resident, one persistent launch per submitted batch,
@@ -167,9 +166,13 @@ struct mi355ndt_handle {
     bool redo = false;                            // collect re-runs it synchronously (its launch gave up)
     bool done_sync = false;                       // processed synchronously inside submit (configuration the one-launch align does not serve)
     long long launch = -1;                        // the launch that started it
-    unsigned* d_done = nullptr;                   // pairs finalised so far
-    mi355ndt_result* h_res = nullptr;             // pinned snapshot of the context's results (after every launch)
-    unsigned* h_flags = nullptr;                  // pinned: [0] pairs finalised, [1] build plan exceeded
+    // a batch's small inputs -- target counts, source counts, guesses -- travel as ONE copy: pinned staging block -> device block, into which
+    // the context engine's d_tgt_cnt / d_src_cnt / d_guess point
+    int* h_in = nullptr; int* d_in = nullptr; size_t in_bytes = 0;
+    void *own_tgt_cnt = nullptr, *own_src_cnt = nullptr, *own_guess = nullptr;   // the engine's own arrays (put back before it is destroyed)
+    // results: MAPPED host memory -- a pair's result record is written there by the updater that finalises it (posted PCIe writes), no copy
+    mi355ndt_result* h_res = nullptr; mi355ndt_result* d_res_map = nullptr;
+    std::vector<float> guesses;                   // (kept for a synchronous re-run)
   };
   bool stream_on = false, s_sync_only = false, s_drop_carry = true;
   int s_nctx = 0, s_max_pairs = 0, s_items = 0, s_ring_cap = 0, s_thresh = 0;
@@ -179,9 +182,9 @@ struct mi355ndt_handle {
   long long s_next_id = 0, s_launches = 0, s_counted = 0;
   AsyncCtl* d_sctl = nullptr;                     // two control blocks: a launch reads the hand-over list of the previous one
   int* d_sring = nullptr;
+  CtxStat* d_sstat = nullptr;                     // per context: pairs finalised, sizes and verdict of its last planned build
   static constexpr int S_EV = 16;
-  hipEvent_t s_ev[S_EV] = {};                     // one per launch (ring)
-  unsigned* h_pin_sinfo = nullptr;                // pinned: per launch slot {abort_, susp, fin, n_live}
+  volatile StreamStatus* h_sstatus = nullptr; StreamStatus* d_sstatus = nullptr;   // mapped ring of per-launch status slots (k_stream_status)
 
   // profiling
   bool prof = false;
@@ -414,9 +417,6 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
   if (h->ev_compute) (void)hipEventDestroy(h->ev_compute);
   for (hipStream_t cs : h->copy_stream) if (cs) (void)hipStreamDestroy(cs);
   if (h->h_pin_actl) (void)hipHostFree(h->h_pin_actl);
-  if (h->d_bflag) (void)hipFree(h->d_bflag);
-  if (h->h_pin_binfo) (void)hipHostFree(h->h_pin_binfo);
-  if (h->h_pin_cnt) (void)hipHostFree(h->h_pin_cnt);
   if (h->h_pin_u) (void)hipHostFree(h->h_pin_u);
   if (h->h_pin_active) (void)hipHostFree(h->h_pin_active);
   if (h->h_pin_guess) (void)hipHostFree(h->h_pin_guess);
@@ -812,12 +812,8 @@ static int build_targets_impl(mi355ndt_handle* h) {
   const size_t pitch = h->tgt_pitch;
   const size_t total = (size_t)B * pitch;
   hipStream_t s = h->stream;
-  if (h->async_build && h->h_pin_cnt && h->pin_cnt_cap >= (size_t)B) {
-    // stream mode: the counts travel through pinned memory, nothing waits (the context's previous batch, which used the staging
-    // copy last, is long finished)
-    memcpy(h->h_pin_cnt, h->h_tgt_cnt.data(), B * sizeof(int));
-    HIPCHK(h, hipMemcpyAsync(h->d_tgt_cnt, h->h_pin_cnt, B * sizeof(int), hipMemcpyHostToDevice, s));
-    h->up_tgt_cnt.clear();
+  if (h->async_build && h->counts_preloaded) {
+    h->up_tgt_cnt.clear();                          // stream mode: the counts came with the batch's one input copy (mi355ndt_stream_submit)
   } else if (h->up_tgt_cnt.size() != (size_t)B || !std::equal(h->up_tgt_cnt.begin(), h->up_tgt_cnt.end(), h->h_tgt_cnt.begin())) {
     HIPCHK(h, hipMemcpyAsync(h->d_tgt_cnt, h->h_tgt_cnt.data(), B * sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHK(h, hipStreamSynchronize(s));   // h_tgt_cnt is pageable
@@ -856,12 +852,10 @@ static int build_targets_impl(mi355ndt_handle* h) {
   k_word_offsets<<<1, 1024, 0, s>>>(h->d_grid, h->d_nwords, B, h->d_word_off);   // d_word_off[0] = total words, [1] = largest grid
   size_t total_words;
   int cb;
-  const bool planned = h->async_build && h->plan_cb > 0 && h->plan_words > 0 && h->plan_words <= h->words_cap && h->d_bflag && h->h_pin_binfo;
+  const bool planned = h->async_build && h->plan_cb > 0 && h->plan_words > 0 && h->plan_words <= h->words_cap && h->d_bstat;
   if (planned) {
     // no wait: the plan's key width and pool size, checked on the device (a batch that does not fit loses its grids and is flagged)
-    k_build_check<<<(B + 255) / 256, 256, 0, s>>>(h->d_word_off, h->d_grid, h->d_nwords, B, (unsigned)std::min(h->plan_words, (size_t)0xFFFFFFFFu), h->plan_cb, h->d_bflag);
-    HIPCHK(h, hipMemcpyAsync(h->h_pin_binfo, h->d_word_off, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipMemcpyAsync(h->h_pin_binfo + 2, h->d_bflag, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    k_build_check<<<(B + 255) / 256, 256, 0, s>>>(h->d_word_off, h->d_grid, h->d_nwords, B, (unsigned)std::min(h->plan_words, (size_t)0xFFFFFFFFu), h->plan_cb, h->d_bstat + 1);
     total_words = h->plan_words;
     cb = h->plan_cb;
   } else {
@@ -871,7 +865,7 @@ static int build_targets_impl(mi355ndt_handle* h) {
     cb = std::max(1, ceil_log2(h->h_pin_u[1] + 1u));   // cell field: every cell index + the all-ones "not binned" value
     if (h->async_build) cb = std::max(cb, h->plan_cb);        // (a wider field sorts the same order: the plan only ever grows)
     h->last_total_words = total_words;
-    if (h->d_bflag) HIPCHK(h, hipMemsetAsync(h->d_bflag, 0, sizeof(unsigned), s));
+    if (h->d_bstat) HIPCHK(h, hipMemsetAsync(h->d_bstat + 3, 0, sizeof(unsigned), s));
   }
   if (total_words > h->words_cap) {
     size_t c = h->words_cap;
@@ -1102,7 +1096,7 @@ struct AsyncLaunch {
   AsyncTab tab;
   int new_ci = 0, n_new = 0;                       // context and number of the pairs that START in this launch (0: only carried pairs)
   PairState* st_new = nullptr; const float* guess_new = nullptr; const int* src_cnt_new = nullptr; const GridDesc* gd_new = nullptr; unsigned* arrived_new = nullptr;
-  int* active_list = nullptr; SweepCtl* sweep_ctl = nullptr;
+  int* active_list = nullptr; SweepCtl* sweep_ctl = nullptr; unsigned* done_new = nullptr;
   AsyncTab* tab_dev = nullptr; int* ring = nullptr; int ring_cap = 0; AsyncCtl* ctl = nullptr; const AsyncCtl* prev = nullptr;
   int items_per_pair = 0, stop_thresh = 0; unsigned debug_abort_pos = 0xFFFFFFFFu;
 };
@@ -1134,7 +1128,7 @@ static int launch_async(mi355ndt_handle* h, const SweepConst& sc, const AsyncLau
   {
     const size_t n = std::max(std::max((size_t)8 * L.ring_cap, (size_t)L.n_new * ASYNC_ARR_STRIDE), sizeof(AsyncCtl) / sizeof(unsigned));
     k_async_prepare<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(L.tab, L.tab_dev, L.new_ci, L.n_new, L.st_new, L.guess_new, L.src_cnt_new, L.gd_new, L.arrived_new,
-                                                               L.active_list, L.sweep_ctl, L.ring, L.ring_cap, L.ctl, L.prev);
+                                                               L.active_list, L.sweep_ctl, L.ring, L.ring_cap, L.ctl, L.prev, L.done_new);
   }
   if (h->prof) HIPCHK(h, ev_begin(h, h->ev_sweep));
   int rc;
@@ -1872,22 +1866,29 @@ int mi355ndt_use_prefiltered(mi355ndt_handle* h, int role) {
 // ---- stream mode ----------------------------------------------------------------------------------------------------------
 // (include/mi355_ndt.h: mi355ndt_stream_*; kernels: ndt_async.hpp.  Replaces a run of batch_bind_device + batch_build_targets +
 //  batch_align triples for batches that arrive one after the other -- scan_matching_odom_nodelet.cpp:144-183 is a stream of frames.)
+// What a submit puts on the stream: ONE input copy, the build's kernels and two fills, the prepare kernel, the persistent launch, the
+// status kernel.  No device-to-host copy, no event: result records and launch status land in mapped host memory.  (The first form of
+// this path issued ~17 copies and fills per batch; at ~20 us of stream time each they cost more than the tail they removed.)
 static bool stream_async_ok(const mi355ndt_handle* h) {
   const bool pca_kd = h->prm.neighbor_mode == MI355NDT_KDTREE && h->prm.variant == MI355NDT_VARIANT_PCA;
   return h->async_align && !mt_is_live(h->prm) && !pca_kd;
 }
 static int stream_free(mi355ndt_handle* h) {
   for (auto& c : h->sctx) {
-    if (c.e) (void)mi355ndt_destroy(c.e);
-    if (c.d_done) (void)hipFree(c.d_done);
+    if (c.e) {
+      if (c.d_in) { c.e->d_tgt_cnt = (int*)c.own_tgt_cnt; c.e->d_src_cnt = (int*)c.own_src_cnt; c.e->d_guess = (float*)c.own_guess; }
+      c.e->d_bstat = nullptr;
+      (void)mi355ndt_destroy(c.e);
+    }
+    if (c.d_in) (void)hipFree(c.d_in);
+    if (c.h_in) (void)hipHostFree(c.h_in);
     if (c.h_res) (void)hipHostFree(c.h_res);
-    if (c.h_flags) (void)hipHostFree(c.h_flags);
     c = mi355ndt_handle::StreamCtx();
   }
   if (h->d_sctl) { (void)hipFree(h->d_sctl); h->d_sctl = nullptr; }
   if (h->d_sring) { (void)hipFree(h->d_sring); h->d_sring = nullptr; }
-  if (h->h_pin_sinfo) { (void)hipHostFree(h->h_pin_sinfo); h->h_pin_sinfo = nullptr; }
-  for (auto& e : h->s_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  if (h->d_sstat) { (void)hipFree(h->d_sstat); h->d_sstat = nullptr; }
+  if (h->h_sstatus) { (void)hipHostFree((void*)h->h_sstatus); h->h_sstatus = nullptr; h->d_sstatus = nullptr; }
   h->stream_on = false; h->s_nctx = 0;
   return MI355NDT_OK;
 }
@@ -1901,6 +1902,8 @@ int mi355ndt_stream_end(mi355ndt_handle* h) {
   for (int c = 0; c < h->s_nctx; c++) {
     mi355ndt_handle* e = h->sctx[c].e;
     if (!e) continue;
+    ev_collect(e, e->ev_sweep, h->P.sweep_ms, h->P.sweep_launches);
+    ev_collect(e, e->ev_update, h->P.update_ms, h->P.update_launches);
     ev_collect(e, e->ev_build, h->P.build_ms, h->P.build_launches);
     h->P.build_alg_bytes += e->P.build_alg_bytes; e->P.build_alg_bytes = 0;
   }
@@ -1931,6 +1934,8 @@ int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts, int max_pairs, siz
   h->s_ring_cap = async_ring_cap(h, (long long)max_pairs + ASYNC_MAX_CARRY);
   if (h->s_ring_cap == 0) h->s_sync_only = true;
   auto fail = [&](int rc) { (void)stream_free(h); return rc; };
+  if (hipMalloc((void**)&h->d_sstat, ASYNC_MAX_CTX * sizeof(CtxStat)) != hipSuccess ||
+      hipMemsetAsync(h->d_sstat, 0, ASYNC_MAX_CTX * sizeof(CtxStat), h->stream) != hipSuccess) return fail(MI355NDT_ERR_HIP);
   for (int c = 0; c < n_contexts; c++) {
     mi355ndt_handle::StreamCtx& S = h->sctx[c];
     int rc = mi355ndt_create(&h->prm, h->device, &S.e);
@@ -1940,26 +1945,28 @@ int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts, int max_pairs, siz
     if (rc) return fail(rc);
     e->f32_sum_order = h->f32_sum_order; e->async_align = h->async_align; e->dyn_shift = h->dyn_shift;
     e->async_build = true;
+    e->ev_pool_target = 128;
     rc = ensure_pair_arrays(e, max_pairs);          // every per-pair array at its final size: no allocation, no wait inside submit
     if (rc) { h->err = e->err; return fail(rc); }
-    if (hipMalloc((void**)&e->d_bflag, 64) != hipSuccess || hipHostMalloc((void**)&e->h_pin_binfo, 64) != hipSuccess ||
-        hipHostMalloc((void**)&e->h_pin_cnt, 2 * (size_t)max_pairs * sizeof(int)) != hipSuccess ||
-        hipMalloc((void**)&S.d_done, 64) != hipSuccess || hipHostMalloc((void**)&S.h_res, (size_t)max_pairs * sizeof(mi355ndt_result)) != hipSuccess ||
-        hipHostMalloc((void**)&S.h_flags, 64) != hipSuccess) { h->err = "stream_begin: allocation failed"; return fail(MI355NDT_ERR_HIP); }
-    e->pin_cnt_cap = (size_t)max_pairs;
-    memset(e->h_pin_binfo, 0, 64); memset(S.h_flags, 0, 64);
-    if (hipMemsetAsync(e->d_bflag, 0, 64, h->stream) != hipSuccess || hipMemsetAsync(S.d_done, 0, 64, h->stream) != hipSuccess) return fail(MI355NDT_ERR_HIP);
+    // the input block: [target counts | source counts | guesses]
+    S.in_bytes = (size_t)max_pairs * (2 * sizeof(int) + 16 * sizeof(float));
+    if (hipMalloc((void**)&S.d_in, S.in_bytes) != hipSuccess || hipHostMalloc((void**)&S.h_in, S.in_bytes) != hipSuccess ||
+        hipHostMalloc((void**)&S.h_res, (size_t)max_pairs * sizeof(mi355ndt_result), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&S.d_res_map, S.h_res, 0) != hipSuccess) { h->err = "stream_begin: allocation failed"; return fail(MI355NDT_ERR_HIP); }
+    S.own_tgt_cnt = e->d_tgt_cnt; S.own_src_cnt = e->d_src_cnt; S.own_guess = e->d_guess;
+    e->d_tgt_cnt = S.d_in; e->d_src_cnt = S.d_in + max_pairs; e->d_guess = (float*)(S.d_in + 2 * (size_t)max_pairs);
+    e->d_bstat = reinterpret_cast<unsigned*>(h->d_sstat + c);
     size_t need = (size_t)max_pairs * h->s_items * NACC;
     if (grow(e->d_partials, e->partials_cap, need) != hipSuccess || grow(e->d_arrived, e->arrived_cap, (size_t)max_pairs * ASYNC_ARR_STRIDE) != hipSuccess)
       { h->err = "stream_begin: allocation failed"; return fail(MI355NDT_ERR_HIP); }
-    e->ev_pool_target = 128;
     if (h->prof) (void)mi355ndt_profile_enable(e, 1);
   }
   if (hipMalloc((void**)&h->d_sctl, 2 * sizeof(AsyncCtl)) != hipSuccess || hipMemsetAsync(h->d_sctl, 0, 2 * sizeof(AsyncCtl), h->stream) != hipSuccess ||
-      hipHostMalloc((void**)&h->h_pin_sinfo, mi355ndt_handle::S_EV * 4 * sizeof(unsigned)) != hipSuccess) return fail(MI355NDT_ERR_HIP);
+      hipHostMalloc((void**)&h->h_sstatus, mi355ndt_handle::S_EV * sizeof(StreamStatus), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&h->d_sstatus, (void*)h->h_sstatus, 0) != hipSuccess) return fail(MI355NDT_ERR_HIP);
+  memset((void*)h->h_sstatus, 0, mi355ndt_handle::S_EV * sizeof(StreamStatus));
   if (!h->d_atab && hipMalloc((void**)&h->d_atab, sizeof(AsyncTab)) != hipSuccess) return fail(MI355NDT_ERR_HIP);
   if (!h->s_sync_only && hipMalloc((void**)&h->d_sring, (size_t)8 * h->s_ring_cap * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); h->s_sync_only = true; }
-  for (auto& e : h->s_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(MI355NDT_ERR_HIP);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   (void)max_tgt;
   h->stream_on = true;
@@ -1967,7 +1974,7 @@ int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts, int max_pairs, siz
 }
 
 // one persistent launch of the stream: the pairs the previous launch suspended + the `n_new` pairs of context `new_ci` (-1: a flush --
-// nothing new, everything runs to its end), then a snapshot of every busy context's results and counters into pinned memory
+// nothing new, everything runs to its end), then the status kernel (launch outcome + every context's counters -> mapped host memory)
 static int stream_launch(mi355ndt_handle* h, int new_ci, int n_new) {
   hipStream_t s = h->stream;
   SweepConst sc;
@@ -1979,7 +1986,8 @@ static int stream_launch(mi355ndt_handle* h, int new_ci, int n_new) {
     mi355ndt_handle* e = h->sctx[c].e;
     if (!e->d_src) continue;                         // never bound: no ticket can name it
     fill_async_ctx(e, L.tab.c[c]);
-    L.tab.c[c].n_done = h->sctx[c].d_done;
+    L.tab.c[c].results = h->sctx[c].d_res_map;
+    L.tab.c[c].n_done = &h->d_sstat[c].done;
     // the context the NEXT submit recycles must be finished by this launch; the others may hand their last pairs over
     L.tab.c[c].must_finish = (flush || c == (new_ci + 1) % h->s_nctx) ? 1 : 0;
   }
@@ -1988,7 +1996,7 @@ static int stream_launch(mi355ndt_handle* h, int new_ci, int n_new) {
   if (!flush) {
     mi355ndt_handle* e = h->sctx[new_ci].e;
     L.st_new = e->d_state; L.guess_new = e->d_guess; L.src_cnt_new = e->d_src_cnt; L.gd_new = e->d_grid; L.arrived_new = e->d_arrived;
-    L.active_list = e->d_active_list; L.sweep_ctl = nullptr;
+    L.active_list = e->d_active_list; L.sweep_ctl = nullptr; L.done_new = &h->d_sstat[new_ci].done;
   }
   L.tab_dev = h->d_atab; L.ring = h->d_sring; L.ring_cap = h->s_ring_cap;
   L.ctl = h->d_sctl + (j & 1); L.prev = h->s_drop_carry ? nullptr : h->d_sctl + ((j + 1) & 1);
@@ -1999,19 +2007,26 @@ static int stream_launch(mi355ndt_handle* h, int new_ci, int n_new) {
   int rc = launch_async(h, sc, L);
   if (rc) return rc;
   h->s_drop_carry = false;
-  for (int c = 0; c < h->s_nctx; c++) {
-    mi355ndt_handle::StreamCtx& S = h->sctx[c];
-    if (!S.busy || S.done_sync) continue;
-    HIPCHK(h, hipMemcpyAsync(S.h_res, S.e->d_results, (size_t)S.n_pairs * sizeof(mi355ndt_result), hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipMemcpyAsync(S.h_flags, S.d_done, sizeof(unsigned), hipMemcpyDeviceToHost, s));        // (after the results: a full count vouches for them)
-    HIPCHK(h, hipMemcpyAsync(S.h_flags + 1, S.e->d_bflag, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-  }
   const int slot = (int)(j % mi355ndt_handle::S_EV);
-  static_assert(offsetof(AsyncCtl, abort_) == 8 && offsetof(AsyncCtl, susp) == 16, "launch status words");
-  HIPCHK(h, hipMemcpyAsync(h->h_pin_sinfo + 4 * slot, &L.ctl->fin, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s));   // fin, abort_, n_live, susp
-  HIPCHK(h, hipEventRecord(h->s_ev[slot], s));
+  k_stream_status<<<1, 64, 0, s>>>(L.ctl, h->d_sstat, reinterpret_cast<volatile unsigned*>(h->d_sstatus + slot), (unsigned)(j + 1));
+  HIPCHK(h, hipGetLastError());
   h->s_launches++;
   h->P.stream_launches++;
+  return MI355NDT_OK;
+}
+
+// wait until launch j has reported (its status slot carries sequence number j + 1): the host polls mapped memory
+static int stream_wait_launch(mi355ndt_handle* h, long long j) {
+  volatile StreamStatus* st = h->h_sstatus + (j % mi355ndt_handle::S_EV);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0; st->seq != (unsigned)(j + 1); spins++) {
+    if ((spins & 1023) == 1023) {
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) { h->err = "stream: the device stopped reporting"; return MI355NDT_ERR_STATE; }
+      std::this_thread::yield();
+    } else cpu_relax();
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  for (; h->s_counted <= j; h->s_counted++) h->P.stream_carried += h->h_sstatus[h->s_counted % mi355ndt_handle::S_EV].susp;   // (launches finish in order)
   return MI355NDT_OK;
 }
 
@@ -2019,29 +2034,41 @@ int mi355ndt_stream_submit(mi355ndt_handle* h, int n_pairs, const float* d_t, co
                            const float* guesses, long long* batch_id) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   if (!h->stream_on) return MI355NDT_ERR_STATE;
-  if (n_pairs < 1 || n_pairs > h->s_max_pairs || !guesses || !batch_id) return MI355NDT_ERR_BAD_ARG;
+  if (n_pairs < 1 || n_pairs > h->s_max_pairs || !guesses || !batch_id || !tc || !scnt) return MI355NDT_ERR_BAD_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   const long long id = h->s_next_id;
   const int ci = (int)(id % h->s_nctx);
   mi355ndt_handle::StreamCtx& S = h->sctx[ci];
   if (S.busy) { h->err = "stream_submit: collect batch " + std::to_string(S.batch_id) + " first (its context is the one this batch needs)"; return MI355NDT_ERR_STATE; }
   mi355ndt_handle* e = S.e;
-  for (int b = 0; b < n_pairs; b++) if (scnt && (size_t)scnt[b] > (size_t)(h->s_items / QUARTERS) * CHUNK_PTS) return MI355NDT_ERR_BAD_ARG;   // more source points than stream_begin was told
+  for (int b = 0; b < n_pairs; b++) if ((size_t)scnt[b] > (size_t)(h->s_items / QUARTERS) * CHUNK_PTS) return MI355NDT_ERR_BAD_ARG;   // more source points than stream_begin was told
   int rc = mi355ndt_batch_bind_device(e, n_pairs, d_t, tc, tp, d_s, scnt, sp);
   if (rc) { h->err = e->err; return rc; }
   e->prm = h->prm;
   S.batch_id = id; S.n_pairs = n_pairs; S.redo = false; S.done_sync = false; S.launch = -1;
-  S.h_flags[0] = 0; S.h_flags[1] = 0;
-  memcpy(e->h_pin_guess, guesses, (size_t)n_pairs * 16 * sizeof(float));
+  S.guesses.assign(guesses, guesses + (size_t)n_pairs * 16);
+  auto run_sync = [&]() -> int {                     // build + align this batch here and now, results into the context's host buffer
+    e->async_build = false; e->counts_preloaded = false;
+    e->up_tgt_cnt.clear(); e->up_src_cnt.clear();
+    int r = mi355ndt_batch_build_targets(e);
+    if (r == MI355NDT_OK) r = mi355ndt_batch_align(e, S.guesses.data(), S.h_res);
+    e->async_build = true;
+    if (r) h->err = e->err;
+    return r;
+  };
   if (h->s_sync_only) {                              // a configuration the one-launch align does not serve: processed here and now
-    e->async_build = false;
-    rc = mi355ndt_batch_build_targets(e);
-    if (rc == MI355NDT_OK) rc = mi355ndt_batch_align(e, guesses, S.h_res);
-    if (rc) { h->err = e->err; return rc; }
+    rc = run_sync();
+    if (rc) return rc;
     S.done_sync = true; S.busy = true;
     *batch_id = id; h->s_next_id++;
     return MI355NDT_OK;
   }
+  // the batch's small inputs in one copy: point counts of both sides, guesses
+  memcpy(S.h_in, tc, (size_t)n_pairs * sizeof(int));
+  memcpy(S.h_in + h->s_max_pairs, scnt, (size_t)n_pairs * sizeof(int));
+  memcpy(S.h_in + 2 * (size_t)h->s_max_pairs, guesses, (size_t)n_pairs * 16 * sizeof(float));
+  HIPCHK(h, hipMemcpyAsync(S.d_in, S.h_in, (size_t)h->s_max_pairs * 2 * sizeof(int) + (size_t)n_pairs * 16 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  e->counts_preloaded = true; e->up_src_cnt.clear(); e->up_tgt_cnt.clear();
   // target build: against the stream's plan when there is one (no wait), else synchronously -- which makes the plan
   e->async_build = true;
   e->plan_cb = h->s_plan_cb; e->plan_words = h->s_plan_words;
@@ -2056,14 +2083,8 @@ int mi355ndt_stream_submit(mi355ndt_handle* h, int n_pairs, const float* d_t, co
     h->s_plan_cb = std::max(h->s_plan_cb, e->last_cb);
     h->s_plan_words = std::max(h->s_plan_words, e->last_total_words + e->last_total_words / 4 + 1024);
   }
-  // align workspace of this context: fixed row geometry for the whole stream (a pair's rows do not depend on it), counts and guesses
-  // through pinned memory
+  // align workspace of this context: fixed row geometry for the whole stream (a pair's rows do not depend on it)
   e->chunks_per_pair = h->s_items / QUARTERS; e->rows_per_pair = e->items_per_pair = h->s_items; e->pts_per_chunk = CHUNK_PTS; e->fine_it = 0;
-  memcpy(e->h_pin_cnt + h->s_max_pairs, e->h_src_cnt.data(), (size_t)n_pairs * sizeof(int));
-  HIPCHK(h, hipMemcpyAsync(e->d_src_cnt, e->h_pin_cnt + h->s_max_pairs, (size_t)n_pairs * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  e->up_src_cnt.clear();
-  HIPCHK(h, hipMemcpyAsync(e->d_guess, e->h_pin_guess, (size_t)n_pairs * 16 * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemsetAsync(S.d_done, 0, sizeof(unsigned), h->stream));
   gauss_constants3(h->prm.outlier_ratio, h->prm.resolution, h->gauss_last);
   S.busy = true;
   S.launch = h->s_launches;
@@ -2071,10 +2092,8 @@ int mi355ndt_stream_submit(mi355ndt_handle* h, int n_pairs, const float* d_t, co
   if (rc) {                                          // the launch cannot be made (not resident): this and every later batch synchronously
     h->s_sync_only = true;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    e->async_build = false;
-    rc = mi355ndt_batch_build_targets(e);
-    if (rc == MI355NDT_OK) rc = mi355ndt_batch_align(e, guesses, S.h_res);
-    if (rc) { S.busy = false; h->err = e->err; return rc; }
+    rc = run_sync();
+    if (rc) { S.busy = false; return rc; }
     S.done_sync = true;
   }
   e->aligned_once = true;
@@ -2086,9 +2105,11 @@ int mi355ndt_stream_submit(mi355ndt_handle* h, int n_pairs, const float* d_t, co
 // by its collect, and the next launch starts without a hand-over list
 static void stream_recover(mi355ndt_handle* h) {
   (void)hipStreamSynchronize(h->stream);
+  CtxStat st[ASYNC_MAX_CTX];
+  if (hipMemcpy(st, h->d_sstat, sizeof st, hipMemcpyDeviceToHost) != hipSuccess) memset(st, 0, sizeof st);
   for (int c = 0; c < h->s_nctx; c++) {
     mi355ndt_handle::StreamCtx& S = h->sctx[c];
-    if (S.busy && !S.done_sync && S.h_flags[0] != (unsigned)S.n_pairs) S.redo = true;
+    if (S.busy && !S.done_sync && st[c].done != (unsigned)S.n_pairs) S.redo = true;
   }
   h->s_drop_carry = true;
   h->P.async_fallbacks++;
@@ -2099,30 +2120,32 @@ int mi355ndt_stream_collect(mi355ndt_handle* h, long long batch_id, mi355ndt_res
   if (!h->stream_on) return MI355NDT_ERR_STATE;
   if (batch_id < 0 || batch_id >= h->s_next_id || !out) return MI355NDT_ERR_BAD_ARG;
   HIPCHK(h, hipSetDevice(h->device));
-  mi355ndt_handle::StreamCtx& S = h->sctx[batch_id % h->s_nctx];
+  const int ci = (int)(batch_id % h->s_nctx);
+  mi355ndt_handle::StreamCtx& S = h->sctx[ci];
   if (!S.busy || S.batch_id != batch_id) return MI355NDT_ERR_BAD_ARG;       // collected already (or its context has been recycled)
   mi355ndt_handle* e = S.e;
   if (!S.done_sync) {
     long long j = S.launch;
+    bool plan_exceeded = false;
     for (;;) {
-      const int slot = (int)(j % mi355ndt_handle::S_EV);
-      HIPCHK(h, hipEventSynchronize(h->s_ev[slot]));
-      for (; h->s_counted <= j; h->s_counted++) h->P.stream_carried += h->h_pin_sinfo[4 * (h->s_counted % mi355ndt_handle::S_EV) + 3];   // (launches finish in order)
-      if (h->h_pin_sinfo[4 * slot + 1]) { h->h_pin_sinfo[4 * slot + 1] = 0; stream_recover(h); }
-      if (S.redo || S.h_flags[1]) break;
-      if (S.h_flags[0] == (unsigned)S.n_pairs) break;
+      int rc = stream_wait_launch(h, j);
+      if (rc) return rc;
+      const StreamStatus st = *const_cast<const StreamStatus*>(h->h_sstatus + (j % mi355ndt_handle::S_EV));
+      if (st.abort_ && !S.redo) stream_recover(h);
+      plan_exceeded = st.ctx[ci].plan_exceeded != 0;
+      if (S.redo || plan_exceeded) break;
+      if (st.ctx[ci].done == (unsigned)S.n_pairs) break;
       if (j + 1 < h->s_launches) { j++; continue; }  // its stragglers ride in a later launch that is already queued
-      int rc = stream_launch(h, -1, 0);              // nothing newer: flush them
+      rc = stream_launch(h, -1, 0);                  // nothing newer: flush them
       if (rc) { stream_recover(h); S.redo = true; break; }
       j = h->s_launches - 1;
     }
-    if (S.redo || S.h_flags[1]) {
+    if (S.redo || plan_exceeded) {
       // the batch did not fit the build plan (its grids were withheld), or its launch gave up: the synchronous path, which also re-makes the plan
       HIPCHK(h, hipStreamSynchronize(h->stream));
-      e->async_build = false;
-      const std::vector<float> gs(e->h_pin_guess, e->h_pin_guess + (size_t)S.n_pairs * 16);    // (batch_align stages its guesses in that very buffer)
+      e->async_build = false; e->counts_preloaded = false; e->up_tgt_cnt.clear(); e->up_src_cnt.clear();
       int rc = mi355ndt_batch_build_targets(e);
-      if (rc == MI355NDT_OK) rc = mi355ndt_batch_align(e, gs.data(), S.h_res);
+      if (rc == MI355NDT_OK) rc = mi355ndt_batch_align(e, S.guesses.data(), S.h_res);
       e->async_build = true;
       if (rc) { h->err = e->err; S.busy = false; return rc; }
       h->s_plan_cb = std::max(h->s_plan_cb, e->last_cb);
@@ -2130,7 +2153,6 @@ int mi355ndt_stream_collect(mi355ndt_handle* h, long long batch_id, mi355ndt_res
       // the synchronous align re-computed its own row geometry: back to the stream's for this context's next batch
       e->chunks_per_pair = h->s_items / QUARTERS; e->rows_per_pair = e->items_per_pair = h->s_items; e->pts_per_chunk = CHUNK_PTS; e->fine_it = 0;
       if (grow(e->d_partials, e->partials_cap, (size_t)h->s_max_pairs * h->s_items * NACC) != hipSuccess) return MI355NDT_ERR_HIP;
-      S.h_flags[1] = 0;
       h->P.stream_redone++;
     }
   }

@@ -43,6 +43,11 @@ struct AsyncCtx {
   int pad_;
 };
 struct AsyncTab { AsyncCtx c[ASYNC_MAX_CTX]; };
+// stream mode, per context, in device memory: what the host wants to know about a context's batch after every launch
+struct CtxStat { unsigned done, total_words, max_cells, plan_exceeded; };   // pairs finalised; the last planned build's sizes and verdict (k_build_check)
+// ... and per launch, in MAPPED host memory (a ring of slots): written by k_stream_status behind the launch, `seq` last -- no copy, no event
+struct StreamStatus { unsigned fin, abort_, n_live, susp; CtxStat ctx[ASYNC_MAX_CTX]; unsigned seq; unsigned pad_[11]; };
+static_assert(sizeof(StreamStatus) == 128, "one status slot is 128 bytes");
 
 struct AsyncCtl {
   unsigned pub;                 // tickets published so far (ticket numbers are handed out by fetch-add)
@@ -66,7 +71,7 @@ struct AsyncCtl {
 // yet" everywhere else -- and the control words.  `prev` is a different block than `ctl` (the stream mode alternates two).
 NDT_KERNEL void k_async_prepare(const AsyncTab tab, AsyncTab* tab_dev, const int new_ci, const int n_new, PairState* st, const float* __restrict__ guess_cm,
                                 const int* __restrict__ src_cnt, const GridDesc* __restrict__ gd, unsigned* arrived, int* active_list, SweepCtl* sweep_ctl /* two of them */,
-                                int* ring, const int ring_cap, AsyncCtl* ctl, const AsyncCtl* prev) {
+                                int* ring, const int ring_cap, AsyncCtl* ctl, const AsyncCtl* prev, unsigned* done_new /* may be null */) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned nc = prev ? min(prev->susp, (unsigned)ASYNC_MAX_CARRY) : 0u;
   const unsigned n_live = nc + (unsigned)n_new;
@@ -80,6 +85,7 @@ NDT_KERNEL void k_async_prepare(const AsyncTab tab, AsyncTab* tab_dev, const int
   if (i < (size_t)n_new * ASYNC_ARR_STRIDE) arrived[i] = 0u;
   if (i < offsetof(AsyncCtl, carry) / sizeof(unsigned)) reinterpret_cast<unsigned*>(ctl)[i] = (i == 0 || i == 3) ? n_live : 0u;   // pub = n_live = tickets out
   if (sweep_ctl && i < 2 * sizeof(SweepCtl) / sizeof(int)) reinterpret_cast<int*>(sweep_ctl)[i] = i == 0 ? n_new : 0;           // n_active of the first
+  if (i == 0 && done_new && n_new > 0) *done_new = 0u;
   if (i == 0) tab_dev->c[0] = tab.c[0];
   if (i == 1) tab_dev->c[1] = tab.c[1];
   if (i == 2) tab_dev->c[2] = tab.c[2];
@@ -250,6 +256,18 @@ __device__ __forceinline__ void async_update(const AsyncCtx& C, const int b, con
     }
   }
   __builtin_amdgcn_s_setprio(0);
+}
+
+// Stream mode: behind every persistent launch, one wave reports to the host through mapped memory -- how the launch ended and where every
+// context's batch stands -- and then posts the launch's sequence number (posted PCIe writes; the host polls the number: no copy, no event).
+NDT_KERNEL void k_stream_status(const AsyncCtl* __restrict__ ctl, const CtxStat* __restrict__ stat, volatile unsigned* host_slot, const unsigned seq) {
+  const int i = threadIdx.x;
+  static_assert(offsetof(AsyncCtl, fin) == 4 && offsetof(AsyncCtl, susp) == 16 && offsetof(StreamStatus, ctx) == 16 && offsetof(StreamStatus, seq) == 80, "status layout");
+  if (i < 4) host_slot[i] = reinterpret_cast<const unsigned*>(ctl)[1 + i];                      // fin, abort_, n_live, susp
+  else if (i < 4 + 4 * ASYNC_MAX_CTX) host_slot[i] = reinterpret_cast<const unsigned*>(stat)[i - 4];
+  __threadfence_system();
+  __syncthreads();
+  if (i == 0) host_slot[20] = seq;
 }
 
 template <bool PCA, int K, int ORD>

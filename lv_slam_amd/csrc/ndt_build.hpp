@@ -133,10 +133,10 @@ __global__ void __launch_bounds__(1024) k_word_offsets(GridDesc* gd, const unsig
 // for `info` = {total bitmap words, cells of the largest grid} (k_word_offsets).  A batch that does not fit the plan must not touch
 // memory it does not own: every grid of it becomes "no grid" (nothing is binned, marked, ranked or summed; its pairs align against an
 // empty target and end at once) and the flag tells the host to run that batch again, synchronously, with a plan that fits.
-__global__ void k_build_check(const unsigned* __restrict__ info, GridDesc* gd, unsigned* nwords, int n_pairs, unsigned plan_words, int plan_cb, unsigned* flag) {
+__global__ void k_build_check(const unsigned* __restrict__ info, GridDesc* gd, unsigned* nwords, int n_pairs, unsigned plan_words, int plan_cb, unsigned* stat /* total, largest, flag */) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool fits = info[0] <= plan_words && (plan_cb >= 31 || info[1] + 1u <= (1u << plan_cb));
-  if (b == 0) *flag = fits ? 0u : 1u;
+  if (b == 0) { stat[0] = info[0]; stat[1] = info[1]; stat[2] = fits ? 0u : 1u; }
   if (fits || b >= n_pairs) return;
   gd[b].status = GRID_CAP; gd[b].ncells = 0; gd[b].nwords = 0; gd[b].word_off = 0; gd[b].n_voxels = 0;
   nwords[b] = 0;

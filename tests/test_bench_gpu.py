@@ -131,7 +131,7 @@ def test_eight_ranks_on_one_device_gloo():
 def test_streamed_headline_carries_both_rates():
     """The N = 1 line: `value` is the streamed job (distinct batches back to back through mi355ndt_stream_*), `value_synchronous` the same steps one
     batch at a time; the streamed results are bit-identical to the synchronous ones, pairs really were handed from launch to launch."""
-    d = run_bench(["--pairs", "24", "--azimuth", "512", "--steps", "6", "--warmup", "1", "--cpu-seconds", "0", "--no-host-clouds", "--config4-pairs", "0", "--seq-frames", "0",
+    d = run_bench(["--pairs", "40", "--azimuth", "512", "--steps", "6", "--warmup", "1", "--cpu-seconds", "0", "--no-host-clouds", "--config4-pairs", "0", "--seq-frames", "0",
                    "--no-other-configs"])
     st = d["config"]["stream"]
     assert st["n_batches"] == 3 and st["n_contexts"] == 3 and st["bit_identical_to_synchronous"] is True and st["batches_rerun"] == 0 and st["launches_that_gave_up"] == 0
