@@ -84,6 +84,7 @@ struct mi355ndt_handle {
   unsigned *d_heads = nullptr, *d_head_cnt = nullptr; size_t heads_cap = 0, head_cnt_cap = 0;   // k_mark's run heads per slice
   float* d_cent = nullptr; double* d_icov64 = nullptr; size_t icov64_cap = 0;
   int* d_kdw = nullptr; size_t kdw_cap = 0; bool kdw_built = false;   // per-leaf weights for ndt_pca + KDTREE (dead leaves included)
+  float4* d_sorted = nullptr; size_t sorted_cap = 0; bool leaf_sorted = false;   // MI355NDT_LEAF_SORTED: the sorted order as points (k_sorted_points)
   unsigned* d_rs_hist = nullptr; unsigned* d_rs_offs = nullptr; size_t rs_cap = 0;   // segmented radix sort: tile histograms / offsets
   unsigned *d_cstart = nullptr, *d_cend = nullptr; size_t cell_cap = 0; bool cells_ready = false; int last_cb = 0;
   double* d_fit = nullptr; size_t fit_cap = 0;
@@ -369,6 +370,7 @@ int mi355ndt_create(const mi355ndt_params* params, int device, mi355ndt_handle**
   h->prm = p;
   gauss_constants3(0.55, 1.0f, h->gauss_last);    // the constructor's gauss_d*_ (impl2:70-76: resolution_ 1.0f, outlier_ratio_ 0.55), whatever the setters say later
   { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
+  if (const char* e = std::getenv("MI355NDT_LEAF_SORTED")) h->leaf_sorted = std::atoi(e) != 0;
   if (const char* e = std::getenv("MI355NDT_FINE_TILES")) { const int v = std::atoi(e); if (v == 1 || v == 2) h->fine_tiles = v; }
   if (const char* e = std::getenv("MI355NDT_ASYNC")) { h->async_align = std::atoi(e) != 0; h->async_force = std::atoi(e) == 2; }
   if (const char* e = std::getenv("MI355NDT_SWEEP_DYN_SHIFT")) { const int v = std::atoi(e); if (v >= 0 && v <= 30) h->dyn_shift = v; }
@@ -406,7 +408,7 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
                   h->d_state, h->d_partials, h->d_guess, h->d_results, h->d_active, h->d_hook, h->d_aligned, h->d_hits, h->d_seg_start, h->d_heads, h->d_head_cnt, h->d_sums,
                   h->d_cent, h->d_icov64, h->d_kdw, h->d_rs_hist, h->d_rs_offs, h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit, h->d_pf_in, h->d_pf_out, h->d_pf_keep, h->d_pf_keys,
                   h->d_pf_vals, h->d_pf_flag, h->d_pf_pos, h->d_pf_mm, h->d_pf_grid, h->d_pf_tmp, h->d_score_pts, h->d_score_part,
-                  h->d_ring, h->d_arrived, h->d_actl, h->d_atab};
+                  h->d_ring, h->d_arrived, h->d_actl, h->d_atab, h->d_sorted};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : {(void*)h->d_grid_of, (void*)h->d_seq, (void*)h->d_seq_out, (void*)h->d_stamps}) if (p) (void)hipFree(p);
   if (h->h_seq_flags) (void)hipHostFree((void*)h->h_seq_flags);
@@ -913,7 +915,17 @@ static int build_targets_impl(mi355ndt_handle* h) {
     k_rank<<<B, 1024, 0, s>>>(h->d_grid, h->d_words, h->d_heads, h->d_head_cnt, nsl, scap, h->d_seg_start);
     // leaf-sum workgroups per target: 64 keeps ~4 targets (3 MB of points) in flight per XCD, inside its 4 MB L2
     const int lb = std::max(1, std::min((int)((rpp + LS_WAVES - 1) / LS_WAVES), 64));
-    if (want_cent) k_leafsum<unsigned, true><<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start,
+    if (h->leaf_sorted) {
+      // the sorted order as 16-byte points first (one streaming gather), then leaf sums that read them contiguously
+      HIPCHK(h, grow(h->d_sorted, h->sorted_cap, total));
+      const int gb = std::max(1, std::min((int)((pitch + 256 * RUN_ILP - 1) / (256 * RUN_ILP)), 64));
+      k_sorted_points<<<xcd_grid(gb, B), 256, 0, s>>>(h->d_tgt, pitch, h->d_vals_b, h->d_sorted, gb, B);
+      const unsigned* sp = reinterpret_cast<const unsigned*>(h->d_sorted);
+      if (want_cent) k_leafsum<unsigned, true, true><<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, sp, h->d_grid, h->d_seg_start,
+                                                                                            h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent, lb, B);
+      else k_leafsum<unsigned, false, true><<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, sp, h->d_grid, h->d_seg_start,
+                                                                                  h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent, lb, B);
+    } else if (want_cent) k_leafsum<unsigned, true><<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start,
                                                                                     h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent, lb, B);
     else k_leafsum<unsigned, false><<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start,
                                                                           h->d_sums, h->d_vox_idx, h->d_vox_n, cb, h->d_cent, lb, B);

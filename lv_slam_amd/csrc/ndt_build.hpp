@@ -262,14 +262,39 @@ __global__ void __launch_bounds__(1024) k_rank(GridDesc* gd, BitWord* words, con
   }
 }
 
+// The sorted order as POINTS: P[j] = (x, y, z) of the point at sorted position j of its target, 16 bytes each.  k_leafsum walks a leaf's run
+// in sorted order; with only the ids sorted (vals) every trip of it is a dependent chain  ids -> three row gathers -> terms,  64 lanes
+// presenting 64 different lines to the vector L1 per row.  This pass does the same gather once, as a stream (every address known up front,
+// RUN_ILP positions per lane in flight), and leaves the leaf sums a coalesced 16-byte read per lane.
+__global__ void __launch_bounds__(256) k_sorted_points(const float* __restrict__ tgt, size_t pitch, const unsigned* __restrict__ vals, float4* __restrict__ sorted,
+                                                        int nx, int n_targets) {
+  int b, bx;
+  if (!xcd_map(nx, n_targets, bx, b)) return;      // a target's positions on one XCD: its points are in that L2 from the sort's first pass
+  const float* X = tgt + (size_t)b * 3 * pitch;
+  const unsigned* V = vals + (size_t)b * pitch;
+  float4* P = sorted + (size_t)b * pitch;
+  const size_t i0 = ((size_t)bx * 256 + threadIdx.x);
+  const size_t stride = (size_t)nx * 256;
+  for (size_t i = i0; i < pitch; i += stride * RUN_ILP) {
+    unsigned v[RUN_ILP];
+    float4 q[RUN_ILP];
+#pragma unroll
+    for (int u = 0; u < RUN_ILP; u++) { const size_t j = i + u * stride; v[u] = j < pitch ? V[j] : 0u; }
+#pragma unroll
+    for (int u = 0; u < RUN_ILP; u++) { const unsigned k = v[u] < pitch ? v[u] : 0u; q[u] = make_float4(X[k], X[pitch + k], X[2 * pitch + k], 0.f); }
+#pragma unroll
+    for (int u = 0; u < RUN_ILP; u++) { const size_t j = i + u * stride; if (j < pitch) P[j] = q[u]; }
+  }
+}
+
 // leaf.mean_ += pt ; leaf.cov_ += pt pt^T (impl:233-237) for every searchable leaf: one WAVE per leaf.
 // The wave gathers 64 points of the leaf's run at a time (the radix sort is stable, so the run is in input
 // order), parks the nine f64 terms of each point in LDS, and lanes 0..8 -- one per accumulator -- add them
 // strictly in input order, which keeps the sums bit-identical to the reference's sequential accumulation.
 #define LS_WAVES 4
-template <typename KeyT, bool CENT>
+template <typename KeyT, bool CENT, bool SORTED = false>
 __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restrict__ tgt, size_t pitch,
-                                                           const KeyT* __restrict__ keys, const unsigned* __restrict__ vals,
+                                                           const KeyT* __restrict__ keys, const unsigned* __restrict__ vals /* SORTED: the float4 points of k_sorted_points */,
                                                            const GridDesc* __restrict__ gd, const unsigned* __restrict__ seg_start,
                                                            double* sums, int* vox_idx, int* vox_n, int cb, float* cent,
                                                            int nx, int n_targets) {
@@ -295,18 +320,22 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restri
     for (size_t j0 = start;; j0 += 64) {
       const size_t j = j0 + lane;
       const bool inb = j < pitch;
-      // key and point id of the run position are fetched together (the point id of a lane past the run's end is unused)
+      // key and point (id) of the run position are fetched together (what a lane past the run's end fetches is unused)
       const KeyT kj = inb ? K[j] : (KeyT)0;
-      const unsigned pi = inb ? V[j] : 0u;
+      float4 pj = make_float4(0.f, 0.f, 0.f, 0.f);
+      unsigned pi = 0u;
+      if (SORTED) { if (inb) pj = reinterpret_cast<const float4*>(vals)[(size_t)b * pitch + j]; }
+      else pi = inb ? V[j] : 0u;
       if (j0 == start) key = __shfl(kj, 0);      // the run's cell: its first entry
       const bool in = inb && kj == key;
       const int m = (int)__popcll(__ballot(in));
       if (in) {
-        const double x = (double)X[pi], y = (double)X[pitch + pi], z = (double)X[2 * pitch + pi];
+        const float fx = SORTED ? pj.x : X[pi], fy = SORTED ? pj.y : X[pitch + pi], fz = SORTED ? pj.z : X[2 * pitch + pi];
+        const double x = (double)fx, y = (double)fy, z = (double)fz;
         double* t = term[wv][lane];
         t[0] = x; t[1] = y; t[2] = z;
         t[3] = x * x; t[4] = x * y; t[5] = x * z; t[6] = y * y; t[7] = y * z; t[8] = z * z;
-        if (CENT) { termf[wv][lane][0] = X[pi]; termf[wv][lane][1] = X[pitch + pi]; termf[wv][lane][2] = X[2 * pitch + pi]; }
+        if (CENT) { termf[wv][lane][0] = fx; termf[wv][lane][1] = fy; termf[wv][lane][2] = fz; }
       }
       __builtin_amdgcn_wave_barrier();
       if (lane < 9) {                            // strictly sequential adds (input order); the LDS reads are batched ahead of them

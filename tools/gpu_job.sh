@@ -35,6 +35,9 @@ for stage in "$@"; do
     timeline_d1) (MODE=direct1 VARIANT=pca MAXIT=64 MI355NDT_LIB=$R/lv_slam_amd/libexp_tl.so timeout 300 python tools/sweep_timeline.py; MODE=direct1 VARIANT=pca RESOLUTION=0.5 AZIMUTH=2048 PAIRS=128 MAXIT=64 MI355NDT_LIB=$R/lv_slam_amd/libexp_tl.so timeout 300 python tools/sweep_timeline.py) 2>&1 | grep -v amdgpu.ids > $O/tl.txt; cat $O/tl.txt ;;
     tests_stream) timeout 1800 python -m pytest tests/test_stream_gpu.py -x -q 2>&1 | tail -30 > $O/pytest.txt; cat $O/pytest.txt ;;
     tests_async_all) timeout 1800 python -m pytest tests/test_gpu_configs.py -m gpu -x -q 2>&1 | tail -25 > $O/pytest.txt; cat $O/pytest.txt ;;
+    kstats_leaf) for v in 0 1; do MI355NDT_LEAF_SORTED=$v timeout 600 tools/kstats.sh kstats_leaf$v --no-host-clouds --no-stream --steps 20 --warmup 3 > $O/out$v.txt 2>&1; grep -E "k_leafsum|k_sorted|k_mark|k_rs_|k_voxels|k_minmax|k_rank|k_align" $O/out$v.txt; done
+                 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "voxel or grid" 2>&1 | tail -5 > $O/pytest0.txt; cat $O/pytest0.txt
+                 MI355NDT_LEAF_SORTED=1 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "voxel or grid" 2>&1 | tail -5 > $O/pytest1.txt; cat $O/pytest1.txt ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
