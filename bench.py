@@ -747,47 +747,48 @@ def timed_stream_job(ctx, eng, W, nb, job_total, steps, warmup, n_batches=3, n_c
     slots = [(W["T"].data_ptr() + k * nb * fsz, W["tcnt"][k * nb:(k + 1) * nb], W["S"].data_ptr() + k * nb * fsz, W["scnt"][k * nb:(k + 1) * nb]) for k in range(n_batches)]
     guesses = np.ascontiguousarray(np.broadcast_to(ctx.G.T.reshape(1, 16), (nb, 16)), dtype=np.float32)
     res = [(ndt.Result * nb)() for _ in range(n_batches)]
-    rec_host = torch.empty(cap, shard.REC_WORDS, dtype=torch.int32).pin_memory() if use_dist else None
-    rec_dev = torch.empty(cap, shard.REC_WORDS, device=dev, dtype=torch.int32) if use_dist else None
+    # pose records: one device block per resident batch, filled by the device as that batch's pairs finish (mi355ndt_stream_pose_records);
+    # a collected batch's block goes straight into the all-gather -- no packing kernel, no host hop on the RCCL path
+    rec_dev = [torch.empty(cap, shard.REC_WORDS, device=dev, dtype=torch.int32) for _ in range(n_contexts)] if use_dist else None
+    rec_host = None if (on_dev or not use_dist) else torch.empty(cap, shard.REC_WORDS, dtype=torch.int32).pin_memory()   # gloo functional check only
     gathered = torch.empty(ctx.world * cap, shard.REC_WORDS, device=dev if on_dev else "cpu", dtype=torch.int32) if use_dist else None
     gather_ev, gather_host_s = [], [0.0]
-    lib = ndt.load_library()
-    import ctypes as C
     eng.stream_begin(n_contexts, nb, W["pitch"], W["pitch"])
     state = {"sub": 0, "col": 0, "ids": []}
 
-    def gather(k, timed):
-        # the pose records of a collected batch: packed on the host from its results (the GPU is busy with the next launch), then the
-        # same all-gather as the synchronous job
-        lib.mi355ndt_pack_pose_records(C.cast(res[k], C.c_void_p), nb, ctx.rank, ctx.world, C.c_void_p(rec_host.data_ptr()), cap)
+    def gather(i, timed):
+        rd = rec_dev[i % n_contexts]                   # the block batch i was submitted with
         h0 = time.perf_counter()
         if on_dev:
-            if gather_ev:
-                gather_ev[-1][1].synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            rec_dev.copy_(rec_host, non_blocking=True)
             e0.record()
-            shard.gather_records(rec_dev, gathered)
+            shard.gather_records(rd, gathered)
             e1.record()
+            state["last_gather"] = e1
             if timed:
                 gather_ev.append((e0, e1))
         else:
+            rec_host.copy_(rd)
             shard.gather_records(rec_host, gathered)
             if timed:
                 gather_host_s[0] += time.perf_counter() - h0
 
     def collect_one(timed):
-        k = state["col"] % n_batches
-        eng.stream_collect_raw(state["ids"][state["col"]], res[k])
+        i = state["col"]
+        eng.stream_collect_raw(state["ids"][i], res[i % n_batches])
         state["col"] += 1
         if use_dist:
-            gather(k, timed)
+            gather(i, timed)
 
     def step(timed=False):
         if state["sub"] - state["col"] >= n_contexts:
             collect_one(timed)
         k = state["sub"] % n_batches
         T, tc, S, sc = slots[k]
+        if use_dist:
+            if on_dev and state.get("last_gather") is not None:
+                state["last_gather"].synchronize()     # (a gather may still be reading the block this batch is about to reuse)
+            eng.stream_pose_records(rec_dev[state["sub"] % n_contexts].data_ptr(), cap, ctx.rank, ctx.world)
         state["ids"].append(eng.stream_submit(T, tc, W["pitch"], S, sc, W["pitch"], guesses))
         state["sub"] += 1
 
@@ -841,8 +842,10 @@ def timed_stream_job(ctx, eng, W, nb, job_total, steps, warmup, n_batches=3, n_c
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         gather_check = {"pairs_gathered": len(got), "permutation_of_all_pair_ids": bool(perm), "own_records_bit_identical_on_every_rank": bool(ok.item()),
                         "record_bytes": 96, "records_per_rank": cap, "backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                        "packed_on_device": False, "host_hop": True,
-                        "why_packed_on_the_host": "a collected batch's results are on the host anyway and the GPU is inside the next batch's launch (mi355ndt_pack_pose_records)"}
+                        "packed_on_device": True, "host_hop": not on_dev,
+                        "packed_by": "the wave that finalises a pair writes its 96-byte record into the batch's gather block (mi355ndt_stream_pose_records): no packing kernel",
+                        "timed_with": "HIP events around all_gather_into_tensor on the stream the collective is ordered on, max over ranks" if on_dev else
+                                      "host clock around the device-to-host copy + gloo all_gather (functional check only), max over ranks"}
     same = None
     if ref is not None:                                # word for word against the synchronous align of the same batches
         same = all(bytes(res[k]) == bytes(ref[k]) for k in range(min(n_batches, len(ref))))

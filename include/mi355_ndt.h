@@ -117,8 +117,12 @@ int mi355ndt_default_params(mi355ndt_params* p);
 int mi355ndt_create(const mi355ndt_params* params, int device, mi355ndt_handle** out);
 int mi355ndt_destroy(mi355ndt_handle* h);
 
-/* replaces the setters of ndt_omp.h:109-203.  A change of `resolution` (or variant / min points /
- * eigenvalue multiplier) re-voxelises the current targets, as setResolution does (ndt_omp.h:126-136). */
+/* replaces the setters of ndt_omp.h:109-203.  A change of variant / min points / eigenvalue multiplier re-voxelises the current targets.
+ * A change of `resolution` does what setResolution does (ndt_omp.h:126-136: `if (input_) init();`): the target is re-voxelised only when a
+ * SOURCE has been set (mi355ndt_set_source / a bound batch); without one the resident grid keeps its leaf size until the next
+ * mi355ndt_set_target, while the Gauss constants of the next align already use the new value (ndt_omp_impl2.hpp:93-100) -- the reference's
+ * behaviour, quirk included.  Deviation: with KDTREE or the live More-Thuente configuration (radius searches over the grid) the target is
+ * re-voxelised at once in either case. */
 int mi355ndt_set_params(mi355ndt_handle* h, const mi355ndt_params* params);
 int mi355ndt_get_params(const mi355ndt_handle* h, mi355ndt_params* out);
 
@@ -271,6 +275,12 @@ int mi355ndt_stream_submit(mi355ndt_handle* h, int n_pairs, const float* d_targe
                            const float* d_sources, const int* source_counts, size_t source_pitch, const float* guesses_colmajor,
                            long long* batch_id);
 int mi355ndt_stream_collect(mi355ndt_handle* h, long long batch_id, mi355ndt_result* out);
+/* Pose records for the multi-GPU gather (the 96-byte layout of mi355ndt_batch_pose_records) of the NEXT batch submitted: `d_records` is a
+ * caller-owned DEVICE buffer of `capacity` records (>= that batch's pairs); record b is written by the device -- by the very wave that
+ * finalises pair b, inside the persistent launch: no packing kernel, no host hop -- with pair_id = id_base + b * id_stride, the other rows
+ * carry pair_id = -1.  Complete when mi355ndt_stream_collect of that batch has returned; the buffer can then go straight into an RCCL
+ * all-gather.  NULL = no records for the next batch (the default). */
+int mi355ndt_stream_pose_records(mi355ndt_handle* h, void* d_records, size_t capacity, int id_base, int id_stride);
 /* Pose records (the 96-byte layout of mi355ndt_batch_pose_records) of a COLLECTED batch, packed on the host from its results into
  * `records` (host memory, `capacity` records; rows >= n carry pair_id = -1).  In stream mode the GPU is busy with the next batch's launch when
  * a batch is collected -- a packing kernel would wait for that launch -- so the 26 KB of a 271-pair batch are packed here and go to the device

@@ -26,6 +26,7 @@ class NormalDistributionsTransform : public pcl::Registration<PointSource, Point
   typedef typename Base::PointCloudSource PointCloudSource;
   typedef typename Base::PointCloudTarget PointCloudTarget;
   typedef typename PointCloudTarget::ConstPtr PointCloudTargetConstPtr;
+  typedef typename PointCloudSource::ConstPtr PointCloudSourceConstPtr;
   using Base::reg_name_; using Base::input_; using Base::target_; using Base::nr_iterations_; using Base::max_iterations_;
   using Base::final_transformation_; using Base::transformation_; using Base::previous_transformation_;
   using Base::transformation_epsilon_; using Base::converged_; using Base::update_visualizer_;
@@ -47,7 +48,13 @@ class NormalDistributionsTransform : public pcl::Registration<PointSource, Point
     push();
     mi355ndt_set_target(h_, cloud->points.data(), cloud->points.size(), sizeof(PointTarget));
   }
-  inline void setResolution(float r) { if (prm_.resolution != r) { prm_.resolution = r; push(); } }   // ndt_omp.h:126-136
+  // ndt_omp.h:126-136: `if (input_) init();` -- the engine keeps the grid when it has no source yet (mi355ndt_set_params), and it has one
+  // exactly when pcl::Registration::input_ is set: setInputSource below hands the cloud over at once
+  inline void setResolution(float r) { if (prm_.resolution != r) { prm_.resolution = r; push(); } }
+  virtual void setInputSource(const PointCloudSourceConstPtr& cloud) {
+    Base::setInputSource(cloud);
+    if (cloud) mi355ndt_set_source(h_, cloud->points.data(), cloud->points.size(), sizeof(PointSource));
+  }
   inline float getResolution() const { return prm_.resolution; }
   inline double getStepSize() const { return prm_.step_size; }
   inline void setStepSize(double s) { prm_.step_size = s; }
@@ -62,7 +69,8 @@ class NormalDistributionsTransform : public pcl::Registration<PointSource, Point
   // ndt_omp.h:232 (impl2:1006-1040): negative log-likelihood of an already transformed cloud against the target grid
   inline double calculateScore(const PointCloudSource& cloud) const {
     double s = 0;
-    mi355ndt_calculate_score(h_, cloud.points.data(), cloud.points.size(), sizeof(PointSource), &s);
+    // (0 is a legitimate score -- nothing in range --, so a failed call must not look like one)
+    if (mi355ndt_calculate_score(h_, cloud.points.data(), cloud.points.size(), sizeof(PointSource), &s) != MI355NDT_OK) return std::numeric_limits<double>::quiet_NaN();
     return s;
   }
   // ndt_omp.h:209-228: [x, y, z, roll, pitch, yaw] -> Translation * AngleAxis(roll, X) * AngleAxis(pitch, Y) * AngleAxis(yaw, Z), f32

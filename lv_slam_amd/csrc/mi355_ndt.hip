@@ -70,6 +70,7 @@ struct mi355ndt_handle {
   bool aligned_once = false;                      // d_state / d_results hold the outcome of an align of the CURRENT batch
   bool icov64_built = false;                      // ... and the f64 inverse covariances computeHessian reads (live More-Thuente)
   bool cent_built = false;                        // last target build also produced the f32 leaf centroids (KDTREE mode)
+  float grid_resolution = 0.f;                    // leaf size the resident grids were built with (setResolution without a source keeps them: ndt_omp.h:126-136)
 
   // build workspace
   unsigned* d_minmax = nullptr;                  // a slice of d_word_off's allocation (zeroed together before every build)
@@ -174,11 +175,13 @@ struct mi355ndt_handle {
     // results: MAPPED host memory -- a pair's result record is written there by the updater that finalises it (posted PCIe writes), no copy
     mi355ndt_result* h_res = nullptr; mi355ndt_result* d_res_map = nullptr;
     std::vector<float> guesses;                   // (kept for a synchronous re-run)
+    PoseRecord* d_pose = nullptr; int pose_cap = 0, pose_base = 0, pose_stride = 1;   // mi355ndt_stream_pose_records (this batch's gather block)
   };
   bool stream_on = false, s_sync_only = false, s_drop_carry = true;
   int s_nctx = 0, s_max_pairs = 0, s_items = 0, s_ring_cap = 0, s_thresh = 0;
   int s_thresh_opt = -1;                          // MI355NDT_OPT_STREAM_THRESHOLD
   int s_plan_cb = 0; size_t s_plan_words = 0;
+  void* s_pose_next = nullptr; size_t s_pose_cap_next = 0; int s_pose_base_next = 0, s_pose_stride_next = 1;   // apply to the next submit
   StreamCtx sctx[ASYNC_MAX_CTX];
   long long s_next_id = 0, s_launches = 0, s_counted = 0;
   AsyncCtl* d_sctl = nullptr;                     // two control blocks: a launch reads the hand-over list of the previous one
@@ -942,6 +945,7 @@ static int build_targets_impl(mi355ndt_handle* h) {
     h->P.build_alg_bytes += pts * (12 + 12 + 4 + 16);
   }
   h->targets_built = true;
+  h->grid_resolution = h->prm.resolution;
   h->cells_ready = false;
   h->last_cb = cb;
   return compute_enqueued(h);                     // asynchronous: a later upload into these rows has to wait for the kernels above
@@ -987,7 +991,10 @@ static void make_sweep_const(const mi355ndt_handle* h, SweepConst& sc) {
   sc.d1 = d1;
   sc.d2f = (float)d2;                        // impl2:578
   sc.pca = h->prm.variant == MI355NDT_VARIANT_PCA;
-  { int ex; float mant = std::frexp(h->prm.resolution, &ex); sc.leaf_pow2 = (mant == 0.5f) && ex > -100 && ex < 100; sc.inv_leaf = 1.0f / h->prm.resolution; }
+  // the lookup divides by the GRID's leaf size (voxel_grid_covariance_omp_impl.hpp:379-381), which is resolution_ except after a setResolution
+  // that found no source and therefore left the grid alone (ndt_omp.h:126-136); the Gauss constants and the kd radius follow resolution_
+  const float leaf = (h->targets_built && h->grid_resolution > 0.f) ? h->grid_resolution : h->prm.resolution;
+  { int ex; float mant = std::frexp(leaf, &ex); sc.leaf_pow2 = (mant == 0.5f) && ex > -100 && ex < 100; sc.inv_leaf = 1.0f / leaf; }
   sc.kd_r2 = (float)((double)h->prm.resolution * (double)h->prm.resolution);   // KdTreeFLANN::radiusSearch: float(radius * radius)
   build_offsets(h->prm.neighbor_mode, sc);
   sc.dyn_shift = h->dyn_shift >= 0 ? h->dyn_shift : (sc.K == 1 ? 3 : 2);
@@ -1108,7 +1115,7 @@ struct AsyncLaunch {
   AsyncTab tab;
   int new_ci = 0, n_new = 0;                       // context and number of the pairs that START in this launch (0: only carried pairs)
   PairState* st_new = nullptr; const float* guess_new = nullptr; const int* src_cnt_new = nullptr; const GridDesc* gd_new = nullptr; unsigned* arrived_new = nullptr;
-  int* active_list = nullptr; SweepCtl* sweep_ctl = nullptr; unsigned* done_new = nullptr;
+  int* active_list = nullptr; SweepCtl* sweep_ctl = nullptr; unsigned* done_new = nullptr; PoseRecord* pose_new = nullptr; int pose_cap = 0;
   AsyncTab* tab_dev = nullptr; int* ring = nullptr; int ring_cap = 0; AsyncCtl* ctl = nullptr; const AsyncCtl* prev = nullptr;
   int items_per_pair = 0, stop_thresh = 0; unsigned debug_abort_pos = 0xFFFFFFFFu;
 };
@@ -1138,9 +1145,9 @@ static int launch_async_o(mi355ndt_handle* h, const SweepConst& sc, const AsyncL
 static int launch_async(mi355ndt_handle* h, const SweepConst& sc, const AsyncLaunch& L) {
   hipStream_t s = h->stream;
   {
-    const size_t n = std::max(std::max((size_t)8 * L.ring_cap, (size_t)L.n_new * ASYNC_ARR_STRIDE), sizeof(AsyncCtl) / sizeof(unsigned));
+    const size_t n = std::max(std::max(std::max((size_t)8 * L.ring_cap, (size_t)L.n_new * ASYNC_ARR_STRIDE), sizeof(AsyncCtl) / sizeof(unsigned)), (size_t)L.pose_cap);
     k_async_prepare<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(L.tab, L.tab_dev, L.new_ci, L.n_new, L.st_new, L.guess_new, L.src_cnt_new, L.gd_new, L.arrived_new,
-                                                               L.active_list, L.sweep_ctl, L.ring, L.ring_cap, L.ctl, L.prev, L.done_new);
+                                                               L.active_list, L.sweep_ctl, L.ring, L.ring_cap, L.ctl, L.prev, L.done_new, L.pose_new, L.pose_cap);
   }
   if (h->prof) HIPCHK(h, ev_begin(h, h->ev_sweep));
   int rc;
@@ -1158,7 +1165,7 @@ static int async_ring_cap(const mi355ndt_handle* h, long long pairs) {
 }
 static void fill_async_ctx(const mi355ndt_handle* e, AsyncCtx& c) {
   c.src = e->d_src; c.pitch = e->src_pitch; c.st = e->d_state; c.gd = e->d_grid; c.words = e->d_words; c.recs = e->d_recs; c.cent = e->d_cent;
-  c.partials = e->d_partials; c.src_cnt = e->d_src_cnt; c.arrived = e->d_arrived; c.results = e->d_results; c.n_done = nullptr; c.must_finish = 1; c.pad_ = 0;
+  c.partials = e->d_partials; c.src_cnt = e->d_src_cnt; c.arrived = e->d_arrived; c.results = e->d_results; c.n_done = nullptr; c.must_finish = 1; c.pose = nullptr; c.pose_base = 0; c.pose_stride = 0; c.pad_ = 0;
 }
 extern "C" {
 static int align_async(mi355ndt_handle* h, const SweepConst& sc, int B, mi355ndt_result* out) {
@@ -1382,7 +1389,13 @@ int mi355ndt_set_params(mi355ndt_handle* h, const mi355ndt_params* p) {
   if (rc) return rc;
   const mi355ndt_params old = h->prm;
   h->prm = *p;
-  const bool regrid = old.resolution != p->resolution || old.variant != p->variant ||
+  // setResolution (ndt_omp.h:126-136): `if (resolution_ != resolution) { resolution_ = resolution; if (input_) init(); }` -- the grid is only
+  // re-made when a SOURCE cloud is set; without one it keeps its leaf size until the next setInputTarget, while the Gauss constants follow
+  // the new value (impl2:93-100).  Reproduced for the DIRECT searches of the single-registration surface; a radius search over the grid
+  // (KDTREE, live More-Thuente) is emulated by a 27-cell probe that needs radius <= leaf, so those re-voxelise as before (documented deviation).
+  const bool radius_search = p->neighbor_mode == MI355NDT_KDTREE || mt_is_live(*p);
+  const bool keep_grid = old.resolution != p->resolution && h->n_pairs == 1 && !h->have_source && !radius_search && h->d_tgt == h->d_tgt_own;
+  const bool regrid = (old.resolution != p->resolution && !keep_grid) || old.variant != p->variant ||
                       old.min_points_per_voxel != p->min_points_per_voxel ||
                       old.min_covar_eigvalue_mult != p->min_covar_eigvalue_mult ||
                       ((p->neighbor_mode == MI355NDT_KDTREE || mt_is_live(*p)) && !h->cent_built) ||   // centroids the build skipped
@@ -2000,6 +2013,7 @@ static int stream_launch(mi355ndt_handle* h, int new_ci, int n_new) {
     fill_async_ctx(e, L.tab.c[c]);
     L.tab.c[c].results = h->sctx[c].d_res_map;
     L.tab.c[c].n_done = &h->d_sstat[c].done;
+    L.tab.c[c].pose = h->sctx[c].busy ? h->sctx[c].d_pose : nullptr; L.tab.c[c].pose_base = h->sctx[c].pose_base; L.tab.c[c].pose_stride = h->sctx[c].pose_stride;
     // the context the NEXT submit recycles must be finished by this launch; the others may hand their last pairs over
     L.tab.c[c].must_finish = (flush || c == (new_ci + 1) % h->s_nctx) ? 1 : 0;
   }
@@ -2009,6 +2023,7 @@ static int stream_launch(mi355ndt_handle* h, int new_ci, int n_new) {
     mi355ndt_handle* e = h->sctx[new_ci].e;
     L.st_new = e->d_state; L.guess_new = e->d_guess; L.src_cnt_new = e->d_src_cnt; L.gd_new = e->d_grid; L.arrived_new = e->d_arrived;
     L.active_list = e->d_active_list; L.sweep_ctl = nullptr; L.done_new = &h->d_sstat[new_ci].done;
+    L.pose_new = h->sctx[new_ci].d_pose; L.pose_cap = h->sctx[new_ci].pose_cap;
   }
   L.tab_dev = h->d_atab; L.ring = h->d_sring; L.ring_cap = h->s_ring_cap;
   L.ctl = h->d_sctl + (j & 1); L.prev = h->s_drop_carry ? nullptr : h->d_sctl + ((j + 1) & 1);
@@ -2059,6 +2074,9 @@ int mi355ndt_stream_submit(mi355ndt_handle* h, int n_pairs, const float* d_t, co
   e->prm = h->prm;
   S.batch_id = id; S.n_pairs = n_pairs; S.redo = false; S.done_sync = false; S.launch = -1;
   S.guesses.assign(guesses, guesses + (size_t)n_pairs * 16);
+  S.d_pose = (PoseRecord*)h->s_pose_next; S.pose_cap = (int)h->s_pose_cap_next; S.pose_base = h->s_pose_base_next; S.pose_stride = h->s_pose_stride_next;
+  h->s_pose_next = nullptr; h->s_pose_cap_next = 0;
+  if (S.d_pose && (size_t)n_pairs > (size_t)S.pose_cap) return MI355NDT_ERR_BAD_ARG;
   auto run_sync = [&]() -> int {                     // build + align this batch here and now, results into the context's host buffer
     e->async_build = false; e->counts_preloaded = false;
     e->up_tgt_cnt.clear(); e->up_src_cnt.clear();
@@ -2113,6 +2131,14 @@ int mi355ndt_stream_submit(mi355ndt_handle* h, int n_pairs, const float* d_t, co
   return MI355NDT_OK;
 }
 
+int mi355ndt_stream_pose_records(mi355ndt_handle* h, void* d_records, size_t capacity, int id_base, int id_stride) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (!h->stream_on) return MI355NDT_ERR_STATE;
+  if ((d_records && capacity == 0) || capacity > (size_t)MAX_PAIRS) return MI355NDT_ERR_BAD_ARG;
+  h->s_pose_next = d_records; h->s_pose_cap_next = d_records ? capacity : 0; h->s_pose_base_next = id_base; h->s_pose_stride_next = id_stride;
+  return MI355NDT_OK;
+}
+
 // a launch gave up (ctl->abort_): nothing it left behind can be trusted to continue from -- every unfinished batch is re-run synchronously
 // by its collect, and the next launch starts without a hand-over list
 static void stream_recover(mi355ndt_handle* h) {
@@ -2136,6 +2162,7 @@ int mi355ndt_stream_collect(mi355ndt_handle* h, long long batch_id, mi355ndt_res
   mi355ndt_handle::StreamCtx& S = h->sctx[ci];
   if (!S.busy || S.batch_id != batch_id) return MI355NDT_ERR_BAD_ARG;       // collected already (or its context has been recycled)
   mi355ndt_handle* e = S.e;
+  bool reran = S.done_sync;                          // went through the synchronous path (then the pose records come from the engine's packer)
   if (!S.done_sync) {
     long long j = S.launch;
     bool plan_exceeded = false;
@@ -2166,7 +2193,12 @@ int mi355ndt_stream_collect(mi355ndt_handle* h, long long batch_id, mi355ndt_res
       e->chunks_per_pair = h->s_items / QUARTERS; e->rows_per_pair = e->items_per_pair = h->s_items; e->pts_per_chunk = CHUNK_PTS; e->fine_it = 0;
       if (grow(e->d_partials, e->partials_cap, (size_t)h->s_max_pairs * h->s_items * NACC) != hipSuccess) return MI355NDT_ERR_HIP;
       h->P.stream_redone++;
+      reran = true;
     }
+  }
+  if (S.d_pose && reran) {       // a batch that went through the synchronous path: its records from the engine's packer
+    int rc = mi355ndt_batch_pose_records(e, S.pose_base, S.pose_stride, S.d_pose, (size_t)S.pose_cap);
+    if (rc) { h->err = e->err; return rc; }
   }
   memcpy(out, S.h_res, (size_t)S.n_pairs * sizeof(mi355ndt_result));
   if (h->prof) {

@@ -40,7 +40,9 @@ struct AsyncCtx {
   double* partials; const int* src_cnt; unsigned* arrived; mi355ndt_result* results;
   unsigned* n_done;             // (may be null) pairs of this context finalised so far, over all launches: the host's "batch complete" test
   int must_finish;              // the context's buffers are recycled after this launch: its pairs are never handed over
-  int pad_;
+  // (may be null) the batch's 96-byte pose records for the multi-GPU gather, written by the updater that finalises a pair:
+  // record b carries pair_id = pose_base + b * pose_stride -- packed on the device with no kernel of its own
+  int pose_base; PoseRecord* pose; int pose_stride, pad_;
 };
 struct AsyncTab { AsyncCtx c[ASYNC_MAX_CTX]; };
 // stream mode, per context, in device memory: what the host wants to know about a context's batch after every launch
@@ -71,7 +73,8 @@ struct AsyncCtl {
 // yet" everywhere else -- and the control words.  `prev` is a different block than `ctl` (the stream mode alternates two).
 NDT_KERNEL void k_async_prepare(const AsyncTab tab, AsyncTab* tab_dev, const int new_ci, const int n_new, PairState* st, const float* __restrict__ guess_cm,
                                 const int* __restrict__ src_cnt, const GridDesc* __restrict__ gd, unsigned* arrived, int* active_list, SweepCtl* sweep_ctl /* two of them */,
-                                int* ring, const int ring_cap, AsyncCtl* ctl, const AsyncCtl* prev, unsigned* done_new /* may be null */) {
+                                int* ring, const int ring_cap, AsyncCtl* ctl, const AsyncCtl* prev, unsigned* done_new /* may be null */,
+                                PoseRecord* pose_new /* may be null */, const int pose_cap) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned nc = prev ? min(prev->susp, (unsigned)ASYNC_MAX_CARRY) : 0u;
   const unsigned n_live = nc + (unsigned)n_new;
@@ -86,6 +89,12 @@ NDT_KERNEL void k_async_prepare(const AsyncTab tab, AsyncTab* tab_dev, const int
   if (i < offsetof(AsyncCtl, carry) / sizeof(unsigned)) reinterpret_cast<unsigned*>(ctl)[i] = (i == 0 || i == 3) ? n_live : 0u;   // pub = n_live = tickets out
   if (sweep_ctl && i < 2 * sizeof(SweepCtl) / sizeof(int)) reinterpret_cast<int*>(sweep_ctl)[i] = i == 0 ? n_new : 0;           // n_active of the first
   if (i == 0 && done_new && n_new > 0) *done_new = 0u;
+  if (pose_new && i < (size_t)pose_cap) {          // every row starts as a padding row (pair_id = -1); a pair's updater fills its own
+    PoseRecord r;
+    memset(&r, 0, sizeof r);
+    r.pair_id = -1;
+    pose_new[i] = r;
+  }
   if (i == 0) tab_dev->c[0] = tab.c[0];
   if (i == 1) tab_dev->c[1] = tab.c[1];
   if (i == 2) tab_dev->c[2] = tab.c[2];
@@ -235,7 +244,14 @@ __device__ __forceinline__ void async_update(const AsyncCtx& C, const int b, con
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_fetch_add((gu32*)&ctl->fin, 1u, RLX_AGENT);
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (finalize_pair's result record)
+      if (C.pose) {
+        PoseRecord r;
+        for (int a = 0; a < 16; a++) r.final_cm[a] = Ssh.final_cm[a];
+        r.score = (float)Ssh.score; r.iterations = Ssh.it; r.converged = Ssh.converged; r.pair_id = C.pose_base + b * C.pose_stride;
+        for (int a = 0; a < 4; a++) r.pad[a] = 0;
+        C.pose[b] = r;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (finalize_pair's result record, the pose record)
       if (C.n_done) __hip_atomic_fetch_add((gu32*)C.n_done, 1u, RLX_AGENT);
       __hip_atomic_fetch_add((gu32*)&ctl->fin, 1u, RLX_AGENT);
     }

@@ -84,7 +84,7 @@ SYMBOLS = [
     "mi355ndt_profile_enable", "mi355ndt_profile_reset", "mi355ndt_profile_get", "mi355ndt_synchronize",
     "mi355ndt_set_latency_mode", "mi355ndt_sequence_run",
     "mi355ndt_calculate_score", "mi355ndt_convert_transform", "mi355ndt_set_option", "mi355ndt_get_option",
-    "mi355ndt_stream_begin", "mi355ndt_stream_submit", "mi355ndt_stream_collect", "mi355ndt_stream_end", "mi355ndt_pack_pose_records",
+    "mi355ndt_stream_begin", "mi355ndt_stream_submit", "mi355ndt_stream_collect", "mi355ndt_stream_end", "mi355ndt_stream_pose_records", "mi355ndt_pack_pose_records",
 ]
 OPT_ASYNC_ALIGN = 2            # mi355ndt_option: 1 (default) = one persistent launch per batch align, 0 = lockstep (update, sweep) rounds; same bits
 OPT_DEBUG_ASYNC_ABORT = 3      # mi355ndt_option (test hook): the wave that claims this position of ring 0 gives up -> the batch is re-run in rounds
@@ -151,6 +151,7 @@ def load_library(path: str = LIB_PATH):
     L.mi355ndt_stream_submit.argtypes = [vp, i, vp, vp, sz, vp, vp, sz, vp, C.POINTER(C.c_longlong)]
     L.mi355ndt_stream_collect.argtypes = [vp, C.c_longlong, vp]
     L.mi355ndt_stream_end.argtypes = [vp]
+    L.mi355ndt_stream_pose_records.argtypes = [vp, vp, sz, i, i]
     L.mi355ndt_pack_pose_records.argtypes = [vp, i, i, i, vp, sz]
     _LIB = L
     return L
@@ -412,6 +413,10 @@ class Engine:
                                                   g.ctypes.data_as(C.c_void_p), C.byref(bid)), "stream_submit")
         return bid.value
 
+    def stream_pose_records(self, d_records_ptr: int, capacity: int, id_base: int, id_stride: int):
+        """The NEXT submitted batch's 96-byte pose records go into this device buffer, written by the device as the pairs finish."""
+        self._chk(self.lib.mi355ndt_stream_pose_records(self.h, C.c_void_p(d_records_ptr), capacity, id_base, id_stride), "stream_pose_records")
+
     def stream_collect_raw(self, batch_id: int, res_array):
         """Block until every pair of the batch is finalised; res_array = (Result * n_pairs)()."""
         self._chk(self.lib.mi355ndt_stream_collect(self.h, batch_id, C.cast(res_array, C.c_void_p)), "stream_collect")
@@ -493,7 +498,7 @@ class NormalDistributionsTransform:
     def setNumThreads(self, n: int):            # ndt_omp.h:109 -- OpenMP thread count; meaningless on the GPU, accepted
         self._num_threads = int(n)
 
-    def setResolution(self, resolution: float):  # ndt_omp.h:126-136 (re-voxelises only if changed and a target is set)
+    def setResolution(self, resolution: float):  # ndt_omp.h:126-136: re-voxelises only if changed AND a source is set (`if (input_) init();`), as the engine does
         if np.float32(resolution) != np.float32(self._prm.resolution):
             self._prm.resolution = float(resolution)
             self._push()

@@ -39,6 +39,12 @@ template <> struct Map<const Matrix4f> {
 };
 }  // namespace Eigen
 
+// PCL 1.8 hands clouds around as boost::shared_ptr (pcl::PointCloud<T>::Ptr / ::ConstPtr); the adaptor only ever goes through those typedefs
+namespace boost {
+template <typename T> using shared_ptr = std::shared_ptr<T>;
+template <typename T, typename... A> shared_ptr<T> make_shared(A&&... a) { return std::make_shared<T>(std::forward<A>(a)...); }
+}  // namespace boost
+
 namespace pcl {
 struct PointXYZI {                      // 32-byte record, x,y,z first (pcl::PointXYZI's layout)
   union { float data[4]; struct { float x, y, z; }; };
@@ -48,8 +54,8 @@ struct PointXYZ { union { float data[4]; struct { float x, y, z; }; }; };
 
 template <typename PointT>
 struct PointCloud {
-  typedef std::shared_ptr<PointCloud<PointT> > Ptr;
-  typedef std::shared_ptr<const PointCloud<PointT> > ConstPtr;
+  typedef boost::shared_ptr<PointCloud<PointT> > Ptr;
+  typedef boost::shared_ptr<const PointCloud<PointT> > ConstPtr;
   std::vector<PointT> points;
   unsigned width = 0, height = 1;
   bool is_dense = true;

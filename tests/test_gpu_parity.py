@@ -473,26 +473,58 @@ def _align_with(prm, tgt, src, G):
     return e.align(G)
 
 
-def test_set_resolution_revoxelises():
+def test_set_resolution_revoxelises_only_when_a_source_is_set():
+    """setResolution (ndt_omp.h:126-136): `if (resolution_ != resolution) { resolution_ = resolution; if (input_) init(); }`.  With a source
+    set the target is re-voxelised at once; WITHOUT one the grid keeps its 1 m leaves until the next setInputTarget while the next align
+    already takes its Gauss constants from the new value (impl2:93-100) -- the oracle reproduces that state with a grid built at 1 m and
+    align parameters at 2 m."""
     tgt, src, _ = synth.make_pair(4, 256, n_beams=32)
     tgt, src = tgt.numpy(), src.numpy()
+    G = synth.default_guess()
+    # (a) source first: re-init
     reg = ndt.NormalDistributionsTransform()
     reg.setTransformationEpsilon(0.01)
     reg.setMaximumIterations(64)
+    reg.setInputSource(src)
     reg.setInputTarget(tgt)
     n1 = reg.engine.get_grid()[3]
-    reg.setResolution(2.0)                     # ndt_omp.h:126-136: re-init because a target is set
+    reg.setResolution(2.0)
     n2 = reg.engine.get_grid()[3]
     assert n1 != n2 and len(reg.getTargetCells()) == n2            # ndt_pca.h:129-133 accessor
     check_voxels(reg.engine, O.Grid(tgt, O.default_params(resolution=2.0)))
-    reg.setInputSource(src)
-    out = reg.align(synth.default_guess())
-    ro = O.align(O.Grid(tgt, O.default_params(resolution=2.0, trans_epsilon=0.01, max_iterations=64)), src, synth.default_guess())
+    out = reg.align(G)
+    ro = O.align(O.Grid(tgt, O.default_params(resolution=2.0, trans_epsilon=0.01, max_iterations=64)), src, G)
     assert reg.getFinalNumIteration() == ro["iterations"] and reg.hasConverged() == ro["converged"]
     dt, dr = se3_err(ro["final"], reg.getFinalTransformation())
     assert dt < 1e-4 and dr < 1e-5
     assert out.shape == src.shape
     assert abs(reg.getTransformationProbability() - ro["trans_probability"]) < 1e-9
+    # (b) no source yet: the grid stays as it is ...
+    reg = ndt.NormalDistributionsTransform()
+    reg.setTransformationEpsilon(0.01)
+    reg.setMaximumIterations(64)
+    reg.setInputTarget(tgt)
+    v1 = reg.engine.get_voxels(0)
+    reg.setResolution(2.0)
+    assert reg.getResolution() == 2.0
+    v2 = reg.engine.get_voxels(0)
+    assert len(v1) == n1 and np.array_equal(v1["idx"], v2["idx"]) and np.array_equal(v1["icov"], v2["icov"])
+    check_voxels(reg.engine, O.Grid(tgt, O.default_params(resolution=1.0)))
+    # ... and the align that follows runs on 1 m leaves with the constants of 2 m
+    reg.setInputSource(src)
+    reg.align(G)
+    g1 = O.Grid(tgt, O.default_params(resolution=1.0))
+    g1.prm = O.default_params(resolution=2.0, trans_epsilon=0.01, max_iterations=64)
+    ro = O.align(g1, src, G)
+    assert reg.getFinalNumIteration() == ro["iterations"] and reg.hasConverged() == ro["converged"]
+    dt, dr = se3_err(ro["final"], reg.getFinalTransformation())
+    assert dt < 1e-4 and dr < 1e-5
+    assert abs(reg.getTransformationProbability() - ro["trans_probability"]) < 1e-9
+    ro_plain = O.align(O.Grid(tgt, O.default_params(resolution=1.0, trans_epsilon=0.01, max_iterations=64)), src, G)
+    assert ro_plain["score"] != ro["score"]                        # (the state really differs from both plain configurations)
+    # the next setInputTarget voxelises at 2 m
+    reg.setInputTarget(tgt)
+    assert reg.engine.get_grid()[3] == n2
 
 
 def test_switch_to_kdtree_after_target():

@@ -239,3 +239,35 @@ def test_cross_xcd_message_passing_litmus():
     assert r.returncode == 0, (r.stdout, r.stderr)
     kv = dict(f.split("=") for f in r.stdout.split())
     assert int(kv["handovers"]) >= 10_000_000 and int(kv["errors"]) == 0 and int(kv["timeouts"]) == 0, r.stdout
+
+
+def test_stream_pose_records_are_written_by_the_device():
+    """mi355ndt_stream_pose_records: a batch's 96-byte gather records appear in the caller's device block as its pairs finish --
+    written inside the persistent launch by the wave that finalises the pair -- and equal what the host packs from the collected results;
+    rows beyond the batch are padding (pair_id = -1)."""
+    import ctypes as C
+    import torch
+    from lv_slam_amd import dist as shard
+    kw = dict(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=ndt.DIRECT7, variant=0)
+    batches, n = make_batches(3300, [30, 22, 30], 512)
+    eng = ndt.Engine(ndt.default_params(**kw))
+    eng.stream_begin(3, 30, n, n)
+    cap = 32
+    blocks = [torch.full((cap, shard.REC_WORDS), 7, device="cuda:0", dtype=torch.int32) for _ in batches]
+    ids = []
+    for k, (T, S, cnt, G) in enumerate(batches):
+        eng.stream_pose_records(blocks[k].data_ptr(), cap, 3 + k, 8)          # pair_id = 3 + k + 8 b
+        ids.append(eng.stream_submit(T.data_ptr(), [n] * len(cnt), n, S.data_ptr(), cnt, n, colmajor(G)))
+    lib = ndt.load_library()
+    for k, (T, S, cnt, G) in enumerate(batches):
+        B = len(cnt)
+        res = (ndt.Result * B)()
+        eng.stream_collect_raw(ids[k], res)
+        want = np.zeros((cap, shard.REC_WORDS), np.int32)
+        assert lib.mi355ndt_pack_pose_records(C.cast(res, C.c_void_p), B, 3 + k, 8, want.ctypes.data_as(C.c_void_p), cap) == 0
+        got = blocks[k].cpu().numpy()
+        assert np.array_equal(got, want), k
+        rec = shard.unpack_records(blocks[k])
+        assert sorted(rec) == [3 + k + 8 * b for b in range(B)] and rec[3 + k]["iterations"] == res[0].iterations
+    eng.stream_end()
+    eng.close()
