@@ -1000,6 +1000,7 @@ static void make_sweep_const(const mi355ndt_handle* h, SweepConst& sc) {
   sc.dyn_shift = h->dyn_shift >= 0 ? h->dyn_shift : (sc.K == 1 ? 3 : 2);
   sc.host_flags = nullptr;
   sc.seq_no = 0;
+  sc.rebase_block = 0;
 }
 
 static int launch_sweep(mi355ndt_handle* h, const SweepConst& sc, int max_pairs = -1) {
@@ -1017,6 +1018,7 @@ static int launch_sweep(mi355ndt_handle* h, const SweepConst& sc, int max_pairs 
   if (h->fine_it) {                              // latency mode: items dealt statically over the whole grid, sized to the work there can be
     const long long items = (long long)(max_pairs > 0 ? max_pairs : h->n_pairs) * h->items_per_pair;
     grid.x = (unsigned)std::max(1LL, std::min((long long)grid.x, (items + WAVES - 1) / WAVES));
+    if (sc.rebase_block) grid.x += 1;              // + the workgroup that computes the next update's re-basing instead of sweeping
     if (sc.pca) { if (sc.K == 1) NDT_LAUNCH_FINE(true, 1); else NDT_LAUNCH_FINE(true, 7); }
     else        { if (sc.K == 1) NDT_LAUNCH_FINE(false, 1); else NDT_LAUNCH_FINE(false, 7); }
   } else if (sc.pca && sc.K == 27) {             // ndt_pca + KDTREE: order-dependent weights, the literal kernel (ndt_sweep_kd.hpp)
@@ -1077,6 +1079,7 @@ static int align_pump(mi355ndt_handle* h, SweepConst sc, int B) {
   h->h_seq_flags[0] = 0; h->h_seq_flags[1] = -1;
   sc.host_flags = h->d_seq_flags;
   sc.seq_no = 1;
+  sc.rebase_block = 1;                           // every fine sweep also prepares the next update's re-basing (its extra workgroup)
   rc = launch_sweep(h, sc);                      // the sweep at the guess
   if (rc) return rc;
   const int depth = 2;
@@ -2312,6 +2315,7 @@ int mi355ndt_sequence_run(mi355ndt_handle* h, int n_frames, const void* const* c
   h->d_grid_of_use = h->d_grid_of;
   SweepConst sc;
   make_sweep_const(h, sc);
+  sc.rebase_block = 1;                           // every fine sweep also prepares the next update's re-basing (its extra workgroup)
   gauss_constants3(h->prm.outlier_ratio, h->prm.resolution, h->gauss_last);
   k_seq_begin<<<1, 64, 0, s>>>(h->d_seq, h->d_state, h->d_grid, h->d_src_cnt, h->d_stamps, h->d_seq_out, h->d_active_list, h->d_ctl, h->d_grid_of, h->d_seq_flags);
   bool stuck = false;

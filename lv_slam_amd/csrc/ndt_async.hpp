@@ -293,7 +293,7 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   __shared__ double exp_tab[64];
   __shared__ PairState Ssh[WAVES];
-  __shared__ double sol[WAVES][8];
+  __shared__ double sol[WAVES][SOL_WORDS];
   if (threadIdx.x < 64) exp_tab[threadIdx.x] = ndtm::c_exp2_64[threadIdx.x];
   __syncthreads();                                 // (the only block barrier: the four waves are independent from here on)
   const int x = blockIdx.x & 7;                    // the ring this workgroup serves

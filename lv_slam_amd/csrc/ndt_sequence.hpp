@@ -147,7 +147,7 @@ k_seq_update(SeqState* seq, PairState* st, const double* __restrict__ partials, 
              int* active_list, SweepCtl* ctl, int* grid_of, volatile int* host_flags,
              double step_max, double eps, int max_iterations) {
   __shared__ double sm[UPD_WAVES][NACC];
-  __shared__ double sol[8];
+  __shared__ double sol[SOL_WORDS];
   SeqState& Q = *seq;
   if (threadIdx.x == 0) sol[6] = 0.0;
   if (threadIdx.x == 0) { Q.launches++; host_flags[1] = Q.launches; }            // launches executed (the host bounds its queue depth with it)
@@ -166,7 +166,9 @@ k_seq_update(SeqState* seq, PairState* st, const double* __restrict__ partials, 
   __syncthreads();
   if (threadIdx.x >= 128) return;
   if (threadIdx.x >= 64) { newton_solve_side(S, sol); return; }                  // the solve, next to wave 0's re-basing of p
-  const int rc = newton_update(S, &results[cur], step_max, eps, max_iterations, 0, sol);
+  // (the re-basing of p for this step was computed under the sweep, by its extra workgroup: ndt_sweep.hpp)
+  const bool rebased = S.phase == PH_STEP && S.reb_tag == (long long)S.sweeps;
+  const int rc = newton_update(S, &results[cur], step_max, eps, max_iterations, 0, sol, rebased);
   if (lane != 0) return;
   if (rc == NEWTON_SWEEP) { active_list[0] = cur; ctl->n_active = 1; return; }
   // ---- the align of frame `cur` is over: scan_matching_odom_nodelet.cpp:221-250

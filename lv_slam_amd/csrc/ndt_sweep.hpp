@@ -482,6 +482,9 @@ __device__ __forceinline__ void sweep_item(const int b, const int rem, const flo
   }
 }
 
+// (ndt_update.hpp, which includes this file)
+__device__ __forceinline__ void newton_rebase(const double p[6], const double dir[6], const double a_t, double pn[6], float inc_cm[16]);
+
 template <bool PCA, int K, int IT = 8, bool FINE = false, int ORD = 0>
 __global__ void __launch_bounds__(SWEEP_THREADS, (SweepTune<PCA, K>::WPE))
 k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict__ st,
@@ -513,6 +516,26 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
     sc.host_flags[0] = sc.seq_no;
   }
   if (n_active == 0) return;                       // nothing left to sweep (the loop's last, empty round)
+  // Latency mode: the re-basing of p that the NEXT Newton update starts with -- log(exp(delta_p) exp(p)) and float(exp(delta_p)), impl2:163-166 --
+  // depends only on what the previous update decided (p, dir, a_t), not on this sweep.  One extra workgroup computes it while the others
+  // sweep (two SE(3) exponentials and a logarithm: ~9 k cycles of a serial f64 chain that used to sit on the update's critical path); the
+  // update picks it up behind the tag (= the pair's sweep count), exactly as the one-launch align does (ndt_async.hpp).
+  const int nblk = FINE && sc.rebase_block ? (int)gridDim.x - 1 : (int)gridDim.x;
+  if (FINE && sc.rebase_block && (int)blockIdx.x == nblk) {
+    if (wv != 0) return;
+    for (int a = 0; a < n_active; a++) {
+      PairState& S = const_cast<PairState&>(st[active_list[a]]);
+      if (S.phase != PH_STEP) continue;              // (wave-uniform: the first sweep of an align has no step behind it)
+      double pn[6]; float inc[16];
+      newton_rebase(S.p, S.dir, S.a_t, pn, inc);
+      if (lane == 0) {
+        for (int k = 0; k < 6; k++) S.reb_pn[k] = pn[k];
+        for (int k = 0; k < 16; k++) S.reb_inc[k] = inc[k];
+        S.reb_tag = (long long)S.sweeps;
+      }
+    }
+    return;
+  }
   const int my_xcd = blockIdx.x & 7;
   // Items of a queue are handed out in two ways.  The first `n_static` rounds are STATIC: wave `wx` of the XCD's `xw` waves takes
   // items wx, wx + xw, ...; only the rest of the queue is claimed with an atomic.  Why: VMEM operations of a wave complete in
@@ -523,8 +546,8 @@ k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict
   // XCD affinity.  Always in latency mode; in batch mode whenever the launch has no more items than waves -- the last rounds of a
   // batch, when a handful of pairs are still iterating: with fewer than eight active pairs most XCDs own no queue and their waves
   // would do nothing but steal, one returning atomic (~4 us) per item.  Which wave runs an item is no part of its result.
-  const bool flat = FINE || (n_active * items_per_pair <= (int)gridDim.x * WAVES);
-  const int xw = flat ? (int)gridDim.x * WAVES : (int)(gridDim.x >> 3) * WAVES;          // waves per XCD (flat: of the whole grid)
+  const bool flat = FINE || (n_active * items_per_pair <= nblk * WAVES);
+  const int xw = flat ? nblk * WAVES : (int)(gridDim.x >> 3) * WAVES;                    // waves per XCD (flat: of the whole grid)
   const int wx = flat ? (int)blockIdx.x * WAVES + wv : (int)(blockIdx.x >> 3) * WAVES + wv;
 #ifdef NDT_TIMELINE
   unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};

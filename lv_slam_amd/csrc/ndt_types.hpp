@@ -90,6 +90,7 @@ struct SweepConst {
   // [0] = its sequence number -- so that the host can pump (update, sweep) launches without waiting for a copy or an event
   volatile int* host_flags;
   int    seq_no;
+  int    rebase_block;         // latency mode: the launch's LAST workgroup does not sweep -- it computes the re-basing of p the next Newton update starts with (ndt_sweep.hpp)
 };
 
 // Neighbour offsets in the reference's probe order.  DIRECT1: voxel_grid_covariance_omp_impl.hpp:441;

@@ -33,7 +33,7 @@ __global__ void k_solve(const double* __restrict__ in, double* __restrict__ out,
 
 // one wave per system: newton_solve_side as k_update's second wave runs it
 __global__ void k_solve_side(const double* __restrict__ in, double* __restrict__ out, PairState* st) {
-  __shared__ double sol[8];
+  __shared__ double sol[SOL_WORDS];
   const int i = blockIdx.x;
   PairState& S = st[i];
   if (threadIdx.x == 0) {

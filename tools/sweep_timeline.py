@@ -1,5 +1,7 @@
 """Where a sweep work item spends its time: per-phase shader-clock totals from a library built with -DNDT_TIMELINE
-(hipcc <the flags of __graft_entry__.HIP_FLAGS> -DNDT_TIMELINE ... -o lv_slam_amd/libexp_tl.so; MI355NDT_LIB=<that file>).
+(hipcc <the flags of __graft_entry__.HIP_FLAGS> -DNDT_TIMELINE -DNDT_SINGLE_TU lv_slam_amd/csrc/mi355_ndt.hip -o lv_slam_amd/libexp_tl.so;
+MI355NDT_LIB=<that file>.  -DNDT_SINGLE_TU: the library normally has two translation units -- the ORD = 1 kernel instantiations live in
+mi355_ndt_ord1.hip -- and the timeline counters (`__device__ g_tl`) may only be defined once: build everything from the one file).
 MODE=direct1|direct7 VARIANT=omp|pca PAIRS=271 AZIMUTH=1024 RESOLUTION=1.0.  The shipped library has no such hook."""
 import sys, os, ctypes
 import numpy as np, torch
