@@ -347,13 +347,24 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
     const AsyncCtx C = tab->c[tw >> ASYNC_CTX_SHIFT];   // (wave-uniform: scalar loads of a table nobody writes during the launch)
     const int b = tw & ((1 << ASYNC_CTX_SHIFT) - 1);
     const int n_b = C.src_cnt[b];
-#pragma unroll 1
-    for (int k = 0; k < CLAIM; k++)
-      sweep_item<PCA, K, 8, false, ORD, true>(b, rem + k, C.src, C.pitch, C.st, C.gd, C.words, C.recs, C.partials, I, sc, C.cent, nullptr, exp_tab, pose_w, n_b, b
-#ifdef NDT_TIMELINE
-                                              , tl, tl_last
+#ifndef ASYNC_D1_PIPE
+#define ASYNC_D1_PIPE 1
 #endif
-                                              );
+    if (K == 1 && ASYNC_D1_PIPE) {                   // DIRECT1: the claim's items as one software pipeline (ndt_sweep.hpp), same rows bit for bit
+      sweep_rows_d1<PCA, ORD, CLAIM>(b, rem, C.src, C.pitch, C.gd, C.words, C.recs, C.partials, I, sc, exp_tab, pose_w, n_b, b
+#ifdef NDT_TIMELINE
+                                     , tl, tl_last
+#endif
+                                     );
+    } else {
+#pragma unroll 1
+      for (int k = 0; k < CLAIM; k++)
+        sweep_item<PCA, K, 8, false, ORD, true>(b, rem + k, C.src, C.pitch, C.st, C.gd, C.words, C.recs, C.partials, I, sc, C.cent, nullptr, exp_tab, pose_w, n_b, b
+#ifdef NDT_TIMELINE
+                                                , tl, tl_last
+#endif
+                                                );
+    }
     // Three memory round trips between two items, each carrying everything that does not depend on the next one:
     //  1. the row stores drain (the row is complete in memory before the arrival that may hand it to an updater) -- and the claim of the
     //     next position, which depends on nothing, returns with them;

@@ -482,6 +482,201 @@ __device__ __forceinline__ void sweep_item(const int b, const int rem, const flo
   }
 }
 
+// DIRECT1 in the one-launch align: NROWS consecutive work items of ONE pair (the two items of a claim, ndt_async.hpp) as one software
+// pipeline.  With one probe per point and ~0.85 hits, a DIRECT1 item is a third evaluation and two thirds waiting for the chain
+// points -> bitmap word -> record (timeline build, pca / 1 m: point wait + transform 11 %, bitmap wait + push 18 %, reduction 10 % of an item).
+// sweep_item probes the whole item at once -- every wait of that chain is exposed once per item.  Here a row's eight tiles go through in four
+// super-tiles of two: while super-tile s is evaluated, the bitmap words of s + 1 and the points of s + 2 are in flight, and the first
+// super-tile of the NEXT row is probed under this row's reduction.  What is evaluated, and in which 64-hit batches, is exactly what
+// sweep_item<PCA, 1, 8> does -- hits enter the queue in point order, full batches leave it in FIFO order, the tail is flushed at the end of
+// every row -- so the rows carry the same bits (tests/test_gpu_configs.py and tests/test_stream_gpu.py hold this function, which the
+// one-launch align uses, against the round-based kernels, which use sweep_item).
+// The staging area holds one row (four super-tiles); a super-tile's slot is free again when its row has been flushed.
+template <bool PCA, int ORD, int NROWS>
+__device__ __forceinline__ void sweep_rows_d1(const int b, const int rem0, const float* __restrict__ src, const size_t pitch,
+                                              const GridDesc* __restrict__ gd, const BitWord* __restrict__ words, const VoxelRec* __restrict__ recs,
+                                              double* partials, const int rows_per_pair, const SweepConst& sc, const double* exp_tab,
+                                              const unsigned pose_w, const int n, const int g_idx
+#ifdef NDT_TIMELINE
+                                              , unsigned long long* tl, unsigned long long& tl_last
+#endif
+                                              ) {
+  constexpr int TP = 2, IT = 8, NST = IT / TP, Q_CAP = 512;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  __shared__ unsigned q_ent[WAVES][Q_CAP];
+  __shared__ float stage[WAVES][64 * IT][6];       // one row of staged points: x'(3), R x (3)
+  const GridDesc& g = gd[g_idx];
+  const float* X = src + (size_t)b * 3 * pitch;
+  const BitWord* W = words + g.word_off;
+  const VoxelRec* R = recs + g.rec_off;
+  const bool grid_ok = (g.status == GRID_OK);
+  float T[12], Rj[9];
+#pragma unroll
+  for (int a = 0; a < 12; a++) T[a] = __uint_as_float(__builtin_amdgcn_readlane(pose_w, a));
+#pragma unroll
+  for (int a = 0; a < 9; a++) Rj[a] = __uint_as_float(__builtin_amdgcn_readlane(pose_w, 12 + a));
+  const float leaf = g.leaf;
+  const int mb0 = g.min_b[0], mb1 = g.min_b[1], mb2 = g.min_b[2];
+  const unsigned e0 = (unsigned)(g.max_b[0] - mb0), e1 = (unsigned)(g.max_b[1] - mb1), e2 = (unsigned)(g.max_b[2] - mb2);
+  const int mul1 = g.mul1, mul2 = g.mul2;
+  const int base = rem0 * (IT * 64);               // first point of the first row
+  constexpr int S_TOTAL = NROWS * NST;
+
+  double acc[43];
+#pragma unroll
+  for (int a = 0; a < 43; a++) acc[a] = 0.0;
+  unsigned nhits = 0;
+  int qhead = 0, qcount = 0;                       // wave-uniform
+
+  struct Batch { unsigned slot; double m0, m1, m2; float C[9]; int weight; };
+  auto fetch = [&](int off, int m, Batch& B) {
+    const int k = lane < m ? lane : m - 1;
+    const unsigned ent = q_ent[wv][(qhead + off + k) & (Q_CAP - 1)];
+    B.slot = ent >> ID_BITS;
+    const VoxelRec& vr = R[ent & ((1u << ID_BITS) - 1)];
+    B.m0 = vr.mean[0]; B.m1 = vr.mean[1]; B.m2 = vr.mean[2];
+#pragma unroll
+    for (int a = 0; a < 9; a++) B.C[a] = vr.icov[a];
+    B.weight = vr.weight;
+  };
+  auto eval_batch = [&](const Batch& B, int m, auto mid) {
+    const float* sp = stage[wv][B.slot];
+    const float xt0 = sp[0], xt1 = sp[1], xt2 = sp[2];
+    float r[3] = {sp[3], sp[4], sp[5]};
+    const bool live = lane < m && B.weight != VOX_DEAD;
+    float u[3] = {(float)((double)xt0 - B.m0), (float)((double)xt1 - B.m1), (float)((double)xt2 - B.m2)};   // impl2:276-279, 574
+    eval_hit<PCA, decltype(mid), false, ORD>(u, r, B.C, sc.d1, sc.d2f, PCA ? (double)B.weight : 1.0, live, acc, exp_tab, mid);
+    nhits += (unsigned)__popcll(__ballot(live));
+    qhead = (qhead + m) & (Q_CAP - 1);
+    qcount -= m;
+  };
+  auto drain_full = [&]() {                        // all full batches, the next batch's records fetched in the middle of the current one (as sweep_item)
+    if (qcount < 64) return;
+    Batch A;
+    fetch(0, 64, A);
+#pragma unroll 1
+    for (;;) {
+      const bool more = qcount >= 128;
+      Batch N;
+      eval_batch(A, 64, [&]() { if (more) fetch(64, 64, N); });
+      if (!more) break;
+      A = N;
+    }
+  };
+
+  // pipeline registers: points of the super-tile after the probed one; probe words of the probed one
+  float nx[TP], ny[TP], nz[TP];
+  uint4 bw[TP];
+  unsigned cellv[TP];
+  auto load_points = [&](const int s) {
+#pragma unroll
+    for (int p = 0; p < TP; p++) {
+      const int i = base + (s * TP + p) * 64 + lane;
+      nx[p] = ny[p] = nz[p] = 0.f;
+      if (s < S_TOTAL && i < n) { nx[p] = X[i]; ny[p] = X[pitch + i]; nz[p] = X[2 * pitch + i]; }
+    }
+  };
+  // transform super-tile s (its points are in nx..), stage it, and issue its bitmap loads
+  auto probe = [&](const int s) {
+#pragma unroll
+    for (int p = 0; p < TP; p++) {
+      const int i = base + (s * TP + p) * 64 + lane;
+      const float px = nx[p], py = ny[p], pz = nz[p];
+      bool ok = grid_ok && i < n && finite3(px, py, pz);
+      float xt[3], r[3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        xt[a] = ((T[a * 4 + 0] * px + T[a * 4 + 1] * py) + T[a * 4 + 2] * pz) + T[a * 4 + 3];
+        r[a] = (Rj[a * 3 + 0] * px + Rj[a * 3 + 1] * py) + Rj[a * 3 + 2] * pz;
+      }
+      ok = ok && finite3(xt[0], xt[1], xt[2]);
+      float* sp = stage[wv][(((s % NST) * TP) + p) * 64 + lane];
+      sp[0] = xt[0]; sp[1] = xt[1]; sp[2] = xt[2]; sp[3] = r[0]; sp[4] = r[1]; sp[5] = r[2];
+      const int c0 = (int)floorf(sc.leaf_pow2 ? xt[0] * sc.inv_leaf : xt[0] / leaf);
+      const int c1 = (int)floorf(sc.leaf_pow2 ? xt[1] * sc.inv_leaf : xt[1] / leaf);
+      const int c2 = (int)floorf(sc.leaf_pow2 ? xt[2] * sc.inv_leaf : xt[2] / leaf);
+      const int r0 = c0 - mb0, r1 = c1 - mb1, r2 = c2 - mb2;
+      const bool inside = ok && (unsigned)r0 <= e0 && (unsigned)r1 <= e1 && (unsigned)r2 <= e2;
+      // (a probe that falls outside the grid -- or belongs to an invalid lane, or to a target without a grid -- reads nothing and misses)
+      cellv[p] = inside ? (unsigned)(r0 + r1 * mul1 + r2 * mul2) : 0u;
+      bw[p] = make_uint4(0u, 0u, 0u, 0u);
+      if (inside) bw[p] = *reinterpret_cast<const uint4*>(W + (cellv[p] >> 6));
+    }
+  };
+  // rank the probed super-tile's cells and push its hits (point order: tile, then lane)
+  auto push = [&](const int s) {
+#pragma unroll
+    for (int p = 0; p < TP; p++) {
+      const unsigned long long bits = ((unsigned long long)bw[p].y << 32) | bw[p].x;
+      const unsigned long long tb = bits << (63u - (cellv[p] & 63u));
+      const unsigned id = bw[p].z + (unsigned)__popcll(tb) - 1u;
+      const bool hit = (long long)tb < 0;
+      const unsigned long long mask = __ballot(hit);
+      if (hit) {
+        const int pos = (qhead + qcount + (int)__popcll(mask & lt_mask)) & (Q_CAP - 1);
+        q_ent[wv][pos] = ((unsigned)((((s % NST) * TP) + p) * 64 + lane) << ID_BITS) | id;
+      }
+      qcount += (int)__popcll(mask);
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  load_points(0);
+  TL_STAMP(1);
+  probe(0);
+  load_points(1);
+  TL_STAMP(2);
+#pragma unroll 1
+  for (int s = 0; s < S_TOTAL; s++) {
+    const bool row_end = (s % NST) == NST - 1;
+    push(s);
+    TL_STAMP(4);
+    if (!row_end) { probe(s + 1); load_points(s + 2); }        // their memory round trips ride under the evaluation below
+    drain_full();
+    TL_STAMP(5);
+    if (!row_end) continue;
+    // ---- the row is complete: flush the tail, then (the staging area is free) probe the next row's first super-tile under the reduction
+    __builtin_amdgcn_wave_barrier();
+    if (qcount > 0) { Batch Bt; fetch(0, qcount, Bt); eval_batch(Bt, qcount, NoHook()); }
+    TL_STAMP(5);
+    if (s + 1 < S_TOTAL) { probe(s + 1); load_points(s + 2); }
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    double P1[22], P2[11];
+#pragma unroll
+    for (int i = 0; i < 22; i++) {
+      const double a = acc[i], b2 = (i + 22 < 43) ? acc[i + 22] : 0.0;
+      const u2v lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b2), false, false);
+      const u2v hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b2), false, false);
+      P1[i] = __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+    }
+#pragma unroll
+    for (int i = 0; i < 11; i++) {
+      const double a = P1[i], b2 = P1[i + 11];
+      const u2v lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b2), false, false);
+      const u2v hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b2), false, false);
+      double v = __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      P2[i] = v;
+    }
+    if ((lane & 15) == 0) {
+      const int row = lane >> 4, rb = 11 * (row & 1) + 22 * (row >> 1);
+      gu64* PG = (gu64*)reinterpret_cast<unsigned long long*>(partials + ((size_t)b * rows_per_pair + rem0 + s / NST) * NACC);
+#pragma unroll
+      for (int i = 0; i < 11; i++) if (rb + i < 43) __hip_atomic_store(PG + rb + i, (unsigned long long)__double_as_longlong(P2[i]), RLX_AGENT);
+      if (lane == 0) __hip_atomic_store(PG + 43, (unsigned long long)__double_as_longlong((double)nhits), RLX_AGENT);
+    }
+#pragma unroll
+    for (int a = 0; a < 43; a++) acc[a] = 0.0;
+    nhits = 0;
+    TL_STAMP(6);
+#ifdef NDT_TIMELINE
+    tl[7] += 1;
+#endif
+  }
+}
+
 // (ndt_update.hpp, which includes this file)
 __device__ __forceinline__ void newton_rebase(const double p[6], const double dir[6], const double a_t, double pn[6], float inc_cm[16]);
 
