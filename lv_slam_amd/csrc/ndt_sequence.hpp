@@ -16,7 +16,7 @@
 #include "ndt_update.hpp"
 
 struct SeqState {
-  int    n_frames, cur, key_id, second_done, done, aligns, launches, pad1;
+  int    n_frames, cur, key_id, second_done, done, aligns, launches, cur_n;   // cur_n: point count of frame `cur` (the update needs it before it has the frame's state)
   double pre_tf_s2k[16], key_pose[16];          // 4x4 f64 row-major
   double keyframe_stamp;
   double d_trans, d_angle, d_time;              // keyframe_delta_trans / _angle / _time (:67-76)
@@ -66,7 +66,7 @@ __global__ void k_seq_begin(SeqState* seq, PairState* st, const GridDesc* __rest
                             volatile int* host_flags) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   SeqState& Q = *seq;
-  Q.cur = 1; Q.key_id = 0; Q.second_done = 0; Q.aligns = 0; Q.done = 0; Q.launches = 0;
+  Q.cur = 1; Q.key_id = 0; Q.second_done = 0; Q.aligns = 0; Q.done = 0; Q.launches = 0; Q.cur_n = Q.n_frames > 1 ? cnt[1] : 0;
   for (int a = 0; a < 16; a++) Q.pre_tf_s2k[a] = Q.key_pose[a] = (a % 5 == 0) ? 1.0 : 0.0;
   Q.keyframe_stamp = stamps[0];
   mi355ndt_seq_frame f;
@@ -135,6 +135,7 @@ __device__ inline int seq_policy(SeqState& Q, PairState& S, PairState& Sn, const
   float G[16];
   for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) G[c * 4 + r] = (float)guess[r * 4 + c];   // guess_trans.cast<float>() (:221)
   grid_of[nxt] = Q.key_id;
+  Q.cur_n = cnt[nxt];
   init_pair_state(Sn, G, cnt[nxt], gd[Q.key_id].status);
   return SEQ_NEXT;
 }
@@ -148,32 +149,46 @@ k_seq_update(SeqState* seq, PairState* st, const double* __restrict__ partials, 
              double step_max, double eps, int max_iterations) {
   __shared__ double sm[UPD_WAVES][NACC];
   __shared__ double sol[SOL_WORDS];
+  // The frame's pair state lives in LDS for the duration of the update: the Newton step reads and writes some sixty of its fields one after the
+  // other, and through a global reference every first touch of a line was a memory round trip of its own (rounds 3-4: 11.5 us per update,
+  // most of it such waits).  Two round trips are left: the run's position (cur, its point count), then the state together with the rows.
+  __shared__ PairState Ssh;
   SeqState& Q = *seq;
   if (threadIdx.x == 0) sol[6] = 0.0;
-  if (threadIdx.x == 0) { Q.launches++; host_flags[1] = Q.launches; }            // launches executed (the host bounds its queue depth with it)
-  if (Q.done) return;                                                            // (block-uniform; the pump's overshoot)
-  const int cur = Q.cur;
-  PairState& S = st[cur];
+  const int done = Q.done, cur = Q.cur, n_src = Q.cur_n;                         // (block-uniform)
+  if (threadIdx.x == 0) { const int l = Q.launches + 1; Q.launches = l; host_flags[1] = l; }   // launches executed (the host bounds its queue depth with it)
+  if (done) return;                                                              // (the pump's overshoot)
+  static_assert(sizeof(PairState) % 8 == 0, "PairState travels as 8-byte words");
+  constexpr int NW = (int)(sizeof(PairState) / 8);
+  unsigned long long* sg = reinterpret_cast<unsigned long long*>(&st[cur]);
+  unsigned long long* sl = reinterpret_cast<unsigned long long*>(&Ssh);
+  for (int i = threadIdx.x; i < NW; i += UPD_THREADS) sl[i] = sg[i];
   const int lane = threadIdx.x & 63;
-  const int nchunks = (S.n_src + pts_per_chunk - 1) / pts_per_chunk;
-  const double v = reduce_pair_rows(partials + (size_t)cur * rows_per_pair * NACC, nchunks, true, sm, true);   // latency mode: chunk rows
+  const int nchunks = (n_src + pts_per_chunk - 1) / pts_per_chunk;
+  const double v = reduce_pair_rows(partials + (size_t)cur * rows_per_pair * NACC, nchunks, true, sm, true);   // latency mode: chunk rows (its barrier also publishes Ssh)
   if (threadIdx.x < NACC) {
-    if (lane == 0) S.score = v;
-    else if (lane < 7) S.g[lane - 1] = v;
-    else if (lane < 43) S.H[lane - 7] = v;
-    else S.hits = (long long)v;
+    if (lane == 0) Ssh.score = v;
+    else if (lane < 7) Ssh.g[lane - 1] = v;
+    else if (lane < 43) Ssh.H[lane - 7] = v;
+    else Ssh.hits = (long long)v;
   }
   __syncthreads();
   if (threadIdx.x >= 128) return;
-  if (threadIdx.x >= 64) { newton_solve_side(S, sol); return; }                  // the solve, next to wave 0's re-basing of p
+  if (threadIdx.x >= 64) { newton_solve_side(Ssh, sol); return; }                // the solve, next to wave 0
   // (the re-basing of p for this step was computed under the sweep, by its extra workgroup: ndt_sweep.hpp)
-  const bool rebased = S.phase == PH_STEP && S.reb_tag == (long long)S.sweeps;
-  const int rc = newton_update(S, &results[cur], step_max, eps, max_iterations, 0, sol, rebased);
-  if (lane != 0) return;
-  if (rc == NEWTON_SWEEP) { active_list[0] = cur; ctl->n_active = 1; return; }
-  // ---- the align of frame `cur` is over: scan_matching_odom_nodelet.cpp:221-250
-  const int kind = seq_policy(Q, S, st[cur + 1 < Q.n_frames ? cur + 1 : cur], cur, grid_of[cur], gd, cnt, stamps, out, grid_of);
-  if (kind == SEQ_END) { __threadfence_system(); host_flags[0] = 1; return; }
-  active_list[0] = kind == SEQ_SAME ? cur : cur + 1;
-  ctl->n_active = 1;
+  const bool rebased = Ssh.phase == PH_STEP && Ssh.reb_tag == (long long)Ssh.sweeps;
+  const int rc = newton_update(Ssh, &results[cur], step_max, eps, max_iterations, 0, sol, rebased);
+  if (lane == 0) {
+    if (rc == NEWTON_SWEEP) { active_list[0] = cur; ctl->n_active = 1; }
+    else {
+      // ---- the align of frame `cur` is over: scan_matching_odom_nodelet.cpp:221-250
+      const int kind = seq_policy(Q, Ssh, st[cur + 1 < Q.n_frames ? cur + 1 : cur], cur, grid_of[cur], gd, cnt, stamps, out, grid_of);
+      if (kind == SEQ_END) { __threadfence_system(); host_flags[0] = 1; }
+      else { active_list[0] = kind == SEQ_SAME ? cur : cur + 1; ctl->n_active = 1; }
+    }
+  }
+  // the state goes back (frame cur's: updated, finalised, or re-initialised for frame 1's second align)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < NW; i += 64) sg[i] = sl[i];
 }
