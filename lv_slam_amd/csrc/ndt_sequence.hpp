@@ -154,10 +154,15 @@ k_seq_update(SeqState* seq, PairState* st, const double* __restrict__ partials, 
   // most of it such waits).  Two round trips are left: the run's position (cur, its point count), then the state together with the rows.
   __shared__ PairState Ssh;
   SeqState& Q = *seq;
+#ifdef NDT_TIMELINE
+  unsigned long long tl[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // (slots 8..14: this kernel's phases, wave 0 / wave 1; tools/seq_run.py)
+  unsigned long long tl_last = __builtin_readcyclecounter();
+#endif
   if (threadIdx.x == 0) sol[6] = 0.0;
   const int done = Q.done, cur = Q.cur, n_src = Q.cur_n;                         // (block-uniform)
   if (threadIdx.x == 0) { const int l = Q.launches + 1; Q.launches = l; host_flags[1] = l; }   // launches executed (the host bounds its queue depth with it)
   if (done) return;                                                              // (the pump's overshoot)
+  TL_STAMP(8);                                                                   // run position
   static_assert(sizeof(PairState) % 8 == 0, "PairState travels as 8-byte words");
   constexpr int NW = (int)(sizeof(PairState) / 8);
   unsigned long long* sg = reinterpret_cast<unsigned long long*>(&st[cur]);
@@ -173,11 +178,20 @@ k_seq_update(SeqState* seq, PairState* st, const double* __restrict__ partials, 
     else Ssh.hits = (long long)v;
   }
   __syncthreads();
+  TL_STAMP(9);                                                                   // state + rows
   if (threadIdx.x >= 128) return;
-  if (threadIdx.x >= 64) { newton_solve_side(Ssh, sol); return; }                // the solve, next to wave 0
+  if (threadIdx.x >= 64) {                                                       // the solve, next to wave 0
+    newton_solve_side(Ssh, sol);
+#ifdef NDT_TIMELINE
+    TL_STAMP(13);
+    if (lane == 0) atomicAdd(&g_tl[13], tl[13]);
+#endif
+    return;
+  }
   // (the re-basing of p for this step was computed under the sweep, by its extra workgroup: ndt_sweep.hpp)
   const bool rebased = Ssh.phase == PH_STEP && Ssh.reb_tag == (long long)Ssh.sweeps;
   const int rc = newton_update(Ssh, &results[cur], step_max, eps, max_iterations, 0, sol, rebased);
+  TL_STAMP(10);                                                                  // Newton step (incl. the wait for the solve)
   if (lane == 0) {
     if (rc == NEWTON_SWEEP) { active_list[0] = cur; ctl->n_active = 1; }
     else {
@@ -190,5 +204,11 @@ k_seq_update(SeqState* seq, PairState* st, const double* __restrict__ partials, 
   // the state goes back (frame cur's: updated, finalised, or re-initialised for frame 1's second align)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
+  TL_STAMP(11);                                                                  // policy (when the frame's align ended)
   for (int i = lane; i < NW; i += 64) sg[i] = sl[i];
+#ifdef NDT_TIMELINE
+  TL_STAMP(12);
+  tl[14] = 1;
+  if (lane == 0) for (int k = 8; k < 15; k++) if (k != 13) atomicAdd(&g_tl[k], tl[k]);
+#endif
 }

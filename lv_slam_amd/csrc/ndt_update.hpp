@@ -508,10 +508,19 @@ k_update(PairState* st, const double* __restrict__ partials, int rows_per_pair, 
          double step_max, double eps, int max_iterations, int reduce_only, int mt) {
   __shared__ double sm[UPD_WAVES][NACC];
   __shared__ double sol[SOL_WORDS];
+  // the pair's state in LDS for the duration of the update (the Newton step touches some sixty of its fields one after the other; through a
+  // global reference every first touch of a line is a memory round trip of its own)
+  __shared__ PairState Ssh;
   const int b = blockIdx.x;
-  PairState& S = st[b];
-  if (S.phase == PH_DONE) return;                                                // (block-uniform)
+  static_assert(sizeof(PairState) % 8 == 0, "PairState travels as 8-byte words");
+  constexpr int NW = (int)(sizeof(PairState) / 8);
+  unsigned long long* sg = reinterpret_cast<unsigned long long*>(&st[b]);
+  unsigned long long* sl = reinterpret_cast<unsigned long long*>(&Ssh);
+  for (int i = threadIdx.x; i < NW; i += UPD_THREADS) sl[i] = sg[i];
   if (threadIdx.x == 0) sol[6] = 0.0;
+  __syncthreads();
+  PairState& S = Ssh;
+  if (S.phase == PH_DONE) return;                                                // (block-uniform)
   if (mt == 2 && S.phase != PH_HESS) return;                                     // only pairs whose Hessian pass just ran
   const int lane = threadIdx.x & 63;
   const int nchunks = (S.n_src + pts_per_chunk - 1) / pts_per_chunk;
@@ -524,15 +533,20 @@ k_update(PairState* st, const double* __restrict__ partials, int rows_per_pair, 
     else { S.hits = (long long)v; if (hits_total) atomicAdd(hits_total, (unsigned long long)v); }
   }
   __syncthreads();                                                               // lane 0 reads what lanes 0..43 just stored
-  if (threadIdx.x >= 128 || reduce_only) return;
-  if (threadIdx.x >= 64) { if (mt == 0) newton_solve_side(S, sol); return; }
-  // (latency mode: the re-basing of p for this step was computed under the sweep, by its extra workgroup -- ndt_sweep.hpp; the tag says so)
-  const bool rebased = mt == 0 && S.phase == PH_STEP && S.reb_tag == (long long)S.sweeps;
-  const int rc = newton_update(S, &results[b], step_max, eps, max_iterations, mt, mt == 0 ? sol : nullptr, rebased);
-  if (lane == 0 && rc == NEWTON_SWEEP) {
-    atomicAdd(active_counter, 1);
-    active_list[atomicAdd(&ctl->n_active, 1)] = b;                               // this pair takes part in the next sweep
+  if (threadIdx.x >= 128) return;
+  if (threadIdx.x >= 64) { if (mt == 0 && !reduce_only) newton_solve_side(S, sol); return; }
+  if (!reduce_only) {
+    // (latency mode: the re-basing of p for this step was computed under the sweep, by its extra workgroup -- ndt_sweep.hpp; the tag says so)
+    const bool rebased = mt == 0 && S.phase == PH_STEP && S.reb_tag == (long long)S.sweeps;
+    const int rc = newton_update(S, &results[b], step_max, eps, max_iterations, mt, mt == 0 ? sol : nullptr, rebased);
+    if (lane == 0 && rc == NEWTON_SWEEP) {
+      atomicAdd(active_counter, 1);
+      active_list[atomicAdd(&ctl->n_active, 1)] = b;                             // this pair takes part in the next sweep
+    }
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < NW; i += 64) sg[i] = sl[i];                             // the state goes back
 }
 
 // output cloud of align(): source moved by final_transformation_ (f32), written as packed x,y,z triples (what goes back over PCIe)
