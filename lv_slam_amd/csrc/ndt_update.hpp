@@ -266,96 +266,33 @@ __device__ __forceinline__ void newton_solve(const PairState& S, double d[6]) {
 }
 // When the More-Thuente loop is dead (mt = 0) the solve depends only on the reduced (g, H) -- not on the re-basing of p that
 // wave 0 runs first -- so a second wave of the block computes it at the same time and hands it over through LDS
-// (`sol`: d[6], then a ready flag, then SOL_WORDS - 8 words of scratch).  Same arithmetic as ndtm::lu_solve6: same bits.
+// (`sol`: d[6], then a ready flag).  Same function, same inputs: same bits.
 //
-// The elimination of [H | e_0..e_5 | -g] (the six columns of H^-1 for the condition estimate, and the Newton step) runs ROW-PARALLEL:
-// lane i < 6 owns row i of the 6 x 13 tableau.  Round 3-4 ran ndtm::lu_solve6_rhs -- ~3 k straight-line instructions -- on seven lanes
-// side by side, one right-hand side each; executed once, cold, it was the longest link of an update's serial chain (16 k cycles,
-// docs/experiments.md 10c).  Here a pivot step is: the six candidates of column k to every lane (v_readlane), the reference
-// order of compare-and-swaps on them (ndtm::lu_solve6_rhs's, which is a chain of pairwise swaps, not an arg-max) evaluated by every lane
-// alike -> a row permutation, one bpermute per tableau word; the pivot row broadcast; every lane below the pivot updates its own row.
-// Every element goes through exactly the operations lu_solve6_rhs applies to it, in the same order.  The back substitution switches to
-// column-parallel (lane c < 7 owns right-hand side c) through the LDS scratch: its sums are ordered (j ascending) and x_j of the lower rows
-// is known last.
-#define SOL_WORDS 96
-__device__ __forceinline__ double rdlane_d(const double v, const int l) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
+// (Round 5 also built the elimination ROW-PARALLEL -- lane i < 6 owning row i of the 6 x 13 tableau [H | I | -g], pivot candidates by
+// v_readlane, the row permutation by ds_bpermute, back substitution column-parallel through LDS: ~1 k instead of ~3 k instructions, bit-identical
+// (tests/test_solve6_gpu.py) -- and measured it slower: 20.6 k against 16 k cycles per update inside the one-launch align, 13.7 k for the solve
+// wave of k_seq_update; the cross-lane traffic of a 6-wide problem costs more than the straight-line code it saves.  docs/experiments.md 10d.)
+#define SOL_WORDS 8
 __device__ __forceinline__ void newton_solve_side(const PairState& S, volatile double* sol) {
+  // lanes 0..5 eliminate [H | e_k] (the columns of H^-1, for the condition estimate), lane 6 [H | -g]: the seven eliminations of
+  // ndtm::lu_solve6 side by side -- same functions, same operands, same order of the final sum: same bits, same decision
   const int lane = threadIdx.x & 63;
   if (lane > 6) return;
-  const int r = lane < 6 ? lane : 0;               // (lane 6 shadows row 0 during the elimination; it owns the Newton step's column afterwards)
-  double a[13];
-#pragma unroll
-  for (int j = 0; j < 6; j++) a[j] = S.H[r * 6 + j];
-#pragma unroll
-  for (int c = 0; c < 6; c++) a[6 + c] = (c == r) ? 1.0 : 0.0;
-  a[12] = -S.g[r];
+  double rhs[6], x[6];
+  for (int a = 0; a < 6; a++) rhs[a] = lane < 6 ? (a == lane ? 1.0 : 0.0) : -S.g[a];
   bool fin = true;
-  for (int q = 0; q < 36; q++) fin = fin && isfinite(S.H[q]);
-  for (int q = 0; q < 6; q++) fin = fin && isfinite(S.g[q]);
-  double pmin = DBL_MAX, pmax = 0.0;
-  bool ok = fin;
-#pragma unroll
-  for (int k = 0; k < 6; k++) {
-    // partial pivoting exactly as ndtm::lu_solve6_rhs does it: for i = k+1..5: if |A[i][k]| > |A[k][k]| swap rows k and i
-    double v[6];
-    int perm[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) { v[i] = rdlane_d(a[k], i); perm[i] = i; }
-#pragma unroll
-    for (int i = k + 1; i < 6; i++) {
-      const bool sw = fabs(v[i]) > fabs(v[k]);
-      const double vk = v[k], vi = v[i];
-      v[k] = sw ? vi : vk; v[i] = sw ? vk : vi;
-      const int pk = perm[k], pi = perm[i];
-      perm[k] = sw ? pi : pk; perm[i] = sw ? pk : pi;
-    }
-    int src = perm[0];
-#pragma unroll
-    for (int i = 1; i < 6; i++) src = (r == i) ? perm[i] : src;
-#pragma unroll
-    for (int j = k; j < 13; j++) a[j] = __shfl(a[j], src);
-    const double piv = v[k];                       // = A[k][k] after the swaps
-    const double ap = fabs(piv);
-    pmin = ap < pmin ? ap : pmin;
-    pmax = ap > pmax ? ap : pmax;
-    if (!(ap > 0.0)) ok = false;                   // (lu_solve6_rhs returns here; what follows is then never used)
-    const double f = a[k] / piv;
-#pragma unroll
-    for (int j = k + 1; j < 13; j++) {
-      const double pkj = rdlane_d(a[j], k);
-      if (r > k) a[j] -= f * pkj;
-    }
-  }
-  if (!(pmin > 1e-6 * pmax) || !(pmax < DBL_MAX)) ok = false;
-  // rows -> LDS, then lane c solves U x = (column c of the right-hand sides)
-  volatile double* T = sol + 8;
-  if (lane < 6) {
-#pragma unroll
-    for (int j = 0; j < 13; j++) T[r * 13 + j] = a[j];
-  }
-  __builtin_amdgcn_wave_barrier();
-  double x[6];
-#pragma unroll
-  for (int i = 5; i >= 0; i--) {
-    double s = T[i * 13 + 6 + lane];
-#pragma unroll
-    for (int j = i + 1; j < 6; j++) s -= T[i * 13 + j] * x[j];
-    x[i] = s / T[i * 13 + i];
-  }
+  for (int a = 0; a < 36; a++) fin = fin && isfinite(S.H[a]);
+  for (int a = 0; a < 6; a++) fin = fin && isfinite(S.g[a]);
+  double pmin, pmax;
+  bool ok = fin && ndtm::lu_solve6_rhs(S.H, rhs, x, pmin, pmax);                 // (the pivots depend on H only: `ok` is the same on all seven lanes)
   const double c2 = (ok && lane < 6) ? ndtm::norm2_6(x) : 0.0;                   // column `lane` of H^-1
   const double r2 = lane < 6 ? ndtm::norm2_6(S.H + 6 * lane) : 0.0;              // row `lane` of H
   double hF2 = 0, invF2 = 0;
   for (int k = 0; k < 6; k++) { invF2 += __shfl(c2, k); hF2 += __shfl(r2, k); }
   if (lane != 6) return;
   ok = ok && ndtm::lu_accept(hF2, invF2);
-  if (!ok) {
-    double rhs[6];
-    for (int q = 0; q < 6; q++) rhs[q] = -S.g[q];
-    ndtm::svd_solve6(S.H, rhs, x);
-  }
-  for (int q = 0; q < 6; q++) sol[q] = x[q];
+  if (!ok) ndtm::svd_solve6(S.H, rhs, x);
+  for (int a = 0; a < 6; a++) sol[a] = x[a];
   __threadfence_block();
   sol[6] = 1.0;
 }

@@ -95,11 +95,92 @@ static void mat3_inverse(const double m[9], double r[9]) {
   r[6] = cof3(m, 0, 2) * invdet; r[7] = cof3(m, 1, 2) * invdet; r[8] = cof3(m, 2, 2) * invdet;
 }
 
+/* Study variant ORA_VAR_EIG_QL: the route of Eigen 3.3's SelfAdjointEigenSolver<Matrix3d>::compute (what voxel_grid_covariance_omp_impl.hpp:333
+ * calls), restated from the published algorithm -- Eigen is not in the reference tree, so this pins nothing; it measures how far another
+ * legitimate eigen-solver moves the inflated covariances (tools/order_sensitivity.py).  Lower triangle; eigenvalues ascending; columns of evecs. */
+static void givens(double p, double q, double* c, double* s) {                    /* Eigen::JacobiRotation::makeGivens, real case */
+  if (q == 0.0) { *c = p < 0 ? -1.0 : 1.0; *s = 0.0; }
+  else if (p == 0.0) { *c = 0.0; *s = q < 0 ? 1.0 : -1.0; }
+  else if (fabs(p) > fabs(q)) { double t = q / p, u = sqrt(1.0 + t * t); if (p < 0) u = -u; *c = 1.0 / u; *s = -t * *c; }
+  else { double t = p / q, u = sqrt(1.0 + t * t); if (q < 0) u = -u; *s = -1.0 / u; *c = -t * *s; }
+}
+static void eigen_sym3_ql(const double Ain[9], double evals[3], double evecs[9]) {
+  double m[3][3] = {{Ain[0], 0, 0}, {Ain[3], Ain[4], 0}, {Ain[6], Ain[7], Ain[8]}};   /* lower triangle */
+  double scale = 0.0;
+  for (int i = 0; i < 3; i++) for (int j = 0; j <= i; j++) if (fabs(m[i][j]) > scale) scale = fabs(m[i][j]);
+  if (scale == 0.0) scale = 1.0;
+  for (int i = 0; i < 3; i++) for (int j = 0; j <= i; j++) m[i][j] /= scale;
+  double diag[3], sub[2], q[3][3];
+  /* tridiagonalization_inplace, 3x3 real special case */
+  diag[0] = m[0][0];
+  const double v1norm2 = m[2][0] * m[2][0];
+  if (v1norm2 <= DBL_MIN) {
+    diag[1] = m[1][1]; diag[2] = m[2][2]; sub[0] = m[1][0]; sub[1] = m[2][1];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) q[i][j] = i == j ? 1.0 : 0.0;
+  } else {
+    const double beta = sqrt(m[1][0] * m[1][0] + v1norm2), inv_beta = 1.0 / beta;
+    const double m01 = m[1][0] * inv_beta, m02 = m[2][0] * inv_beta;
+    const double qq = 2.0 * m01 * m[2][1] + m02 * (m[2][2] - m[1][1]);
+    diag[1] = m[1][1] + m02 * qq; diag[2] = m[2][2] - m02 * qq;
+    sub[0] = beta; sub[1] = m[2][1] - m01 * qq;
+    q[0][0] = 1; q[0][1] = 0; q[0][2] = 0; q[1][0] = 0; q[1][1] = m01; q[1][2] = m02; q[2][0] = 0; q[2][1] = m02; q[2][2] = -m01;
+  }
+  /* computeFromTridiagonal_impl: implicit symmetric QR steps with Wilkinson shift */
+  int end = 2, start = 0, iter = 0;
+  const double prec = 2.0 * DBL_EPSILON;
+  while (end > 0) {
+    for (int i = start; i < end; i++)
+      if (fabs(sub[i]) <= (fabs(diag[i]) + fabs(diag[i + 1])) * prec || fabs(sub[i]) <= DBL_MIN) sub[i] = 0.0;
+    while (end > 0 && sub[end - 1] == 0.0) end--;
+    if (end <= 0) break;
+    if (++iter > 30 * 3) break;
+    start = end - 1;
+    while (start > 0 && sub[start - 1] != 0.0) start--;
+    /* tridiagonal_qr_step */
+    const double td = (diag[end - 1] - diag[end]) * 0.5, e = sub[end - 1];
+    double mu = diag[end];
+    if (td == 0.0) mu -= fabs(e);
+    else {
+      const double e2 = e * e, h = hypot(td, e);
+      if (e2 == 0.0) mu -= (e / (td + (td > 0 ? 1.0 : -1.0))) * (e / h);
+      else mu -= e2 / (td + (td > 0 ? h : -h));
+    }
+    double x = diag[start] - mu, z = sub[start];
+    for (int k = start; k < end; k++) {
+      double c, s;
+      givens(x, z, &c, &s);
+      const double sdk = s * diag[k] + c * sub[k], dkp1 = s * sub[k] + c * diag[k + 1];
+      diag[k] = c * (c * diag[k] - s * sub[k]) - s * (c * sub[k] - s * diag[k + 1]);
+      diag[k + 1] = s * sdk + c * dkp1;
+      sub[k] = c * sdk - s * dkp1;
+      if (k > start) sub[k - 1] = c * sub[k - 1] - s * z;
+      x = sub[k];
+      if (k < end - 1) { z = -s * sub[k + 1]; sub[k + 1] = c * sub[k + 1]; }
+      for (int i = 0; i < 3; i++) {                 /* q.applyOnTheRight(k, k+1, rot) */
+        const double qi = q[i][k], qj = q[i][k + 1];
+        q[i][k] = c * qi - s * qj;
+        q[i][k + 1] = s * qi + c * qj;
+      }
+    }
+  }
+  /* ascending selection sort of the eigenvalues, columns follow */
+  for (int i = 0; i < 2; i++) {
+    int k = i;
+    for (int j = i + 1; j < 3; j++) if (diag[j] < diag[k]) k = j;
+    if (k != i) {
+      double t = diag[i]; diag[i] = diag[k]; diag[k] = t;
+      for (int r = 0; r < 3; r++) { t = q[r][i]; q[r][i] = q[r][k]; q[r][k] = t; }
+    }
+  }
+  for (int j = 0; j < 3; j++) { evals[j] = diag[j] * scale; for (int i = 0; i < 3; i++) evecs[i * 3 + j] = q[i][j]; }
+}
+
 /* Symmetric 3x3 eigen-decomposition, cyclic Jacobi; reads the LOWER triangle only
  * (as Eigen::SelfAdjointEigenSolver::compute does, voxel_grid_covariance_omp_impl.hpp:333).
  * Eigenvalues ascending; eigenvectors are the columns of evecs (row-major storage).
  * Uses only + - * / sqrt so a device restatement can be bit-identical. */
 void ora_eigen_sym3(const double Ain[9], double evals[3], double evecs[9]) {
+  if (g_var & ORA_VAR_EIG_QL) { eigen_sym3_ql(Ain, evals, evecs); return; }
   double a[3][3], v[3][3];
   a[0][0] = Ain[0]; a[1][1] = Ain[4]; a[2][2] = Ain[8];
   a[0][1] = a[1][0] = Ain[3]; a[0][2] = a[2][0] = Ain[6]; a[1][2] = a[2][1] = Ain[7];
@@ -570,6 +651,12 @@ static void finish_leaf(ora_leaf* L, const double S[3], const double C[9], const
     mat3_inverse(cov, L->icov);                                      /* impl:359 */
     int bad = 0;
     for (int a = 0; a < 9; a++) if (!isfinite(L->icov[a])) bad = 1;  /* impl:360-364 (NaN treated as inf) */
+    if (g_var & ORA_VAR_ICOV_INF) {                                  /* study variant: the reference's test as written -- Eigen's coefficient visitors */
+      static const int cm[9] = {0, 3, 6, 1, 4, 7, 2, 5, 8};          /* column-major visiting order of a row-major 3x3 */
+      double mx = L->icov[0], mn = L->icov[0];
+      for (int a = 1; a < 9; a++) { const double v = L->icov[cm[a]]; if (v > mx) mx = v; if (v < mn) mn = v; }
+      bad = (mx == (double)INFINITY) || (mn == -(double)INFINITY);
+    }
     if (bad) L->n = -1;
   }
 }

@@ -168,7 +168,12 @@ enum {
   ORA_VAR_NORM_TREE  = 8,   /* mean_.norm() of the ndt_pca weight as sqrt(x0^2 + (x1^2 + x2^2)) */
   ORA_VAR_SOLVE_LU   = 16,  /* Newton step by LU with partial pivoting instead of the one-sided-Jacobi SVD */
   ORA_VAR_SOLVE_SVD2 = 32,  /* ... by a two-sided Jacobi SVD arranged like Eigen's JacobiSVD */
-  ORA_VAR_EIG_ORDER  = 64   /* 3x3 symmetric eigen-solver with the other cyclic rotation order */
+  ORA_VAR_EIG_ORDER  = 64,  /* 3x3 symmetric eigen-solver with the other cyclic rotation order */
+  ORA_VAR_EIG_QL     = 128, /* 3x3 symmetric eigen-solver the way Eigen 3.3's SelfAdjointEigenSolver::compute goes about it: scale, Householder
+                               tridiagonalisation (the 3x3 special case), implicit symmetric QR steps with Wilkinson shift, ascending sort --
+                               restated from the published algorithm (the library is not in the reference tree); a study variant, not a pin */
+  ORA_VAR_ICOV_INF   = 256  /* voxel_grid_covariance_omp_impl.hpp:360-364 literally: a leaf dies only when icov_.maxCoeff() == +inf or
+                               minCoeff() == -inf (Eigen's visitors skip a NaN unless it is the first coefficient); canonical: any non-finite entry */
 };
 void ora_set_variant(unsigned flags, int acc_chunk);
 unsigned ora_get_variant(void);

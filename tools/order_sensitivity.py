@@ -33,7 +33,7 @@ CASES = {   # BASELINE configs 3/4 and the nodelet's own configuration (scan_mat
     "pca_d1": dict(variant=1, neighbor_mode=3, resolution=1.0, azimuth=1024),
     "pca_d7_r05": dict(variant=1, neighbor_mode=2, resolution=0.5, azimuth=2048),
 }
-SUM02, SUM012, EXPF, NORM, LU, SVD2, EIG = 1, 2, 4, 8, 16, 32, 64
+SUM02, SUM012, EXPF, NORM, LU, SVD2, EIG, EIGQL, ICOVINF = 1, 2, 4, 8, 16, 32, 64, 128, 256
 # (name, flags, f64 partial-sum length, what it stands for)
 VARIANTS = [
     ("canonical", 0, 256, "the oracle as every parity test uses it"),
@@ -43,13 +43,15 @@ VARIANTS = [
     ("solve_lu", LU, 256, "Newton step by LU with partial pivoting (what the HIP path does for a well-conditioned H)"),
     ("solve_svd_two_sided", SVD2, 256, "Newton step by a two-sided Jacobi SVD arranged like Eigen's JacobiSVD"),
     ("eig_other_order", EIG, 256, "3x3 eigen-solver with the other cyclic rotation order (another rounding of evecs / inflated covariances)"),
+    ("eig_tridiagonal_qr", EIGQL, 256, "3x3 eigen-solver the way Eigen 3.3's SelfAdjointEigenSolver::compute works (Householder tridiagonalisation + implicit QR steps with Wilkinson shift) instead of cyclic Jacobi: other last bits in evecs, hence in every inflated covariance and its inverse"),
+    ("icov_inf_test_as_written", ICOVINF, 256, "a leaf dies only when icov_.maxCoeff() == +inf or minCoeff() == -inf (impl:360-364 literally, Eigen's visitors) instead of on any non-finite entry"),
     ("acc_chunk_2048", 0, 2048, "f64 partial sums over 2048 points (the HIP path's chunk length)"),
     ("acc_chunk_8", 0, 8, "f64 partial sums over 8 points (the reference's guided-schedule granule)"),
     ("acc_sequential", 0, 1 << 30, "one sequential f64 accumulation (the reference with num_threads = 1)"),
     ("norm_x0+(x1+x2)", NORM, 256, "ndt_pca weight: mean_.norm() as Eigen's unrolled 3-term redux (changes (int)dimension_2d_ when it lands on an integer)"),
     ("eigen_like_all", SUM02 | EXPF | NORM | SVD2 | EIG, 2048, "all of the above that Eigen 3.3 + SSE plausibly does, together"),
 ]
-BUILD_FLAGS = NORM | EIG          # variants that change the voxel grid itself
+BUILD_FLAGS = NORM | EIG | EIGQL | ICOVINF          # variants that change the voxel grid itself
 
 
 def se3_err(A, B):
