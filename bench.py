@@ -81,6 +81,7 @@ def parse():
     ap.add_argument("--no-stream", action="store_true", help="skip the streamed job: `value` is then the synchronous job's rate (as in rounds 1-4)")
     ap.add_argument("--stream-contexts", type=int, default=3, help="batches resident in the engine's stream mode (2..4)")
     ap.add_argument("--stream-batches", type=int, default=3, help="distinct batches the streamed job rotates through")
+    ap.add_argument("--stream-reserve", type=int, default=None, help="workgroup slots the stream's launches leave free for the next batch's build (MI355NDT_OPT_STREAM_RESERVE; default: the engine's)")
     ap.add_argument("--kitti-dir", default=None,
                     help="a KITTI odometry sequence's velodyne directory (<seq>/velodyne/*.bin, N x 4 f32): consecutive frames (k, k+1) become the "
                          "pairs of the run instead of the synthetic scans (scripts/lidar_odom_kitti.sh:6); clouds are ragged, `data` says \"kitti\"")
@@ -564,7 +565,7 @@ def parity_leg(a, W, G, res_np, B, seconds, threads):
 
 class Ctx:
     """What every leg of a run shares: the rank's place in the job, its device, the process group (or None)."""
-    rank = 0; world = 1; local = 0; dev = None; dist = None; backend = "nccl"; use_dist = False; on_dev = True; shard = None; ndt = None; G = None
+    rank = 0; world = 1; local = 0; dev = None; dist = None; backend = "nccl"; use_dist = False; on_dev = True; shard = None; ndt = None; G = None; stream_reserve = None
 
 
 def cloud_np(W, side, k):
@@ -753,6 +754,8 @@ def timed_stream_job(ctx, eng, W, nb, job_total, steps, warmup, n_batches=3, n_c
     rec_host = None if (on_dev or not use_dist) else torch.empty(cap, shard.REC_WORDS, dtype=torch.int32).pin_memory()   # gloo functional check only
     gathered = torch.empty(ctx.world * cap, shard.REC_WORDS, device=dev if on_dev else "cpu", dtype=torch.int32) if use_dist else None
     gather_ev, gather_host_s = [], [0.0]
+    if ctx.stream_reserve is not None:
+        eng.set_option(ndt.OPT_STREAM_RESERVE, ctx.stream_reserve)
     eng.stream_begin(n_contexts, nb, W["pitch"], W["pitch"])
     state = {"sub": 0, "col": 0, "ids": []}
 
@@ -1007,6 +1010,7 @@ def main():
     ctx = Ctx()
     ctx.rank, ctx.world, ctx.local, ctx.dev, ctx.dist, ctx.backend, ctx.use_dist = rank, world, local, dev, dist, backend, use_dist
     ctx.on_dev, ctx.shard, ctx.ndt, ctx.G = backend == "nccl", shard, ndt, synth.default_guess()
+    ctx.stream_reserve = a.stream_reserve
     G = ctx.G
 
     strong = a.total_pairs > 0

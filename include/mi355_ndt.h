@@ -197,7 +197,12 @@ enum mi355ndt_option {
   /* Stream mode (mi355ndt_stream_*): a launch hands its last `value` unfinished pairs over to the next launch instead of iterating them alone
    * on an otherwise idle GPU.  -1 (default): as many as it takes to keep every resident wave busy (resident waves / work items per sweep);
    * 0: never (every launch runs its own pairs to the end: pipelining of the host side only).  No result bit depends on it. */
-  MI355NDT_OPT_STREAM_THRESHOLD = 4
+  MI355NDT_OPT_STREAM_THRESHOLD = 4,
+  /* Stream mode, read by mi355ndt_stream_begin: the persistent launches leave `value` workgroup slots free (rounded down to a multiple of 8)
+   * and the NEXT batch's target build runs on a stream of its own beside the launch instead of between two launches -- the build streams
+   * through HBM, the launch saturates the vector ALUs.  Needs >= 3 contexts (a context is rebuilt one launch earlier, so its pairs are carried
+   * through one launch less).  -1 (default): the environment variable MI355NDT_STREAM_RESERVE, else 0 = off.  No result bit depends on it. */
+  MI355NDT_OPT_STREAM_RESERVE = 5
 };
 int mi355ndt_set_option(mi355ndt_handle* h, int option, int value);
 int mi355ndt_get_option(const mi355ndt_handle* h, int option, int* value);

@@ -180,6 +180,7 @@ struct mi355ndt_handle {
   bool stream_on = false, s_sync_only = false, s_drop_carry = true;
   int s_nctx = 0, s_max_pairs = 0, s_items = 0, s_ring_cap = 0, s_thresh = 0;
   int s_thresh_opt = -1;                          // MI355NDT_OPT_STREAM_THRESHOLD
+  int s_reserve_opt = -1;                         // MI355NDT_OPT_STREAM_RESERVE
   int s_plan_cb = 0; size_t s_plan_words = 0;
   void* s_pose_next = nullptr; size_t s_pose_cap_next = 0; int s_pose_base_next = 0, s_pose_stride_next = 1;   // apply to the next submit
   StreamCtx sctx[ASYNC_MAX_CTX];
@@ -188,6 +189,10 @@ struct mi355ndt_handle {
   int* d_sring = nullptr;
   CtxStat* d_sstat = nullptr;                     // per context: pairs finalised, sizes and verdict of its last planned build
   static constexpr int S_EV = 16;
+  // Build under the launch: with s_reserve_wg > 0 the contexts' engines run their builds on s_build_stream, the persistent launches leave
+  // that many workgroup slots free, and events order  launch j-2 done -> build of batch j -> launch j
+  hipStream_t s_build_stream = nullptr; int s_reserve_wg = 0;
+  hipEvent_t s_ev_built[ASYNC_MAX_CTX] = {}; hipEvent_t s_ev_launched[S_EV] = {};
   volatile StreamStatus* h_sstatus = nullptr; StreamStatus* d_sstatus = nullptr;   // mapped ring of per-launch status slots (k_stream_status)
 
   // profiling
@@ -1121,6 +1126,7 @@ struct AsyncLaunch {
   int* active_list = nullptr; SweepCtl* sweep_ctl = nullptr; unsigned* done_new = nullptr; PoseRecord* pose_new = nullptr; int pose_cap = 0;
   AsyncTab* tab_dev = nullptr; int* ring = nullptr; int ring_cap = 0; AsyncCtl* ctl = nullptr; const AsyncCtl* prev = nullptr;
   int items_per_pair = 0, stop_thresh = 0; unsigned debug_abort_pos = 0xFFFFFFFFu;
+  int reserve_wg = 0;
 };
 template <bool PCA, int K, int ORD>
 static int launch_async_t(mi355ndt_handle* h, const SweepConst& sc, const AsyncLaunch& L) {
@@ -1135,7 +1141,9 @@ static int launch_async_t(mi355ndt_handle* h, const SweepConst& sc, const AsyncL
   // late -- another engine's launch holds its CU -- finds the launch over or joins in; a launch that cannot progress ends itself
   // (bounded polls) and the caller falls back to the rounds.
   if (per_cu < wpe || h->n_cu * wpe < 8) return MI355NDT_ERR_UNSUPPORTED;
-  dim3 grid((unsigned)(h->n_cu * wpe));
+  // (stream mode may withhold some workgroups so that the next batch's target build, on a stream of its own, finds wave slots
+  //  beside this launch: L.reserve_wg, a multiple of 8 so that every ring loses the same number of waves)
+  dim3 grid((unsigned)std::max(8, h->n_cu * wpe - L.reserve_wg));
   kern<<<grid, SWEEP_THREADS, 0, h->stream>>>(L.tab_dev, L.items_per_pair, L.ring, L.ring_cap, L.ctl, sc, h->prof ? h->d_hits : nullptr,
                                              h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations, L.stop_thresh, L.debug_abort_pos);
   return MI355NDT_OK;
@@ -1755,6 +1763,11 @@ int mi355ndt_set_option(mi355ndt_handle* h, int option, int value) {
     h->s_thresh_opt = value;
     return MI355NDT_OK;
   }
+  if (option == MI355NDT_OPT_STREAM_RESERVE) {
+    if (value < -1 || value > 4096) return MI355NDT_ERR_BAD_ARG;
+    h->s_reserve_opt = value;
+    return MI355NDT_OK;
+  }
   return MI355NDT_ERR_BAD_ARG;
 }
 int mi355ndt_get_option(const mi355ndt_handle* h, int option, int* value) {
@@ -1764,6 +1777,7 @@ int mi355ndt_get_option(const mi355ndt_handle* h, int option, int* value) {
   if (option == MI355NDT_OPT_ASYNC_ALIGN) { *value = h->async_force ? 2 : (h->async_align ? 1 : 0); return MI355NDT_OK; }
   if (option == MI355NDT_OPT_DEBUG_ASYNC_ABORT) { *value = h->debug_abort_pos == 0xFFFFFFFFu ? -1 : (int)h->debug_abort_pos; return MI355NDT_OK; }
   if (option == MI355NDT_OPT_STREAM_THRESHOLD) { *value = h->s_thresh_opt; return MI355NDT_OK; }
+  if (option == MI355NDT_OPT_STREAM_RESERVE) { *value = h->s_reserve_opt; return MI355NDT_OK; }
   return MI355NDT_ERR_BAD_ARG;
 }
 
@@ -1913,6 +1927,9 @@ static int stream_free(mi355ndt_handle* h) {
     if (c.h_res) (void)hipHostFree(c.h_res);
     c = mi355ndt_handle::StreamCtx();
   }
+  for (auto& e : h->s_ev_built) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  for (auto& e : h->s_ev_launched) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  if (h->s_build_stream) { (void)hipStreamSynchronize(h->s_build_stream); (void)hipStreamDestroy(h->s_build_stream); h->s_build_stream = nullptr; }
   if (h->d_sctl) { (void)hipFree(h->d_sctl); h->d_sctl = nullptr; }
   if (h->d_sring) { (void)hipFree(h->d_sring); h->d_sring = nullptr; }
   if (h->d_sstat) { (void)hipFree(h->d_sstat); h->d_sstat = nullptr; }
@@ -1925,6 +1942,7 @@ int mi355ndt_stream_end(mi355ndt_handle* h) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   if (!h->stream_on) return MI355NDT_OK;
   (void)hipSetDevice(h->device);
+  if (h->s_build_stream) (void)hipStreamSynchronize(h->s_build_stream);
   (void)hipStreamSynchronize(h->stream);
   // the contexts' build timings and byte counts belong to this handle's profile
   for (int c = 0; c < h->s_nctx; c++) {
@@ -1959,6 +1977,15 @@ int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts, int max_pairs, siz
     if (const char* e = std::getenv("MI355NDT_STREAM_THRESH")) t = std::atoi(e);
     h->s_thresh = std::max(0, std::min(t, ASYNC_MAX_CARRY));
   }
+  {
+    // MI355NDT_STREAM_RESERVE (workgroups, rounded to a multiple of 8; default 0 = the build runs between the launches, on the same stream)
+    int r = 0;
+    if (const char* e = std::getenv("MI355NDT_STREAM_RESERVE")) r = std::atoi(e);
+    if (h->s_reserve_opt >= 0) r = h->s_reserve_opt;
+    r = std::max(0, std::min(r, h->n_cu * sweep_wpe(sc.pca != 0, sc.K) / 2)) & ~7;
+    if (n_contexts < 3) r = 0;                       // (the overlapped build needs its context free one launch earlier: at least three contexts)
+    h->s_reserve_wg = r;
+  }
   h->s_ring_cap = async_ring_cap(h, (long long)max_pairs + ASYNC_MAX_CARRY);
   if (h->s_ring_cap == 0) h->s_sync_only = true;
   auto fail = [&](int rc) { (void)stream_free(h); return rc; };
@@ -1969,7 +1996,12 @@ int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts, int max_pairs, siz
     int rc = mi355ndt_create(&h->prm, h->device, &S.e);
     if (rc) return fail(rc);
     mi355ndt_handle* e = S.e;
-    rc = mi355ndt_set_stream(e, h->stream);
+    if (h->s_reserve_wg > 0 && !h->s_build_stream) {
+      if (hipStreamCreateWithFlags(&h->s_build_stream, hipStreamNonBlocking) != hipSuccess) return fail(MI355NDT_ERR_HIP);
+      for (auto& ev : h->s_ev_built) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(MI355NDT_ERR_HIP);
+      for (auto& ev : h->s_ev_launched) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(MI355NDT_ERR_HIP);
+    }
+    rc = mi355ndt_set_stream(e, h->s_reserve_wg > 0 ? h->s_build_stream : h->stream);
     if (rc) return fail(rc);
     e->f32_sum_order = h->f32_sum_order; e->async_align = h->async_align; e->dyn_shift = h->dyn_shift;
     e->async_build = true;
@@ -1995,6 +2027,7 @@ int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts, int max_pairs, siz
   memset((void*)h->h_sstatus, 0, mi355ndt_handle::S_EV * sizeof(StreamStatus));
   if (!h->d_atab && hipMalloc((void**)&h->d_atab, sizeof(AsyncTab)) != hipSuccess) return fail(MI355NDT_ERR_HIP);
   if (!h->s_sync_only && hipMalloc((void**)&h->d_sring, (size_t)8 * h->s_ring_cap * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); h->s_sync_only = true; }
+  if (h->s_build_stream) HIPCHK(h, hipStreamSynchronize(h->s_build_stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   (void)max_tgt;
   h->stream_on = true;
@@ -2018,7 +2051,11 @@ static int stream_launch(mi355ndt_handle* h, int new_ci, int n_new) {
     L.tab.c[c].n_done = &h->d_sstat[c].done;
     L.tab.c[c].pose = h->sctx[c].busy ? h->sctx[c].d_pose : nullptr; L.tab.c[c].pose_base = h->sctx[c].pose_base; L.tab.c[c].pose_stride = h->sctx[c].pose_stride;
     // the context the NEXT submit recycles must be finished by this launch; the others may hand their last pairs over
-    L.tab.c[c].must_finish = (flush || c == (new_ci + 1) % h->s_nctx) ? 1 : 0;
+    // (with the build under the launch -- s_reserve_wg -- that context is already being rebuilt during the NEXT launch: one earlier)
+    const int ahead = h->s_reserve_wg > 0 ? 2 : 1;
+    bool mf = flush;
+    for (int a = 1; a <= ahead; a++) mf = mf || c == (new_ci + a) % h->s_nctx;
+    L.tab.c[c].must_finish = mf ? 1 : 0;
   }
   const long long j = h->s_launches;
   L.new_ci = flush ? 0 : new_ci; L.n_new = flush ? 0 : n_new;
@@ -2033,13 +2070,16 @@ static int stream_launch(mi355ndt_handle* h, int new_ci, int n_new) {
   // (the automatic threshold never hands over more than a quarter of the batch: a batch too small to fill the GPU has no bulk to hide stragglers under)
   const bool thresh_given = h->s_thresh_opt >= 0 || std::getenv("MI355NDT_STREAM_THRESH");
   L.items_per_pair = h->s_items; L.stop_thresh = flush ? 0 : (thresh_given ? h->s_thresh : std::min(h->s_thresh, n_new / 4)); L.debug_abort_pos = h->debug_abort_pos;
+  L.reserve_wg = flush ? 0 : h->s_reserve_wg;
   h->ev_last_fresh = false;                          // (the contexts' builds sit between two launches on this stream)
+  if (!flush && h->s_reserve_wg > 0) HIPCHK(h, hipStreamWaitEvent(s, h->s_ev_built[new_ci], 0));   // this batch's grids (built on the other stream)
   int rc = launch_async(h, sc, L);
   if (rc) return rc;
   h->s_drop_carry = false;
   const int slot = (int)(j % mi355ndt_handle::S_EV);
   k_stream_status<<<1, 64, 0, s>>>(L.ctl, h->d_sstat, reinterpret_cast<volatile unsigned*>(h->d_sstatus + slot), (unsigned)(j + 1));
   HIPCHK(h, hipGetLastError());
+  if (h->s_reserve_wg > 0) HIPCHK(h, hipEventRecord(h->s_ev_launched[slot], s));
   h->s_launches++;
   h->P.stream_launches++;
   return MI355NDT_OK;
@@ -2100,7 +2140,9 @@ int mi355ndt_stream_submit(mi355ndt_handle* h, int n_pairs, const float* d_t, co
   memcpy(S.h_in, tc, (size_t)n_pairs * sizeof(int));
   memcpy(S.h_in + h->s_max_pairs, scnt, (size_t)n_pairs * sizeof(int));
   memcpy(S.h_in + 2 * (size_t)h->s_max_pairs, guesses, (size_t)n_pairs * 16 * sizeof(float));
-  HIPCHK(h, hipMemcpyAsync(S.d_in, S.h_in, (size_t)h->s_max_pairs * 2 * sizeof(int) + (size_t)n_pairs * 16 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  if (h->s_reserve_wg > 0 && h->s_launches >= 2)     // this context's previous batch was finished by the launch before the last one (must_finish)
+    HIPCHK(h, hipStreamWaitEvent(e->stream, h->s_ev_launched[(h->s_launches - 2) % mi355ndt_handle::S_EV], 0));
+  HIPCHK(h, hipMemcpyAsync(S.d_in, S.h_in, (size_t)h->s_max_pairs * 2 * sizeof(int) + (size_t)n_pairs * 16 * sizeof(float), hipMemcpyHostToDevice, e->stream));
   e->counts_preloaded = true; e->up_src_cnt.clear(); e->up_tgt_cnt.clear();
   // target build: against the stream's plan when there is one (no wait), else synchronously -- which makes the plan
   e->async_build = true;
@@ -2116,6 +2158,7 @@ int mi355ndt_stream_submit(mi355ndt_handle* h, int n_pairs, const float* d_t, co
     h->s_plan_cb = std::max(h->s_plan_cb, e->last_cb);
     h->s_plan_words = std::max(h->s_plan_words, e->last_total_words + e->last_total_words / 4 + 1024);
   }
+  if (h->s_reserve_wg > 0) HIPCHK(h, hipEventRecord(h->s_ev_built[ci], e->stream));
   // align workspace of this context: fixed row geometry for the whole stream (a pair's rows do not depend on it)
   e->chunks_per_pair = h->s_items / QUARTERS; e->rows_per_pair = e->items_per_pair = h->s_items; e->pts_per_chunk = CHUNK_PTS; e->fine_it = 0;
   gauss_constants3(h->prm.outlier_ratio, h->prm.resolution, h->gauss_last);
@@ -2124,6 +2167,7 @@ int mi355ndt_stream_submit(mi355ndt_handle* h, int n_pairs, const float* d_t, co
   rc = stream_launch(h, ci, n_pairs);
   if (rc) {                                          // the launch cannot be made (not resident): this and every later batch synchronously
     h->s_sync_only = true;
+    if (h->s_build_stream) HIPCHK(h, hipStreamSynchronize(h->s_build_stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     rc = run_sync();
     if (rc) { S.busy = false; return rc; }
@@ -2145,6 +2189,7 @@ int mi355ndt_stream_pose_records(mi355ndt_handle* h, void* d_records, size_t cap
 // a launch gave up (ctl->abort_): nothing it left behind can be trusted to continue from -- every unfinished batch is re-run synchronously
 // by its collect, and the next launch starts without a hand-over list
 static void stream_recover(mi355ndt_handle* h) {
+  if (h->s_build_stream) (void)hipStreamSynchronize(h->s_build_stream);
   (void)hipStreamSynchronize(h->stream);
   CtxStat st[ASYNC_MAX_CTX];
   if (hipMemcpy(st, h->d_sstat, sizeof st, hipMemcpyDeviceToHost) != hipSuccess) memset(st, 0, sizeof st);
@@ -2184,6 +2229,7 @@ int mi355ndt_stream_collect(mi355ndt_handle* h, long long batch_id, mi355ndt_res
     }
     if (S.redo || plan_exceeded) {
       // the batch did not fit the build plan (its grids were withheld), or its launch gave up: the synchronous path, which also re-makes the plan
+      if (h->s_build_stream) HIPCHK(h, hipStreamSynchronize(h->s_build_stream));
       HIPCHK(h, hipStreamSynchronize(h->stream));
       e->async_build = false; e->counts_preloaded = false; e->up_tgt_cnt.clear(); e->up_src_cnt.clear();
       int rc = mi355ndt_batch_build_targets(e);

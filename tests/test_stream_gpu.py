@@ -82,16 +82,17 @@ def stream_results(batches, n, kw, nctx, thresh, depth=None, opts=()):
     return got, pr
 
 
-@pytest.mark.parametrize("mode,variant,nctx,thresh", [(ndt.DIRECT7, 0, 3, -1), (ndt.DIRECT7, 0, 2, 8), (ndt.DIRECT1, 1, 4, 24), (ndt.DIRECT1, 1, 2, 0),
-                                                     (ndt.DIRECT7, 1, 3, 128), (ndt.KDTREE, 0, 3, 6)])
-def test_stream_equals_the_synchronous_batches(mode, variant, nctx, thresh):
+@pytest.mark.parametrize("mode,variant,nctx,thresh,reserve", [(ndt.DIRECT7, 0, 3, -1, 0), (ndt.DIRECT7, 0, 2, 8, 0), (ndt.DIRECT1, 1, 4, 24, 0), (ndt.DIRECT1, 1, 2, 0, 0),
+                                                             (ndt.DIRECT7, 1, 3, 128, 0), (ndt.KDTREE, 0, 3, 6, 0),
+                                                             (ndt.DIRECT7, 0, 3, -1, 64), (ndt.DIRECT1, 1, 4, 24, 128), (ndt.DIRECT7, 1, 3, 128, 32)])
+def test_stream_equals_the_synchronous_batches(mode, variant, nctx, thresh, reserve):
     """Seven distinct ragged batches (17..40 pairs of 32,768 points, uneven iteration counts) streamed with 2, 3 or 4 resident contexts and
     hand-over thresholds from "never" to "always": every result word of every pair equals the round-based synchronous align's -- whether
     the pair finished in its own launch, or was suspended once or several times and finished under later batches."""
     kw = dict(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=mode, variant=variant)
     batches, n = make_batches(2000, [40, 33, 40, 17, 40, 29, 40], 512)
     ref = sync_results(batches, n, kw)
-    got, pr = stream_results(batches, n, kw, nctx, thresh)
+    got, pr = stream_results(batches, n, kw, nctx, thresh, opts=((ndt.OPT_STREAM_RESERVE, reserve),))      # reserve > 0: every batch's build runs beside the previous launch
     for bi, (r, g) in enumerate(zip(ref, got)):
         assert len(r) == len(g)
         for k, (x, y) in enumerate(zip(r, g)):

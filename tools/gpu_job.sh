@@ -38,6 +38,7 @@ for stage in "$@"; do
     kstats_leaf) for v in 0 1; do MI355NDT_LEAF_SORTED=$v timeout 600 tools/kstats.sh kstats_leaf$v --no-host-clouds --no-stream --steps 20 --warmup 3 > $O/out$v.txt 2>&1; grep -E "k_leafsum|k_sorted|k_mark|k_rs_|k_voxels|k_minmax|k_rank|k_align" $O/out$v.txt; done
                  timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "voxel or grid" 2>&1 | tail -5 > $O/pytest0.txt; cat $O/pytest0.txt
                  MI355NDT_LEAF_SORTED=1 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "voxel or grid" 2>&1 | tail -5 > $O/pytest1.txt; cat $O/pytest1.txt ;;
+    reserve_sweep) for r in 0 32 64 128; do for c in "" "--variant pca --mode direct1" "--variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128" "--variant pca --mode direct7 --resolution 0.5 --azimuth 2048 --pairs 128"; do timeout 600 python bench.py $c --stream-reserve $r --stream-contexts ${NCTX:-4} --cpu-seconds 0 --no-host-clouds --seq-frames 0 --config4-pairs 0 --no-other-configs 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('reserve $r', d['config']['workload'][:44], 'stream', d['value'], 'sync', d['value_synchronous'], 'ms', d['ms_per_step'], d['ms_per_step_synchronous'], 'launch', r['avg_launch_us'], 'build', r['build_ms_per_step'], 'frac', r['frac'], d['config']['stream']['pairs_handed_over'])"; done; done > $O/out.txt 2>&1; cat $O/out.txt ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
