@@ -1973,7 +1973,9 @@ int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts, int max_pairs, siz
   {
     const int iu = h->s_items / ASYNC_CLAIM(sc.K == 1 ? 1 : 7);
     const int waves = h->n_cu * sweep_wpe(sc.pca != 0, sc.K) * WAVES;
-    int t = h->s_thresh_opt >= 0 ? h->s_thresh_opt : (waves + iu - 1) / std::max(1, iu);
+    // automatic: four sweeps' worth of positions per resident wave -- `tools/gpu_job.sh thresh_sweep`: config 5 gains up to T = 32-64 (DIRECT7 19.1 / 19.4 / 19.5 k,
+    // DIRECT1 39.4 / 40.1 / 40.9 / 41.1 k registrations/s at T = 8 / 16 / 32 / 64), the 65,536-point configurations do not care -- capped at a quarter of the batch (stream_launch)
+    int t = h->s_thresh_opt >= 0 ? h->s_thresh_opt : 4 * ((waves + iu - 1) / std::max(1, iu));
     if (const char* e = std::getenv("MI355NDT_STREAM_THRESH")) t = std::atoi(e);
     h->s_thresh = std::max(0, std::min(t, ASYNC_MAX_CARRY));
   }

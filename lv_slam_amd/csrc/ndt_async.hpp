@@ -45,6 +45,18 @@ struct AsyncCtx {
   int pose_base; PoseRecord* pose; int pose_stride, pad_;
 };
 struct AsyncTab { AsyncCtx c[ASYNC_MAX_CTX]; };
+// generic -> global -> generic: the round trip through address space 1 is how the compiler learns that a pointer read from memory points
+// into device memory (it then emits global_load / global_store instead of flat_*)
+template <typename T> __device__ __forceinline__ T* as_global(T* p) {
+  return (T*)(__attribute__((address_space(1))) T*)p;
+}
+__device__ __forceinline__ AsyncCtx async_ctx_global(const AsyncCtx& in) {
+  AsyncCtx c = in;
+  c.src = as_global(in.src); c.st = as_global(in.st); c.gd = as_global(in.gd); c.words = as_global(in.words); c.recs = as_global(in.recs);
+  c.cent = as_global(in.cent); c.partials = as_global(in.partials); c.src_cnt = as_global(in.src_cnt); c.arrived = as_global(in.arrived);
+  c.results = as_global(in.results); c.n_done = as_global(in.n_done); c.pose = as_global(in.pose);
+  return c;
+}
 // stream mode, per context, in device memory: what the host wants to know about a context's batch after every launch
 struct CtxStat { unsigned done, total_words, max_cells, plan_exceeded; };   // pairs finalised; the last planned build's sizes and verdict (k_build_check)
 // ... and per launch, in MAPPED host memory (a ring of slots): written by k_stream_status behind the launch, `seq` last -- no copy, no event
@@ -337,14 +349,17 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
   if (lane == 0 && (int)(pos / (unsigned)Iu) < ring_cap) tw = (int)__hip_atomic_load(ringx + pos / (unsigned)Iu, RLX_AGENT);
   tw = wait_ticket((int)(pos / (unsigned)Iu), tw);
   if (tw < 0) return;
-  unsigned pose_w = sweep_pose_words(tab->c[tw >> ASYNC_CTX_SHIFT].st + (tw & ((1 << ASYNC_CTX_SHIFT) - 1)));
+  unsigned pose_w = sweep_pose_words(as_global(tab->c[tw >> ASYNC_CTX_SHIFT].st) + (tw & ((1 << ASYNC_CTX_SHIFT) - 1)));
 #pragma unroll 1
   for (;;) {
     // (test hook, MI355NDT_OPT_DEBUG_ASYNC_ABORT: the wave that claimed this position of ring 0 gives up as a wave whose ticket never came would)
     if (x == 0 && pos == debug_abort_pos) { if (lane == 0) give_up(); break; }
     const int rem = (int)(pos % (unsigned)Iu) * CLAIM;
     TL_STAMP(10);                                  // hand-over: claim, ticket, (update)
-    const AsyncCtx C = tab->c[tw >> ASYNC_CTX_SHIFT];   // (wave-uniform: scalar loads of a table nobody writes during the launch)
+    // (wave-uniform: scalar loads of a table nobody writes during the launch.  A pointer that comes out of memory is a FLAT pointer to the
+    //  compiler -- flat loads are slower than global ones and also count against the LDS counter, which cost the DIRECT7 launch 5.5 % when the
+    //  table replaced the kernel arguments -- so every pointer is told where it points: as_global)
+    const AsyncCtx C = async_ctx_global(tab->c[tw >> ASYNC_CTX_SHIFT]);
     const int b = tw & ((1 << ASYNC_CTX_SHIFT) - 1);
     const int n_b = C.src_cnt[b];
 #ifndef ASYNC_D1_PIPE
@@ -384,7 +399,7 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
     ntw = __builtin_amdgcn_readfirstlane(ntw);
     //  3. the next pair's pose -- in flight while this wave updates (if it has to), then together with the next item's point loads.
     unsigned npose = 0;
-    if (ntw >= 0) npose = sweep_pose_words(tab->c[ntw >> ASYNC_CTX_SHIFT].st + (ntw & ((1 << ASYNC_CTX_SHIFT) - 1)));
+    if (ntw >= 0) npose = sweep_pose_words(as_global(tab->c[ntw >> ASYNC_CTX_SHIFT].st) + (ntw & ((1 << ASYNC_CTX_SHIFT) - 1)));
     TL_STAMP(8);                                   // row drain + claim, arrival + ticket
     if ((old + (unsigned)CLAIM) % (unsigned)I == 0u) {   // this was the sweep's last item: this wave is the pair's updater
       async_update(C, b, tw, n_b, I, Ssh[wv], sol[wv], ring, ring_cap, ctl, n_live, stop_thresh, hits_total, step_max, eps, max_iterations
@@ -397,7 +412,7 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
     if (ntw < 0) {                                 // the next position's ticket does not exist yet
       ntw = wait_ticket(tn, ntw);
       if (ntw < 0) break;
-      npose = sweep_pose_words(tab->c[ntw >> ASYNC_CTX_SHIFT].st + (ntw & ((1 << ASYNC_CTX_SHIFT) - 1)));
+      npose = sweep_pose_words(as_global(tab->c[ntw >> ASYNC_CTX_SHIFT].st) + (ntw & ((1 << ASYNC_CTX_SHIFT) - 1)));
     }
     tw = ntw; pos = npos; pose_w = npose;
   }

@@ -39,6 +39,11 @@ for stage in "$@"; do
                  timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "voxel or grid" 2>&1 | tail -5 > $O/pytest0.txt; cat $O/pytest0.txt
                  MI355NDT_LEAF_SORTED=1 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "voxel or grid" 2>&1 | tail -5 > $O/pytest1.txt; cat $O/pytest1.txt ;;
     reserve_sweep) for r in 0 32 64 128; do for c in "" "--variant pca --mode direct1" "--variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128" "--variant pca --mode direct7 --resolution 0.5 --azimuth 2048 --pairs 128"; do timeout 600 python bench.py $c --stream-reserve $r --stream-contexts ${NCTX:-4} --cpu-seconds 0 --no-host-clouds --seq-frames 0 --config4-pairs 0 --no-other-configs 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('reserve $r', d['config']['workload'][:44], 'stream', d['value'], 'sync', d['value_synchronous'], 'ms', d['ms_per_step'], d['ms_per_step_synchronous'], 'launch', r['avg_launch_us'], 'build', r['build_ms_per_step'], 'frac', r['frac'], d['config']['stream']['pairs_handed_over'])"; done; done > $O/out.txt 2>&1; cat $O/out.txt ;;
+    ab_r04) for rep in 1 2; do for c in "" "--variant pca --mode direct1" "--variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128"; do
+                 (cd tools/ab_r04 && timeout 600 python bench.py $c --cpu-seconds 0 --no-host-clouds --seq-frames 0 --config4-pairs 0 --no-other-configs 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('r04 ', d['config']['workload'][:40], d['value'], d['ms_per_step'], 'launch', r['avg_launch_us'], 'build', r['build_ms_per_step'])")
+                 timeout 600 python bench.py $c --no-stream --cpu-seconds 0 --no-host-clouds --seq-frames 0 --config4-pairs 0 --no-other-configs 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('HEAD', d['config']['workload'][:40], d['value'], d['ms_per_step'], 'launch', r['avg_launch_us'], 'build', r['build_ms_per_step'])"
+               done; done > $O/out.txt 2>&1; cat $O/out.txt ;;
+    thresh_sweep) for t in 4 8 16 32 64; do for c in "" "--variant pca --mode direct1" "--variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128" "--variant pca --mode direct7 --resolution 0.5 --azimuth 2048 --pairs 128"; do MI355NDT_STREAM_THRESH=$t timeout 600 python bench.py $c --cpu-seconds 0 --no-host-clouds --seq-frames 0 --config4-pairs 0 --no-other-configs 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('thresh $t', d['config']['workload'][:44], 'stream', d['value'], 'sync', d['value_synchronous'], 'launch', r['avg_launch_us'], 'frac', r['frac'], d['config']['stream']['pairs_handed_over'], d['config']['stream']['launches'])"; done; done > $O/out.txt 2>&1; cat $O/out.txt ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
