@@ -47,8 +47,12 @@ struct AsyncCtx {
 struct AsyncTab { AsyncCtx c[ASYNC_MAX_CTX]; };
 // generic -> global -> generic: the round trip through address space 1 is how the compiler learns that a pointer read from memory points
 // into device memory (it then emits global_load / global_store instead of flat_*)
+// (the empty asm between the two casts keeps the optimiser from folding them into nothing before the address-space inference has seen them;
+//  "+s": the pointers are wave-uniform and stay in scalar registers)
 template <typename T> __device__ __forceinline__ T* as_global(T* p) {
-  return (T*)(__attribute__((address_space(1))) T*)p;
+  __attribute__((address_space(1))) T* g = (__attribute__((address_space(1))) T*)p;
+  asm volatile("" : "+s"(g));
+  return (T*)g;
 }
 __device__ __forceinline__ AsyncCtx async_ctx_global(const AsyncCtx& in) {
   AsyncCtx c = in;
