@@ -1128,6 +1128,8 @@ struct AsyncLaunch {
   int items_per_pair = 0, stop_thresh = 0; unsigned debug_abort_pos = 0xFFFFFFFFu;
   int reserve_wg = 0;
 };
+#define NDT_CTX_ARGS(i) L.tab.c[i].src, L.tab.c[i].pitch, L.tab.c[i].st, L.tab.c[i].gd, L.tab.c[i].words, L.tab.c[i].recs, L.tab.c[i].partials, L.tab.c[i].src_cnt, \
+                        L.tab.c[i].arrived, L.tab.c[i].cent
 template <bool PCA, int K, int ORD>
 static int launch_async_t(mi355ndt_handle* h, const SweepConst& sc, const AsyncLaunch& L) {
   auto kern = k_align_async<PCA, K, ORD>;
@@ -1145,7 +1147,8 @@ static int launch_async_t(mi355ndt_handle* h, const SweepConst& sc, const AsyncL
   //  beside this launch: L.reserve_wg, a multiple of 8 so that every ring loses the same number of waves)
   dim3 grid((unsigned)std::max(8, h->n_cu * wpe - L.reserve_wg));
   kern<<<grid, SWEEP_THREADS, 0, h->stream>>>(L.tab_dev, L.items_per_pair, L.ring, L.ring_cap, L.ctl, sc, h->prof ? h->d_hits : nullptr,
-                                             h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations, L.stop_thresh, L.debug_abort_pos);
+                                             h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations, L.stop_thresh, L.debug_abort_pos,
+                                             NDT_CTX_ARGS(0), NDT_CTX_ARGS(1), NDT_CTX_ARGS(2), NDT_CTX_ARGS(3));
   return MI355NDT_OK;
 }
 template <bool PCA, int K>

@@ -45,20 +45,29 @@ struct AsyncCtx {
   int pose_base; PoseRecord* pose; int pose_stride, pad_;
 };
 struct AsyncTab { AsyncCtx c[ASYNC_MAX_CTX]; };
-// generic -> global -> generic: the round trip through address space 1 is how the compiler learns that a pointer read from memory points
-// into device memory (it then emits global_load / global_store instead of flat_*)
-// (the empty asm between the two casts keeps the optimiser from folding them into nothing before the address-space inference has seen them;
-//  "+s": the pointers are wave-uniform and stay in scalar registers)
-template <typename T> __device__ __forceinline__ T* as_global(T* p) {
-  __attribute__((address_space(1))) T* g = (__attribute__((address_space(1))) T*)p;
-  asm volatile("" : "+s"(g));
-  return (T*)g;
-}
-__device__ __forceinline__ AsyncCtx async_ctx_global(const AsyncCtx& in) {
-  AsyncCtx c = in;
-  c.src = as_global(in.src); c.st = as_global(in.st); c.gd = as_global(in.gd); c.words = as_global(in.words); c.recs = as_global(in.recs);
-  c.cent = as_global(in.cent); c.partials = as_global(in.partials); c.src_cnt = as_global(in.src_cnt); c.arrived = as_global(in.arrived);
-  c.results = as_global(in.results); c.n_done = as_global(in.n_done); c.pose = as_global(in.pose);
+// A pointer that comes out of memory is a FLAT pointer to the compiler: flat loads are slower than global ones, also count against the LDS
+// counter, and cost the DIRECT7 launch 4-8 % against round 4 on the same box when the table first replaced the kernel arguments (a cast
+// through address space 1 and back is folded away; an empty asm between the two casts keeps it but makes the pointer opaque, which was worse
+// still: tools/ab_libs.sh).  So the device reads the table through a mirror of AsyncCtx whose fields ARE global pointers -- same layout,
+// the address space is part of the type -- and hands them on as ordinary pointers the compiler knows the origin of.
+#define NDT_GP(T) __attribute__((address_space(1))) T*
+struct AsyncCtxG {
+  NDT_GP(const float) src; size_t pitch;
+  NDT_GP(PairState) st; NDT_GP(const GridDesc) gd; NDT_GP(const BitWord) words; NDT_GP(const VoxelRec) recs; NDT_GP(const float) cent;
+  NDT_GP(double) partials; NDT_GP(const int) src_cnt; NDT_GP(unsigned) arrived; NDT_GP(mi355ndt_result) results;
+  NDT_GP(unsigned) n_done;
+  int must_finish;
+  int pose_base; NDT_GP(PoseRecord) pose; int pose_stride, pad_;
+};
+static_assert(sizeof(AsyncCtxG) == sizeof(AsyncCtx) && offsetof(AsyncCtxG, pose) == offsetof(AsyncCtx, pose) && offsetof(AsyncCtxG, n_done) == offsetof(AsyncCtx, n_done),
+              "AsyncCtxG mirrors AsyncCtx");
+__device__ __forceinline__ AsyncCtx async_ctx_load(const AsyncTab* __restrict__ tab, const int ci) {
+  const AsyncCtxG& g = reinterpret_cast<const AsyncCtxG*>(tab->c)[ci];
+  AsyncCtx c;
+  c.src = (const float*)g.src; c.pitch = g.pitch; c.st = (PairState*)g.st; c.gd = (const GridDesc*)g.gd; c.words = (const BitWord*)g.words;
+  c.recs = (const VoxelRec*)g.recs; c.cent = (const float*)g.cent; c.partials = (double*)g.partials; c.src_cnt = (const int*)g.src_cnt;
+  c.arrived = (unsigned*)g.arrived; c.results = (mi355ndt_result*)g.results; c.n_done = (unsigned*)g.n_done; c.must_finish = g.must_finish;
+  c.pose_base = g.pose_base; c.pose = (PoseRecord*)g.pose; c.pose_stride = g.pose_stride; c.pad_ = 0;
   return c;
 }
 // stream mode, per context, in device memory: what the host wants to know about a context's batch after every launch
@@ -302,10 +311,19 @@ NDT_KERNEL void k_stream_status(const AsyncCtl* __restrict__ ctl, const CtxStat*
   if (i == 0) host_slot[20] = seq;
 }
 
+// What a work item touches -- points, grid, bitmap, records, rows, counts, arrival counters -- reaches the kernel as KERNEL ARGUMENTS, one set
+// per context, selected by the ticket's context index; the table in memory keeps what only an update needs (results, completion counter,
+// pose records, must_finish).  Measured on one box (tools/ab_libs.sh, DIRECT7 / config 3, one launch): pointers read from the table -- flat,
+// cast through address space 1, or typed global -- 4,070-4,220 us; the same pointers as kernel arguments 3,890 us = round 4's 3,880: the
+// compiler knows a kernel argument's address space, that it is wave-uniform and (for the restrict-qualified ones) what it cannot alias.
+#define NDT_CTX_PARAMS(i) const float* __restrict__ src##i, size_t pitch##i, PairState* st##i, const GridDesc* __restrict__ gd##i, const BitWord* __restrict__ words##i, \
+                          const VoxelRec* __restrict__ recs##i, double* partials##i, const int* __restrict__ src_cnt##i, unsigned* arrived##i, const float* __restrict__ cent##i
+#define NDT_CTX_SEL(f, ci) ((ci) == 0 ? f##0 : (ci) == 1 ? f##1 : (ci) == 2 ? f##2 : f##3)
 template <bool PCA, int K, int ORD>
 __global__ void __launch_bounds__(SWEEP_THREADS, (SweepTune<PCA, K>::WPE))
 k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, int ring_cap, AsyncCtl* ctl, SweepConst sc, unsigned long long* hits_total,
-              double step_max, double eps, int max_iterations, int stop_thresh, unsigned debug_abort_pos) {
+              double step_max, double eps, int max_iterations, int stop_thresh, unsigned debug_abort_pos,
+              NDT_CTX_PARAMS(0), NDT_CTX_PARAMS(1), NDT_CTX_PARAMS(2), NDT_CTX_PARAMS(3)) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   __shared__ double exp_tab[64];
   __shared__ PairState Ssh[WAVES];
@@ -353,17 +371,18 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
   if (lane == 0 && (int)(pos / (unsigned)Iu) < ring_cap) tw = (int)__hip_atomic_load(ringx + pos / (unsigned)Iu, RLX_AGENT);
   tw = wait_ticket((int)(pos / (unsigned)Iu), tw);
   if (tw < 0) return;
-  unsigned pose_w = sweep_pose_words(as_global(tab->c[tw >> ASYNC_CTX_SHIFT].st) + (tw & ((1 << ASYNC_CTX_SHIFT) - 1)));
+  unsigned pose_w = sweep_pose_words(NDT_CTX_SEL(st, tw >> ASYNC_CTX_SHIFT) + (tw & ((1 << ASYNC_CTX_SHIFT) - 1)));
 #pragma unroll 1
   for (;;) {
     // (test hook, MI355NDT_OPT_DEBUG_ASYNC_ABORT: the wave that claimed this position of ring 0 gives up as a wave whose ticket never came would)
     if (x == 0 && pos == debug_abort_pos) { if (lane == 0) give_up(); break; }
     const int rem = (int)(pos % (unsigned)Iu) * CLAIM;
     TL_STAMP(10);                                  // hand-over: claim, ticket, (update)
-    // (wave-uniform: scalar loads of a table nobody writes during the launch.  A pointer that comes out of memory is a FLAT pointer to the
-    //  compiler -- flat loads are slower than global ones and also count against the LDS counter, which cost the DIRECT7 launch 5.5 % when the
-    //  table replaced the kernel arguments -- so every pointer is told where it points: as_global)
-    const AsyncCtx C = async_ctx_global(tab->c[tw >> ASYNC_CTX_SHIFT]);
+    const int ci = tw >> ASYNC_CTX_SHIFT;
+    AsyncCtx C = async_ctx_load(tab, ci);            // (wave-uniform scalar loads of a table nobody writes during the launch: the update's fields)
+    C.src = NDT_CTX_SEL(src, ci); C.pitch = NDT_CTX_SEL(pitch, ci); C.st = NDT_CTX_SEL(st, ci); C.gd = NDT_CTX_SEL(gd, ci); C.words = NDT_CTX_SEL(words, ci);
+    C.recs = NDT_CTX_SEL(recs, ci); C.partials = NDT_CTX_SEL(partials, ci); C.src_cnt = NDT_CTX_SEL(src_cnt, ci); C.arrived = NDT_CTX_SEL(arrived, ci);
+    C.cent = NDT_CTX_SEL(cent, ci);
     const int b = tw & ((1 << ASYNC_CTX_SHIFT) - 1);
     const int n_b = C.src_cnt[b];
 #ifndef ASYNC_D1_PIPE
@@ -403,7 +422,7 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
     ntw = __builtin_amdgcn_readfirstlane(ntw);
     //  3. the next pair's pose -- in flight while this wave updates (if it has to), then together with the next item's point loads.
     unsigned npose = 0;
-    if (ntw >= 0) npose = sweep_pose_words(as_global(tab->c[ntw >> ASYNC_CTX_SHIFT].st) + (ntw & ((1 << ASYNC_CTX_SHIFT) - 1)));
+    if (ntw >= 0) npose = sweep_pose_words(NDT_CTX_SEL(st, ntw >> ASYNC_CTX_SHIFT) + (ntw & ((1 << ASYNC_CTX_SHIFT) - 1)));
     TL_STAMP(8);                                   // row drain + claim, arrival + ticket
     if ((old + (unsigned)CLAIM) % (unsigned)I == 0u) {   // this was the sweep's last item: this wave is the pair's updater
       async_update(C, b, tw, n_b, I, Ssh[wv], sol[wv], ring, ring_cap, ctl, n_live, stop_thresh, hits_total, step_max, eps, max_iterations
@@ -416,7 +435,7 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
     if (ntw < 0) {                                 // the next position's ticket does not exist yet
       ntw = wait_ticket(tn, ntw);
       if (ntw < 0) break;
-      npose = sweep_pose_words(as_global(tab->c[ntw >> ASYNC_CTX_SHIFT].st) + (ntw & ((1 << ASYNC_CTX_SHIFT) - 1)));
+      npose = sweep_pose_words(NDT_CTX_SEL(st, ntw >> ASYNC_CTX_SHIFT) + (ntw & ((1 << ASYNC_CTX_SHIFT) - 1)));
     }
     tw = ntw; pos = npos; pose_w = npose;
   }
