@@ -51,7 +51,7 @@ def sec1():
     ours, other_calls, other_ns = [], 0, 0.0
     for r in rows:
         n = r["Name"]
-        if any(k in n for k in ("k_sweep", "k_align_async", "k_async_begin", "k_async_prepare", "k_calc_score", "k_update", "k_leafsum", "k_rs_", "k_keys", "k_mark", "k_segstart", "k_minmax", "k_voxels", "k_rank",
+        if any(k in n for k in ("k_sweep", "k_align_async", "k_async_begin", "k_async_prepare", "k_stream_status", "k_build_check", "k_sorted_points", "k_calc_score", "k_update", "k_leafsum", "k_rs_", "k_keys", "k_mark", "k_segstart", "k_minmax", "k_voxels", "k_rank",
                                 "k_init_state", "k_griddesc", "k_seq_", "k_set_word_off", "k_word_offsets", "k_pose_records", "k_deinterleave", "k_hessian", "k_fitness", "k_cellrange", "k_transform", "rocprim",
                                 "rocclr")):
             ours.append(r)
@@ -106,7 +106,7 @@ def sec3():
         "launches_counted": n, "fetch_size_kb_avg_per_launch": fe_avg, "write_size_kb_avg_per_launch": wr_avg, "fetch_correction": 2.0,
         "traffic_bytes_per_launch": (2.0 * fe_avg + wr_avg) * 1024, "traffic_bytes_per_launch_uncorrected": (fe_avg + wr_avg) * 1024,
         "full_launch": {"fetch_kb": fe[kmax], "write_kb": wr[kmax]},
-        "algorithmic_bytes_per_launch": bench["roofline"]["alg_bytes_per_launch"],
+        "algorithmic_bytes_per_launch": (bench.get("roofline_synchronous") or bench["roofline"])["alg_bytes_per_launch"],
         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --cpu-seconds 0 --steps 4 --warmup 1`, "
                   "--kernel-include-regex 'k_sweep|k_align_async', no trace domains; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE x2 is the gfx950 "
                   "half-counting correction of MI355X_MICROARCH.md (HBM section), calibrated on the compulsory traffic of a full launch "
@@ -146,7 +146,8 @@ def sec4():
     # ---- SQ counters of the sweep (tools/pmc_kernel.sh summaries) -> what bounds it: VALU issue
     for tag, key, benchfile, outname in (("sq_direct7", "271x65536:omp:direct7:1.0", "bench.json", f"{TAG}_valu.json"),
                                          ("sq_pca_direct1", "271x65536:pca:direct1:1.0", "bench_pca_d1.json", f"{TAG}_valu_pca_direct1.json"),
-                                         ("sq_cfg5_d1", "128x131072:pca:direct1:0.5", "bench_cfg5_d1.json", f"{TAG}_valu_cfg5_d1.json")):
+                                         ("sq_cfg5_d1", "128x131072:pca:direct1:0.5", "bench_cfg5_d1.json", f"{TAG}_valu_cfg5_d1.json"),
+                                         ("sq_cfg5_d7", "128x131072:pca:direct7:0.5", "bench_cfg5.json", f"{TAG}_valu_cfg5_d7.json")):
         pth = os.path.join(SRC, f"pmc_{tag}.txt")
         if not os.path.exists(pth) or not os.path.exists(os.path.join(SRC, benchfile)):
             continue
@@ -155,7 +156,8 @@ def sec4():
         if "SQ_ACTIVE_INST_VALU" not in c:
             continue
         b = load_line(os.path.join(SRC, benchfile))
-        hits_per_launch = b["roofline"]["hits_per_point"] * (b["roofline"]["alg_bytes_per_launch"] / (12 + 4 * {"direct7": 7, "direct1": 1}[b["config"]["neighbor_mode"]] + 64 * b["roofline"]["hits_per_point"]))
+        rs = b.get("roofline_synchronous") or b["roofline"]          # (the counter passes run the synchronous job: its launches)
+        hits_per_launch = b["roofline"]["hits_per_point"] * (rs["alg_bytes_per_launch"] / (12 + 4 * {"direct7": 7, "direct1": 1}[b["config"]["neighbor_mode"]] + 64 * b["roofline"]["hits_per_point"]))
         cycles = c["GRBM_GUI_ACTIVE"] / 8.0                       # the counter sums the eight XCDs
         valu = {
             "workload_key": key, "kernel": "k_align_async", "source_counters": f"profiles/{TAG}_pmc_{tag}.txt (rocprofv3 --pmc passes of tools/pmc_kernel.sh, mean per dispatch)",
@@ -186,7 +188,7 @@ def sec5():
     global traffic, fe, wr, sw, kmax, bench
     # ---- build / update kernels: counter summaries + reduced ratios (profiles/reduce_pmc.py)
     import subprocess
-    for name in ("build", "update"):
+    for name in ("build", "update", "build_sorted"):
         pth = os.path.join(SRC, f"pmc_{name}.txt")
         if os.path.exists(pth) and os.path.getsize(pth) > 100:
             open(os.path.join(OUT, f"{TAG}_pmc_{name}.txt"), "w").write(open(pth).read())

@@ -136,11 +136,12 @@ def test_streamed_headline_carries_both_rates():
     st = d["config"]["stream"]
     assert st["n_batches"] == 3 and st["n_contexts"] == 3 and st["bit_identical_to_synchronous"] is True and st["batches_rerun"] == 0 and st["launches_that_gave_up"] == 0
     assert st["launches"] >= 6 and st["pairs_handed_over"] > 0
-    assert d["value"] > 0 and d["value_synchronous"] > 0 and "streamed" in d["config"]["mode"]
-    assert d["roofline"]["launches"] >= 6 and d["roofline_synchronous"]["launches"] == 6
+    assert d["value_streamed"] > 0 and d["value_synchronous"] > 0 and d["value"] == max(d["value_streamed"], d["value_synchronous"])
+    assert d["config"]["mode"].startswith("streamed" if d["value"] == d["value_streamed"] else "synchronous") and "faster of the two modes" in d["config"]["mode"]
+    assert d["roofline_streamed"]["launches"] >= 6 and d["roofline_synchronous"]["launches"] == 6
     d0 = run_bench(["--pairs", "8", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-host-clouds", "--config4-pairs", "0", "--seq-frames", "0",
                     "--no-other-configs", "--no-stream"])
-    assert d0["config"]["stream"] is None and d0["value"] == d0["value_synchronous"] and d0["config"]["mode"].startswith("synchronous")
+    assert d0["config"]["stream"] is None and d0["value"] == d0["value_synchronous"] and d0["value_streamed"] is None and d0["config"]["mode"].startswith("synchronous")
 
 
 def test_kitti_directory_as_input(tmp_path):

@@ -15,8 +15,9 @@ trace)
   # per-kernel times (trace only, no counters)
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py $QUIET --steps 20 --warmup 3 > $O/kt_bench.json 2> $O/kt.log
   # HBM-side traffic of the sweep: FETCH_SIZE and WRITE_SIZE in separate passes, no trace domains
-  timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex 'k_sweep|k_align_async' --output-format csv -d $O/fetch -- python $R/bench.py $QUIET --steps 4 --warmup 1 > /dev/null 2> $O/fetch.log
-  timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex 'k_sweep|k_align_async' --output-format csv -d $O/write -- python $R/bench.py $QUIET --steps 4 --warmup 1 > /dev/null 2> $O/write.log
+  # (--no-stream: the synchronous job's launches only, one kind of dispatch per pass; the streamed job runs the same kernel on the same pairs)
+  timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex 'k_sweep|k_align_async' --output-format csv -d $O/fetch -- python $R/bench.py $QUIET --no-stream --steps 4 --warmup 1 > /dev/null 2> $O/fetch.log
+  timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex 'k_sweep|k_align_async' --output-format csv -d $O/write -- python $R/bench.py $QUIET --no-stream --steps 4 --warmup 1 > /dev/null 2> $O/write.log
   rm -rf $O/kt/*/*.db $O/fetch/*/*.db $O/write/*/*.db
   cd $R
   timeout 400 tools/kstats.sh final_kd1 --no-host-clouds --variant pca --mode direct1 --steps 20 --warmup 3 > $O/kstats_pca_d1.txt 2>&1
@@ -25,11 +26,13 @@ trace)
 pmc)
   cd $R
   # SQ / TCP / TCC counters: the sweep on the headline workload, the live nodelet's configuration and config 5 with DIRECT1; the build kernels; the update
-  timeout 500 tools/pmc_kernel.sh 'k_sweep|k_align_async' sq_direct7 > $O/pmc_sq_direct7.txt 2>&1
-  timeout 500 tools/pmc_kernel.sh 'k_sweep|k_align_async' sq_pca_direct1 --variant pca --mode direct1 > $O/pmc_sq_pca_direct1.txt 2>&1
-  timeout 500 tools/pmc_kernel.sh 'k_sweep|k_align_async' sq_cfg5_d1 --variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128 > $O/pmc_sq_cfg5_d1.txt 2>&1
-  timeout 500 tools/pmc_kernel.sh 'k_leafsum|k_rs_|k_voxels|k_mark|k_rank|k_minmax|k_griddesc|k_word_offsets' sq_build > $O/pmc_build.txt 2>&1
-  timeout 500 tools/pmc_kernel.sh 'k_seq_update|k_update' sq_update --seq-frames 65 > $O/pmc_update.txt 2>&1
+  timeout 500 tools/pmc_kernel.sh 'k_sweep|k_align_async' sq_direct7 --no-stream > $O/pmc_sq_direct7.txt 2>&1
+  timeout 500 tools/pmc_kernel.sh 'k_sweep|k_align_async' sq_pca_direct1 --no-stream --variant pca --mode direct1 > $O/pmc_sq_pca_direct1.txt 2>&1
+  timeout 500 tools/pmc_kernel.sh 'k_sweep|k_align_async' sq_cfg5_d1 --no-stream --variant pca --mode direct1 --resolution 0.5 --azimuth 2048 --pairs 128 > $O/pmc_sq_cfg5_d1.txt 2>&1
+  timeout 500 tools/pmc_kernel.sh 'k_sweep|k_align_async' sq_cfg5_d7 --no-stream --variant pca --mode direct7 --resolution 0.5 --azimuth 2048 --pairs 128 > $O/pmc_sq_cfg5_d7.txt 2>&1
+  timeout 500 tools/pmc_kernel.sh 'k_leafsum|k_rs_|k_voxels|k_mark|k_rank|k_minmax|k_griddesc|k_word_offsets' sq_build --no-stream > $O/pmc_build.txt 2>&1
+  MI355NDT_LEAF_SORTED=1 timeout 500 tools/pmc_kernel.sh 'k_leafsum|k_sorted_points' sq_build_sorted --no-stream > $O/pmc_build_sorted.txt 2>&1
+  timeout 500 tools/pmc_kernel.sh 'k_seq_update|k_update' sq_update --no-stream --seq-frames 65 > $O/pmc_update.txt 2>&1
   timeout 300 tools/pmc_calib.sh > $O/pmc_valu_calib.log 2>&1; cp $R/gpurun_out/pmc_calib/calib.json $O/pmc_valu_calib.json
   ;;
 bench)
@@ -60,7 +63,7 @@ esac
 done
 # reduce on the box (the raw traces are far too large to travel back) and drop the raw directories
 cd $R
-python profiles/summarize.py r04 $O/reduced > $O/summarize.log 2>&1
+python profiles/summarize.py r05 $O/reduced > $O/summarize.log 2>&1
 rm -rf $O/kt $O/fetch $O/write $R/gpurun_out/final_kd1/kt $R/gpurun_out/final_kc5/kt $R/gpurun_out/pmc_sq_*
 tail -5 $O/summarize.log
 for f in bench.log kt.log; do echo "== $f"; tail -4 $O/$f; done
