@@ -2420,6 +2420,13 @@ int mi355ndt_sequence_run(mi355ndt_handle* h, int n_frames, const void* const* c
 
 
 #ifdef NDT_TIMELINE
+extern "C" int mi355ndt_debug_leaf_timeline(unsigned long long* out) {
+  unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ltl), sizeof(z)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_ltl), z, sizeof(z)) != hipSuccess) return -1;
+  return 0;
+}
 extern "C" int mi355ndt_debug_timeline(unsigned long long* out) {
   unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (hipDeviceSynchronize() != hipSuccess) return -1;

@@ -291,6 +291,22 @@ __global__ void __launch_bounds__(256) k_sorted_points(const float* __restrict__
 // The wave gathers 64 points of the leaf's run at a time (the radix sort is stable, so the run is in input
 // order), parks the nine f64 terms of each point in LDS, and lanes 0..8 -- one per accumulator -- add them
 // strictly in input order, which keeps the sums bit-identical to the reference's sequential accumulation.
+#ifdef NDT_TIMELINE
+// per-phase shader-clock totals of the leaf sums (tools/leaf_timeline.py): [0..4] phases, [8] chunks, [9] leaves, [10] waves, [11] wave lifetimes
+__device__ unsigned long long g_ltl[16];
+#define LTL_DECL unsigned long long ltl[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ltl_last = __builtin_readcyclecounter(); const unsigned long long ltl_t0 = ltl_last
+#define LTL_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); ltl[k] += t_ - ltl_last; ltl_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define LTL_COUNT(k, v) do { ltl[k] += (unsigned long long)(v); } while (0)
+// (a sample of the waves adds its totals: 70 k waves adding to twelve words are a load of their own)
+#define LTL_FLUSH() do { ltl[10] = 1; ltl[11] = __builtin_readcyclecounter() - ltl_t0; if ((threadIdx.x & 63) == 0 && (blockIdx.x % 24) == (threadIdx.x >> 6) * 5) for (int k_ = 0; k_ < 12; k_++) atomicAdd(&g_ltl[k_], ltl[k_]); } while (0)
+#define LTL_ARRIVED1(a) asm volatile("" : "+v"(a))
+#else
+#define LTL_DECL do {} while (0)
+#define LTL_STAMP(k) do {} while (0)
+#define LTL_COUNT(k, v) do {} while (0)
+#define LTL_FLUSH() do {} while (0)
+#define LTL_ARRIVED1(a) do {} while (0)
+#endif
 #define LS_WAVES 4
 template <typename KeyT, bool CENT, bool SORTED = false>
 __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restrict__ tgt, size_t pitch,
@@ -309,7 +325,9 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restri
   const float* X = tgt + (size_t)b * 3 * pitch;
   const int id0 = bx * LS_WAVES + wv, idstep = nx * LS_WAVES;
   size_t start_next = id0 < g.n_voxels ? seg_start[g.rec_off + id0] : 0;
+  LTL_DECL;
   for (int id = id0; id < g.n_voxels; id += idstep) {
+    LTL_COUNT(9, 1);
     const size_t start = start_next;
     if (id + idstep < g.n_voxels) start_next = seg_start[g.rec_off + id + idstep];   // next leaf's run start, one leaf ahead
     // accumulator order: S0 S1 S2 C00 C01 C02 C11 C12 C22 ; cov_ is seeded with Identity (voxel_grid_covariance_omp.h:101)
@@ -326,11 +344,18 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restri
       unsigned pi = 0u;
       if (SORTED) { if (inb) pj = reinterpret_cast<const float4*>(vals)[(size_t)b * pitch + j]; }
       else pi = inb ? V[j] : 0u;
+#ifdef NDT_TIMELINE
+      { KeyT kq = kj; LTL_ARRIVED1(kq); LTL_ARRIVED1(pi); LTL_ARRIVED1(pj.x); }
+      LTL_STAMP(0);                              // keys and ids have arrived
+      LTL_COUNT(8, 1);
+#endif
       if (j0 == start) key = __shfl(kj, 0);      // the run's cell: its first entry
       const bool in = inb && kj == key;
       const int m = (int)__popcll(__ballot(in));
       if (in) {
-        const float fx = SORTED ? pj.x : X[pi], fy = SORTED ? pj.y : X[pitch + pi], fz = SORTED ? pj.z : X[2 * pitch + pi];
+        float fx = SORTED ? pj.x : X[pi], fy = SORTED ? pj.y : X[pitch + pi], fz = SORTED ? pj.z : X[2 * pitch + pi];
+        LTL_ARRIVED1(fx); LTL_ARRIVED1(fy); LTL_ARRIVED1(fz);
+        LTL_STAMP(1);                            // the rows have arrived
         const double x = (double)fx, y = (double)fy, z = (double)fz;
         double* t = term[wv][lane];
         t[0] = x; t[1] = y; t[2] = z;
@@ -338,6 +363,7 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restri
         if (CENT) { termf[wv][lane][0] = fx; termf[wv][lane][1] = fy; termf[wv][lane][2] = fz; }
       }
       __builtin_amdgcn_wave_barrier();
+      LTL_STAMP(2);                              // terms in LDS
       if (lane < 9) {                            // strictly sequential adds (input order); the LDS reads are batched ahead of them
         int l = 0;
         for (; l + 8 <= m; l += 8) {
@@ -352,6 +378,7 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restri
         for (int l = 0; l < m; l++) accf += termf[wv][l][lane - 9];
       }
       __builtin_amdgcn_wave_barrier();
+      LTL_STAMP(3);                              // sums
       cnt += m;
       if (m < 64) break;
     }
@@ -361,7 +388,9 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restri
       vox_idx[g.rec_off + id] = (int)((unsigned)key & ((1u << cb) - 1u));
       vox_n[g.rec_off + id] = cnt;
     }
+    LTL_STAMP(4);                                // stores issued, loop
   }
+  LTL_FLUSH();
 }
 
 // second pass of applyFilter (impl:282-367; pca impl:364-397): one thread per searchable leaf
