@@ -202,7 +202,11 @@ enum mi355ndt_option {
    * and the NEXT batch's target build runs on a stream of its own beside the launch instead of between two launches -- the build streams
    * through HBM, the launch saturates the vector ALUs.  Needs >= 3 contexts (a context is rebuilt one launch earlier, so its pairs are carried
    * through one launch less).  -1 (default): the environment variable MI355NDT_STREAM_RESERVE, else 0 = off.  No result bit depends on it. */
-  MI355NDT_OPT_STREAM_RESERVE = 5
+  MI355NDT_OPT_STREAM_RESERVE = 5,
+  /* Test hook, default 0xFF (off).  Bit x clear: the workgroups of a one-launch align that serve ring x leave at once, as if XCD x held no
+   * workgroup of this launch (another engine's launch filling it).  The launch must still finish every pair -- waiting waves serve the
+   * published positions of other rings (ndt_async.hpp) -- with the same bits; mask 0 is refused. */
+  MI355NDT_OPT_DEBUG_ASYNC_RINGS = 6
 };
 int mi355ndt_set_option(mi355ndt_handle* h, int option, int value);
 int mi355ndt_get_option(const mi355ndt_handle* h, int option, int* value);

@@ -109,6 +109,7 @@ struct mi355ndt_handle {
   AsyncCtl* h_pin_actl = nullptr;
   AsyncTab* d_atab = nullptr;                     // the launch's context table (ndt_async.hpp)
   unsigned debug_abort_pos = 0xFFFFFFFFu;         // MI355NDT_OPT_DEBUG_ASYNC_ABORT (test hook): the wave that claims this position of ring 0 gives up
+  unsigned debug_ring_mask = 0xFFu;               // MI355NDT_OPT_DEBUG_ASYNC_RINGS (test hook): rings whose workgroups take part
   int f32_sum_order = 0;                          // MI355NDT_OPT_F32_SUM_ORDER: 0 = (t0 + t1) + t2 (canonical), 1 = (t0 + t2) + t1 (Eigen 3.3 SSE predux pairing)
   double gauss_last[3] = {0, 0, 0};               // gauss_d1_/d2_/d3_ as the constructor / the last computeTransformation left them (calculateScore reads them)
   float* d_score_pts = nullptr; size_t score_pts_cap = 0; double* d_score_part = nullptr; size_t score_part_cap = 0;   // calculateScore workspace
@@ -1125,7 +1126,7 @@ struct AsyncLaunch {
   PairState* st_new = nullptr; const float* guess_new = nullptr; const int* src_cnt_new = nullptr; const GridDesc* gd_new = nullptr; unsigned* arrived_new = nullptr;
   int* active_list = nullptr; SweepCtl* sweep_ctl = nullptr; unsigned* done_new = nullptr; PoseRecord* pose_new = nullptr; int pose_cap = 0;
   AsyncTab* tab_dev = nullptr; int* ring = nullptr; int ring_cap = 0; AsyncCtl* ctl = nullptr; const AsyncCtl* prev = nullptr;
-  int items_per_pair = 0, stop_thresh = 0; unsigned debug_abort_pos = 0xFFFFFFFFu;
+  int items_per_pair = 0, stop_thresh = 0; unsigned debug_abort_pos = 0xFFFFFFFFu, debug_ring_mask = 0xFFu;
   int reserve_wg = 0;
 };
 #define NDT_CTX_ARGS(i) L.tab.c[i].src, L.tab.c[i].pitch, L.tab.c[i].st, L.tab.c[i].gd, L.tab.c[i].words, L.tab.c[i].recs, L.tab.c[i].partials, L.tab.c[i].src_cnt, \
@@ -1138,16 +1139,16 @@ static int launch_async_t(mi355ndt_handle* h, const SweepConst& sc, const AsyncL
   int& per_cu = per_cu_of_device[h->device & 63];
   if (per_cu == 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SWEEP_THREADS, 0) != hipSuccess) { per_cu = 0; (void)hipGetLastError(); return MI355NDT_ERR_UNSUPPORTED; }
   const int wpe = sweep_wpe(PCA, K);
-  // Every ring needs waves of its own (workgroup L serves ring L % 8), and the launch is sized to be resident as a whole.  Residency is
-  // no condition of correctness: positions are claimed, so the resident waves of a ring do all of its work and a workgroup that starts
-  // late -- another engine's launch holds its CU -- finds the launch over or joins in; a launch that cannot progress ends itself
-  // (bounded polls) and the caller falls back to the rounds.
+  // Workgroup L serves ring L % 8 first, and the launch is sized to be resident as a whole.  Residency is no condition of correctness:
+  // positions are claimed, a waiting wave serves the published positions of OTHER rings too (ndt_async.hpp: an XCD that holds no workgroup
+  // of this launch -- another engine's launch fills it -- leaves no ticket unserved), a workgroup that starts late finds the launch over
+  // or joins in; a launch that cannot progress all the same ends itself (bounded polls) and the caller falls back to the rounds.
   if (per_cu < wpe || h->n_cu * wpe < 8) return MI355NDT_ERR_UNSUPPORTED;
   // (stream mode may withhold some workgroups so that the next batch's target build, on a stream of its own, finds wave slots
   //  beside this launch: L.reserve_wg, a multiple of 8 so that every ring loses the same number of waves)
   dim3 grid((unsigned)std::max(8, h->n_cu * wpe - L.reserve_wg));
   kern<<<grid, SWEEP_THREADS, 0, h->stream>>>(L.tab_dev, L.items_per_pair, L.ring, L.ring_cap, L.ctl, sc, h->prof ? h->d_hits : nullptr,
-                                             h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations, L.stop_thresh, L.debug_abort_pos,
+                                             h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations, L.stop_thresh, L.debug_abort_pos, L.debug_ring_mask,
                                              NDT_CTX_ARGS(0), NDT_CTX_ARGS(1), NDT_CTX_ARGS(2), NDT_CTX_ARGS(3));
   return MI355NDT_OK;
 }
@@ -1201,7 +1202,7 @@ static int align_async(mi355ndt_handle* h, const SweepConst& sc, int B, mi355ndt
   L.st_new = h->d_state; L.guess_new = h->d_guess; L.src_cnt_new = h->d_src_cnt; L.gd_new = h->d_grid; L.arrived_new = h->d_arrived;
   L.active_list = h->d_active_list; L.sweep_ctl = h->d_ctl;
   L.tab_dev = h->d_atab; L.ring = h->d_ring; L.ring_cap = ring_cap; L.ctl = h->d_actl; L.prev = nullptr;
-  L.items_per_pair = h->items_per_pair; L.stop_thresh = 0; L.debug_abort_pos = h->debug_abort_pos;
+  L.items_per_pair = h->items_per_pair; L.stop_thresh = 0; L.debug_abort_pos = h->debug_abort_pos; L.debug_ring_mask = h->debug_ring_mask;
   int rc = launch_async(h, sc, L);
   if (rc) return rc;
   HIPCHK(h, hipMemcpyAsync(h->h_pin_actl, h->d_actl, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, s));   // pub, fin, abort_, n_live, susp
@@ -1761,6 +1762,11 @@ int mi355ndt_set_option(mi355ndt_handle* h, int option, int value) {
     h->debug_abort_pos = value < 0 ? 0xFFFFFFFFu : (unsigned)value;
     return MI355NDT_OK;
   }
+  if (option == MI355NDT_OPT_DEBUG_ASYNC_RINGS) {
+    if ((value & 0xFF) == 0) return MI355NDT_ERR_BAD_ARG;
+    h->debug_ring_mask = (unsigned)value & 0xFFu;
+    return MI355NDT_OK;
+  }
   if (option == MI355NDT_OPT_STREAM_THRESHOLD) {
     if (value < -1 || value > ASYNC_MAX_CARRY) return MI355NDT_ERR_BAD_ARG;
     h->s_thresh_opt = value;
@@ -1779,6 +1785,7 @@ int mi355ndt_get_option(const mi355ndt_handle* h, int option, int* value) {
   if (option == MI355NDT_OPT_F32_SUM_ORDER) { *value = h->f32_sum_order; return MI355NDT_OK; }
   if (option == MI355NDT_OPT_ASYNC_ALIGN) { *value = h->async_force ? 2 : (h->async_align ? 1 : 0); return MI355NDT_OK; }
   if (option == MI355NDT_OPT_DEBUG_ASYNC_ABORT) { *value = h->debug_abort_pos == 0xFFFFFFFFu ? -1 : (int)h->debug_abort_pos; return MI355NDT_OK; }
+  if (option == MI355NDT_OPT_DEBUG_ASYNC_RINGS) { *value = (int)h->debug_ring_mask; return MI355NDT_OK; }
   if (option == MI355NDT_OPT_STREAM_THRESHOLD) { *value = h->s_thresh_opt; return MI355NDT_OK; }
   if (option == MI355NDT_OPT_STREAM_RESERVE) { *value = h->s_reserve_opt; return MI355NDT_OK; }
   return MI355NDT_ERR_BAD_ARG;
@@ -2074,7 +2081,7 @@ static int stream_launch(mi355ndt_handle* h, int new_ci, int n_new) {
   L.ctl = h->d_sctl + (j & 1); L.prev = h->s_drop_carry ? nullptr : h->d_sctl + ((j + 1) & 1);
   // (the automatic threshold never hands over more than a quarter of the batch: a batch too small to fill the GPU has no bulk to hide stragglers under)
   const bool thresh_given = h->s_thresh_opt >= 0 || std::getenv("MI355NDT_STREAM_THRESH");
-  L.items_per_pair = h->s_items; L.stop_thresh = flush ? 0 : (thresh_given ? h->s_thresh : std::min(h->s_thresh, n_new / 4)); L.debug_abort_pos = h->debug_abort_pos;
+  L.items_per_pair = h->s_items; L.stop_thresh = flush ? 0 : (thresh_given ? h->s_thresh : std::min(h->s_thresh, n_new / 4)); L.debug_abort_pos = h->debug_abort_pos; L.debug_ring_mask = h->debug_ring_mask;
   L.reserve_wg = flush ? 0 : h->s_reserve_wg;
   h->ev_last_fresh = false;                          // (the contexts' builds sit between two launches on this stream)
   if (!flush && h->s_reserve_wg > 0) HIPCHK(h, hipStreamWaitEvent(s, h->s_ev_built[new_ci], 0));   // this batch's grids (built on the other stream)

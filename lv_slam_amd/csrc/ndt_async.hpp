@@ -90,6 +90,9 @@ struct AsyncCtl {
 #ifndef ASYNC_CLAIM
 #define ASYNC_CLAIM(K) ((K) == 1 ? 2 : 1)
 #endif
+#ifndef ASYNC_HELP_RINGS
+#define ASYNC_HELP_RINGS 1       // 0 (experiments only): waves serve their own ring alone, as in round 4 -- tests/test_stream_gpu.py's ring-mask test then gives up
+#endif
 #define ASYNC_SPIN_LIMIT (1u << 23)      // polls of ~1 us: a device that stopped making progress ends the launch after seconds, not never
 
 // Everything the launch reads before it has written it, set by ONE kernel on the stream in front of it (never inside the launch): the
@@ -322,7 +325,7 @@ NDT_KERNEL void k_stream_status(const AsyncCtl* __restrict__ ctl, const CtxStat*
 template <bool PCA, int K, int ORD>
 __global__ void __launch_bounds__(SWEEP_THREADS, (SweepTune<PCA, K>::WPE))
 k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, int ring_cap, AsyncCtl* ctl, SweepConst sc, unsigned long long* hits_total,
-              double step_max, double eps, int max_iterations, int stop_thresh, unsigned debug_abort_pos,
+              double step_max, double eps, int max_iterations, int stop_thresh, unsigned debug_abort_pos, unsigned debug_ring_mask,
               NDT_CTX_PARAMS(0), NDT_CTX_PARAMS(1), NDT_CTX_PARAMS(2), NDT_CTX_PARAMS(3)) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   __shared__ double exp_tab[64];
@@ -331,6 +334,7 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
   if (threadIdx.x < 64) exp_tab[threadIdx.x] = ndtm::c_exp2_64[threadIdx.x];
   __syncthreads();                                 // (the only block barrier: the four waves are independent from here on)
   const int x = blockIdx.x & 7;                    // the ring this workgroup serves
+  if (!((debug_ring_mask >> x) & 1u)) return;      // (test hook, MI355NDT_OPT_DEBUG_ASYNC_RINGS: an XCD that holds no workgroup of this launch)
   const gu32* ringx = (const gu32*)reinterpret_cast<const unsigned*>(ring + (size_t)x * ring_cap);
   const gu32* fin_p = (const gu32*)&ctl->fin;
   gu32* pos_p = (gu32*)&ctl->pos[x * ASYNC_POS_STRIDE];
@@ -347,19 +351,58 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
     __hip_atomic_store((gu32*)&ctl->abort_, 1u, RLX_AGENT);
     __hip_atomic_store((gu32*)&ctl->fin, n_live, RLX_AGENT);
   };
-  // wait (one lane, relaxed polls with sleeps) until ticket `t` of this ring exists; -2: the launch is over
-  auto wait_ticket = [&](const int t, int have) -> int {
+  // Wait (one lane, relaxed polls with sleeps) until the ticket of the claimed position `p` of this ring exists; -2: the launch is over.
+  // A wave that waits HELPS THE OTHER RINGS meanwhile: tickets go round the eight rings (ticket g -> ring g & 7), a ring is served by the
+  // workgroups of one XCD (blockIdx & 7), and nothing guarantees that every XCD holds workgroups of this launch -- two engines launching at
+  // the same time can end up with one launch resident on half of the XCDs and the other on the other half, each waiting for tickets that sit
+  // in rings nobody of its own serves, for ever (observed: `test_two_engines_on_two_threads_share_the_gpu`, one launch in ~10^3 gave up after
+  // its poll budget).  So: while its own ticket is not there, the wave looks at another ring y per poll; if y has a position whose ticket is
+  // already published (position counter / Iu < tickets published into y, from the global ticket counter `pub`), it takes exactly that position
+  // with a compare-and-swap -- never a blind claim: a claimed position cannot be abandoned, and its own claim `p` stays pending --, serves it,
+  // and comes back for `p` (`held`).  Every published position is thus servable by ANY resident wave of the launch; which wave serves an
+  // item never enters a result (rows depend on the pair, the chunk and the input order).
+  bool held = false;                               // an own claim whose ticket was not there when the wave went to help
+  unsigned held_pos = 0;
+  const gu64* pubfin_p = (const gu64*)reinterpret_cast<const unsigned long long*>(ctl);   // {pub, fin}: the first two words of the control block
+  static_assert(offsetof(AsyncCtl, pub) == 0 && offsetof(AsyncCtl, fin) == 4, "pub and fin are polled as one 8-byte word");
+  auto wait_ticket = [&](unsigned& p, int have) -> int {
     int w = have;
+    unsigned sp = p;
+    int st = 0;
     if (lane == 0) {
       unsigned spins = 0;
+      const int t = (int)(p / (unsigned)Iu);
       while (w < 0) {
-        if (__hip_atomic_load(fin_p, RLX_AGENT) >= n_live) { w = -2; break; }
+        const unsigned long long pf = __hip_atomic_load(pubfin_p, RLX_AGENT);        // pub (low word) and fin with one poll of the line
+        if ((unsigned)(pf >> 32) >= n_live) { w = -2; break; }
+        if (ASYNC_HELP_RINGS && (spins & 3u) == 3u) {   // (every fourth poll, not in the first microseconds of a wait) a servable position of another ring?
+          const unsigned y = ((unsigned)x + 1u + (spins >> 2) % 7u) & 7u;
+          gu32* pos_y = (gu32*)&ctl->pos[y * ASYNC_POS_STRIDE];
+          const unsigned q = __hip_atomic_load(pos_y, RLX_AGENT);
+          const unsigned pubv = (unsigned)pf;
+          const unsigned slots_y = pubv > y ? ((pubv - 1u - y) >> 3) + 1u : 0u;     // tickets g < pubv with g & 7 == y
+          const unsigned tq = q / (unsigned)Iu;
+          if (tq < slots_y && (int)tq < ring_cap) {
+            unsigned expect = q;
+            if (__hip_atomic_compare_exchange_strong(pos_y, &expect, q + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+              const gu32* slot = (const gu32*)reinterpret_cast<const unsigned*>(ring + (size_t)y * ring_cap + tq);
+              int ws = (int)__hip_atomic_load(slot, RLX_AGENT);
+              unsigned lag = 0;                    // (the counter runs one store ahead of the ticket word)
+              while (ws < 0 && ++lag <= ASYNC_SPIN_LIMIT) { __builtin_amdgcn_s_sleep(2); ws = (int)__hip_atomic_load(slot, RLX_AGENT); }
+              if (ws < 0) { give_up(); w = -2; break; }
+              w = ws; sp = q; st = 1;
+              break;
+            }
+          }
+        }
         __builtin_amdgcn_s_sleep(32);
         if (t < ring_cap) w = (int)__hip_atomic_load(ringx + t, RLX_AGENT);
         if (++spins > ASYNC_SPIN_LIMIT) { give_up(); w = -2; break; }
       }
     }
-    return __builtin_amdgcn_readfirstlane(w);
+    w = __builtin_amdgcn_readfirstlane(w);
+    if (__builtin_amdgcn_readfirstlane(st)) { held = true; held_pos = p; p = __builtin_amdgcn_readfirstlane(sp); }
+    return w;
   };
   // Positions of the ring's item stream (ticket 0's items, ticket 1's, ...) are CLAIMED, one returning fetch-add per item.  Static dealing
   // (wave w takes positions w, w + W, ...) was built and measured first: every update makes its wave late for good, a ticket completes when
@@ -369,7 +412,7 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
   pos = __builtin_amdgcn_readfirstlane(pos);
   int tw = -1;                                     // ticket word: context << 24 | pair slot
   if (lane == 0 && (int)(pos / (unsigned)Iu) < ring_cap) tw = (int)__hip_atomic_load(ringx + pos / (unsigned)Iu, RLX_AGENT);
-  tw = wait_ticket((int)(pos / (unsigned)Iu), tw);
+  tw = wait_ticket(pos, tw);
   if (tw < 0) return;
   unsigned pose_w = sweep_pose_words(NDT_CTX_SEL(st, tw >> ASYNC_CTX_SHIFT) + (tw & ((1 << ASYNC_CTX_SHIFT) - 1)));
 #pragma unroll 1
@@ -406,8 +449,9 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
     // Three memory round trips between two items, each carrying everything that does not depend on the next one:
     //  1. the row stores drain (the row is complete in memory before the arrival that may hand it to an updater) -- and the claim of the
     //     next position, which depends on nothing, returns with them;
-    unsigned npos = 0;
-    if (lane == 0) npos = __hip_atomic_fetch_add(pos_p, 1u, RLX_AGENT);
+    unsigned npos = held_pos;                      // (a claim still pending from before the wave went to help another ring comes first)
+    if (lane == 0 && !held) npos = __hip_atomic_fetch_add(pos_p, 1u, RLX_AGENT);
+    held = false;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     npos = __builtin_amdgcn_readfirstlane(npos);
     const int tn = (int)(npos / (unsigned)Iu);
@@ -433,7 +477,7 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
       TL_STAMP(15);                                // the deferred re-basing (off the pair's critical path)
     }
     if (ntw < 0) {                                 // the next position's ticket does not exist yet
-      ntw = wait_ticket(tn, ntw);
+      ntw = wait_ticket(npos, ntw);                 // (may come back with a position of another ring: `held`)
       if (ntw < 0) break;
       npose = sweep_pose_words(NDT_CTX_SEL(st, ntw >> ASYNC_CTX_SHIFT) + (ntw & ((1 << ASYNC_CTX_SHIFT) - 1)));
     }

@@ -88,6 +88,7 @@ SYMBOLS = [
 ]
 OPT_ASYNC_ALIGN = 2            # mi355ndt_option: 1 (default) = one persistent launch per batch align, 0 = lockstep (update, sweep) rounds; same bits
 OPT_DEBUG_ASYNC_ABORT = 3      # mi355ndt_option (test hook): the wave that claims this position of ring 0 gives up -> the batch is re-run in rounds
+OPT_DEBUG_ASYNC_RINGS = 6      # mi355ndt_option (test hook): bit x clear -> ring x of a one-launch align has no workgroups of its own
 OPT_STREAM_RESERVE = 5         # mi355ndt_option: workgroup slots the stream's launches leave free for the next batch's build (0 = off)
 OPT_STREAM_THRESHOLD = 4       # mi355ndt_option: pairs a stream launch hands over to the next one (-1 = auto, 0 = none)
 OPT_F32_SUM_ORDER = 1          # mi355ndt_option: 0 = (t0 + t1) + t2 (canonical), 1 = (t0 + t2) + t1 (Eigen 3.3 SSE predux pairing)

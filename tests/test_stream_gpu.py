@@ -3,6 +3,7 @@ consumes a stream of frames (scan_matching_odom_nodelet.cpp:144-183) -- against 
 on the launch that happened to serve it, so EVERY result word of every batch equals mi355ndt_batch_align's (whose bits the other GPU
 tests hold against the oracle).  Also the safety net of the one-launch align: a launch that gives up is re-run by the round-based path."""
 import threading
+import time
 
 import numpy as np
 import pytest
@@ -183,6 +184,39 @@ def test_one_launch_align_that_gives_up_is_rerun_by_the_rounds():
         for k, (x, y) in enumerate(zip(r, g)):
             assert same(x, y), (bi, k)
     assert pr["async_fallbacks"] >= 1 and pr["stream_redone"] >= 1
+
+
+@pytest.mark.parametrize("mask", [0x0F, 0xA5, 0x01])
+def test_rings_without_workgroups_of_their_own_are_served_by_the_others(mask):
+    """Tickets go round the eight rings and a ring is served by the workgroups of one XCD; nothing guarantees that every XCD holds workgroups
+    of a launch (two engines launching at once can split the XCDs between them: seen once in ~10^3 launches as a launch that gave up after
+    its poll budget).  MI355NDT_OPT_DEBUG_ASYNC_RINGS takes the workgroups of some rings out of the launch on purpose: the waves that are
+    there must serve every ring's published positions (ndt_async.hpp: a waiting wave takes servable positions of other rings), the launch
+    must end with every pair finished -- ONE launch, no fallback -- and with the same bits; also through the stream."""
+    kw = dict(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=ndt.DIRECT7, variant=0)
+    batches, n = make_batches(2900, [40, 40, 40], 512)
+    ref = sync_results(batches, n, kw)
+    eng = ndt.Engine(ndt.default_params(**kw))
+    eng.set_option(ndt.OPT_ASYNC_ALIGN, 2)                   # the one-launch align whatever the batch size
+    eng.set_option(ndt.OPT_DEBUG_ASYNC_RINGS, mask)
+    eng.profile_enable(True)
+    T, S, cnt, G = batches[0]
+    eng.batch_bind_device(T.data_ptr(), [n] * 40, n, S.data_ptr(), cnt, n)
+    eng.batch_build_targets()
+    t0 = time.time()
+    for rep in range(3):
+        res = eng.batch_align(G)
+        for k, (x, y) in enumerate(zip(ref[0], res)):
+            assert same(x, y), (rep, k)
+    pr = eng.profile_get()
+    assert pr["async_fallbacks"] == 0 and pr["sweep_launches"] == 3 and pr["update_launches"] == 0
+    assert time.time() - t0 < 5.0                            # (a launch that waits for its poll budget takes ~10 s)
+    eng.close()
+    got, pr = stream_results(batches, n, kw, 3, -1, opts=((ndt.OPT_DEBUG_ASYNC_RINGS, mask),))
+    for bi, (r, g) in enumerate(zip(ref, got)):
+        for k, (x, y) in enumerate(zip(r, g)):
+            assert same(x, y), (bi, k)
+    assert pr["async_fallbacks"] == 0 and pr["stream_redone"] == 0
 
 
 def test_two_engines_on_two_threads_share_the_gpu():
