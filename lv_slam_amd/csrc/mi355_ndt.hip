@@ -1135,9 +1135,13 @@ template <bool PCA, int K, int ORD>
 static int launch_async_t(mi355ndt_handle* h, const SweepConst& sc, const AsyncLaunch& L) {
   auto kern = k_align_async<PCA, K, ORD>;
   // (asked once per instantiation and device: the query sits between the prepare kernel and the launch, on the host's critical path)
-  static int per_cu_of_device[64] = {0};
-  int& per_cu = per_cu_of_device[h->device & 63];
-  if (per_cu == 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SWEEP_THREADS, 0) != hipSuccess) { per_cu = 0; (void)hipGetLastError(); return MI355NDT_ERR_UNSUPPORTED; }
+  // (engines on several host threads come through here at once: the cached answer is an atomic, the query writes into a local)
+  static std::atomic<int> per_cu_of_device[64];
+  int per_cu = per_cu_of_device[h->device & 63].load(std::memory_order_relaxed);
+  if (per_cu == 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SWEEP_THREADS, 0) != hipSuccess) { (void)hipGetLastError(); return MI355NDT_ERR_UNSUPPORTED; }
+    per_cu_of_device[h->device & 63].store(per_cu, std::memory_order_relaxed);
+  }
   const int wpe = sweep_wpe(PCA, K);
   // Workgroup L serves ring L % 8 first, and the launch is sized to be resident as a whole.  Residency is no condition of correctness:
   // positions are claimed, a waiting wave serves the published positions of OTHER rings too (ndt_async.hpp: an XCD that holds no workgroup
