@@ -93,6 +93,8 @@ struct AsyncCtl {
 #ifndef ASYNC_HELP_RINGS
 #define ASYNC_HELP_RINGS 1       // 0 (experiments only): waves serve their own ring alone, as in round 4 -- tests/test_stream_gpu.py's ring-mask test then gives up
 #endif
+#define ASYNC_HELP_AFTER 64u         // polls (~1 us each) a wave waits for its own ticket before it looks at other rings: the help is for a launch
+                                     // that would otherwise not finish, and costs a launch that needs none 0.3-1.4 % when it starts at once (measured)
 #define ASYNC_SPIN_LIMIT (1u << 23)      // polls of ~1 us: a device that stopped making progress ends the launch after seconds, not never
 
 // Everything the launch reads before it has written it, set by ONE kernel on the stream in front of it (never inside the launch): the
@@ -356,12 +358,13 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
   // workgroups of one XCD (blockIdx & 7), and nothing guarantees that every XCD holds workgroups of this launch -- two engines launching at
   // the same time can end up with one launch resident on half of the XCDs and the other on the other half, each waiting for tickets that sit
   // in rings nobody of its own serves, for ever (observed: `test_two_engines_on_two_threads_share_the_gpu`, one launch in ~10^3 gave up after
-  // its poll budget).  So: while its own ticket is not there, the wave looks at another ring y per poll; if y has a position whose ticket is
+  // its poll budget).  So: once its own ticket has not come for ASYNC_HELP_AFTER polls, the wave looks at another ring y every fourth poll; if y has a position whose ticket is
   // already published (position counter / Iu < tickets published into y, from the global ticket counter `pub`), it takes exactly that position
   // with a compare-and-swap -- never a blind claim: a claimed position cannot be abandoned, and its own claim `p` stays pending --, serves it,
   // and comes back for `p` (`held`).  Every published position is thus servable by ANY resident wave of the launch; which wave serves an
   // item never enters a result (rows depend on the pair, the chunk and the input order).
   bool held = false;                               // an own claim whose ticket was not there when the wave went to help
+  bool helped = false;                             // the last wait ended with a position of another ring
   unsigned held_pos = 0;
   const gu64* pubfin_p = (const gu64*)reinterpret_cast<const unsigned long long*>(ctl);   // {pub, fin}: the first two words of the control block
   static_assert(offsetof(AsyncCtl, pub) == 0 && offsetof(AsyncCtl, fin) == 4, "pub and fin are polled as one 8-byte word");
@@ -370,12 +373,12 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
     unsigned sp = p;
     int st = 0;
     if (lane == 0) {
-      unsigned spins = 0;
+      unsigned spins = helped ? ASYNC_HELP_AFTER : 0u;   // (a wave that came back from helping goes on helping at once)
       const int t = (int)(p / (unsigned)Iu);
       while (w < 0) {
         const unsigned long long pf = __hip_atomic_load(pubfin_p, RLX_AGENT);        // pub (low word) and fin with one poll of the line
         if ((unsigned)(pf >> 32) >= n_live) { w = -2; break; }
-        if (ASYNC_HELP_RINGS && (spins & 3u) == 3u) {   // (every fourth poll, not in the first microseconds of a wait) a servable position of another ring?
+        if (ASYNC_HELP_RINGS && spins >= ASYNC_HELP_AFTER && (spins & 3u) == 3u) {   // a servable position of another ring?
           const unsigned y = ((unsigned)x + 1u + (spins >> 2) % 7u) & 7u;
           gu32* pos_y = (gu32*)&ctl->pos[y * ASYNC_POS_STRIDE];
           const unsigned q = __hip_atomic_load(pos_y, RLX_AGENT);
@@ -401,7 +404,8 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
       }
     }
     w = __builtin_amdgcn_readfirstlane(w);
-    if (__builtin_amdgcn_readfirstlane(st)) { held = true; held_pos = p; p = __builtin_amdgcn_readfirstlane(sp); }
+    helped = __builtin_amdgcn_readfirstlane(st) != 0;
+    if (helped) { held = true; held_pos = p; p = __builtin_amdgcn_readfirstlane(sp); }
     return w;
   };
   // Positions of the ring's item stream (ticket 0's items, ticket 1's, ...) are CLAIMED, one returning fetch-add per item.  Static dealing
