@@ -261,11 +261,71 @@ def run_sequence(case, rng, kw, fails, oracle_only):
         eng.close()
 
 
+STREAM_P = 0.0   # --stream: probability that a case goes through mi355ndt_stream_* instead of one of the other entry paths
+
+
+def run_stream(case, rng, kw, fails, oracle_only):
+    """Three ragged batches of 2..5 pairs through mi355ndt_stream_begin / _submit / _collect (2..4 contexts, a random hand-over threshold,
+    device-resident SoA clouds) against the oracle pair by pair.  Non-finite points are dropped before the upload on both sides: the stream
+    binds device buffers, which carry finite points (the host-cloud entry points do that filtering themselves)."""
+    import torch
+    ctx = dict(case=case, path="stream", **kw)
+    STATS["paths"]["stream"] = STATS["paths"].get("stream", 0) + 1
+    gp, op = ndt.default_params(**kw), O.default_params(**kw)
+    n_pairs = int(rng.integers(2, 6))
+    nctx = int(rng.integers(2, 5))
+    thresh = int(rng.choice([-1, 0, 1, 3]))
+    batches = []
+    for _ in range(3):
+        sc = []
+        for _ in range(n_pairs):
+            t, s_, G = scene(rng, case)
+            t = np.ascontiguousarray(t[np.isfinite(t).all(1)], np.float32)
+            s_ = np.ascontiguousarray(s_[np.isfinite(s_).all(1)], np.float32)
+            if len(t) == 0 or len(s_) == 0:
+                t, s_, G = scene(np.random.default_rng([case, 7]), 1)        # (a plain scan pair)
+                t = np.ascontiguousarray(t[np.isfinite(t).all(1)], np.float32); s_ = np.ascontiguousarray(s_[np.isfinite(s_).all(1)], np.float32)
+            sc.append((t, s_, G))
+        batches.append(sc)
+    oracle_res = [[ora_align(O.Grid(t, op), s_, G) for t, s_, G in sc] for sc in batches]
+    if oracle_only:
+        return
+    pitch = (max(max(len(t), len(s_)) for sc in batches for t, s_, _ in sc) + 63) // 64 * 64
+    dev = torch.device("cuda:0")
+    bufs = []
+    for sc in batches:
+        T = torch.zeros(n_pairs, 3, pitch, device=dev); S = torch.zeros(n_pairs, 3, pitch, device=dev)
+        for b, (t, s_, _) in enumerate(sc):
+            T[b, :, :len(t)] = torch.from_numpy(t.T.copy()).to(dev); S[b, :, :len(s_)] = torch.from_numpy(s_.T.copy()).to(dev)
+        bufs.append((T, S, [len(t) for t, _, _ in sc], [len(s_) for _, s_, _ in sc],
+                     np.ascontiguousarray(np.stack([G.T.reshape(16) for _, _, G in sc]), np.float32)))
+    torch.cuda.synchronize()
+    eng = ndt.Engine(gp)
+    try:
+        eng.set_option(ndt.OPT_STREAM_THRESHOLD, thresh)
+        eng.stream_begin(nctx, n_pairs, pitch, pitch)
+        ids, got = [], []
+        for T, S, tc, scn, G in bufs:
+            if len(ids) - len(got) >= nctx:
+                got.append(eng.stream_collect(ids[len(got)], n_pairs))
+            ids.append(eng.stream_submit(T.data_ptr(), tc, pitch, S.data_ptr(), scn, pitch, G))
+        while len(got) < len(ids):
+            got.append(eng.stream_collect(ids[len(got)], n_pairs))
+        eng.stream_end()
+        for j, (res, ores, sc) in enumerate(zip(got, oracle_res, batches)):
+            for b in range(n_pairs):
+                compare(res[b], ores[b], f"stream[{j}][{b}] ctx={nctx} thresh={thresh}", fails, ctx, lambda j=j, b=b: ora_align(O.Grid(batches[j][b][0], op), batches[j][b][1], batches[j][b][2]))
+    finally:
+        eng.close()
+
+
 def run_case(case, seed, fails, oracle_only=False):
     rng = np.random.default_rng([seed, case])
     kw = params(rng)
     gp, op = ndt.default_params(**kw), O.default_params(**kw)
     path = rng.choice(["single", "single_latency", "batch", "batch_latency", "sequence"], p=[0.25, 0.2, 0.25, 0.2, 0.1])
+    if STREAM_P > 0 and rng.random() < STREAM_P:
+        return run_stream(case, rng, kw, fails, oracle_only)
     if path == "sequence":
         return run_sequence(case, rng, kw, fails, oracle_only)
     if rng.random() < AUX_P:
@@ -370,10 +430,12 @@ def main():
     ap.add_argument("--oracle-only", action="store_true", help="CPU dry run: scenes + oracle only")
     ap.add_argument("--aux", type=float, default=None, help="probability of the prefilter / fitness / output-cloud checks per case (default 0.15)")
     ap.add_argument("--seconds", type=float, default=1e9, help="stop after this much wall time")
+    ap.add_argument("--stream", type=float, default=0.0, help="probability that a case goes through mi355ndt_stream_* (three ragged batches, 2..4 contexts)")
     a = ap.parse_args()
     if a.summarize:
         return summarize(a.summarize, a.out)
-    global AUX_P
+    global AUX_P, STREAM_P
+    STREAM_P = a.stream
     if a.aux is not None:
         AUX_P = a.aux
     fails, errors, done = [], [], 0
