@@ -13,6 +13,8 @@
 // The wave that retires a pair's last item (one returning agent-scope fetch-add per item on a per-pair counter) becomes that pair's UPDATER: it adds the pair's rows with k_update's fixed tree, runs the Newton step
 // (newton_update, ndt_update.hpp -- same code, same bits) and either publishes the pair's next ticket or finalises the pair.
 // Publication is round-robin over the rings, so the rings stay balanced to one ticket however the iteration counts are distributed.
+// A wave that has waited for its own ring's ticket for a while serves already-published positions of OTHER rings meanwhile (wait_ticket in
+// k_align_async): no ring depends on the workgroups of one XCD being resident -- two engines launching at once can split the XCDs between them.
 //
 // Visibility inside one launch (MI355X: per-XCD L2s are not coherent with each other, a CU's L1 is never refreshed by another CU's
 // stores): every word that crosses workgroups -- partial rows, PairState, ring slots, counters -- is written AND read with agent-scope
