@@ -158,6 +158,8 @@ struct mi355ndt_handle {
   int plan_cb = 0; size_t plan_words = 0;
   unsigned* d_bstat = nullptr;                    // (not owned: the parent's CtxStat of this context) [1] total words, [2] largest grid, [3] plan exceeded
   bool counts_preloaded = false;                  // the parent has put this batch's point counts (and guesses) on the device already
+  bool build_stamped = false;                    // stream mode + profiling: build times come from stamps in the launch's status slot, not from events
+  bool word_off_cleared = false;                 // stream mode: k_stream_inputs has cleared d_word_off for the next build (no fill)
   size_t last_total_words = 0;                    // of the last synchronous build
 
   // ---- stream mode (mi355ndt_stream_*, the parent handle): n_contexts batches resident, one persistent launch per submitted batch,
@@ -171,7 +173,7 @@ struct mi355ndt_handle {
     long long launch = -1;                        // the launch that started it
     // a batch's small inputs -- target counts, source counts, guesses -- travel as ONE copy: pinned staging block -> device block, into which
     // the context engine's d_tgt_cnt / d_src_cnt / d_guess point
-    int* h_in = nullptr; int* d_in = nullptr; size_t in_bytes = 0;
+    int* h_in = nullptr; int* d_in = nullptr; size_t in_bytes = 0; unsigned* h_in_dev = nullptr;   // (h_in is mapped: the device reads it itself)
     void *own_tgt_cnt = nullptr, *own_src_cnt = nullptr, *own_guess = nullptr;   // the engine's own arrays (put back before it is destroyed)
     // results: MAPPED host memory -- a pair's result record is written there by the updater that finalises it (posted PCIe writes), no copy
     mi355ndt_result* h_res = nullptr; mi355ndt_result* d_res_map = nullptr;
@@ -855,9 +857,11 @@ static int build_targets_impl(mi355ndt_handle* h) {
     h->recs_cap = need; h->recs_per_pair = rpp;
   }
   h->ev_last_fresh = false;
-  if (h->prof) HIPCHK(h, ev_begin(h, h->ev_build));
+  const bool build_events = h->prof && !(h->build_stamped && h->async_build);   // (the stream's builds are stamped by the kernels around them)
+  if (build_events) HIPCHK(h, ev_begin(h, h->ev_build));
   const int gx = (int)((pitch + 255) / 256);
-  HIPCHK(h, hipMemsetAsync(h->d_word_off, 0, (2 + 6 * (size_t)h->cap_pairs) * sizeof(unsigned), s));
+  if (!h->word_off_cleared) HIPCHK(h, hipMemsetAsync(h->d_word_off, 0, (2 + 6 * (size_t)h->cap_pairs) * sizeof(unsigned), s));   // (stream mode: k_stream_inputs did)
+  h->word_off_cleared = false;
   k_minmax<<<dim3(std::max(1, std::min((gx + 3) / 4 / MM_ILP, 64)), B), 256, 0, s>>>(h->d_tgt, pitch, h->d_tgt_cnt, h->d_minmax);
   k_griddesc<<<(B + 63) / 64, 64, 0, s>>>(h->d_minmax, h->d_grid, h->d_nwords, h->prm.resolution, B, (unsigned)rpp);
   k_word_offsets<<<1, 1024, 0, s>>>(h->d_grid, h->d_nwords, B, h->d_word_off);   // d_word_off[0] = total words, [1] = largest grid
@@ -944,7 +948,7 @@ static int build_targets_impl(mi355ndt_handle* h) {
                                                                   mt_live ? h->d_icov64 : nullptr, want_kdw ? h->d_kdw : nullptr);
   HIPCHK(h, hipGetLastError());
   if (h->prof) {
-    HIPCHK(h, ev_end(h, h->ev_build));
+    if (build_events) HIPCHK(h, ev_end(h, h->ev_build));
     double pts = 0;
     for (int b = 0; b < B; b++) pts += h->h_tgt_cnt[b];
     // B_build: minmax 12 + binning 12 + key write 12 + sort r/w + grouped gather 16 per point (+ records)
@@ -1127,6 +1131,8 @@ struct AsyncLaunch {
   int* active_list = nullptr; SweepCtl* sweep_ctl = nullptr; unsigned* done_new = nullptr; PoseRecord* pose_new = nullptr; int pose_cap = 0;
   AsyncTab* tab_dev = nullptr; int* ring = nullptr; int ring_cap = 0; AsyncCtl* ctl = nullptr; const AsyncCtl* prev = nullptr;
   int items_per_pair = 0, stop_thresh = 0; unsigned debug_abort_pos = 0xFFFFFFFFu, debug_ring_mask = 0xFFu;
+  unsigned long long* stamp_end = nullptr;       // stream mode + profiling: where k_async_prepare stamps the end of the build in front of it
+  int claim_items = 1;                           // DIRECT7 items per claimed position (DIRECT1: always ASYNC_CLAIM(1) = 2; ndt_async.hpp)
   int reserve_wg = 0;
 };
 #define NDT_CTX_ARGS(i) L.tab.c[i].src, L.tab.c[i].pitch, L.tab.c[i].st, L.tab.c[i].gd, L.tab.c[i].words, L.tab.c[i].recs, L.tab.c[i].partials, L.tab.c[i].src_cnt, \
@@ -1152,7 +1158,7 @@ static int launch_async_t(mi355ndt_handle* h, const SweepConst& sc, const AsyncL
   //  beside this launch: L.reserve_wg, a multiple of 8 so that every ring loses the same number of waves)
   dim3 grid((unsigned)std::max(8, h->n_cu * wpe - L.reserve_wg));
   kern<<<grid, SWEEP_THREADS, 0, h->stream>>>(L.tab_dev, L.items_per_pair, L.ring, L.ring_cap, L.ctl, sc, h->prof ? h->d_hits : nullptr,
-                                             h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations, L.stop_thresh, L.debug_abort_pos, L.debug_ring_mask,
+                                             h->prm.step_size, h->prm.trans_epsilon, h->prm.max_iterations, L.stop_thresh, L.debug_abort_pos, L.debug_ring_mask, L.claim_items,
                                              NDT_CTX_ARGS(0), NDT_CTX_ARGS(1), NDT_CTX_ARGS(2), NDT_CTX_ARGS(3));
   return MI355NDT_OK;
 }
@@ -1166,7 +1172,7 @@ static int launch_async(mi355ndt_handle* h, const SweepConst& sc, const AsyncLau
   {
     const size_t n = std::max(std::max(std::max((size_t)8 * L.ring_cap, (size_t)L.n_new * ASYNC_ARR_STRIDE), sizeof(AsyncCtl) / sizeof(unsigned)), (size_t)L.pose_cap);
     k_async_prepare<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(L.tab, L.tab_dev, L.new_ci, L.n_new, L.st_new, L.guess_new, L.src_cnt_new, L.gd_new, L.arrived_new,
-                                                               L.active_list, L.sweep_ctl, L.ring, L.ring_cap, L.ctl, L.prev, L.done_new, L.pose_new, L.pose_cap);
+                                                               L.active_list, L.sweep_ctl, L.ring, L.ring_cap, L.ctl, L.prev, L.done_new, L.pose_new, L.pose_cap, L.stamp_end);
   }
   if (h->prof) HIPCHK(h, ev_begin(h, h->ev_sweep));
   int rc;
@@ -1985,7 +1991,7 @@ int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts, int max_pairs, siz
   SweepConst sc;
   make_sweep_const(h, sc);
   {
-    const int iu = h->s_items / ASYNC_CLAIM(sc.K == 1 ? 1 : 7);
+    const int iu = h->s_items / (sc.K == 1 || sc.K == 7 ? 2 : 1);   // positions per ticket (stream_launch: two DIRECT7 items per claim when pairs are handed over)
     const int waves = h->n_cu * sweep_wpe(sc.pca != 0, sc.K) * WAVES;
     // automatic: four sweeps' worth of positions per resident wave -- `tools/gpu_job.sh thresh_sweep`: config 5 gains up to T = 32-64 (DIRECT7 19.1 / 19.4 / 19.5 k,
     // DIRECT1 39.4 / 40.1 / 40.9 / 41.1 k registrations/s at T = 8 / 16 / 32 / 64), the 65,536-point configurations do not care -- capped at a quarter of the batch (stream_launch)
@@ -2026,7 +2032,8 @@ int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts, int max_pairs, siz
     if (rc) { h->err = e->err; return fail(rc); }
     // the input block: [target counts | source counts | guesses]
     S.in_bytes = (size_t)max_pairs * (2 * sizeof(int) + 16 * sizeof(float));
-    if (hipMalloc((void**)&S.d_in, S.in_bytes) != hipSuccess || hipHostMalloc((void**)&S.h_in, S.in_bytes) != hipSuccess ||
+    if (hipMalloc((void**)&S.d_in, S.in_bytes) != hipSuccess || hipHostMalloc((void**)&S.h_in, S.in_bytes, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&S.h_in_dev, S.h_in, 0) != hipSuccess ||
         hipHostMalloc((void**)&S.h_res, (size_t)max_pairs * sizeof(mi355ndt_result), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer((void**)&S.d_res_map, S.h_res, 0) != hipSuccess) { h->err = "stream_begin: allocation failed"; return fail(MI355NDT_ERR_HIP); }
     S.own_tgt_cnt = e->d_tgt_cnt; S.own_src_cnt = e->d_src_cnt; S.own_guess = e->d_guess;
@@ -2066,9 +2073,12 @@ static int stream_launch(mi355ndt_handle* h, int new_ci, int n_new) {
     L.tab.c[c].results = h->sctx[c].d_res_map;
     L.tab.c[c].n_done = &h->d_sstat[c].done;
     L.tab.c[c].pose = h->sctx[c].busy ? h->sctx[c].d_pose : nullptr; L.tab.c[c].pose_base = h->sctx[c].pose_base; L.tab.c[c].pose_stride = h->sctx[c].pose_stride;
-    // the context the NEXT submit recycles must be finished by this launch; the others may hand their last pairs over
-    // (with the build under the launch -- s_reserve_wg -- that context is already being rebuilt during the NEXT launch: one earlier)
-    const int ahead = h->s_reserve_wg > 0 ? 2 : 1;
+    // The context the NEXT submit recycles must be finished by this launch; the others may hand their last pairs over.  With three or more
+    // contexts the context after that one must finish too: its batch is then complete one launch BEFORE the submit that recycles it, so the
+    // host collects it and enqueues the next build while a launch is still running -- otherwise every collect returns at the very end of a
+    // launch and the GPU idles for as long as the host takes to notice, collect and enqueue (~0.1-0.2 ms per batch, measured as the
+    // difference between a streamed step and its kernels).  (The build under the launch -- s_reserve_wg -- needs the same.)
+    const int ahead = (h->s_reserve_wg > 0 || h->s_nctx >= 3) ? 2 : 1;
     bool mf = flush;
     for (int a = 1; a <= ahead; a++) mf = mf || c == (new_ci + a) % h->s_nctx;
     L.tab.c[c].must_finish = mf ? 1 : 0;
@@ -2087,8 +2097,12 @@ static int stream_launch(mi355ndt_handle* h, int new_ci, int n_new) {
   const bool thresh_given = h->s_thresh_opt >= 0 || std::getenv("MI355NDT_STREAM_THRESH");
   L.items_per_pair = h->s_items; L.stop_thresh = flush ? 0 : (thresh_given ? h->s_thresh : std::min(h->s_thresh, n_new / 4)); L.debug_abort_pos = h->debug_abort_pos; L.debug_ring_mask = h->debug_ring_mask;
   L.reserve_wg = flush ? 0 : h->s_reserve_wg;
+  // two DIRECT7 items per claim halve the hand-overs between items (+1.4-2 %); the coarser positions lengthen a launch's own tail, so only
+  // where the tail is handed on (docs/experiments.md 10d)
+  L.claim_items = (sc.K == 7 && L.stop_thresh > 0) ? 2 : 1;
   h->ev_last_fresh = false;                          // (the contexts' builds sit between two launches on this stream)
   if (!flush && h->s_reserve_wg > 0) HIPCHK(h, hipStreamWaitEvent(s, h->s_ev_built[new_ci], 0));   // this batch's grids (built on the other stream)
+  L.stamp_end = (!flush && h->prof) ? &h->d_sstatus[j % mi355ndt_handle::S_EV].build_t1 : nullptr;
   int rc = launch_async(h, sc, L);
   if (rc) return rc;
   h->s_drop_carry = false;
@@ -2112,7 +2126,13 @@ static int stream_wait_launch(mi355ndt_handle* h, long long j) {
     } else cpu_relax();
   }
   std::atomic_thread_fence(std::memory_order_acquire);
-  for (; h->s_counted <= j; h->s_counted++) h->P.stream_carried += h->h_sstatus[h->s_counted % mi355ndt_handle::S_EV].susp;   // (launches finish in order)
+  for (; h->s_counted <= j; h->s_counted++) {       // (launches finish in order)
+    volatile StreamStatus* c = h->h_sstatus + (h->s_counted % mi355ndt_handle::S_EV);
+    h->P.stream_carried += c->susp;
+    const unsigned long long b0 = c->build_t0, b1 = c->build_t1;
+    if (b0 && b1 > b0) { h->P.build_ms += (double)(b1 - b0) * 1e-5; h->P.build_launches++; }   // wall_clock64: 100 MHz
+    c->build_t0 = 0; c->build_t1 = 0;
+  }
   return MI355NDT_OK;
 }
 
@@ -2158,7 +2178,12 @@ int mi355ndt_stream_submit(mi355ndt_handle* h, int n_pairs, const float* d_t, co
   memcpy(S.h_in + 2 * (size_t)h->s_max_pairs, guesses, (size_t)n_pairs * 16 * sizeof(float));
   if (h->s_reserve_wg > 0 && h->s_launches >= 2)     // this context's previous batch was finished by the launch before the last one (must_finish)
     HIPCHK(h, hipStreamWaitEvent(e->stream, h->s_ev_launched[(h->s_launches - 2) % mi355ndt_handle::S_EV], 0));
-  HIPCHK(h, hipMemcpyAsync(S.d_in, S.h_in, (size_t)h->s_max_pairs * 2 * sizeof(int) + (size_t)n_pairs * 16 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  // (one workgroup reads the block from mapped host memory and clears the build's word block: no copy, no fill -- k_stream_inputs)
+  k_stream_inputs<<<1, 1024, 0, e->stream>>>(S.h_in_dev, reinterpret_cast<unsigned*>(S.d_in), (unsigned)(2 * (size_t)h->s_max_pairs + (size_t)n_pairs * 16),
+                                            e->d_word_off, (unsigned)(2 + 6 * (size_t)e->cap_pairs),
+                                            h->prof ? &h->d_sstatus[h->s_launches % mi355ndt_handle::S_EV].build_t0 : nullptr);
+  e->word_off_cleared = true;
+  e->build_stamped = h->prof;
   e->counts_preloaded = true; e->up_src_cnt.clear(); e->up_tgt_cnt.clear();
   // target build: against the stream's plan when there is one (no wait), else synchronously -- which makes the plan
   e->async_build = true;

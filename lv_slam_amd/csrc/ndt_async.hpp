@@ -75,7 +75,9 @@ __device__ __forceinline__ AsyncCtx async_ctx_load(const AsyncTab* __restrict__ 
 // stream mode, per context, in device memory: what the host wants to know about a context's batch after every launch
 struct CtxStat { unsigned done, total_words, max_cells, plan_exceeded; };   // pairs finalised; the last planned build's sizes and verdict (k_build_check)
 // ... and per launch, in MAPPED host memory (a ring of slots): written by k_stream_status behind the launch, `seq` last -- no copy, no event
-struct StreamStatus { unsigned fin, abort_, n_live, susp; CtxStat ctx[ASYNC_MAX_CTX]; unsigned seq; unsigned pad_[11]; };
+struct StreamStatus { unsigned fin, abort_, n_live, susp; CtxStat ctx[ASYNC_MAX_CTX]; unsigned seq; unsigned pad0_;
+                      unsigned long long build_t0, build_t1;   // wall_clock64 (100 MHz) at the start of the launch's batch's build (k_stream_inputs) and at its end (k_async_prepare)
+                      unsigned pad_[6]; };
 static_assert(sizeof(StreamStatus) == 128, "one status slot is 128 bytes");
 
 struct AsyncCtl {
@@ -106,8 +108,9 @@ struct AsyncCtl {
 NDT_KERNEL void k_async_prepare(const AsyncTab tab, AsyncTab* tab_dev, const int new_ci, const int n_new, PairState* st, const float* __restrict__ guess_cm,
                                 const int* __restrict__ src_cnt, const GridDesc* __restrict__ gd, unsigned* arrived, int* active_list, SweepCtl* sweep_ctl /* two of them */,
                                 int* ring, const int ring_cap, AsyncCtl* ctl, const AsyncCtl* prev, unsigned* done_new /* may be null */,
-                                PoseRecord* pose_new /* may be null */, const int pose_cap) {
+                                PoseRecord* pose_new /* may be null */, const int pose_cap, unsigned long long* stamp /* may be null */) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && stamp) *stamp = (unsigned long long)wall_clock64();     // (stream mode, profiling: the end of the build in front of this kernel)
   const unsigned nc = prev ? min(prev->susp, (unsigned)ASYNC_MAX_CARRY) : 0u;
   const unsigned n_live = nc + (unsigned)n_new;
   if (i < (size_t)8 * ring_cap) {
@@ -306,11 +309,24 @@ __device__ __forceinline__ void async_update(const AsyncCtx& C, const int b, con
   __builtin_amdgcn_s_setprio(0);
 }
 
+// Stream mode: a batch's small inputs (point counts of both sides, guesses: ~20 KB) are READ by one workgroup from the mapped host block the
+// submit filled, and the build's word block (totals, extremes) is cleared by the same kernel -- instead of a host-to-device copy and a fill,
+// each of which costs the stream ~12-16 us of idle time around it on top of its own (rocprofv3 timeline of a streamed run).
+// It is also the first kernel of the batch's target build: with profiling on it stamps the build's start into the launch's status slot (mapped
+// host memory) and k_async_prepare, the first kernel behind the build, stamps its end -- the stream's builds are timed without events (an event
+// record between two kernels costs the stream ~10 us of idle time).
+NDT_KERNEL void k_stream_inputs(const unsigned* __restrict__ host_in, unsigned* __restrict__ dev_in, const unsigned n_in, unsigned* __restrict__ clear, const unsigned n_clear,
+                                unsigned long long* stamp) {
+  if (threadIdx.x == 0 && stamp) *stamp = (unsigned long long)wall_clock64();
+  for (unsigned i = threadIdx.x; i < n_in; i += blockDim.x) dev_in[i] = host_in[i];
+  for (unsigned i = threadIdx.x; i < n_clear; i += blockDim.x) clear[i] = 0u;
+}
+
 // Stream mode: behind every persistent launch, one wave reports to the host through mapped memory -- how the launch ended and where every
 // context's batch stands -- and then posts the launch's sequence number (posted PCIe writes; the host polls the number: no copy, no event).
 NDT_KERNEL void k_stream_status(const AsyncCtl* __restrict__ ctl, const CtxStat* __restrict__ stat, volatile unsigned* host_slot, const unsigned seq) {
   const int i = threadIdx.x;
-  static_assert(offsetof(AsyncCtl, fin) == 4 && offsetof(AsyncCtl, susp) == 16 && offsetof(StreamStatus, ctx) == 16 && offsetof(StreamStatus, seq) == 80, "status layout");
+  static_assert(offsetof(AsyncCtl, fin) == 4 && offsetof(AsyncCtl, susp) == 16 && offsetof(StreamStatus, ctx) == 16 && offsetof(StreamStatus, seq) == 80 && offsetof(StreamStatus, build_t0) == 88, "status layout");
   if (i < 4) host_slot[i] = reinterpret_cast<const unsigned*>(ctl)[1 + i];                      // fin, abort_, n_live, susp
   else if (i < 4 + 4 * ASYNC_MAX_CTX) host_slot[i] = reinterpret_cast<const unsigned*>(stat)[i - 4];
   __threadfence_system();
@@ -329,7 +345,7 @@ NDT_KERNEL void k_stream_status(const AsyncCtl* __restrict__ ctl, const CtxStat*
 template <bool PCA, int K, int ORD>
 __global__ void __launch_bounds__(SWEEP_THREADS, (SweepTune<PCA, K>::WPE))
 k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, int ring_cap, AsyncCtl* ctl, SweepConst sc, unsigned long long* hits_total,
-              double step_max, double eps, int max_iterations, int stop_thresh, unsigned debug_abort_pos, unsigned debug_ring_mask,
+              double step_max, double eps, int max_iterations, int stop_thresh, unsigned debug_abort_pos, unsigned debug_ring_mask, int claim_items,
               NDT_CTX_PARAMS(0), NDT_CTX_PARAMS(1), NDT_CTX_PARAMS(2), NDT_CTX_PARAMS(3)) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   __shared__ double exp_tab[64];
@@ -345,7 +361,10 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
   const unsigned n_live = ctl->n_live;             // (written by k_async_prepare, the kernel in front of this one; constant during the launch)
   const int I = items_per_pair;
   // DIRECT1 items are short (one probe per point, ~0.85 hits): two consecutive items of a pair per claim / arrival halve the hand-overs
-  constexpr int CLAIM = ASYNC_CLAIM(K);
+  // ... and so do two DIRECT7 items per claim where the launch hands its tail on (stream mode: +1.4-2 % measured; a launch that runs its own
+  // tail loses with the coarser positions -- config 5, synchronous: -11 % --, so the host decides per launch: `claim_items`, DIRECT1: always two)
+  constexpr int CLAIM_D1 = ASYNC_CLAIM(1);
+  const int CLAIM = K == 1 ? CLAIM_D1 : (claim_items == 2 ? 2 : 1);
   const int Iu = I / CLAIM;                        // positions per ticket (items_per_pair is a multiple of four)
 #ifdef NDT_TIMELINE
   unsigned long long tl[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -438,7 +457,7 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
 #define ASYNC_D1_PIPE 1
 #endif
     if (K == 1 && ASYNC_D1_PIPE) {                   // DIRECT1: the claim's items as one software pipeline (ndt_sweep.hpp), same rows bit for bit
-      sweep_rows_d1<PCA, ORD, CLAIM>(b, rem, C.src, C.pitch, C.gd, C.words, C.recs, C.partials, I, sc, exp_tab, pose_w, n_b, b
+      sweep_rows_d1<PCA, ORD, CLAIM_D1>(b, rem, C.src, C.pitch, C.gd, C.words, C.recs, C.partials, I, sc, exp_tab, pose_w, n_b, b
 #ifdef NDT_TIMELINE
                                      , tl, tl_last
 #endif

@@ -7,7 +7,7 @@
 #define NDT_KD_ARGS_T (const float*, size_t, const PairState*, const GridDesc*, const BitWord*, const VoxelRec*, const float*, const int*, double*, int, const int*, \
                        SweepCtl*, SweepCtl*, SweepConst)
 #define NDT_CTX_T const float*, size_t, PairState*, const GridDesc*, const BitWord*, const VoxelRec*, double*, const int*, unsigned*, const float*
-#define NDT_ASYNC_ARGS_T (const AsyncTab*, int, int*, int, AsyncCtl*, SweepConst, unsigned long long*, double, double, int, int, unsigned, unsigned, NDT_CTX_T, NDT_CTX_T, NDT_CTX_T, NDT_CTX_T)
+#define NDT_ASYNC_ARGS_T (const AsyncTab*, int, int*, int, AsyncCtl*, SweepConst, unsigned long long*, double, double, int, int, unsigned, unsigned, int, NDT_CTX_T, NDT_CTX_T, NDT_CTX_T, NDT_CTX_T)
 // X(prefix) is expanded once per kernel: prefix = `extern template` or `template`
 #define NDT_ORD1_KERNELS(X)                                                                                   \
   X __global__ void k_sweep<false, 1, 8, false, 1> NDT_SWEEP_ARGS_T;  X __global__ void k_sweep<true, 1, 8, false, 1> NDT_SWEEP_ARGS_T;   \

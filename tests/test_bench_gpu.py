@@ -134,7 +134,7 @@ def test_streamed_headline_carries_both_rates():
     d = run_bench(["--pairs", "40", "--azimuth", "512", "--steps", "6", "--warmup", "1", "--cpu-seconds", "0", "--no-host-clouds", "--config4-pairs", "0", "--seq-frames", "0",
                    "--no-other-configs"])
     st = d["config"]["stream"]
-    assert st["n_batches"] == 3 and st["n_contexts"] == 3 and st["bit_identical_to_synchronous"] is True and st["batches_rerun"] == 0 and st["launches_that_gave_up"] == 0
+    assert st["n_batches"] == 4 and st["n_contexts"] == 4 and st["bit_identical_to_synchronous"] is True and st["batches_rerun"] == 0 and st["launches_that_gave_up"] == 0
     assert st["launches"] >= 6 and st["pairs_handed_over"] > 0
     assert d["value_streamed"] > 0 and d["value_synchronous"] > 0 and d["value"] == max(d["value_streamed"], d["value_synchronous"])
     assert d["config"]["mode"].startswith("streamed" if d["value"] == d["value_streamed"] else "synchronous") and "faster of the two modes" in d["config"]["mode"]
