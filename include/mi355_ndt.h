@@ -272,8 +272,10 @@ int mi355ndt_batch_pose_records(mi355ndt_handle* h, int id_base, int id_stride, 
  *              serves it: results are bit-identical to mi355ndt_batch_align's);
  *   collect(k) blocks until every pair of batch k is finalised -- normally a launch or two after its own; if nothing newer has been
  *              submitted it flushes the stragglers itself.
- * Batch k's context is recycled by submit(k + n_contexts), so at most n_contexts batches may be uncollected, and a pair is carried
- * through at most n_contexts - 1 further launches (the last of them runs it to its end).
+ * Batch k's context is recycled by submit(k + n_contexts), so at most n_contexts batches may be uncollected.  A pair is carried through at
+ * most n_contexts - 2 further launches (one with two contexts): a batch is complete one launch before its context is recycled, so that the
+ * host can collect it and enqueue the next build while a launch is still running.  Four contexts suit workloads whose launches end in long
+ * tails (BASELINE config 5), three or four anything else.
  * Inputs are device-resident SoA buffers as in mi355ndt_batch_bind_device (zero-copy); batch k's buffers must stay valid and unchanged
  * until collect(k) has returned.  Parameters and options are those of the handle at mi355ndt_stream_begin; the handle's single-registration
  * and batch calls are unavailable (MI355NDT_ERR_STATE) between begin and end.  Served for every configuration the one-launch align
