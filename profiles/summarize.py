@@ -51,7 +51,7 @@ def sec1():
     ours, other_calls, other_ns = [], 0, 0.0
     for r in rows:
         n = r["Name"]
-        if any(k in n for k in ("k_sweep", "k_align_async", "k_async_begin", "k_async_prepare", "k_stream_status", "k_build_check", "k_sorted_points", "k_calc_score", "k_update", "k_leafsum", "k_rs_", "k_keys", "k_mark", "k_segstart", "k_minmax", "k_voxels", "k_rank",
+        if any(k in n for k in ("k_sweep", "k_align_async", "k_async_begin", "k_async_prepare", "k_stream_status", "k_stream_inputs", "k_build_check", "k_sorted_points", "k_calc_score", "k_update", "k_leafsum", "k_rs_", "k_keys", "k_mark", "k_segstart", "k_minmax", "k_voxels", "k_rank",
                                 "k_init_state", "k_griddesc", "k_seq_", "k_set_word_off", "k_word_offsets", "k_pose_records", "k_deinterleave", "k_hessian", "k_fitness", "k_cellrange", "k_transform", "rocprim",
                                 "rocclr")):
             ours.append(r)
