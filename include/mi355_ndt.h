@@ -206,7 +206,15 @@ enum mi355ndt_option {
   /* Test hook, default 0xFF (off).  Bit x clear: the workgroups of a one-launch align that serve ring x leave at once, as if XCD x held no
    * workgroup of this launch (another engine's launch filling it).  The launch must still finish every pair -- waiting waves serve the
    * published positions of other rings (ndt_async.hpp) -- with the same bits; mask 0 is refused. */
-  MI355NDT_OPT_DEBUG_ASYNC_RINGS = 6
+  MI355NDT_OPT_DEBUG_ASYNC_RINGS = 6,
+  /* Arithmetic of the derivative sweep.  0 (default): every f32 / f64 operation of updateDerivatives (ndt_omp_impl2.hpp:566-619) as the CPU
+   * restatement of the reference performs it, one rounding per operation, 43 f64 sums per lane -- results equal the oracle's bit for bit.
+   * 1: tolerance arithmetic, held to north_star's SE(3) tolerance (trans < 1e-4 m, rot < 1e-5 rad against the reference arithmetic) instead:
+   * fused multiply-adds, the hardware exp2, a symmetric inverse covariance (21 symmetric + 9 point-Hessian sums instead of 36), f32 sums per
+   * work item (512 points) widened to f64 from there on, leaf sums of the target build as a tree instead of in input order.  The point
+   * transform and the voxel lookup are untouched (same leaves for the same pose).  Served for DIRECT1 / DIRECT7 with the dead More-Thuente
+   * loop (every configuration lv_slam ships); other configurations ignore the option.  Measured cost in accuracy: BASELINE.md 5a. */
+  MI355NDT_OPT_ARITH = 7
 };
 int mi355ndt_set_option(mi355ndt_handle* h, int option, int value);
 int mi355ndt_get_option(const mi355ndt_handle* h, int option, int* value);

@@ -44,8 +44,10 @@
 #include "ndt_async.hpp"
 #ifndef NDT_SINGLE_TU      // the ORD = 1 instantiations come from mi355_ndt_ord1.hip (built side by side with this file)
 #include "ndt_ord1_list.hpp"
+#include "ndt_fast_list.hpp"
 #define NDT_DECLARE extern template
 NDT_ORD1_KERNELS(NDT_DECLARE)
+NDT_FAST_KERNELS(NDT_DECLARE)
 #endif
 
 
@@ -110,6 +112,8 @@ struct mi355ndt_handle {
   AsyncTab* d_atab = nullptr;                     // the launch's context table (ndt_async.hpp)
   unsigned debug_abort_pos = 0xFFFFFFFFu;         // MI355NDT_OPT_DEBUG_ASYNC_ABORT (test hook): the wave that claims this position of ring 0 gives up
   unsigned debug_ring_mask = 0xFFu;               // MI355NDT_OPT_DEBUG_ASYNC_RINGS (test hook): rings whose workgroups take part
+  int arith = 0;                                  // MI355NDT_OPT_ARITH: 0 = the oracle's arithmetic, operation by operation; 1 = tolerance arithmetic (ndt_sweep.hpp: eval_hit_fast)
+  VoxelRecF* d_recs_fast = nullptr; size_t recs_fast_cap = 0; bool recs_fast_built = false;   // ... and the records its sweeps read (k_voxels writes them beside d_recs)
   int f32_sum_order = 0;                          // MI355NDT_OPT_F32_SUM_ORDER: 0 = (t0 + t1) + t2 (canonical), 1 = (t0 + t2) + t1 (Eigen 3.3 SSE predux pairing)
   double gauss_last[3] = {0, 0, 0};               // gauss_d1_/d2_/d3_ as the constructor / the last computeTransformation left them (calculateScore reads them)
   float* d_score_pts = nullptr; size_t score_pts_cap = 0; double* d_score_part = nullptr; size_t score_part_cap = 0;   // calculateScore workspace
@@ -419,7 +423,7 @@ int mi355ndt_destroy(mi355ndt_handle* h) {
                   h->d_state, h->d_partials, h->d_guess, h->d_results, h->d_active, h->d_hook, h->d_aligned, h->d_hits, h->d_seg_start, h->d_heads, h->d_head_cnt, h->d_sums,
                   h->d_cent, h->d_icov64, h->d_kdw, h->d_rs_hist, h->d_rs_offs, h->d_active_list, h->d_ctl, h->d_cstart, h->d_cend, h->d_fit, h->d_pf_in, h->d_pf_out, h->d_pf_keep, h->d_pf_keys,
                   h->d_pf_vals, h->d_pf_flag, h->d_pf_pos, h->d_pf_mm, h->d_pf_grid, h->d_pf_tmp, h->d_score_pts, h->d_score_part,
-                  h->d_ring, h->d_arrived, h->d_actl, h->d_atab, h->d_sorted};
+                  h->d_ring, h->d_arrived, h->d_actl, h->d_atab, h->d_sorted, h->d_recs_fast};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : {(void*)h->d_grid_of, (void*)h->d_seq, (void*)h->d_seq_out, (void*)h->d_stamps}) if (p) (void)hipFree(p);
   if (h->h_seq_flags) (void)hipHostFree((void*)h->h_seq_flags);
@@ -893,6 +897,9 @@ static int build_targets_impl(mi355ndt_handle* h) {
   h->cent_built = want_cent;
   h->icov64_built = mt_live;
   if (mt_live) HIPCHK(h, grow(h->d_icov64, h->icov64_cap, h->recs_cap * 9));
+  const bool want_fast = h->arith == 1;
+  if (want_fast) HIPCHK(h, grow(h->d_recs_fast, h->recs_fast_cap, h->recs_cap));
+  h->recs_fast_built = want_fast;
   const bool want_kdw = h->prm.neighbor_mode == MI355NDT_KDTREE && h->prm.variant == MI355NDT_VARIANT_PCA;
   h->kdw_built = want_kdw;
   if (want_kdw) HIPCHK(h, grow(h->d_kdw, h->kdw_cap, h->recs_cap));
@@ -945,7 +952,7 @@ static int build_targets_impl(mi355ndt_handle* h) {
   }
   k_voxels<<<dim3((unsigned)((rpp + 255) / 256), B), 256, 0, s>>>(h->d_grid, h->d_sums, h->d_recs, h->d_vox_n,
                                                                   h->prm.min_covar_eigvalue_mult, h->prm.variant == MI355NDT_VARIANT_PCA,
-                                                                  mt_live ? h->d_icov64 : nullptr, want_kdw ? h->d_kdw : nullptr);
+                                                                  mt_live ? h->d_icov64 : nullptr, want_kdw ? h->d_kdw : nullptr, want_fast ? h->d_recs_fast : nullptr);
   HIPCHK(h, hipGetLastError());
   if (h->prof) {
     if (build_events) HIPCHK(h, ev_end(h, h->ev_build));
@@ -1011,20 +1018,36 @@ static void make_sweep_const(const mi355ndt_handle* h, SweepConst& sc) {
   sc.host_flags = nullptr;
   sc.seq_no = 0;
   sc.rebase_block = 0;
+  sc.d1f = (float)d1;
+  sc.kq = (float)(-0.5 * (double)sc.d2f * 1.4426950408889634);   // exp(-d2 q / 2) = 2^(kq q)
+}
+
+// The arithmetic a sweep runs in: 2 = tolerance arithmetic (MI355NDT_OPT_ARITH = 1; instantiated for DIRECT1 / DIRECT7 with the dead More-Thuente
+// loop -- every configuration lv_slam ships; the other searches and the live line search keep the exact kernels), else the f32 sum order.
+static bool want_fast(const mi355ndt_handle* h, const SweepConst& sc) { return h->arith == 1 && (sc.K == 1 || sc.K == 7) && !mt_is_live(h->prm); }
+static int sweep_ord(const mi355ndt_handle* h, const SweepConst& sc) {
+  // (a stream's parent handle owns no grids: its contexts' engines build them, with the option as it stood at mi355ndt_stream_begin)
+  if (want_fast(h, sc) && (h->recs_fast_built || h->stream_on)) return 2;
+  return h->f32_sum_order;
+}
+static const VoxelRec* sweep_recs(const mi355ndt_handle* h, const SweepConst& sc) {
+  return sweep_ord(h, sc) == 2 ? reinterpret_cast<const VoxelRec*>(h->d_recs_fast) : h->d_recs;
 }
 
 static int launch_sweep(mi355ndt_handle* h, const SweepConst& sc, int max_pairs = -1) {
   // persistent waves: SWEEP_WPE workgroups per CU pull (pair, chunk, quarter) items until the per-XCD queues are dry
-  dim3 grid((unsigned)(h->n_cu * sweep_wpe(sc.pca != 0, sc.K)));
+  const int ord = sweep_ord(h, sc);
+  dim3 grid((unsigned)(h->n_cu * sweep_wpe(sc.pca != 0, sc.K, ord == 2)));
   if (h->prof) HIPCHK(h, ev_begin(h, h->ev_sweep));
-#define NDT_SWEEP_ARGS h->d_src, h->src_pitch, h->d_state, h->d_grid, h->d_words, h->d_recs, h->d_partials, h->items_per_pair, h->d_active_list, \
+#define NDT_SWEEP_ARGS h->d_src, h->src_pitch, h->d_state, h->d_grid, h->d_words, sweep_recs(h, sc), h->d_partials, h->items_per_pair, h->d_active_list, \
       h->d_ctl + h->ctl_idx, h->d_ctl + (h->ctl_idx ^ 1), sc, h->d_cent, h->d_grid_of_use
   // (the f32 sum order is a template parameter: the alternative order costs no instruction, only a second set of instantiations)
-#define NDT_LAUNCH_SWEEP(P, KK) do { if (h->f32_sum_order == 1) k_sweep<P, KK, 8, false, 1><<<grid, SWEEP_THREADS, 0, h->stream>>>(NDT_SWEEP_ARGS); \
+#define NDT_LAUNCH_SWEEP(P, KK) do { if (ord == 1) k_sweep<P, KK, 8, false, 1><<<grid, SWEEP_THREADS, 0, h->stream>>>(NDT_SWEEP_ARGS); \
                                      else k_sweep<P, KK, 8, false, 0><<<grid, SWEEP_THREADS, 0, h->stream>>>(NDT_SWEEP_ARGS); } while (0)
+#define NDT_LAUNCH_SWEEP17(P, KK) do { if (ord == 2) k_sweep<P, KK, 8, false, 2><<<grid, SWEEP_THREADS, 0, h->stream>>>(NDT_SWEEP_ARGS); else NDT_LAUNCH_SWEEP(P, KK); } while (0)
 #define NDT_LAUNCH_FINE_O(P, KK, O) do { if (h->fine_it == 1) k_sweep<P, KK, 1, true, O><<<grid, SWEEP_THREADS, 0, h->stream>>>(NDT_SWEEP_ARGS); \
                                          else k_sweep<P, KK, 2, true, O><<<grid, SWEEP_THREADS, 0, h->stream>>>(NDT_SWEEP_ARGS); } while (0)
-#define NDT_LAUNCH_FINE(P, KK) do { if (h->f32_sum_order == 1) NDT_LAUNCH_FINE_O(P, KK, 1); else NDT_LAUNCH_FINE_O(P, KK, 0); } while (0)
+#define NDT_LAUNCH_FINE(P, KK) do { if (ord == 2) NDT_LAUNCH_FINE_O(P, KK, 2); else if (ord == 1) NDT_LAUNCH_FINE_O(P, KK, 1); else NDT_LAUNCH_FINE_O(P, KK, 0); } while (0)
   if (h->fine_it) {                              // latency mode: items dealt statically over the whole grid, sized to the work there can be
     const long long items = (long long)(max_pairs > 0 ? max_pairs : h->n_pairs) * h->items_per_pair;
     grid.x = (unsigned)std::max(1LL, std::min((long long)grid.x, (items + WAVES - 1) / WAVES));
@@ -1035,12 +1058,13 @@ static int launch_sweep(mi355ndt_handle* h, const SweepConst& sc, int max_pairs 
 #define NDT_KD_ARGS h->d_src, h->src_pitch, h->d_state, h->d_grid, h->d_words, h->d_recs, h->d_cent, h->d_kdw, h->d_partials, h->chunks_per_pair, \
         h->d_active_list, h->d_ctl + h->ctl_idx, h->d_ctl + (h->ctl_idx ^ 1), sc
     const dim3 kdgrid((unsigned)h->chunks_per_pair, (unsigned)h->n_pairs);
-    if (h->f32_sum_order == 1) k_sweep_pca_kd<1><<<kdgrid, SWEEP_THREADS, 0, h->stream>>>(NDT_KD_ARGS);
+    if (ord == 1) k_sweep_pca_kd<1><<<kdgrid, SWEEP_THREADS, 0, h->stream>>>(NDT_KD_ARGS);
     else k_sweep_pca_kd<0><<<kdgrid, SWEEP_THREADS, 0, h->stream>>>(NDT_KD_ARGS);
 #undef NDT_KD_ARGS
-  } else if (sc.pca) { if (sc.K == 1) NDT_LAUNCH_SWEEP(true, 1); else if (sc.K == 7) NDT_LAUNCH_SWEEP(true, 7); else NDT_LAUNCH_SWEEP(true, 26); }
-  else        { if (sc.K == 1) NDT_LAUNCH_SWEEP(false, 1); else if (sc.K == 7) NDT_LAUNCH_SWEEP(false, 7); else if (sc.K == 26) NDT_LAUNCH_SWEEP(false, 26);
+  } else if (sc.pca) { if (sc.K == 1) NDT_LAUNCH_SWEEP17(true, 1); else if (sc.K == 7) NDT_LAUNCH_SWEEP17(true, 7); else NDT_LAUNCH_SWEEP(true, 26); }
+  else        { if (sc.K == 1) NDT_LAUNCH_SWEEP17(false, 1); else if (sc.K == 7) NDT_LAUNCH_SWEEP17(false, 7); else if (sc.K == 26) NDT_LAUNCH_SWEEP(false, 26);
                 else NDT_LAUNCH_SWEEP(false, 27); }
+#undef NDT_LAUNCH_SWEEP17
 #undef NDT_LAUNCH_SWEEP
 #undef NDT_LAUNCH_FINE
 #undef NDT_LAUNCH_FINE_O
@@ -1148,7 +1172,7 @@ static int launch_async_t(mi355ndt_handle* h, const SweepConst& sc, const AsyncL
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SWEEP_THREADS, 0) != hipSuccess) { (void)hipGetLastError(); return MI355NDT_ERR_UNSUPPORTED; }
     per_cu_of_device[h->device & 63].store(per_cu, std::memory_order_relaxed);
   }
-  const int wpe = sweep_wpe(PCA, K);
+  const int wpe = sweep_wpe(PCA, K, ORD == 2);
   // Workgroup L serves ring L % 8 first, and the launch is sized to be resident as a whole.  Residency is no condition of correctness:
   // positions are claimed, a waiting wave serves the published positions of OTHER rings too (ndt_async.hpp: an XCD that holds no workgroup
   // of this launch -- another engine's launch fills it -- leaves no ticket unserved), a workgroup that starts late finds the launch over
@@ -1164,6 +1188,7 @@ static int launch_async_t(mi355ndt_handle* h, const SweepConst& sc, const AsyncL
 }
 template <bool PCA, int K>
 static int launch_async_o(mi355ndt_handle* h, const SweepConst& sc, const AsyncLaunch& L) {
+  if constexpr (K == 1 || K == 7) { if (sweep_ord(h, sc) == 2) return launch_async_t<PCA, K, 2>(h, sc, L); }
   return h->f32_sum_order == 1 ? launch_async_t<PCA, K, 1>(h, sc, L) : launch_async_t<PCA, K, 0>(h, sc, L);
 }
 // prepare kernel + the persistent launch on the engine's stream (HIP events around the launch when profiling)
@@ -1189,7 +1214,9 @@ static int async_ring_cap(const mi355ndt_handle* h, long long pairs) {
   return cap > (1LL << 26) ? 0 : (int)cap;        // 8 rings x 2^26 words = 2 GB: beyond that the rounds are the right tool anyway
 }
 static void fill_async_ctx(const mi355ndt_handle* e, AsyncCtx& c) {
-  c.src = e->d_src; c.pitch = e->src_pitch; c.st = e->d_state; c.gd = e->d_grid; c.words = e->d_words; c.recs = e->d_recs; c.cent = e->d_cent;
+  SweepConst sc;
+  make_sweep_const(e, sc);
+  c.src = e->d_src; c.pitch = e->src_pitch; c.st = e->d_state; c.gd = e->d_grid; c.words = e->d_words; c.recs = sweep_recs(e, sc); c.cent = e->d_cent;
   c.partials = e->d_partials; c.src_cnt = e->d_src_cnt; c.arrived = e->d_arrived; c.results = e->d_results; c.n_done = nullptr; c.must_finish = 1; c.pose = nullptr; c.pose_base = 0; c.pose_stride = 0; c.pad_ = 0;
 }
 extern "C" {
@@ -1241,7 +1268,7 @@ static int batch_align_impl(mi355ndt_handle* h, const float* guesses, mi355ndt_r
   { int rcu = uploads_before_compute(h); if (rcu) return rcu; }
   const bool mt_live = mt_is_live(h->prm);                       // impl2:888: More-Thuente loop + computeHessian are live
   const bool pca_kd = h->prm.neighbor_mode == MI355NDT_KDTREE && h->prm.variant == MI355NDT_VARIANT_PCA;
-  if (!h->targets_built || (mt_live && !h->icov64_built) || (pca_kd && !h->kdw_built)) { int rc = mi355ndt_batch_build_targets(h); if (rc) return rc; }
+  if (!h->targets_built || (mt_live && !h->icov64_built) || (pca_kd && !h->kdw_built) || (h->arith == 1 && !h->recs_fast_built)) { int rc = mi355ndt_batch_build_targets(h); if (rc) return rc; }
   int rc = prep_align_ws(h);
   if (rc) return rc;
   const int B = h->n_pairs;
@@ -1257,7 +1284,7 @@ static int batch_align_impl(mi355ndt_handle* h, const float* guesses, mi355ndt_r
   // One launch for the whole align (ndt_async.hpp) when the batch offers more work items than the GPU has resident waves.  A smaller batch
   // -- a single registration above all -- keeps the round-based kernels, whose flat dealing spreads a pair's items over every XCD: a ticket
   // is served by ONE ring (an eighth of the waves), which costs a lone 65,536-point pair 0.39 ms against 0.31 ms per align.
-  const bool big_batch = (long long)B * h->items_per_pair > (long long)h->n_cu * sweep_wpe(sc.pca != 0, sc.K) * WAVES;
+  const bool big_batch = (long long)B * h->items_per_pair > (long long)h->n_cu * sweep_wpe(sc.pca != 0, sc.K, sweep_ord(h, sc) == 2) * WAVES;
   if (h->async_align && (big_batch || h->async_force) && !h->fine_it && !mt_live && !pca_kd) {
     rc = align_async(h, sc, B, out);                                // (prepares the pair states itself: k_async_prepare)
     if (rc == MI355NDT_OK) { h->aligned_once = true; return MI355NDT_OK; }
@@ -1512,7 +1539,7 @@ static int hook_ready(mi355ndt_handle* h) {
   HIPCHK(h, hipSetDevice(h->device));
   { int rcu = uploads_before_compute(h); if (rcu) return rcu; }
   const bool pca_kd = h->prm.neighbor_mode == MI355NDT_KDTREE && h->prm.variant == MI355NDT_VARIANT_PCA;
-  if (!h->targets_built || (pca_kd && !h->kdw_built)) { int rc = mi355ndt_batch_build_targets(h); if (rc) return rc; }
+  if (!h->targets_built || (pca_kd && !h->kdw_built) || (h->arith == 1 && !h->recs_fast_built)) { int rc = mi355ndt_batch_build_targets(h); if (rc) return rc; }
   return prep_align_ws(h);
 }
 
@@ -1757,9 +1784,16 @@ int mi355ndt_convert_transform(const double x[6], float out[16]) {
 
 int mi355ndt_set_option(mi355ndt_handle* h, int option, int value) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  // (what a stream's launches and its contexts' synchronous re-runs compute with was fixed at mi355ndt_stream_begin: not changed mid-stream)
+  if (h->stream_on && (option == MI355NDT_OPT_F32_SUM_ORDER || option == MI355NDT_OPT_ARITH || option == MI355NDT_OPT_ASYNC_ALIGN)) NOT_IN_STREAM(h);
   if (option == MI355NDT_OPT_F32_SUM_ORDER) {
     if (value != 0 && value != 1) return MI355NDT_ERR_BAD_ARG;
     h->f32_sum_order = value;
+    return MI355NDT_OK;
+  }
+  if (option == MI355NDT_OPT_ARITH) {
+    if (value != 0 && value != 1) return MI355NDT_ERR_BAD_ARG;
+    h->arith = value;                            // (grids built before lack the records of the other arithmetic: the next align rebuilds them)
     return MI355NDT_OK;
   }
   if (option == MI355NDT_OPT_ASYNC_ALIGN) {
@@ -1793,6 +1827,7 @@ int mi355ndt_get_option(const mi355ndt_handle* h, int option, int* value) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   if (!value) return MI355NDT_ERR_BAD_ARG;
   if (option == MI355NDT_OPT_F32_SUM_ORDER) { *value = h->f32_sum_order; return MI355NDT_OK; }
+  if (option == MI355NDT_OPT_ARITH) { *value = h->arith; return MI355NDT_OK; }
   if (option == MI355NDT_OPT_ASYNC_ALIGN) { *value = h->async_force ? 2 : (h->async_align ? 1 : 0); return MI355NDT_OK; }
   if (option == MI355NDT_OPT_DEBUG_ASYNC_ABORT) { *value = h->debug_abort_pos == 0xFFFFFFFFu ? -1 : (int)h->debug_abort_pos; return MI355NDT_OK; }
   if (option == MI355NDT_OPT_DEBUG_ASYNC_RINGS) { *value = (int)h->debug_ring_mask; return MI355NDT_OK; }
@@ -1988,11 +2023,14 @@ int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts, int max_pairs, siz
   h->s_sync_only = !stream_async_ok(h);
   h->s_next_id = 0; h->s_launches = 0; h->s_counted = 0; h->s_drop_carry = true;
   h->s_plan_cb = 0; h->s_plan_words = 0;
+  // the grids a streamed launch reads are the contexts' (built at prm.resolution); whatever single-registration grid the parent still holds
+  // -- possibly one a setResolution without a source left at another leaf size (ndt_omp.h:126-136) -- is no part of the stream
+  h->targets_built = false; h->grid_resolution = 0.f; h->recs_fast_built = false;
   SweepConst sc;
   make_sweep_const(h, sc);
   {
     const int iu = h->s_items / (sc.K == 1 || sc.K == 7 ? 2 : 1);   // positions per ticket (stream_launch: two DIRECT7 items per claim when pairs are handed over)
-    const int waves = h->n_cu * sweep_wpe(sc.pca != 0, sc.K) * WAVES;
+    const int waves = h->n_cu * sweep_wpe(sc.pca != 0, sc.K, want_fast(h, sc)) * WAVES;
     // automatic: four sweeps' worth of positions per resident wave -- `tools/gpu_job.sh thresh_sweep`: config 5 gains up to T = 32-64 (DIRECT7 19.1 / 19.4 / 19.5 k,
     // DIRECT1 39.4 / 40.1 / 40.9 / 41.1 k registrations/s at T = 8 / 16 / 32 / 64), the 65,536-point configurations do not care -- capped at a quarter of the batch (stream_launch)
     int t = h->s_thresh_opt >= 0 ? h->s_thresh_opt : 4 * ((waves + iu - 1) / std::max(1, iu));
@@ -2004,7 +2042,7 @@ int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts, int max_pairs, siz
     int r = 0;
     if (const char* e = std::getenv("MI355NDT_STREAM_RESERVE")) r = std::atoi(e);
     if (h->s_reserve_opt >= 0) r = h->s_reserve_opt;
-    r = std::max(0, std::min(r, h->n_cu * sweep_wpe(sc.pca != 0, sc.K) / 2)) & ~7;
+    r = std::max(0, std::min(r, h->n_cu * sweep_wpe(sc.pca != 0, sc.K, want_fast(h, sc)) / 2)) & ~7;
     if (n_contexts < 3) r = 0;                       // (the overlapped build needs its context free one launch earlier: at least three contexts)
     h->s_reserve_wg = r;
   }
@@ -2025,7 +2063,7 @@ int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts, int max_pairs, siz
     }
     rc = mi355ndt_set_stream(e, h->s_reserve_wg > 0 ? h->s_build_stream : h->stream);
     if (rc) return fail(rc);
-    e->f32_sum_order = h->f32_sum_order; e->async_align = h->async_align; e->dyn_shift = h->dyn_shift;
+    e->f32_sum_order = h->f32_sum_order; e->arith = h->arith; e->async_align = h->async_align; e->dyn_shift = h->dyn_shift;
     e->async_build = true;
     e->ev_pool_target = 128;
     rc = ensure_pair_arrays(e, max_pairs);          // every per-pair array at its final size: no allocation, no wait inside submit

@@ -343,7 +343,7 @@ NDT_KERNEL void k_stream_status(const AsyncCtl* __restrict__ ctl, const CtxStat*
                           const VoxelRec* __restrict__ recs##i, double* partials##i, const int* __restrict__ src_cnt##i, unsigned* arrived##i, const float* __restrict__ cent##i
 #define NDT_CTX_SEL(f, ci) ((ci) == 0 ? f##0 : (ci) == 1 ? f##1 : (ci) == 2 ? f##2 : f##3)
 template <bool PCA, int K, int ORD>
-__global__ void __launch_bounds__(SWEEP_THREADS, (SweepTune<PCA, K>::WPE))
+__global__ void __launch_bounds__(SWEEP_THREADS, (SweepTune<PCA, K, ORD>::WPE))
 k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, int ring_cap, AsyncCtl* ctl, SweepConst sc, unsigned long long* hits_total,
               double step_max, double eps, int max_iterations, int stop_thresh, unsigned debug_abort_pos, unsigned debug_ring_mask, int claim_items,
               NDT_CTX_PARAMS(0), NDT_CTX_PARAMS(1), NDT_CTX_PARAMS(2), NDT_CTX_PARAMS(3)) {
@@ -456,7 +456,7 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
 #ifndef ASYNC_D1_PIPE
 #define ASYNC_D1_PIPE 1
 #endif
-    if (K == 1 && ASYNC_D1_PIPE) {                   // DIRECT1: the claim's items as one software pipeline (ndt_sweep.hpp), same rows bit for bit
+    if constexpr (K == 1 && ASYNC_D1_PIPE && ORD != 2) {   // DIRECT1 (exact arithmetic): the claim's items as one software pipeline (ndt_sweep.hpp), same rows bit for bit
       sweep_rows_d1<PCA, ORD, CLAIM_D1>(b, rem, C.src, C.pitch, C.gd, C.words, C.recs, C.partials, I, sc, exp_tab, pose_w, n_b, b
 #ifdef NDT_TIMELINE
                                      , tl, tl_last

@@ -395,7 +395,8 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restri
 
 // second pass of applyFilter (impl:282-367; pca impl:364-397): one thread per searchable leaf
 __global__ void __launch_bounds__(256) k_voxels(const GridDesc* __restrict__ gd, const double* __restrict__ sums,
-                                                 VoxelRec* recs, int* vox_n, double eig_mult, int pca, double* icov64, int* kd_weight) {
+                                                 VoxelRec* recs, int* vox_n, double eig_mult, int pca, double* icov64, int* kd_weight,
+                                                 VoxelRecF* recs_fast /* tolerance arithmetic only, else null */) {
   const int b = blockIdx.y;
   const GridDesc& g = gd[b];
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -453,6 +454,15 @@ __global__ void __launch_bounds__(256) k_voxels(const GridDesc* __restrict__ gd,
   }
   recs[g.rec_off + id] = r;
   vox_n[g.rec_off + id] = n_out;
+  if (recs_fast) {                               // the record as the tolerance-arithmetic sweep reads it (ndt_types.hpp)
+    VoxelRecF f;
+    for (int a = 0; a < 3; a++) { f.mh[a] = (float)r.mean[a]; f.ml[a] = (float)(r.mean[a] - (double)f.mh[a]); }
+    f.c[0] = r.icov[0]; f.c[1] = 0.5f * (r.icov[1] + r.icov[3]); f.c[2] = 0.5f * (r.icov[2] + r.icov[6]);
+    f.c[3] = r.icov[4]; f.c[4] = 0.5f * (r.icov[5] + r.icov[7]); f.c[5] = r.icov[8];
+    f.pad_[0] = f.pad_[1] = f.pad_[2] = 0.f;
+    f.weight = r.weight;
+    recs_fast[g.rec_off + id] = f;
+  }
   // ndt_pca + KDTREE reads the weight of EVERY leaf radiusSearch returns: (int)dimension_2d_ as computed (also when the
   // inverse failed afterwards), and the constructor's 0 for an eigen-failed leaf (voxel_grid_covariance_pca.h:143)
   if (kd_weight) kd_weight[g.rec_off + id] = kd_w;

@@ -104,6 +104,98 @@ __device__ __forceinline__ void eval_hit(const float u_in[3], const float r[3], 
 #undef NDT_ACC
 }
 
+// ------------------------------------------------------------------------------------ tolerance arithmetic (ORD = 2)
+// MI355NDT_OPT_ARITH = 1: the same evaluation -- updateDerivatives with the patterns of computePointDerivatives_AngleAxisd folded in -- priced
+// for north_star's tolerance (trans < 1e-4 m, rot < 1e-5 rad) instead of bit-equality with the oracle.  What changes against eval_hit:
+//   * fused multiply-adds, one v_exp_f32 (exp(-d2 q / 2) = 2^(kq q)) instead of the f64 table + polynomial, d1 as f32;
+//   * the inverse covariance as a symmetric matrix (six entries), so J^T C J is symmetric and H = S + [0 0; 0 Z] with S symmetric:
+//     21 sums for S, and the asymmetric part (impl2:522-530, 607) Z = r y^T - (y . r) I needs only A = sum e r y^T (9 sums; the trace term
+//     is recovered from A's diagonal when the row is written);
+//   * 37 f32 accumulators per lane instead of 43 f64 ones; a lane adds ~35 terms into them per work item (512 points) before they are widened
+//     and go through the f64 wave tree and the f64 row sums of the update as before.
+// What does NOT change: the point transform and the cell lookup (uncontracted f32, SURVEY.md H3: which leaf a point meets is discontinuous),
+// the validity gate of impl2:588-589, the Newton update.  The oracle is never asked to follow: this mode is held to the tolerance, not to bits
+// (tests/test_tolerance_mode.py, bench.py `tolerance_mode`).
+#define NACC_F 37
+__host__ __device__ constexpr int fsym(int i, int j) { return i <= j ? 7 + i * 6 - i * (i - 1) / 2 + (j - i) : 7 + j * 6 - j * (j - 1) / 2 + (i - j); }
+#define FA_BASE 28             // A[i][j] = a[FA_BASE + 3 i + j]
+template <bool PCA, typename Mid = NoHook>
+__device__ __forceinline__ void eval_hit_fast(const float u[3], const float r[3], const float c[6], const float d1f, const float d2f, const float kq,
+                                              const float w, const bool ok_in, float a[NACC_F], Mid mid = Mid()) {
+  const float c00 = c[0], c01 = c[1], c02 = c[2], c11 = c[3], c12 = c[4], c22 = c[5];
+  float y[3];
+  y[0] = fmaf(c02, u[2], fmaf(c01, u[1], c00 * u[0]));
+  y[1] = fmaf(c12, u[2], fmaf(c11, u[1], c01 * u[0]));
+  y[2] = fmaf(c22, u[2], fmaf(c12, u[1], c02 * u[0]));
+  const float q = fmaf(u[2], y[2], fmaf(u[1], y[1], u[0] * y[0]));
+  const float e0 = __builtin_amdgcn_exp2f(kq * q);                               // impl2:581
+  const float e1 = d2f * e0;                                                     // impl2:585
+  const bool ok = ok_in && !(e1 > 1.f || e1 < 0.f || e1 != e1);                  // impl2:588-589
+  float e = e1 * d1f, s = -d1f * e0;                                             // impl2:592, 583
+  if (PCA) { e *= w; s *= w; }
+  e = ok ? e : 0.f;
+  s = ok ? s : 0.f;
+  a[0] += s;
+  // v = J^T y = [y ; r x y] (impl2:595 with CJ's columns 0..2 = C)
+  float v[6] = {y[0], y[1], y[2], fmaf(r[1], y[2], -(r[2] * y[1])), fmaf(r[2], y[0], -(r[0] * y[2])), fmaf(r[0], y[1], -(r[1] * y[0]))};
+#pragma unroll
+  for (int k = 0; k < 6; k++) a[1 + k] = fmaf(e, v[k], a[1 + k]);                // impl2:597
+  __builtin_amdgcn_sched_barrier(0);
+  mid();
+  __builtin_amdgcn_sched_barrier(0);
+  // M = C (-[r]x): columns 3..5 of CJ (impl2:594)
+  const float C[3][3] = {{c00, c01, c02}, {c01, c11, c12}, {c02, c12, c22}};
+  float M[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    M[i][0] = fmaf(C[i][2], r[1], -(C[i][1] * r[2]));
+    M[i][1] = fmaf(C[i][0], r[2], -(C[i][2] * r[0]));
+    M[i][2] = fmaf(C[i][1], r[0], -(C[i][0] * r[1]));
+  }
+  float dv[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) dv[k] = -d2f * v[k];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = i; j < 3; j++) a[fsym(i, j)] = fmaf(e, fmaf(dv[i], v[j], C[i][j]), a[fsym(i, j)]);          // translation block
+#pragma unroll
+    for (int k = 0; k < 3; k++) a[fsym(i, 3 + k)] = fmaf(e, fmaf(dv[i], v[3 + k], M[i][k]), a[fsym(i, 3 + k)]);   // translation x rotation
+  }
+  // rotation block of J^T C J: [r]x M (symmetric: six entries)
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float rr0 = fmaf(r[1], M[2][k], -(r[2] * M[1][k]));
+    const float rr1 = fmaf(r[2], M[0][k], -(r[0] * M[2][k]));
+    const float rr2 = fmaf(r[0], M[1][k], -(r[1] * M[0][k]));
+    if (k >= 0) a[fsym(3, 3 + k)] = fmaf(e, fmaf(dv[3], v[3 + k], rr0), a[fsym(3, 3 + k)]);
+    if (k >= 1) a[fsym(4, 3 + k)] = fmaf(e, fmaf(dv[4], v[3 + k], rr1), a[fsym(4, 3 + k)]);
+    if (k >= 2) a[fsym(5, 3 + k)] = fmaf(e, fmaf(dv[5], v[3 + k], rr2), a[fsym(5, 3 + k)]);
+  }
+  // A = e r y^T: the point-Hessian term (impl2:522-530, 607), z_{3+i}[3+j] = r_i y_j - delta_ij (y . r)
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const float er = e * r[i];
+#pragma unroll
+    for (int j = 0; j < 3; j++) a[FA_BASE + 3 * i + j] = fmaf(er, y[j], a[FA_BASE + 3 * i + j]);
+  }
+}
+// the 37 sums of a lane -> the 43 entries of a partial row (score, g, H row-major), widened
+__device__ __forceinline__ void fast_acc_to_row(const float a[NACC_F], double acc[43]) {
+#pragma unroll
+  for (int k = 0; k < 7; k++) acc[k] = (double)a[k];
+  const double tr = ((double)a[FA_BASE] + (double)a[FA_BASE + 4]) + (double)a[FA_BASE + 8];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      double h = (double)a[fsym(i, j)];
+      if (i >= 3 && j >= 3) { h += (double)a[FA_BASE + 3 * (i - 3) + (j - 3)]; if (i == j) h -= tr; }
+      acc[7 + i * 6 + j] = h;
+    }
+  }
+}
+
 // Neighbour offset `a` (0..2) of probe q for a K-probe search, resolved at compile time in the sweep
 // (same tables and order as c_off above).
 __host__ __device__ constexpr int probe_off(int K, int q, int a) {
@@ -147,14 +239,28 @@ struct SweepCtl {               // 9 ints; two of them alternate: the sweep that
 // (tools/sweep_only.py, bench.py): ndt_omp at 1 m / 65,536 pts 1-3 % faster, but at 0.5 m / 131,072 pts (four times the voxel
 // records, fewer cache hits) 3 % slower, and ndt_pca 12 % slower there -- the prefetch matters as soon as records miss in L2,
 // so LEAN stays off.
-template <bool PCA, int K>
+#ifndef FAST_WPE
+#define FAST_WPE 4             // tolerance arithmetic: 37 f32 accumulators instead of 43 f64 ones leave room for four waves per SIMD
+#endif
+#ifndef FAST_TP7
+#define FAST_TP7 1
+#endif
+#ifndef FAST_TP1
+#define FAST_TP1 2
+#endif
+#ifndef FAST_PIPE
+#define FAST_PIPE 1
+#endif
+template <bool PCA, int K, int ORD = 0>
 struct SweepTune {
+  static constexpr bool FAST = (ORD == 2);
   static constexpr bool LEAN = false;
-  static constexpr int  WPE  = LEAN ? 3 : SWEEP_WPE;                       // workgroups per CU = waves per SIMD
-  static constexpr bool PIPE = !LEAN;                                      // fetch batch k+1's records in the middle of batch k
-  static constexpr int  TP   = LEAN ? 1 : (K == 1 ? 8 : (K <= 7 ? 2 : 1));  // tiles probed together (8 = the whole work item)
+  static constexpr int  WPE  = FAST ? FAST_WPE : (LEAN ? 3 : SWEEP_WPE);                       // workgroups per CU = waves per SIMD
+  static constexpr bool PIPE = FAST ? (FAST_PIPE != 0) : !LEAN;                                      // fetch batch k+1's records in the middle of batch k
+  // tiles probed together (8 = the whole work item); tolerance arithmetic: small super-tiles keep the LDS of a workgroup under a quarter of the CU's
+  static constexpr int  TP   = FAST ? (K == 1 ? FAST_TP1 : FAST_TP7) : (LEAN ? 1 : (K == 1 ? 8 : (K <= 7 ? 2 : 1)));
 };
-static inline int sweep_wpe(bool pca, int K) { (void)pca; (void)K; return SWEEP_WPE; }
+static inline int sweep_wpe(bool pca, int K, bool fast = false) { (void)pca; (void)K; return fast ? FAST_WPE : SWEEP_WPE; }
 
 // IT = tiles of 64 points per work item.  8 is the batch mode described above (a wave-quarter of a 2048-point chunk).
 // FINE (latency mode): small items (IT = 1 or 2) dealt statically over ALL waves of the grid, for a sweep over one or a
@@ -191,6 +297,9 @@ __device__ __forceinline__ void sweep_item(const int b, const int rem, const flo
 #endif
                                            ) {
   constexpr bool KD = (K == 27);
+  constexpr bool FAST = (ORD == 2);                // tolerance arithmetic (eval_hit_fast): `recs` holds VoxelRecF records
+  static_assert(!FAST || K == 1 || K == 7, "tolerance arithmetic is instantiated for DIRECT1 / DIRECT7");
+  typedef SweepTune<PCA, K, ORD> Tune;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   // ndt_pca's per-hit multiplier is the product of the hit's own weight and those of the point's LATER hits, known only in phase A.
@@ -198,16 +307,18 @@ __device__ __forceinline__ void sweep_item(const int b, const int rem, const flo
   // load in the probe stage, no weight queue, dead leaves filtered in phase B exactly as for ndt_omp.
   constexpr bool PCAQ = PCA && K > 1;
   // per-wave hit queue: must hold a leftover (< 64) plus everything one probe group can push: TP tiles x min(K, Q_GROUP) probes x 64
-  constexpr int Q_CAP = (K > 1 && K <= Q_GROUP) ? 1024 : 512;
+  constexpr int TP = Tune::TP < IT ? Tune::TP : IT;
+  constexpr int Q_NEED = (IT / TP > 1 ? 64 : 0) + TP * (K < Q_GROUP ? K : Q_GROUP) * 64;
+  constexpr int Q_CAP = FAST ? (Q_NEED <= 128 ? 128 : Q_NEED <= 256 ? 256 : Q_NEED <= 512 ? 512 : 1024) : ((K > 1 && K <= Q_GROUP) ? 1024 : 512);
+  static_assert(Q_NEED <= Q_CAP, "hit queue");
   __shared__ unsigned q_ent[WAVES][Q_CAP];
   // ndt_pca weight of a queued hit: the suffix product (f64: up to ~150^7) -- for DIRECT1 just the leaf's own integer weight
-  typedef typename std::conditional<K == 1, int, double>::type QW;
+  typedef typename std::conditional<K == 1, int, typename std::conditional<FAST, float, double>::type>::type QW;
   __shared__ QW q_w[PCAQ ? WAVES : 1][PCAQ ? Q_CAP : 1];
   // TP tiles of 64 points are probed together ("super-tile"): their point transforms, then ALL their bitmap loads, then all
   // their ballots -- the probe stage costs a few L2 round trips per super-tile, not per tile.  DIRECT1 has one probe per point
   // and ~0.9 hits, so it is probe-stage bound: 4 tiles at a time; DIRECT7: 2 (14 bitmap words in flight); the 26/27-cell
   // searches already have 7-probe groups inside one tile.
-  constexpr int TP = SweepTune<PCA, K>::TP < IT ? SweepTune<PCA, K>::TP : IT;
   constexpr int NBUF = (IT / TP > 1) ? 2 : 1;   // a super-tile that is the whole item needs no second buffer
   __shared__ float stage[WAVES][NBUF * 64 * TP][6];   // (two) super-tiles of staged points: x'(3), R x (3)
 
@@ -236,29 +347,44 @@ __device__ __forceinline__ void sweep_item(const int b, const int rem, const flo
   const int xb0 = g.max_b[0], xb1 = g.max_b[1], xb2 = g.max_b[2];
   const int mul1 = g.mul1, mul2 = g.mul2, nwords = g.nwords;
   {
-    double acc[43];
+    typedef typename std::conditional<FAST, float, double>::type AccT;
+    AccT acc[FAST ? NACC_F : 43];
 #pragma unroll
-    for (int a = 0; a < 43; a++) acc[a] = 0.0;
+    for (int a = 0; a < (FAST ? NACC_F : 43); a++) acc[a] = (AccT)0;
     unsigned nhits = 0;                              // wave-uniform
     int qhead = 0, qcount = 0;                       // wave-uniform
     int q_old = 0;                                   // queued entries that reference the OTHER staging half (older tile)
     const int wbase = rem * (IT * 64);
 
     // One batch of queued hits (one per lane): queue entry + the voxel record it points at, in registers.
-    struct Batch { unsigned slot; double m0, m1, m2; float C[9]; int weight; double w; };
+    struct BatchX { unsigned slot; double m0, m1, m2; float C[9]; int weight; double w; };
+    struct BatchF { unsigned slot; float mh[3], ml[3], c[6]; int weight; float w; };
+    typedef typename std::conditional<FAST, BatchF, BatchX>::type Batch;
     // read the `m` hits that sit `off` entries behind the queue head; lanes >= m re-read the last entry (and contribute +0)
     auto fetch = [&](int off, int m, Batch& B) {
       const int k = lane < m ? lane : m - 1;
       const unsigned ent = q_ent[wv][(qhead + off + k) & (Q_CAP - 1)];
       B.slot = ent >> ID_BITS;
-      const VoxelRec& vr = R[ent & ((1u << ID_BITS) - 1)];
-      B.m0 = vr.mean[0]; B.m1 = vr.mean[1]; B.m2 = vr.mean[2];
+      if constexpr (FAST) {
+        const VoxelRecF& vr = reinterpret_cast<const VoxelRecF*>(R)[ent & ((1u << ID_BITS) - 1)];
 #pragma unroll
-      for (int a = 0; a < 9; a++) B.C[a] = vr.icov[a];
-      B.weight = vr.weight;
-      B.w = 1.0;
-      if (PCAQ) B.w = (double)q_w[wv][(qhead + off + k) & (Q_CAP - 1)];
-      else if (PCA) B.w = (double)vr.weight;
+        for (int a = 0; a < 3; a++) { B.mh[a] = vr.mh[a]; B.ml[a] = vr.ml[a]; }
+#pragma unroll
+        for (int a = 0; a < 6; a++) B.c[a] = vr.c[a];
+        B.weight = vr.weight;
+        B.w = 1.f;
+        if (PCAQ) B.w = (float)q_w[wv][(qhead + off + k) & (Q_CAP - 1)];
+        else if (PCA) B.w = (float)vr.weight;
+      } else {
+        const VoxelRec& vr = R[ent & ((1u << ID_BITS) - 1)];
+        B.m0 = vr.mean[0]; B.m1 = vr.mean[1]; B.m2 = vr.mean[2];
+#pragma unroll
+        for (int a = 0; a < 9; a++) B.C[a] = vr.icov[a];
+        B.weight = vr.weight;
+        B.w = 1.0;
+        if (PCAQ) B.w = (double)q_w[wv][(qhead + off + k) & (Q_CAP - 1)];
+        else if (PCA) B.w = (double)vr.weight;
+      }
     };
     // evaluate a fetched batch (running `mid` half way through) and retire its `m` queue entries
     auto eval_batch = [&](const Batch& B, int m, auto mid) {
@@ -267,8 +393,13 @@ __device__ __forceinline__ void sweep_item(const int b, const int rem, const flo
       float r[3] = {sp[3], sp[4], sp[5]};
       // ndt_omp: leaves with nr_points = -1 (eigen / inverse failure) are not neighbours (impl:395): filtered here
       const bool live = lane < m && (PCAQ || KD || B.weight != VOX_DEAD);
-      float u[3] = {(float)((double)xt0 - B.m0), (float)((double)xt1 - B.m1), (float)((double)xt2 - B.m2)};   // impl2:276-279, 574
-      eval_hit<PCA, decltype(mid), KD, ORD>(u, r, B.C, sc.d1, sc.d2f, B.w, live, acc, exp_tab, mid);
+      if constexpr (FAST) {
+        float u[3] = {(xt0 - B.mh[0]) - B.ml[0], (xt1 - B.mh[1]) - B.ml[1], (xt2 - B.mh[2]) - B.ml[2]};
+        eval_hit_fast<PCA, decltype(mid)>(u, r, B.c, sc.d1f, sc.d2f, sc.kq, B.w, live, acc, mid);
+      } else {
+        float u[3] = {(float)((double)xt0 - B.m0), (float)((double)xt1 - B.m1), (float)((double)xt2 - B.m2)};   // impl2:276-279, 574
+        eval_hit<PCA, decltype(mid), KD, ORD>(u, r, B.C, sc.d1, sc.d2f, B.w, live, acc, exp_tab, mid);
+      }
       nhits += PCAQ ? (unsigned)m : (unsigned)__popcll(__ballot(live));
       qhead = (qhead + m) & (Q_CAP - 1);
       qcount -= m;
@@ -283,7 +414,7 @@ __device__ __forceinline__ void sweep_item(const int b, const int rem, const flo
     // All full batches in the queue, software-pipelined: the next batch's record loads are issued in the middle of the
     // current batch's arithmetic (before its 36 Hessian terms), so their L2 latency is off the critical path.
     auto drain_full = [&]() {
-      if (!SweepTune<PCA, K>::PIPE) {              // plain: one batch after the other
+      if (!Tune::PIPE) {                           // plain: one batch after the other
         while (qcount >= 64) drain(64);
         return;
       }
@@ -434,10 +565,16 @@ __device__ __forceinline__ void sweep_item(const int b, const int rem, const flo
     // rows, so 43 -> 22 -> 11 values remain per lane before the in-row butterfly (66 swaps + 88 shuffles + 77 adds
     // instead of 516 shuffles + 258 adds per item).
     typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    double accd[43];
+    if constexpr (FAST) fast_acc_to_row(acc, accd);
+    else {
+#pragma unroll
+      for (int i = 0; i < 43; i++) accd[i] = acc[i];
+    }
     double P1[22], P2[11];
 #pragma unroll
     for (int i = 0; i < 22; i++) {
-      const double a = acc[i], b2 = (i + 22 < 43) ? acc[i + 22] : 0.0;
+      const double a = accd[i], b2 = (i + 22 < 43) ? accd[i + 22] : 0.0;
       const u2v lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b2), false, false);
       const u2v hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b2), false, false);
       // lanes 0..31: value i of lanes L and L+32;  lanes 32..63: value i+22 of lanes L-32 and L
@@ -681,7 +818,7 @@ __device__ __forceinline__ void sweep_rows_d1(const int b, const int rem0, const
 __device__ __forceinline__ void newton_rebase(const double p[6], const double dir[6], const double a_t, double pn[6], float inc_cm[16]);
 
 template <bool PCA, int K, int IT = 8, bool FINE = false, int ORD = 0>
-__global__ void __launch_bounds__(SWEEP_THREADS, (SweepTune<PCA, K>::WPE))
+__global__ void __launch_bounds__(SWEEP_THREADS, (SweepTune<PCA, K, ORD>::WPE))
 k_sweep(const float* __restrict__ src, size_t pitch, const PairState* __restrict__ st,
         const GridDesc* __restrict__ gd, const BitWord* __restrict__ words, const VoxelRec* __restrict__ recs,
         double* partials, int rows_per_pair, const int* __restrict__ active_list, SweepCtl* ctl, SweepCtl* ctl_next, SweepConst sc,

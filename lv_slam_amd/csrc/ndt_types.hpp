@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <climits>
+#include <cstddef>
 #include <cstring>
 #include "mi355_ndt.h"
 
@@ -52,6 +53,18 @@ struct VoxelRec {              // 64 B, what one (point, voxel) evaluation reads
 };
 #define VOX_DEAD INT_MIN
 
+// MI355NDT_OPT_ARITH = 1 (tolerance arithmetic): what one evaluation reads then -- the same 64-byte slot, written by k_voxels
+// beside the exact record.  The f64 mean as an f32 head + tail (x' - mh is exact for a point in or next to the leaf's cell, so
+// (x' - mh) - ml is the reference's f32(f64(x') - mean) to a rounding), the inverse covariance as its six unique entries (off-diagonals:
+// the mean of the two the cofactor inverse produced), `weight` where VoxelRec has it (the probe stage of ndt_pca reads it from either).
+struct alignas(16) VoxelRecF {
+  float mh[3], ml[3];
+  float c[6];                  // c00 c01 c02 c11 c12 c22
+  float pad_[3];
+  int   weight;
+};
+static_assert(sizeof(VoxelRecF) == sizeof(VoxelRec) && offsetof(VoxelRecF, weight) == offsetof(VoxelRec, weight), "the two record forms share slot size and weight word");
+
 struct PairState {
   float  T[12];                // 3x4 row-major point transform (f32)
   float  Rj[9];                // rotation used for the point Jacobian (f32)
@@ -91,6 +104,8 @@ struct SweepConst {
   volatile int* host_flags;
   int    seq_no;
   int    rebase_block;         // latency mode: the launch's LAST workgroup does not sweep -- it computes the re-basing of p the next Newton update starts with (ndt_sweep.hpp)
+  // tolerance arithmetic (ORD = 2 instantiations only): d1 as f32, and kq = -d2 / 2 * log2(e): exp(-d2 q / 2) = 2^(kq q), one v_exp_f32
+  float  d1f, kq;
 };
 
 // Neighbour offsets in the reference's probe order.  DIRECT1: voxel_grid_covariance_omp_impl.hpp:441;

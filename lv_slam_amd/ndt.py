@@ -91,6 +91,7 @@ OPT_DEBUG_ASYNC_ABORT = 3      # mi355ndt_option (test hook): the wave that clai
 OPT_DEBUG_ASYNC_RINGS = 6      # mi355ndt_option (test hook): bit x clear -> ring x of a one-launch align has no workgroups of its own
 OPT_STREAM_RESERVE = 5         # mi355ndt_option: workgroup slots the stream's launches leave free for the next batch's build (0 = off)
 OPT_STREAM_THRESHOLD = 4       # mi355ndt_option: pairs a stream launch hands over to the next one (-1 = auto, 0 = none)
+OPT_ARITH = 7                  # mi355ndt_option: 0 = the oracle's arithmetic operation by operation (default), 1 = tolerance arithmetic (held to 1e-4 m / 1e-5 rad, not to bits)
 OPT_F32_SUM_ORDER = 1          # mi355ndt_option: 0 = (t0 + t1) + t2 (canonical), 1 = (t0 + t2) + t1 (Eigen 3.3 SSE predux pairing)
 
 _LIB = None
@@ -591,6 +592,9 @@ class NormalDistributionsTransform:
         if rc != OK:
             raise NDTError(rc, "convert_transform")
         return out.reshape(4, 4).T.copy()
+
+    def setArithmetic(self, mode: int):                # not in the reference: mi355ndt_set_option(MI355NDT_OPT_ARITH)
+        self._eng.set_option(OPT_ARITH, int(mode))
 
     def setF32SumOrder(self, order: int):              # not in the reference: mi355ndt_set_option(MI355NDT_OPT_F32_SUM_ORDER)
         self._eng.set_option(OPT_F32_SUM_ORDER, int(order))
