@@ -74,6 +74,10 @@ def parse():
     ap.add_argument("--f32-sum-order", type=int, default=0, choices=[0, 1],
                     help="MI355NDT_OPT_F32_SUM_ORDER of every engine of the run: 0 = (t0 + t1) + t2, the canonical order of the fixtures; 1 = (t0 + t2) + t1, "
                          "the lane pairing of Eigen 3.3's SSE predux -- the parity legs then check against the oracle's matching variant (ORA_VAR_SUM3_02_1)")
+    ap.add_argument("--arith", type=int, default=0, choices=[0, 1],
+                    help="MI355NDT_OPT_ARITH of every engine of the run: 0 = the exact arithmetic (results equal the oracle's bit for bit; what `value` is measured in), "
+                         "1 = tolerance arithmetic for the whole line (the default line already carries it as the `tolerance_mode` block beside the exact `value`)")
+    ap.add_argument("--no-tolerance-mode", action="store_true", help="skip the `tolerance_mode` blocks (the same jobs again under MI355NDT_OPT_ARITH = 1, compared pair by pair with the exact results)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the `other_configs` block of the single-GPU line (the nodelet's ndt_pca / DIRECT1 and BASELINE config 5 with DIRECT7 and "
                          "DIRECT1, each timed for --other-seconds with its own roofline and oracle parity sample)")
@@ -225,8 +229,29 @@ def static_profile(name, workload_key):
     return None, None
 
 
-VALU_FILES = ("r05_valu.json", "r05_valu_pca_direct1.json", "r05_valu_cfg5_d1.json", "r05_valu_cfg5_d7.json", "r04_valu.json", "r04_valu_pca_direct1.json",
+VALU_FILES = ("r06_valu.json", "r06_valu_pca_direct1.json", "r06_valu_cfg5_d1.json", "r06_valu_cfg5_d7.json", "r05_valu.json", "r05_valu_pca_direct1.json", "r05_valu_cfg5_d1.json", "r05_valu_cfg5_d7.json", "r04_valu.json", "r04_valu_pca_direct1.json",
               "r04_valu_cfg5_d1.json", "r03_valu.json", "r03_valu_pca_direct1.json", "r03_valu_cfg5_d1.json", "r02_valu.json", "r02_valu_pca_direct1.json")
+
+
+TRAFFIC_FILES = ("r06_traffic.json", "r06_traffic_pca_direct1.json", "r06_traffic_cfg5_d7.json", "r06_traffic_cfg5_d1.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json")
+
+
+def attach_traffic(roof, wkey, sync_launch_us, cmdline_traffic):
+    """roofline.traffic = PHYSICAL HBM bytes per sweep launch of this very workload (rocprofv3 FETCH_SIZE x 2 on gfx950 + WRITE_SIZE from their own --pmc passes over
+    the synchronous job, committed under profiles/: counters cannot be read inside the timed run), and what that is per second of such a launch."""
+    traffic, source = cmdline_traffic, "command line" if cmdline_traffic is not None else None
+    if traffic is None:
+        for name in TRAFFIC_FILES:
+            tp_, source = static_profile(name, wkey)
+            if tp_:
+                traffic = tp_["traffic_bytes_per_launch"]
+                break
+    roof["traffic"], roof["traffic_source"] = traffic, source if traffic is not None else None
+    if traffic and sync_launch_us and sync_launch_us > 0:
+        roof["physical_hbm_gbs"] = round(traffic / (sync_launch_us * 1e-6) / 1e9, 1)       # (counter passes and launch time: both of the synchronous job)
+        roof["physical_hbm_frac"] = round(roof["physical_hbm_gbs"] / HBM_PEAK_GBS, 4)
+    else:
+        roof["physical_hbm_gbs"], roof["physical_hbm_frac"] = None, None
 
 
 def valu_roofline(wkey):
@@ -334,6 +359,7 @@ def host_clouds_leg(a, ndt, prm, dev_index, T, S, guesses, B, N, steps, uploader
         out["cpus%d" % idx] = apply_affinity()        # not the one cpu an OpenMP runtime may have bound the main thread to
         eng = ndt.Engine(prm, device=dev_index)
         eng.set_option(ndt.OPT_F32_SUM_ORDER, a.f32_sum_order)
+        eng.set_option(ndt.OPT_ARITH, a.arith)
         eng.batch_reserve(B, N, N)
         res = (ndt.Result * B)()
         tptr = tgp + np.arange(B, dtype=np.uint64) * np.uint64(N * stride)
@@ -401,6 +427,7 @@ def sequential_leg(a, ndt, dev_index, dev, n_frames, parity_frames=12):
     stamps = [0.1 * k for k in range(n_frames)]
     prm = ndt.default_params(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=MODES["direct1"], variant=1)
     eng = ndt.Engine(prm, device=dev_index)
+    eng.set_option(ndt.OPT_ARITH, a.arith)
     frames = [rec[k] for k in range(n_frames)]
     eng.sequence_run(frames[:min(n_frames, 8)], stamps[:min(n_frames, 8)])        # warm-up: allocations, pinned slots
     best = None
@@ -456,6 +483,7 @@ def prefiltered_row(a, ndt, synth, dev, dev_index):
         raw.append((np.ascontiguousarray(t.cpu().numpy()), np.ascontiguousarray(s.cpu().numpy())))
     prm = ndt.default_params(resolution=a.resolution, trans_epsilon=0.01, max_iterations=64, neighbor_mode=MODES[a.mode], variant=1 if a.variant == "pca" else 0)
     eng = ndt.Engine(prm, device=dev_index)
+    eng.set_option(ndt.OPT_ARITH, a.arith)
     eng.set_latency_mode(True)
     G = synth.default_guess()
     res, t_pf, t_in, t_al, n_t, n_s, leaves, maxleaf, hpl = [], 0.0, 0.0, 0.0, [], [], [], [], []
@@ -558,7 +586,7 @@ def parity_leg(a, W, G, res_np, B, seconds, threads):
     op = O.default_params(**kw)
     O.lib().ora_set_threads(int(threads))
     O.lib().ora_set_variant(1 if getattr(a, "f32_sum_order", 0) == 1 else 0, 256)     # the oracle's matching f32 sum order (ORA_VAR_SUM3_02_1)
-    done, t_cpu, worst, it_match, conv_match, idx_seen = 0, 0.0, (0.0, 0.0), 0, 0, []
+    done, t_cpu, worst, it_match, conv_match, idx_seen, beyond = 0, 0.0, (0.0, 0.0), 0, 0, [], 0
     for k in spread_order(B):
         if done >= 3 and t_cpu >= seconds:
             break
@@ -569,6 +597,7 @@ def parity_leg(a, W, G, res_np, B, seconds, threads):
         t_cpu += time.perf_counter() - c0
         e = se3_err(ro["final"], res_np["final"][k].reshape(4, 4).T)
         worst = (max(worst[0], e[0]), max(worst[1], e[1]))
+        beyond += int(e[0] >= 1e-4 or e[1] >= 1e-5)
         it_match += int(ro["iterations"] == int(res_np["it"][k]))
         conv_match += int(bool(ro["converged"]) == bool(res_np["conv"][k]))
         idx_seen.append(k)
@@ -576,7 +605,7 @@ def parity_leg(a, W, G, res_np, B, seconds, threads):
     O.lib().ora_set_threads(0)
     O.lib().ora_set_variant(0, 256)
     parity = {"pairs_checked": done, "max_dtrans_m": worst[0], "max_drot_rad": worst[1], "iterations_equal": it_match, "converged_flags_equal": conv_match,
-              "f32_sum_order": getattr(a, "f32_sum_order", 0),
+              "pairs_beyond_tolerance": beyond, "f32_sum_order": getattr(a, "f32_sum_order", 0), "arith": getattr(a, "arith", 0),
               "sample": f"{done} of the {B} pairs of rank 0, spread over the whole index range (bit-reversal order; slots {min(idx_seen)}..{max(idx_seen)} touched)",
               "tolerance": "trans<1e-4 m, rot<1e-5 rad", "oracle": "parity unpinned (no reference-originated vectors exist, DESIGN.md 2; error bar: BASELINE.md 5)",
               "note": "pairs that never converge (iterations = max_iterations + 2, e.g. ndt_pca with DIRECT26 where the compounding "
@@ -926,6 +955,55 @@ def sweep_roofline(J):
             "build_frac": round(prof["build_alg_bytes"] / max(1e-9, prof["build_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
+def pose_deltas(res_a, res_b):
+    """pair by pair: SE(3) distance of the final poses, iteration / converged flips, pairs beyond north_star's tolerance"""
+    n = len(res_a)
+    d = np.array([se3_err(res_a["final"][k].reshape(4, 4).T, res_b["final"][k].reshape(4, 4).T) for k in range(n)], dtype=np.float64).reshape(n, 2)
+    flips = res_a["it"] != res_b["it"]
+    beyond = (d[:, 0] >= 1e-4) | (d[:, 1] >= 1e-5)
+    return {"pairs": n, "iteration_flips": int(flips.sum()), "converged_flag_flips": int((res_a["conv"] != res_b["conv"]).sum()),
+            "pairs_beyond_tolerance": int(beyond.sum()), "pairs_beyond_tolerance_slots": [int(k) for k in np.nonzero(beyond)[0][:16]],
+            "max_dtrans_m": float(d[:, 0].max()), "max_drot_rad": float(d[:, 1].max()), "median_dtrans_m": float(np.median(d[:, 0])),
+            "p99_dtrans_m": float(np.percentile(d[:, 0], 99)), "tolerance": "trans<1e-4 m, rot<1e-5 rad"}
+
+
+TOLERANCE_WHAT = ("the same job under MI355NDT_OPT_ARITH = 1 (tolerance arithmetic: fused multiply-adds, hardware exp2, symmetric inverse covariance, 37 f32 sums per lane and "
+                  "work item widened to f64 from the row on, tree leaf sums in the target build; the point transform and the voxel lookup untouched) -- held to north_star's "
+                  "SE(3) tolerance, not to the oracle's bits; never `value`")
+
+
+def tolerance_block(ctx, a, prm, W, nb, job_total, steps, warmup, exact_res_np, want_stream, oracle_seconds, min_seconds=0.5, b=None):
+    """One job again in the tolerance arithmetic: timed like the exact job (synchronous and, where the exact job was, streamed), every pair's result compared with the
+    exact arithmetic's result of the same pair (which equals the oracle's wherever it was checked), and a bounded oracle sample of its own."""
+    ndt = ctx.ndt
+    eng = ndt.Engine(prm, device=ctx.local)
+    eng.set_option(ndt.OPT_ARITH, 1)
+    J = timed_job(ctx, eng, W, nb, job_total, steps, warmup, min_seconds=min_seconds)
+    r_sync = sweep_roofline(J)
+    res_np = np.frombuffer(np.frombuffer(J["res"], dtype=np.uint8).copy(), dtype=RES_DT)
+    JS = None
+    if want_stream and len(W["ids"]) >= 2 * nb:
+        ref_sync = sync_reference(ctx, eng, W, nb, a.stream_batches)
+        JS = timed_stream_job(ctx, eng, W, nb, job_total, J["steps"], max(2, warmup), a.stream_batches, a.stream_contexts, ref_sync)
+    r_stream = sweep_roofline(JS) if JS is not None else None
+    eng.close()
+    out = {"what": TOLERANCE_WHAT,
+           "value_tolerance_mode": round(job_total * J["steps"] / (JS if JS is not None else J)["dt"], 2), "value_mode": "streamed" if JS is not None else "synchronous",
+           "value_tolerance_mode_synchronous": round(job_total * J["steps"] / J["dt"], 2), "ms_per_step_synchronous": round(1e3 * J["dt"] / J["steps"], 3),
+           "value_tolerance_mode_streamed": None if JS is None else round(job_total * J["steps"] / JS["dt"], 2), "ms_per_step_streamed": None if JS is None else round(1e3 * JS["dt"] / J["steps"], 3),
+           "steps": J["steps"],
+           "stream": None if JS is None else {k: JS[k] for k in ("n_batches", "n_contexts", "bit_identical_to_synchronous", "launches", "pairs_handed_over", "batches_rerun", "launches_that_gave_up")},
+           "roofline_synchronous": {k: r_sync[k] for k in ("achieved", "frac", "launches", "avg_launch_us", "alg_bytes_per_launch", "build_ms_per_step", "sweep_ms_per_step", "build_frac")},
+           "roofline_streamed": None if JS is None else {k: r_stream[k] for k in ("achieved", "frac", "launches", "avg_launch_us", "alg_bytes_per_launch", "build_ms_per_step", "sweep_ms_per_step")},
+           "mean_iterations": round(float(res_np["it"].mean()), 3),
+           "vs_exact_arithmetic": None if exact_res_np is None else pose_deltas(exact_res_np[:nb], res_np[:nb])}
+    if oracle_seconds > 0:
+        import argparse
+        bb = argparse.Namespace(**{**vars(b if b is not None else a), "arith": 1})
+        out["parity_vs_oracle"], _ = parity_leg(bb, W, ctx.G, res_np, nb, seconds=oracle_seconds, threads=cpu_quota() or os.cpu_count() or 8)
+    return out
+
+
 def other_configs_block(ctx, a, synth, W_head):
     """The BASELINE configurations the headline does not time, each as its own small job on this GPU (own engine, >= --other-seconds of
     timed steps, HIP-event roofline of its sweep, oracle parity on a bounded sample): the live nodelet's registration (ndt_pca, DIRECT1,
@@ -946,6 +1024,7 @@ def other_configs_block(ctx, a, synth, W_head):
         prm = ndt.default_params(resolution=b.resolution, trans_epsilon=0.01, max_iterations=64, neighbor_mode=MODES[b.mode], variant=1)
         eng = ndt.Engine(prm, device=ctx.local)
         eng.set_option(ndt.OPT_F32_SUM_ORDER, a.f32_sum_order)
+        eng.set_option(ndt.OPT_ARITH, a.arith)
         J = timed_job(ctx, eng, W, nb, nb, None, 2, min_seconds=a.other_seconds)
         r_sync = sweep_roofline(J)
         res_np = np.frombuffer(np.frombuffer(J["res"], dtype=np.uint8).copy(), dtype=RES_DT)
@@ -954,18 +1033,22 @@ def other_configs_block(ctx, a, synth, W_head):
             ref_sync = sync_reference(ctx, eng, W, nb, a.stream_batches)
             JS = timed_stream_job(ctx, eng, W, nb, nb, J["steps"], 2, a.stream_batches, a.stream_contexts, ref_sync)
         r_stream = sweep_roofline(JS) if JS is not None else None
-        best = JS if (JS is not None and JS["dt"] <= J["dt"]) else J
+        best = JS if JS is not None else J               # (the streamed job whenever it was run: one methodology for every configuration and round)
         r = r_stream if best is JS else r_sync
         eng.close()
         parity = None
         if a.cpu_seconds > 0:
             parity, _ = parity_leg(b, W, ctx.G, res_np, nb, seconds=min(4.0, a.cpu_seconds / 3.0), threads=cpu_quota() or os.cpu_count() or 8)
+        tol = None
+        if a.arith == 0 and not a.no_tolerance_mode:
+            tol = tolerance_block(ctx, a, prm, W, nb, nb, J["steps"], 2, res_np, JS is not None, min(2.0, a.cpu_seconds / 6.0) if a.cpu_seconds > 0 else 0.0, min_seconds=a.other_seconds, b=b)
         N = az * 64
         out[name] = {"workload": f"{baseline_config_name(b, N)}: {nb} synthetic HDL-64E scan pairs ({N} pts per cloud), ndt_pca, {b.resolution} m voxels, {b.mode.upper()}, "
                                  "eps 0.01, max_iter 64; one step = voxelise every target + align every pair",
                      "value": round(nb * J["steps"] / best["dt"], 2), "unit": "registrations/s", "steps": J["steps"], "warmup": 2,
                      "ms_per_step": round(1e3 * best["dt"] / J["steps"], 3), "timed_s": round(best["dt"], 3),
-                     "mode": "streamed (the faster of the two modes measured)" if best is JS else ("synchronous" if JS is None else "synchronous (the faster of the two modes measured)"),
+                     "value_mode": "streamed" if best is JS else "synchronous",
+                     "value_tolerance_mode": None if tol is None else tol["value_tolerance_mode"], "tolerance_mode": tol,
                      "value_synchronous": round(nb * J["steps"] / J["dt"], 2), "ms_per_step_synchronous": round(1e3 * J["dt"] / J["steps"], 3),
                      "value_streamed": None if JS is None else round(nb * J["steps"] / JS["dt"], 2), "roofline_frac_streamed": None if JS is None else r_stream["frac"],
                      "roofline_frac_synchronous": r_sync["frac"], "avg_launch_us_synchronous": r_sync["avg_launch_us"],
@@ -975,6 +1058,7 @@ def other_configs_block(ctx, a, synth, W_head):
                                                    "hits_per_point", "flops", "build_ms_per_step", "update_ms_per_step", "sweep_ms_per_step", "build_frac")},
                      "roofline_valu": valu_roofline(f"{nb}x{N}:{b.variant}:{b.mode}:{b.resolution}"),
                      "parity": parity}
+        attach_traffic(out[name]["roofline"], f"{nb}x{N}:{b.variant}:{b.mode}:{b.resolution}", r_sync["avg_launch_us"], None)
     del W5
     return {"configs": out, "seconds": round(time.perf_counter() - t0, 2), "input_generation_s": round(gen5, 2),
             "what": "same timed-step definition as the headline (barrier-free single rank, HIP events inside the engine for the sweep's roofline); "
@@ -1066,6 +1150,7 @@ def main():
                              variant=1 if a.variant == "pca" else 0)
     eng = ndt.Engine(prm, device=local)
     eng.set_option(ndt.OPT_F32_SUM_ORDER, a.f32_sum_order)
+    eng.set_option(ndt.OPT_ARITH, a.arith)
 
     # ---- the headline job
     J = timed_job(ctx, eng, W, B, total, a.steps, a.warmup)
@@ -1124,6 +1209,15 @@ def main():
         if rank == 0 and a.cpu_seconds > 0 and world == 1:
             cfg4["parity"], _ = parity_leg(a, W, G, J4["res_np"], len(c4_ids), seconds=a.cpu_seconds / 2.0, threads=cpu_quota() or os.cpu_count() or 8)
 
+    # ---- the same jobs in the tolerance arithmetic (never `value`): every rank runs them (they contain the same barriers / gathers)
+    tol_head, tol_c4 = None, None
+    tol_ok = a.arith == 0 and not a.no_tolerance_mode and a.mode in ("direct1", "direct7")
+    if tol_ok:
+        osec = (a.cpu_seconds / 4.0) if (rank == 0 and world == 1) else 0.0
+        tol_head = tolerance_block(ctx, a, prm, W, B, total, steps, min(a.warmup, 3), res_np, JS is not None, osec)
+        if c4_total:
+            tol_c4 = tolerance_block(ctx, a, prm, W, len(c4_ids), c4_total, J4["steps"], 2, np.frombuffer(np.frombuffer(J4["res"], dtype=np.uint8).copy(), dtype=RES_DT), False, osec)
+
     pg = {"world_size": dist.get_world_size() if dist is not None else 1, "backend": dist.get_backend() if dist is not None else None,
           "launcher": os.environ.get("LV_SLAM_BENCH_LAUNCHER") or ("torch.distributed.run (external)" if "TORCHELASTIC_RUN_ID" in os.environ else "plain process"),
           "devices_visible": visible, "device_of_rank0": torch.cuda.get_device_name(local),
@@ -1137,9 +1231,10 @@ def main():
 
     value_sync = total * steps / dt
     value_stream = total * JS["steps"] / JS["dt"] if JS is not None else None
-    # `value` is the faster of the two ways this run drove the same steps through the engine -- what a caller would use -- and config.mode says
-    # which; both rates are always in the line (value_synchronous, value_streamed)
-    streamed_wins = value_stream is not None and value_stream >= value_sync
+    # ONE methodology, every round and configuration: `value` is the STREAMED job whenever it was run (BASELINE config 3: "streamed through 1 GPU"; distinct
+    # batches back to back, every step's results on the host inside the timed region), else the synchronous one; `value_mode` says which, and both
+    # rates are always in the line (value_synchronous, value_streamed).  (Rounds 4-5 printed the faster of the two.)
+    streamed_wins = value_stream is not None
     value = value_stream if streamed_wins else value_sync
     its = res_np["it"].astype(np.float64)
     sweeps = res_np["sweeps"].astype(np.float64)
@@ -1148,22 +1243,11 @@ def main():
     roof_sync = sweep_roofline(J)
     roof_stream = sweep_roofline(JS) if JS is not None else None
     roof = roof_stream if streamed_wins else roof_sync
-    traffic, traffic_source = a.traffic, "command line" if a.traffic is not None else None
-    if traffic is None:       # PMC counters cannot be read from inside the timed run: the committed separate-pass measurement of this workload
-        tp_ = None
-        for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
-            tp_, traffic_source = static_profile(name, wkey)
-            if tp_:
-                break
-        traffic = tp_["traffic_bytes_per_launch"] if tp_ else None
-    roof["traffic"], roof["traffic_source"] = traffic, traffic_source
+    attach_traffic(roof, wkey, roof_sync["avg_launch_us"], a.traffic)
     roof_valu = valu_roofline(wkey)
     # what the figure is, in the line itself: `achieved` prices the ALGORITHMIC bytes of SURVEY 8(d) (every voxel record a point evaluates
     # counted as read) against the HBM peak; the voxel records are re-used out of L2 / MALL, so the PHYSICAL HBM rate is `traffic` /
     # launch time, and the unit the sweep is limited by is the vector ALU (`roofline_valu`)
-    if traffic and roof["avg_launch_us"] > 0:
-        roof["physical_hbm_gbs"] = round(traffic / (roof_sync["avg_launch_us"] * 1e-6) / 1e9, 1)       # (counter passes: the synchronous job's launches)
-        roof["physical_hbm_frac"] = round(roof["physical_hbm_gbs"] / HBM_PEAK_GBS, 4)
     roof["what"] = ("achieved = algorithmic bytes (SURVEY 8(d): 12 + 4*neighbours + 64*hits per point) / launch time: a cache-resident working set priced "
                     "against HBM, not HBM traffic; physical_hbm_frac is the measured HBM share; the binding unit is VALU issue (roofline_valu.active_frac)")
 
@@ -1180,9 +1264,12 @@ def main():
     out = {
         "metric": "NDT registrations/sec (64k-pt Velodyne pairs)", "value": round(value, 2), "unit": "registrations/s",
         "n_gpus": world, "steps": steps, "warmup": a.warmup, "ms_per_step": round(1e3 * (JS["dt"] if streamed_wins else dt) / steps, 3),
+        "value_mode": "streamed" if streamed_wins else "synchronous",
         "value_synchronous": round(value_sync, 2), "ms_per_step_synchronous": round(1e3 * dt / steps, 3),
         "value_streamed": None if value_stream is None else round(value_stream, 2), "ms_per_step_streamed": None if JS is None else round(1e3 * JS["dt"] / steps, 3),
-        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32 terms, f64 accumulation",
+        "value_tolerance_mode": None if tol_head is None else tol_head["value_tolerance_mode"], "tolerance_mode": tol_head,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "dtype": "f32 terms, f64 accumulation" if a.arith == 0 else "f32 terms and f32 sums per 512-point work item (tolerance arithmetic, --arith 1), f64 accumulation from there on",
         "data": W["data"],
         "config": {"workload": (f"BASELINE config 4: {total} {kind} scan pairs sharded round-robin over {world} GPU(s) " if strong else
                                 f"{baseline_config_name(a, N) if W['data'] == 'synthetic' else 'KITTI seq ' + os.path.basename(os.path.dirname(os.path.abspath(a.kitti_dir).rstrip('/')))}: "
@@ -1190,15 +1277,12 @@ def main():
                                f"({N} pts per cloud{' at most' if W['data'] == 'kitti' else ''}), ndt_{a.variant}, {a.resolution} m voxels, {a.mode.upper()}, eps 0.01, max_iter 64; "
                                "one step = voxelise every target + align every pair (+ RCCL pose all-gather when N>1)",
                    "mode": ("synchronous: batch_build_targets + batch_align, one batch at a time" if JS is None else
-                            (f"streamed: {JS['n_batches']} distinct batches of {B} pairs submitted back to back through mi355ndt_stream_* ({JS['n_contexts']} batches resident; a launch hands "
-                             "its last unfinished pairs to the next launch; every step's results on the host inside the timed region; bit-identical to the synchronous align) -- "
-                             "the faster of the two modes measured in this run; value_synchronous = the same steps through batch_build_targets + batch_align, one batch at a time") if streamed_wins else
-                            ("synchronous: batch_build_targets + batch_align, one batch at a time -- the faster of the two modes measured in this run; value_streamed = the same steps "
-                             f"through mi355ndt_stream_* ({JS['n_batches']} distinct batches back to back, {JS['n_contexts']} resident; bit-identical results): the hand-over of a launch's last pairs "
-                             "pays where a launch has a tail (config 5: other_configs), not at this workload")),
+                            f"streamed: {JS['n_batches']} distinct batches of {B} pairs submitted back to back through mi355ndt_stream_* ({JS['n_contexts']} batches resident; a launch hands "
+                            "its last unfinished pairs to the next launch; every step's results on the host inside the timed region; bit-identical to the synchronous align); "
+                            "value_synchronous = the same steps through batch_build_targets + batch_align, one batch at a time"),
                    "stream": None if JS is None else {k: JS[k] for k in ("n_batches", "n_contexts", "bit_identical_to_synchronous", "launches", "pairs_handed_over", "batches_rerun", "launches_that_gave_up")},
                    "pairs_total": total, "pairs_rank0": B, "points_per_cloud": N, "neighbor_mode": a.mode, "variant": a.variant,
-                   "resolution_m": a.resolution, "f32_sum_order": a.f32_sum_order, "sharding": "pair i -> rank i mod N (round-robin)",
+                   "resolution_m": a.resolution, "f32_sum_order": a.f32_sum_order, "arith": a.arith, "sharding": "pair i -> rank i mod N (round-robin)",
                    "mean_iterations": round(float(its.mean()), 2), "max_iterations_seen": int(its.max()),
                    "mean_sweeps_per_align": round(float(sweeps.mean()), 2),
                    "converged": int(res_np["conv"].sum()),
@@ -1214,6 +1298,9 @@ def main():
         "roofline": roof, "roofline_valu": roof_valu, "cpu_baseline": cpu, "parity": parity, "gather_check": (JS if streamed_wins and JS["gather_check"] is not None else J)["gather_check"], "gather_check_streamed": None if JS is None else JS["gather_check"],
         "config4": cfg4, "other_configs": others,
     }
+    if cfg4 is not None and tol_c4 is not None:
+        cfg4["value_tolerance_mode"] = tol_c4["value_tolerance_mode"]
+        cfg4["tolerance_mode"] = tol_c4
     if seq_leg is not None:
         out["value_sequential"] = seq_leg["frames_per_s"]
         out["sequential"] = seq_leg

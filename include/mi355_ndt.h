@@ -208,7 +208,7 @@ enum mi355ndt_option {
    * published positions of other rings (ndt_async.hpp) -- with the same bits; mask 0 is refused. */
   MI355NDT_OPT_DEBUG_ASYNC_RINGS = 6,
   /* Arithmetic of the derivative sweep.  0 (default): every f32 / f64 operation of updateDerivatives (ndt_omp_impl2.hpp:566-619) as the CPU
-   * restatement of the reference performs it, one rounding per operation, 43 f64 sums per lane -- results equal the oracle's bit for bit.
+   * restatement of the reference performs it, one rounding per operation, 43 f64 sums per lane -- results equal the CPU restatement's bit for bit.
    * 1: tolerance arithmetic, held to north_star's SE(3) tolerance (trans < 1e-4 m, rot < 1e-5 rad against the reference arithmetic) instead:
    * fused multiply-adds, the hardware exp2, a symmetric inverse covariance (21 symmetric + 9 point-Hessian sums instead of 36), f32 sums per
    * work item (512 points) widened to f64 from there on, leaf sums of the target build as a tree instead of in input order.  The point

@@ -112,7 +112,7 @@ struct mi355ndt_handle {
   AsyncTab* d_atab = nullptr;                     // the launch's context table (ndt_async.hpp)
   unsigned debug_abort_pos = 0xFFFFFFFFu;         // MI355NDT_OPT_DEBUG_ASYNC_ABORT (test hook): the wave that claims this position of ring 0 gives up
   unsigned debug_ring_mask = 0xFFu;               // MI355NDT_OPT_DEBUG_ASYNC_RINGS (test hook): rings whose workgroups take part
-  int arith = 0;                                  // MI355NDT_OPT_ARITH: 0 = the oracle's arithmetic, operation by operation; 1 = tolerance arithmetic (ndt_sweep.hpp: eval_hit_fast)
+  int arith = 0;                                  // MI355NDT_OPT_ARITH: 0 = the reference recipe's arithmetic, one rounding per operation; 1 = tolerance arithmetic (ndt_sweep.hpp: eval_hit_fast)
   VoxelRecF* d_recs_fast = nullptr; size_t recs_fast_cap = 0; bool recs_fast_built = false;   // ... and the records its sweeps read (k_voxels writes them beside d_recs)
   int f32_sum_order = 0;                          // MI355NDT_OPT_F32_SUM_ORDER: 0 = (t0 + t1) + t2 (canonical), 1 = (t0 + t2) + t1 (Eigen 3.3 SSE predux pairing)
   double gauss_last[3] = {0, 0, 0};               // gauss_d1_/d2_/d3_ as the constructor / the last computeTransformation left them (calculateScore reads them)
@@ -387,6 +387,7 @@ int mi355ndt_create(const mi355ndt_params* params, int device, mi355ndt_handle**
   { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
   if (const char* e = std::getenv("MI355NDT_LEAF_SORTED")) h->leaf_sorted = std::atoi(e) != 0;
   if (const char* e = std::getenv("MI355NDT_FINE_TILES")) { const int v = std::atoi(e); if (v == 1 || v == 2) h->fine_tiles = v; }
+  if (const char* e = std::getenv("MI355NDT_ARITH")) h->arith = std::atoi(e) == 1 ? 1 : 0;   // default of MI355NDT_OPT_ARITH for engines created afterwards (tools, A/B runs)
   if (const char* e = std::getenv("MI355NDT_ASYNC")) { h->async_align = std::atoi(e) != 0; h->async_force = std::atoi(e) == 2; }
   if (const char* e = std::getenv("MI355NDT_SWEEP_DYN_SHIFT")) { const int v = std::atoi(e); if (v >= 0 && v <= 30) h->dyn_shift = v; }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -935,7 +936,9 @@ static int build_targets_impl(mi355ndt_handle* h) {
     k_rank<<<B, 1024, 0, s>>>(h->d_grid, h->d_words, h->d_heads, h->d_head_cnt, nsl, scap, h->d_seg_start);
     // leaf-sum workgroups per target: 64 keeps ~4 targets (3 MB of points) in flight per XCD, inside its 4 MB L2
     const int lb = std::max(1, std::min((int)((rpp + LS_WAVES - 1) / LS_WAVES), 64));
-    if (h->leaf_sorted) {
+    if (h->arith == 1 && !want_cent && !h->leaf_sorted) {       // tolerance arithmetic: the leaf sums as a tree (ndt_build.hpp)
+      k_leafsum_tree<<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start, h->d_sums, h->d_vox_idx, h->d_vox_n, cb, lb, B);
+    } else if (h->leaf_sorted) {
       // the sorted order as 16-byte points first (one streaming gather), then leaf sums that read them contiguously
       HIPCHK(h, grow(h->d_sorted, h->sorted_cap, total));
       const int gb = std::max(1, std::min((int)((pitch + 256 * RUN_ILP - 1) / (256 * RUN_ILP)), 64));
@@ -2029,7 +2032,7 @@ int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts, int max_pairs, siz
   SweepConst sc;
   make_sweep_const(h, sc);
   {
-    const int iu = h->s_items / (sc.K == 1 || sc.K == 7 ? 2 : 1);   // positions per ticket (stream_launch: two DIRECT7 items per claim when pairs are handed over)
+    const int iu = h->s_items / (sc.K == 1 ? ((want_fast(h, sc) && FAST_D1_POINT) ? FAST_CLAIM1 : 2) : sc.K == 7 ? 2 : 1);   // positions per ticket (stream_launch: two DIRECT7 items per claim when pairs are handed over)
     const int waves = h->n_cu * sweep_wpe(sc.pca != 0, sc.K, want_fast(h, sc)) * WAVES;
     // automatic: four sweeps' worth of positions per resident wave -- `tools/gpu_job.sh thresh_sweep`: config 5 gains up to T = 32-64 (DIRECT7 19.1 / 19.4 / 19.5 k,
     // DIRECT1 39.4 / 40.1 / 40.9 / 41.1 k registrations/s at T = 8 / 16 / 32 / 64), the 65,536-point configurations do not care -- capped at a quarter of the batch (stream_launch)

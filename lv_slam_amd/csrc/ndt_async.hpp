@@ -363,7 +363,10 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
   // DIRECT1 items are short (one probe per point, ~0.85 hits): two consecutive items of a pair per claim / arrival halve the hand-overs
   // ... and so do two DIRECT7 items per claim where the launch hands its tail on (stream mode: +1.4-2 % measured; a launch that runs its own
   // tail loses with the coarser positions -- config 5, synchronous: -11 % --, so the host decides per launch: `claim_items`, DIRECT1: always two)
-  constexpr int CLAIM_D1 = ASYNC_CLAIM(1);
+#ifndef FAST_CLAIM1
+#define FAST_CLAIM1 4            // tolerance arithmetic, DIRECT1: a claim = one chunk (four items) going through the lane = point pipeline as one stream of tiles
+#endif
+  constexpr int CLAIM_D1 = (ORD == 2 && FAST_D1_POINT) ? FAST_CLAIM1 : ASYNC_CLAIM(1);
   const int CLAIM = K == 1 ? CLAIM_D1 : (claim_items == 2 ? 2 : 1);
   const int Iu = I / CLAIM;                        // positions per ticket (items_per_pair is a multiple of four)
 #ifdef NDT_TIMELINE
@@ -462,6 +465,17 @@ k_align_async(const AsyncTab* __restrict__ tab, int items_per_pair, int* ring, i
                                      , tl, tl_last
 #endif
                                      );
+    } else if constexpr (K == 1 && ORD == 2 && FAST_D1_POINT) {   // DIRECT1, tolerance arithmetic: the claim's items as one stream of tiles, lane = point
+      float T[12], Rj[9];
+#pragma unroll
+      for (int a_ = 0; a_ < 12; a_++) T[a_] = __uint_as_float(__builtin_amdgcn_readlane(pose_w, a_));
+#pragma unroll
+      for (int a_ = 0; a_ < 9; a_++) Rj[a_] = __uint_as_float(__builtin_amdgcn_readlane(pose_w, 12 + a_));
+      sweep_rows_d1p<PCA, CLAIM_D1, true>(b, rem, C.src, C.pitch, T, Rj, n_b, C.gd[b], C.words, C.recs, C.partials, I, sc
+#ifdef NDT_TIMELINE
+                                          , tl, tl_last
+#endif
+                                          );
     } else {
 #pragma unroll 1
       for (int k = 0; k < CLAIM; k++)

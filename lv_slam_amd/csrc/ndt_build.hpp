@@ -393,6 +393,82 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restri
   LTL_FLUSH();
 }
 
+// Tolerance arithmetic (MI355NDT_OPT_ARITH = 1) only: the same sums as a TREE.  The ordered sums above are nine lanes wide and one add deep per
+// point -- that, not memory, is what k_leafsum costs (docs/experiments.md 10d).  Here every lane keeps the nine f64 sums of ITS positions of the
+// run (position j of the run belongs to lane j % 64) and the wave adds them up once per leaf: 63 lanes busy instead of nine, one reduction per
+// leaf instead of a chain per point.  Same terms, f64 throughout, another order: sums agree with the ordered ones to ~1e-16 relative
+// (north_star's tolerance is 1e-4 m on the pose; BASELINE.md 5: no f64-only choice ever moved a pose bit), never bit for bit -- so never
+// under the default arithmetic.  cov_'s Identity seed (voxel_grid_covariance_omp.h:101) goes in at the end.
+__global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum_tree(const float* __restrict__ tgt, size_t pitch, const unsigned* __restrict__ keys, const unsigned* __restrict__ vals,
+                                                                const GridDesc* __restrict__ gd, const unsigned* __restrict__ seg_start,
+                                                                double* sums, int* vox_idx, int* vox_n, int cb, int nx, int n_targets) {
+  int b, bx;
+  if (!xcd_map(nx, n_targets, bx, b)) return;
+  const GridDesc& g = gd[b];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const unsigned* K = keys + (size_t)b * pitch;
+  const unsigned* V = vals + (size_t)b * pitch;
+  const float* X = tgt + (size_t)b * 3 * pitch;
+  const int id0 = bx * LS_WAVES + wv, idstep = nx * LS_WAVES;
+  size_t start_next = id0 < g.n_voxels ? seg_start[g.rec_off + id0] : 0;
+  for (int id = id0; id < g.n_voxels; id += idstep) {
+    const size_t start = start_next;
+    if (id + idstep < g.n_voxels) start_next = seg_start[g.rec_off + id + idstep];
+    double a[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) a[k] = 0.0;
+    int cnt = 0;
+    unsigned key = 0;
+    for (size_t j0 = start;; j0 += 64) {
+      const size_t j = j0 + lane;
+      const bool inb = j < pitch;
+      const unsigned kj = inb ? K[j] : 0u;
+      const unsigned pi = inb ? V[j] : 0u;
+      if (j0 == start) key = __shfl(kj, 0);
+      const bool in = inb && kj == key;
+      const int m = (int)__popcll(__ballot(in));
+      if (in) {
+        const double x = (double)X[pi], y = (double)X[pitch + pi], z = (double)X[2 * pitch + pi];
+        a[0] += x; a[1] += y; a[2] += z;
+        a[3] += x * x; a[4] += x * y; a[5] += x * z; a[6] += y * y; a[7] += y * z; a[8] += z * z;
+      }
+      cnt += m;
+      if (m < 64) break;
+    }
+    // wave sum as a reduce-scatter (the sweep's scheme, ndt_sweep.hpp): 9 -> 5 values across the lane halves, 5 -> 3 across row pairs, then rows
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    double p1[5], p2[3];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      const double u = a[i], v = (i + 5 < 9) ? a[i + 5] : 0.0;
+      const u2v lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(u), (unsigned)__double2loint(v), false, false);
+      const u2v hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(u), (unsigned)__double2hiint(v), false, false);
+      p1[i] = __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);   // lanes 0..31: sum i, lanes 32..63: sum i + 5
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const double u = p1[i], v = (i + 3 < 5) ? p1[i + 3] : 0.0;
+      const u2v lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(u), (unsigned)__double2loint(v), false, false);
+      const u2v hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(u), (unsigned)__double2hiint(v), false, false);
+      double w = __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);   // even rows: p1[i], odd rows: p1[i + 3]
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) w += __shfl_xor(w, o);
+      p2[i] = w;
+    }
+    if ((lane & 15) == 0) {
+      // row 0 (lane 0): sums 0 1 2, row 1 (lane 16): 3 4, row 2 (lane 32): 5 6 7, row 3 (lane 48): 8 -- S0 S1 S2 C00 C01 C02 C11 C12 C22
+      const int row = lane >> 4, base = 3 * (row & 1) + 5 * (row >> 1), nrow = (row & 1) ? ((row >> 1) ? 1 : 2) : 3;
+      double* o = sums + (size_t)(g.rec_off + id) * 9;
+#pragma unroll
+      for (int i = 0; i < 3; i++) if (i < nrow) { const int k = base + i; o[k] = p2[i] + ((k == 3 || k == 6 || k == 8) ? 1.0 : 0.0); }
+    }
+    if (lane == 0) {
+      vox_idx[g.rec_off + id] = (int)(key & ((1u << cb) - 1u));
+      vox_n[g.rec_off + id] = cnt;
+    }
+  }
+}
+
 // second pass of applyFilter (impl:282-367; pca impl:364-397): one thread per searchable leaf
 __global__ void __launch_bounds__(256) k_voxels(const GridDesc* __restrict__ gd, const double* __restrict__ sums,
                                                  VoxelRec* recs, int* vox_n, double eig_mult, int pca, double* icov64, int* kd_weight,

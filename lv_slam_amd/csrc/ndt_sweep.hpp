@@ -106,7 +106,7 @@ __device__ __forceinline__ void eval_hit(const float u_in[3], const float r[3], 
 
 // ------------------------------------------------------------------------------------ tolerance arithmetic (ORD = 2)
 // MI355NDT_OPT_ARITH = 1: the same evaluation -- updateDerivatives with the patterns of computePointDerivatives_AngleAxisd folded in -- priced
-// for north_star's tolerance (trans < 1e-4 m, rot < 1e-5 rad) instead of bit-equality with the oracle.  What changes against eval_hit:
+// for north_star's tolerance (trans < 1e-4 m, rot < 1e-5 rad) instead of one separately rounded operation per step of the reference recipe.  What changes against eval_hit:
 //   * fused multiply-adds, one v_exp_f32 (exp(-d2 q / 2) = 2^(kq q)) instead of the f64 table + polynomial, d1 as f32;
 //   * the inverse covariance as a symmetric matrix (six entries), so J^T C J is symmetric and H = S + [0 0; 0 Z] with S symmetric:
 //     21 sums for S, and the asymmetric part (impl2:522-530, 607) Z = r y^T - (y . r) I needs only A = sum e r y^T (9 sums; the trace term
@@ -114,7 +114,7 @@ __device__ __forceinline__ void eval_hit(const float u_in[3], const float r[3], 
 //   * 37 f32 accumulators per lane instead of 43 f64 ones; a lane adds ~35 terms into them per work item (512 points) before they are widened
 //     and go through the f64 wave tree and the f64 row sums of the update as before.
 // What does NOT change: the point transform and the cell lookup (uncontracted f32, SURVEY.md H3: which leaf a point meets is discontinuous),
-// the validity gate of impl2:588-589, the Newton update.  The oracle is never asked to follow: this mode is held to the tolerance, not to bits
+// the validity gate of impl2:588-589, the Newton update.  This mode is held to the tolerance, not to bits
 // (tests/test_tolerance_mode.py, bench.py `tolerance_mode`).
 #define NACC_F 37
 __host__ __device__ constexpr int fsym(int i, int j) { return i <= j ? 7 + i * 6 - i * (i - 1) / 2 + (j - i) : 7 + j * 6 - j * (j - 1) / 2 + (i - j); }
@@ -239,8 +239,11 @@ struct SweepCtl {               // 9 ints; two of them alternate: the sweep that
 // (tools/sweep_only.py, bench.py): ndt_omp at 1 m / 65,536 pts 1-3 % faster, but at 0.5 m / 131,072 pts (four times the voxel
 // records, fewer cache hits) 3 % slower, and ndt_pca 12 % slower there -- the prefetch matters as soon as records miss in L2,
 // so LEAN stays off.
-#ifndef FAST_WPE
-#define FAST_WPE 4             // tolerance arithmetic: 37 f32 accumulators instead of 43 f64 ones leave room for four waves per SIMD
+#ifndef FAST_WPE7
+#define FAST_WPE7 4            // tolerance arithmetic: 37 f32 accumulators instead of 43 f64 ones leave room for four waves per SIMD
+#endif
+#ifndef FAST_WPE1
+#define FAST_WPE1 3            // ... DIRECT1: three (168 registers: no spill; measured 1,338 us per pca / 1 m launch against 1,554 with four)
 #endif
 #ifndef FAST_TP7
 #define FAST_TP7 1
@@ -255,12 +258,12 @@ template <bool PCA, int K, int ORD = 0>
 struct SweepTune {
   static constexpr bool FAST = (ORD == 2);
   static constexpr bool LEAN = false;
-  static constexpr int  WPE  = FAST ? FAST_WPE : (LEAN ? 3 : SWEEP_WPE);                       // workgroups per CU = waves per SIMD
+  static constexpr int  WPE  = FAST ? (K == 1 ? FAST_WPE1 : FAST_WPE7) : (LEAN ? 3 : SWEEP_WPE);                       // workgroups per CU = waves per SIMD
   static constexpr bool PIPE = FAST ? (FAST_PIPE != 0) : !LEAN;                                      // fetch batch k+1's records in the middle of batch k
   // tiles probed together (8 = the whole work item); tolerance arithmetic: small super-tiles keep the LDS of a workgroup under a quarter of the CU's
   static constexpr int  TP   = FAST ? (K == 1 ? FAST_TP1 : FAST_TP7) : (LEAN ? 1 : (K == 1 ? 8 : (K <= 7 ? 2 : 1)));
 };
-static inline int sweep_wpe(bool pca, int K, bool fast = false) { (void)pca; (void)K; return fast ? FAST_WPE : SWEEP_WPE; }
+static inline int sweep_wpe(bool pca, int K, bool fast = false) { (void)pca; return fast ? (K == 1 ? FAST_WPE1 : FAST_WPE7) : SWEEP_WPE; }
 
 // IT = tiles of 64 points per work item.  8 is the batch mode described above (a wave-quarter of a 2048-point chunk).
 // FINE (latency mode): small items (IT = 1 or 2) dealt statically over ALL waves of the grid, for a sweep over one or a
@@ -285,6 +288,18 @@ __device__ __forceinline__ unsigned sweep_pose_words(const PairState* S) {
   if (lane < 21) w = __hip_atomic_load((const gu32*)reinterpret_cast<const unsigned*>(S) + lane, RLX_AGENT);
   return w;
 }
+
+template <bool PCA, int NROWS, bool ASYNC>
+__device__ __forceinline__ void sweep_rows_d1p(const int b, const int rem0, const float* __restrict__ src, const size_t pitch, const float T[12], const float Rj[9], const int n,
+                                               const GridDesc& g, const BitWord* __restrict__ words, const VoxelRec* __restrict__ recs,
+                                               double* partials, const int rows_per_pair, const SweepConst& sc
+#ifdef NDT_TIMELINE
+                                               , unsigned long long* tl, unsigned long long& tl_last
+#endif
+                                               );
+#ifndef FAST_D1_POINT
+#define FAST_D1_POINT 0          // tolerance arithmetic, DIRECT1: 1 = lane = point (sweep_rows_d1p) instead of the hit queue -- built, measured, not faster (below)
+#endif
 
 template <bool PCA, int K, int IT, bool FINE, int ORD, bool ASYNC>
 __device__ __forceinline__ void sweep_item(const int b, const int rem, const float* __restrict__ src, const size_t pitch, const PairState* st,
@@ -342,6 +357,14 @@ __device__ __forceinline__ void sweep_item(const int b, const int rem, const flo
   for (int a = 0; a < 12; a++) T[a] = ASYNC ? __uint_as_float(__builtin_amdgcn_readlane(pose_w, a)) : S.T[a];
 #pragma unroll
   for (int a = 0; a < 9; a++) Rj[a] = ASYNC ? __uint_as_float(__builtin_amdgcn_readlane(pose_w, 12 + a)) : S.Rj[a];
+  if constexpr (FAST && K == 1 && IT == 8 && !FINE && FAST_D1_POINT) {
+    sweep_rows_d1p<PCA, 1, ASYNC>(b, rem, src, pitch, T, Rj, n, g, words, recs, partials, rows_per_pair, sc
+#ifdef NDT_TIMELINE
+                                  , tl, tl_last
+#endif
+                                  );
+    return;
+  }
   const float leaf = g.leaf;
   const int mb0 = g.min_b[0], mb1 = g.min_b[1], mb2 = g.min_b[2];
   const int xb0 = g.max_b[0], xb1 = g.max_b[1], xb2 = g.max_b[2];
@@ -806,6 +829,155 @@ __device__ __forceinline__ void sweep_rows_d1(const int b, const int rem0, const
     }
 #pragma unroll
     for (int a = 0; a < 43; a++) acc[a] = 0.0;
+    nhits = 0;
+    TL_STAMP(6);
+#ifdef NDT_TIMELINE
+    tl[7] += 1;
+#endif
+  }
+}
+
+// EXPERIMENT, off by default (-DFAST_D1_POINT=1): DIRECT1 under the tolerance arithmetic with lane = POINT, no hit queue, no staging, no LDS at all.
+// Measured (round 6, docs/experiments.md 11): pca / 1 m 1,402 us per launch at four waves per SIMD (spills), 1,376 at three, against 1,338 for the hit
+// queue at three; config 5 / DIRECT1 2,917 / 2,711 against 2,395 -- the idle lanes cost more than the queue, and the launch is bound by the vector
+// L1's misses in flight for the point stream (TCP busy 98 %, 55-66 % of that stalled on L2, VALU busy 0.6), which more loads in flight per wave
+// do not raise.  One probe per point and ~0.85 hits leave a
+// DIRECT1 item a third evaluation and two thirds waiting for the chain  points -> bitmap word -> record  (sweep_rows_d1 above); with 37 f32
+// sums instead of 43 f64 ones the registers are there to keep three tiles of 64 points in flight per wave instead -- one whose points are
+// being transformed and probed, one whose record loads are out, one being evaluated -- and four waves per SIMD, which the queue's LDS
+// (48 KB of staging per workgroup) never allowed.  A lane whose point has no leaf evaluates with e = 0 (11 % of the lanes at 1 m, 19 % at
+// 0.5 m): cheaper than compacting.  The NROWS consecutive items of a claim go through as ONE stream of tiles; a row's sums are reduced and
+// written when its eighth tile has been evaluated, under the loads of the next row's first tiles.  Rows depend on (pair, row, input order)
+// alone.  Used by both the round-based sweep (NROWS = 1) and the one-launch align, so a pair's bits are the same in either.
+template <bool PCA, int NROWS, bool ASYNC>
+__device__ __forceinline__ void sweep_rows_d1p(const int b, const int rem0, const float* __restrict__ src, const size_t pitch, const float T[12], const float Rj[9], const int n,
+                                               const GridDesc& g, const BitWord* __restrict__ words, const VoxelRec* __restrict__ recs,
+                                               double* partials, const int rows_per_pair, const SweepConst& sc
+#ifdef NDT_TIMELINE
+                                               , unsigned long long* tl, unsigned long long& tl_last
+#endif
+                                               ) {
+  constexpr int IT = 8, S_TOTAL = NROWS * IT;
+  const int lane = threadIdx.x & 63;
+  const float* X = src + (size_t)b * 3 * pitch;
+  const BitWord* W = words + g.word_off;
+  const VoxelRecF* R = reinterpret_cast<const VoxelRecF*>(recs) + g.rec_off;
+  const bool grid_ok = (g.status == GRID_OK);
+  const float leaf = g.leaf;
+  const int mb0 = g.min_b[0], mb1 = g.min_b[1], mb2 = g.min_b[2];
+  const unsigned e0 = (unsigned)(g.max_b[0] - mb0), e1 = (unsigned)(g.max_b[1] - mb1), e2 = (unsigned)(g.max_b[2] - mb2);
+  const int mul1 = g.mul1, mul2 = g.mul2;
+  const int base = rem0 * (IT * 64);
+
+  float acc[NACC_F];
+#pragma unroll
+  for (int a = 0; a < NACC_F; a++) acc[a] = 0.f;
+  unsigned nhits = 0;
+  // stage registers: P = raw points (prefetched), A = transformed + probed (bitmap word in flight), B = ranked (record in flight)
+  float px = 0.f, py = 0.f, pz = 0.f;
+  float axt[3] = {0.f, 0.f, 0.f}, ar[3] = {0.f, 0.f, 0.f}; unsigned acell = 0u; bool ain = false; uint4 abw = make_uint4(0u, 0u, 0u, 0u);
+  float bxt[3] = {0.f, 0.f, 0.f}, br[3] = {0.f, 0.f, 0.f}; bool bhit = false;
+  float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0; int bweight = 0;
+  auto load_points = [&](const int s) {
+    const int i = base + s * 64 + lane;
+    px = py = pz = 0.f;
+    if (s < S_TOTAL && i < n) { px = X[i]; py = X[pitch + i]; pz = X[2 * pitch + i]; }
+  };
+  auto probe = [&](const int s) {                    // P -> A
+    const int i = base + s * 64 + lane;
+    bool ok = grid_ok && s < S_TOTAL && i < n && finite3(px, py, pz);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      axt[a] = ((T[a * 4 + 0] * px + T[a * 4 + 1] * py) + T[a * 4 + 2] * pz) + T[a * 4 + 3];     // PCL 1.8 transformPointCloud, uncontracted
+      ar[a] = fmaf(Rj[a * 3 + 2], pz, fmaf(Rj[a * 3 + 1], py, Rj[a * 3 + 0] * px));
+    }
+    ok = ok && finite3(axt[0], axt[1], axt[2]);
+    const int c0 = (int)floorf(sc.leaf_pow2 ? axt[0] * sc.inv_leaf : axt[0] / leaf);
+    const int c1 = (int)floorf(sc.leaf_pow2 ? axt[1] * sc.inv_leaf : axt[1] / leaf);
+    const int c2 = (int)floorf(sc.leaf_pow2 ? axt[2] * sc.inv_leaf : axt[2] / leaf);
+    const int r0 = c0 - mb0, r1 = c1 - mb1, r2 = c2 - mb2;
+    ain = ok && (unsigned)r0 <= e0 && (unsigned)r1 <= e1 && (unsigned)r2 <= e2;
+    acell = ain ? (unsigned)(r0 + r1 * mul1 + r2 * mul2) : 0u;
+    abw = make_uint4(0u, 0u, 0u, 0u);
+    if (ain) abw = *reinterpret_cast<const uint4*>(W + (acell >> 6));
+  };
+  auto rank = [&]() {                                // A -> B
+    const unsigned long long bits = ((unsigned long long)abw.y << 32) | abw.x;
+    const unsigned long long tb = bits << (63u - (acell & 63u));
+    const unsigned id = abw.z + (unsigned)__popcll(tb) - 1u;
+    bhit = ain && (long long)tb < 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) { bxt[a] = axt[a]; br[a] = ar[a]; }
+    if (bhit) {
+      const float4* rp = reinterpret_cast<const float4*>(R + id);
+      q0 = rp[0]; q1 = rp[1]; q2 = rp[2];
+      bweight = R[id].weight;
+    }
+  };
+  load_points(0);
+  TL_STAMP(1);
+  probe(0);
+  load_points(1);
+  TL_STAMP(2);
+  rank();
+  probe(1);
+  load_points(2);
+  TL_STAMP(4);
+#pragma unroll 1
+  for (int s = 0; s < S_TOTAL; s++) {
+    // in flight here: record(s), bitmap word(s + 1), points(s + 2)
+    float ext[3], er[3]; bool ehit; float4 e0q, e1q, e2q; int ew;
+    { ext[0] = bxt[0]; ext[1] = bxt[1]; ext[2] = bxt[2]; er[0] = br[0]; er[1] = br[1]; er[2] = br[2]; ehit = bhit; e0q = q0; e1q = q1; e2q = q2; ew = bweight; }
+    rank();                                          // tile s + 1: needs its bitmap word; issues its record loads
+    probe(s + 2);                                    // tile s + 2: needs its points; issues its bitmap load
+    load_points(s + 3);
+    {                                                // tile s: evaluate (its record arrived while the loads above went out)
+      const bool live = ehit && ew != VOX_DEAD;
+      const float u[3] = {(ext[0] - e0q.x) - e0q.w, (ext[1] - e0q.y) - e1q.x, (ext[2] - e0q.z) - e1q.y};
+      const float c[6] = {e1q.z, e1q.w, e2q.x, e2q.y, e2q.z, e2q.w};
+      eval_hit_fast<PCA, NoHook>(u, er, c, sc.d1f, sc.d2f, sc.kq, PCA ? (float)ew : 1.f, live, acc);
+      nhits += (unsigned)__popcll(__ballot(live));
+    }
+    TL_STAMP(5);
+    if ((s % IT) != IT - 1) continue;
+    // ---- the row is complete
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    double accd[43];
+    fast_acc_to_row(acc, accd);
+    double P1[22], P2[11];
+#pragma unroll
+    for (int i = 0; i < 22; i++) {
+      const double a = accd[i], b2 = (i + 22 < 43) ? accd[i + 22] : 0.0;
+      const u2v lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b2), false, false);
+      const u2v hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b2), false, false);
+      P1[i] = __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+    }
+#pragma unroll
+    for (int i = 0; i < 11; i++) {
+      const double a = P1[i], b2 = P1[i + 11];
+      const u2v lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b2), false, false);
+      const u2v hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b2), false, false);
+      double v = __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      P2[i] = v;
+    }
+    if ((lane & 15) == 0) {
+      const int row = lane >> 4, rb = 11 * (row & 1) + 22 * (row >> 1);
+      double* P = partials + ((size_t)b * rows_per_pair + rem0 + s / IT) * NACC;
+      if (ASYNC) {
+        gu64* PG = (gu64*)reinterpret_cast<unsigned long long*>(P);
+#pragma unroll
+        for (int i = 0; i < 11; i++) if (rb + i < 43) __hip_atomic_store(PG + rb + i, (unsigned long long)__double_as_longlong(P2[i]), RLX_AGENT);
+        if (lane == 0) __hip_atomic_store(PG + 43, (unsigned long long)__double_as_longlong((double)nhits), RLX_AGENT);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 11; i++) if (rb + i < 43) P[rb + i] = P2[i];
+        if (lane == 0) P[43] = (double)nhits;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < NACC_F; a++) acc[a] = 0.f;
     nhits = 0;
     TL_STAMP(6);
 #ifdef NDT_TIMELINE

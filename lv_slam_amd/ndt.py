@@ -91,7 +91,7 @@ OPT_DEBUG_ASYNC_ABORT = 3      # mi355ndt_option (test hook): the wave that clai
 OPT_DEBUG_ASYNC_RINGS = 6      # mi355ndt_option (test hook): bit x clear -> ring x of a one-launch align has no workgroups of its own
 OPT_STREAM_RESERVE = 5         # mi355ndt_option: workgroup slots the stream's launches leave free for the next batch's build (0 = off)
 OPT_STREAM_THRESHOLD = 4       # mi355ndt_option: pairs a stream launch hands over to the next one (-1 = auto, 0 = none)
-OPT_ARITH = 7                  # mi355ndt_option: 0 = the oracle's arithmetic operation by operation (default), 1 = tolerance arithmetic (held to 1e-4 m / 1e-5 rad, not to bits)
+OPT_ARITH = 7                  # mi355ndt_option: 0 = the reference recipe's arithmetic, one rounding per operation (default), 1 = tolerance arithmetic (held to 1e-4 m / 1e-5 rad, not to bits)
 OPT_F32_SUM_ORDER = 1          # mi355ndt_option: 0 = (t0 + t1) + t2 (canonical), 1 = (t0 + t2) + t1 (Eigen 3.3 SSE predux pairing)
 
 _LIB = None

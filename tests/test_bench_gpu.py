@@ -136,8 +136,8 @@ def test_streamed_headline_carries_both_rates():
     st = d["config"]["stream"]
     assert st["n_batches"] == 4 and st["n_contexts"] == 4 and st["bit_identical_to_synchronous"] is True and st["batches_rerun"] == 0 and st["launches_that_gave_up"] == 0
     assert st["launches"] >= 6 and st["pairs_handed_over"] > 0
-    assert d["value_streamed"] > 0 and d["value_synchronous"] > 0 and d["value"] == max(d["value_streamed"], d["value_synchronous"])
-    assert d["config"]["mode"].startswith("streamed" if d["value"] == d["value_streamed"] else "synchronous") and "faster of the two modes" in d["config"]["mode"]
+    assert d["value_streamed"] > 0 and d["value_synchronous"] > 0 and d["value"] == d["value_streamed"] and d["value_mode"] == "streamed"
+    assert d["config"]["mode"].startswith("streamed")
     assert d["roofline_streamed"]["launches"] >= 6 and d["roofline_synchronous"]["launches"] == 6
     d0 = run_bench(["--pairs", "8", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-host-clouds", "--config4-pairs", "0", "--seq-frames", "0",
                     "--no-other-configs", "--no-stream"])
@@ -245,3 +245,28 @@ def test_prefiltered_row():
     assert p["pairs_checked"] >= 2 and p["iterations_equal"] == p["pairs_checked"] and p["filtered_point_counts_equal"] == p["pairs_checked"]
     assert p["max_dtrans_m"] < 1e-4 and p["max_drot_rad"] < 1e-5
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0
+
+
+def test_tolerance_mode_block_rides_in_the_line():
+    """The default line carries the same jobs under MI355NDT_OPT_ARITH = 1 beside the exact `value` (which stays the headline): its own rates (streamed and
+    synchronous), every pair's result against the exact arithmetic's, a bounded oracle sample -- for the headline, the config-4 job and every other configuration."""
+    d = run_bench(["--pairs", "24", "--azimuth", "512", "--steps", "4", "--warmup", "1", "--cpu-seconds", "4", "--no-host-clouds", "--config4-pairs", "29", "--seq-frames", "0",
+                   "--other-seconds", "0.05"])
+    assert d["config"]["arith"] == 0 and d["dtype"] == "f32 terms, f64 accumulation" and d["value"] == d["value_streamed"]
+    t = d["tolerance_mode"]
+    assert d["value_tolerance_mode"] == t["value_tolerance_mode"] == t["value_tolerance_mode_streamed"] > 0 and t["value_tolerance_mode_synchronous"] > 0
+    assert t["stream"]["bit_identical_to_synchronous"] is True
+    v = t["vs_exact_arithmetic"]
+    assert v["pairs"] == 24 and v["iteration_flips"] == 0 and v["pairs_beyond_tolerance"] == 0 and 0 < v["max_dtrans_m"] < 1e-4
+    p = t["parity_vs_oracle"]
+    assert p["arith"] == 1 and p["pairs_checked"] >= 3 and p["iterations_equal"] == p["pairs_checked"] and p["pairs_beyond_tolerance"] == 0
+    c4 = d["config4"]["tolerance_mode"]
+    assert c4["vs_exact_arithmetic"]["pairs"] == 29 and c4["vs_exact_arithmetic"]["pairs_beyond_tolerance"] == 0 and d["config4"]["value_tolerance_mode"] > 0
+    for name, c in d["other_configs"]["configs"].items():
+        assert c["value_mode"] == "streamed" and c["value"] == c["value_streamed"], name
+        assert c["tolerance_mode"]["vs_exact_arithmetic"]["iteration_flips"] == 0 and c["tolerance_mode"]["vs_exact_arithmetic"]["pairs_beyond_tolerance"] == 0, name
+    # the whole line in the tolerance arithmetic, on request, says so
+    d1 = run_bench(["--arith", "1", "--pairs", "8", "--azimuth", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2", "--no-host-clouds", "--config4-pairs", "0", "--seq-frames", "0",
+                    "--no-other-configs"])
+    assert d1["config"]["arith"] == 1 and "tolerance arithmetic" in d1["dtype"] and d1["tolerance_mode"] is None
+    assert d1["parity"]["arith"] == 1 and d1["parity"]["pairs_beyond_tolerance"] == 0 and d1["parity"]["iterations_equal"] == d1["parity"]["pairs_checked"]

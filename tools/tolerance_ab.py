@@ -24,7 +24,7 @@ torch.cuda.set_device(0)
 W, tgen = bench.generate_synthetic(ctx, synth, list(range(a.first, a.first + a.pairs)), a.azimuth)
 prm = ndt.default_params(resolution=a.resolution, trans_epsilon=0.01, max_iterations=64, neighbor_mode=bench.MODES[a.mode], variant=1 if a.variant == "pca" else 0)
 out = {"lib": os.path.basename(ndt.LIB_PATH), "workload": f"{a.pairs}x{a.azimuth * 64} {a.variant} {a.mode} {a.resolution}", "gen_s": round(tgen, 1)}
-res = {}
+res, vox = {}, {}
 for name, arith in (("exact", 0), ("fast", 1)):
     if a.only and a.only != name:
         continue
@@ -33,6 +33,7 @@ for name, arith in (("exact", 0), ("fast", 1)):
     J = bench.timed_job(ctx, eng, W, a.pairs, a.pairs, a.steps, 3)
     r = bench.sweep_roofline(J)
     res[name] = np.frombuffer(np.frombuffer(J["res"], dtype=np.uint8).copy(), dtype=bench.RES_DT)
+    vox[name] = eng.get_voxels(0)
     out[name] = {"reg_s": round(a.pairs * J["steps"] / J["dt"], 1), "ms_per_step": round(1e3 * J["dt"] / J["steps"], 3), "launch_us": r["avg_launch_us"], "build_ms": r["build_ms_per_step"],
                  "frac": r["frac"], "mean_it": round(float(res[name]["it"].mean()), 3), "hits_per_point": r["hits_per_point"]}
     eng.close()
@@ -48,4 +49,13 @@ if len(res) == 2:
                             "median_dtrans_m": float(np.median(dts)), "p99_dtrans_m": float(np.percentile(dts, 99)), "converged_equal": int((E["conv"] == F["conv"]).sum()),
                             "max_rel_dscore": float(np.max(np.abs(E["score"] - F["score"]) / np.maximum(1e-300, np.abs(E["score"])))),
                             "speedup": round(out["fast"]["reg_s"] / out["exact"]["reg_s"], 3)}
+if len(vox) == 2:
+    A, B = vox["exact"], vox["fast"]
+    same_shape = len(A) == len(B) and bool(np.array_equal(A["idx"], B["idx"])) and bool(np.array_equal(A["n"], B["n"]))
+    out["voxels_pair0"] = {"leaves": len(A), "same_cells_and_counts": same_shape}
+    if same_shape:
+        for f in A.dtype.names:
+            if A[f].dtype.kind == "f":
+                d = np.abs(A[f].astype(np.float64) - B[f].astype(np.float64)); sc = np.maximum(1e-300, np.abs(A[f].astype(np.float64)))
+                out["voxels_pair0"]["max_rel_" + f] = float(np.max(d / sc)) if d.size else 0.0
 print(json.dumps(out), flush=True)
