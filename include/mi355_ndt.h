@@ -98,6 +98,9 @@ typedef struct mi355ndt_profile {
   long long stream_launches; /* stream mode: persistent launches (one per submitted batch + flushes) */
   long long stream_carried;  /* stream mode: pairs handed over from one launch to the next (stragglers that finished under a later batch) */
   long long stream_redone;   /* stream mode: batches re-run synchronously (build plan exceeded, or a launch gave up) */
+  long long cloud_uploads;   /* host clouds staged and sent over PCIe (set_target / set_source / batch_set_* / calculate_score / prefilter), counted always */
+  long long cloud_upload_bytes;
+  long long cloud_promotions; /* mi355ndt_promote_source_to_target calls (device-to-device instead of an upload) */
 } mi355ndt_profile;
 
 typedef struct mi355ndt_handle mi355ndt_handle;
@@ -137,6 +140,10 @@ const char* mi355ndt_last_error(const mi355ndt_handle* h);
 int mi355ndt_set_target(mi355ndt_handle* h, const void* pts, size_t n, size_t stride_bytes);
 /* replaces pcl::Registration::setInputSource(cloud) */
 int mi355ndt_set_source(mi355ndt_handle* h, const void* pts, size_t n, size_t stride_bytes);
+/* The cloud last handed over as SOURCE becomes the target (device-to-device copy + init()), without crossing PCIe again: the nodelet's keyframe switch
+ * `key = filtered; reg_s2k.setInputTarget(key);` (scan_matching_odom_nodelet.cpp:240-243) right after `filtered` was aligned as the source.  Same result as
+ * mi355ndt_set_target on the same cloud.  MI355NDT_ERR_STATE without a source (single-registration surface only). */
+int mi355ndt_promote_source_to_target(mi355ndt_handle* h);
 /* replaces align(output, guess) -> computeTransformation(output, guess) (ndt_omp_impl2.hpp:87-188) */
 int mi355ndt_align(mi355ndt_handle* h, const float guess_colmajor[16], mi355ndt_result* out);
 /* the `output` cloud of align(): source transformed by the final pose (f32, PCL 1.8 scalar form).

@@ -32,7 +32,7 @@ class NormalDistributionsTransform : public pcl::Registration<PointSource, Point
   using Base::transformation_epsilon_; using Base::converged_; using Base::update_visualizer_;
 
  public:
-  explicit NormalDistributionsTransform(int variant = MI355NDT_VARIANT_OMP, int device = 0) : h_(nullptr), trans_probability_(0) {
+  explicit NormalDistributionsTransform(int variant = MI355NDT_VARIANT_OMP, int device = 0) : h_(nullptr), trans_probability_(0), dev_src_(nullptr), dev_src_n_(0) {
     reg_name_ = "NormalDistributionsTransform";
     mi355ndt_default_params(&prm_);            // ctor defaults of ndt_omp_impl2.hpp:53-83
     prm_.variant = variant;
@@ -46,14 +46,22 @@ class NormalDistributionsTransform : public pcl::Registration<PointSource, Point
   inline void setInputTarget(const PointCloudTargetConstPtr& cloud) {   // ndt_omp.h:116-121
     Base::setInputTarget(cloud);
     push();
+    // the keyframe switch of scan_matching_odom_nodelet.cpp:240-243 -- `key = filtered; setInputTarget(key)` -- names the very cloud the device
+    // holds as the source: device-to-device instead of a second trip over PCIe (same grid, mi355ndt_promote_source_to_target)
+    if (same_cloud(cloud.get(), cloud->points.size()) && mi355ndt_promote_source_to_target(h_) == MI355NDT_OK) return;
     mi355ndt_set_target(h_, cloud->points.data(), cloud->points.size(), sizeof(PointTarget));
   }
   // ndt_omp.h:126-136: `if (input_) init();` -- the engine keeps the grid when it has no source yet (mi355ndt_set_params), and it has one
   // exactly when pcl::Registration::input_ is set: setInputSource below hands the cloud over at once
   inline void setResolution(float r) { if (prm_.resolution != r) { prm_.resolution = r; push(); } }
+  // The cloud goes to the device HERE, once: computeTransformation does not send it again as long as input_ still names the same cloud object
+  // and size (pcl::Registration holds a ConstPtr: a caller that rewrites the points of a cloud it has handed over must call setInputSource
+  // again, as PCL's own cached kd-trees require).  A PCL whose Registration::setInputSource is not virtual and is called through a base
+  // pointer never comes through here; computeTransformation then finds no record of the cloud and uploads it itself.
   virtual void setInputSource(const PointCloudSourceConstPtr& cloud) {
     Base::setInputSource(cloud);
-    if (cloud) mi355ndt_set_source(h_, cloud->points.data(), cloud->points.size(), sizeof(PointSource));
+    dev_src_ = nullptr; dev_src_n_ = 0;
+    if (cloud && mi355ndt_set_source(h_, cloud->points.data(), cloud->points.size(), sizeof(PointSource)) == MI355NDT_OK) { dev_src_ = cloud.get(); dev_src_n_ = cloud->points.size(); }
   }
   inline float getResolution() const { return prm_.resolution; }
   inline double getStepSize() const { return prm_.step_size; }
@@ -80,6 +88,8 @@ class NormalDistributionsTransform : public pcl::Registration<PointSource, Point
     trans = Eigen::Map<const Eigen::Matrix4f>(m);
   }
   static void convertTransform(const Eigen::Matrix<double, 6, 1>& x, Eigen::Affine3f& trans) { convertTransform(x, trans.matrix()); }
+  // not in the reference: the engine behind the object (mi355ndt_set_option, mi355ndt_profile_get, ...)
+  inline mi355ndt_handle* handle() const { return h_; }
   inline double getTransformationProbability() const { return trans_probability_; }
   inline int getFinalNumIteration() const { return nr_iterations_; }
   // pclpca's getTargetCells() (ndt_pca.h:129-133) hands out the VoxelGridCovariance itself; that container lives on the GPU here,
@@ -111,7 +121,10 @@ class NormalDistributionsTransform : public pcl::Registration<PointSource, Point
   // ndt_omp.h:256-267 / ndt_omp_impl2.hpp:87-188.  PCL's align() has already copied the source into `output`.
   virtual void computeTransformation(PointCloudSource& output, const Eigen::Matrix4f& guess) {
     push();
-    mi355ndt_set_source(h_, input_->points.data(), input_->points.size(), sizeof(PointSource));
+    if (!same_cloud(input_.get(), input_->points.size())) {         // (not handed over by setInputSource: see there)
+      dev_src_ = nullptr; dev_src_n_ = 0;
+      if (mi355ndt_set_source(h_, input_->points.data(), input_->points.size(), sizeof(PointSource)) == MI355NDT_OK) { dev_src_ = input_.get(); dev_src_n_ = input_->points.size(); }
+    }
     mi355ndt_result r;
     nr_iterations_ = 0;
     converged_ = false;
@@ -134,9 +147,13 @@ class NormalDistributionsTransform : public pcl::Registration<PointSource, Point
     if (update_visualizer_ != 0) update_visualizer_(output, std::vector<int>(), *target_, std::vector<int>());
   }
 
+  bool same_cloud(const void* cloud, size_t n) const { return cloud != nullptr && cloud == dev_src_ && n == dev_src_n_; }
+
   mi355ndt_handle* h_;
   mi355ndt_params prm_;
   double trans_probability_;
+  const void* dev_src_;          // the cloud object (and its size) the device holds as the source
+  size_t dev_src_n_;
 };
 
 }  // namespace mi355ndt

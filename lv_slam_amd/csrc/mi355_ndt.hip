@@ -192,6 +192,7 @@ struct mi355ndt_handle {
   void* s_pose_next = nullptr; size_t s_pose_cap_next = 0; int s_pose_base_next = 0, s_pose_stride_next = 1;   // apply to the next submit
   StreamCtx sctx[ASYNC_MAX_CTX];
   long long s_next_id = 0, s_launches = 0, s_counted = 0;
+  long long s_recovered_upto = -1;                // launches up to this one have had their abort handled (stream_recover runs once per aborted launch, not once per collect that walks past its slot)
   AsyncCtl* d_sctl = nullptr;                     // two control blocks: a launch reads the hand-over list of the previous one
   int* d_sring = nullptr;
   CtxStat* d_sstat = nullptr;                     // per context: pairs finalised, sizes and verdict of its last planned build
@@ -633,6 +634,8 @@ static int upload_cloud(mi355ndt_handle* h, float* d_base, size_t pitch, int pai
     u->used = e == hipSuccess;
     u->filling = false;
     h->uploads_pending = true;
+    h->P.cloud_uploads++;                          // (counted whether or not event profiling is on: tests/test_adaptor.py holds the drop-in to one per frame)
+    h->P.cloud_upload_bytes += (long long)(n * 3 * sizeof(float));
     if (e != hipSuccess) { h->err = std::string("upload: ") + hipGetErrorString(e); return MI355NDT_ERR_HIP; }
   }
   return MI355NDT_OK;
@@ -1963,6 +1966,27 @@ int mi355ndt_use_prefiltered(mi355ndt_handle* h, int role) {
   return compute_enqueued(h);
 }
 
+// The nodelet's keyframe switch (scan_matching_odom_nodelet.cpp:240-243: `key = filtered; reg_s2k.setInputTarget(key);`) makes the cloud that was
+// just aligned as SOURCE the next target: it is on the device already -- device-to-device into the target rows, then init() as setInputTarget does.
+int mi355ndt_promote_source_to_target(mi355ndt_handle* h) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  NOT_IN_STREAM(h);
+  if (h->n_pairs != 1 || !h->have_source || h->d_src != h->d_src_own || !h->d_src_own) return MI355NDT_ERR_STATE;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t m = (size_t)h->h_src_cnt[0];
+  int rc = ensure_single(h, true, m);
+  if (rc) return rc;
+  rc = uploads_before_compute(h);                 // the source's upload has to have landed; an earlier target upload must not land after these copies
+  if (rc) return rc;
+  const size_t dp = h->tgt_pitch, sp = h->src_pitch;
+  HIPCHK(h, hipMemsetAsync(h->d_tgt_own, 0, 3 * dp * sizeof(float), h->stream));
+  for (int a = 0; a < 3; a++)
+    if (m) HIPCHK(h, hipMemcpyAsync(h->d_tgt_own + a * dp, h->d_src_own + a * sp, m * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  h->h_tgt_cnt[0] = (int)m; h->have_target = true; h->targets_built = false;
+  h->P.cloud_promotions++;
+  return mi355ndt_batch_build_targets(h);
+}
+
 // ---- stream mode ----------------------------------------------------------------------------------------------------------
 // (include/mi355_ndt.h: mi355ndt_stream_*; kernels: ndt_async.hpp.  Replaces a run of batch_bind_device + batch_build_targets +
 //  batch_align triples for batches that arrive one after the other -- scan_matching_odom_nodelet.cpp:144-183 is a stream of frames.)
@@ -2024,7 +2048,7 @@ int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts, int max_pairs, siz
   h->s_nctx = n_contexts; h->s_max_pairs = max_pairs;
   h->s_items = std::max(1, (int)((max_src + CHUNK_PTS - 1) / CHUNK_PTS)) * QUARTERS;
   h->s_sync_only = !stream_async_ok(h);
-  h->s_next_id = 0; h->s_launches = 0; h->s_counted = 0; h->s_drop_carry = true;
+  h->s_next_id = 0; h->s_launches = 0; h->s_counted = 0; h->s_drop_carry = true; h->s_recovered_upto = -1;
   h->s_plan_cb = 0; h->s_plan_words = 0;
   // the grids a streamed launch reads are the contexts' (built at prm.resolution); whatever single-registration grid the parent still holds
   // -- possibly one a setResolution without a source left at another leaf size (ndt_omp.h:126-136) -- is no part of the stream
@@ -2280,6 +2304,7 @@ static void stream_recover(mi355ndt_handle* h) {
     if (S.busy && !S.done_sync && st[c].done != (unsigned)S.n_pairs) S.redo = true;
   }
   h->s_drop_carry = true;
+  h->s_recovered_upto = h->s_launches - 1;       // everything enqueued so far has drained and been marked: a later collect that reads this launch's abort flag again has nothing to do
   h->P.async_fallbacks++;
 }
 
@@ -2300,7 +2325,7 @@ int mi355ndt_stream_collect(mi355ndt_handle* h, long long batch_id, mi355ndt_res
       int rc = stream_wait_launch(h, j);
       if (rc) return rc;
       const StreamStatus st = *const_cast<const StreamStatus*>(h->h_sstatus + (j % mi355ndt_handle::S_EV));
-      if (st.abort_ && !S.redo) stream_recover(h);
+      if (st.abort_ && !S.redo && j > h->s_recovered_upto) stream_recover(h);
       plan_exceeded = st.ctx[ci].plan_exceeded != 0;
       if (S.redo || plan_exceeded) break;
       if (st.ctx[ci].done == (unsigned)S.n_pairs) break;

@@ -55,7 +55,8 @@ class Profile(C.Structure):
                 ("sweep_hits", C.c_longlong), ("sweep_points", C.c_longlong), ("build_ms", C.c_double),
                 ("build_launches", C.c_longlong), ("build_alg_bytes", C.c_double), ("update_ms", C.c_double),
                 ("update_launches", C.c_longlong), ("async_fallbacks", C.c_longlong), ("stream_launches", C.c_longlong),
-                ("stream_carried", C.c_longlong), ("stream_redone", C.c_longlong)]
+                ("stream_carried", C.c_longlong), ("stream_redone", C.c_longlong), ("cloud_uploads", C.c_longlong), ("cloud_upload_bytes", C.c_longlong),
+                ("cloud_promotions", C.c_longlong)]
 
 
 class SeqParams(C.Structure):
@@ -77,7 +78,7 @@ class SeqStats(C.Structure):
 SYMBOLS = [
     "mi355ndt_version", "mi355ndt_device_count", "mi355ndt_host_numa_node", "mi355ndt_default_params", "mi355ndt_create", "mi355ndt_destroy",
     "mi355ndt_set_params", "mi355ndt_get_params", "mi355ndt_set_stream", "mi355ndt_last_error",
-    "mi355ndt_set_target", "mi355ndt_set_source", "mi355ndt_align", "mi355ndt_get_aligned", "mi355ndt_get_incremental",
+    "mi355ndt_set_target", "mi355ndt_set_source", "mi355ndt_promote_source_to_target", "mi355ndt_align", "mi355ndt_get_aligned", "mi355ndt_get_incremental",
     "mi355ndt_get_fitness_score", "mi355ndt_fitness_score_T", "mi355ndt_prefilter", "mi355ndt_use_prefiltered", "mi355ndt_derivatives", "mi355ndt_compute_hessian", "mi355ndt_derivatives_T", "mi355ndt_get_grid", "mi355ndt_get_voxels",
     "mi355ndt_batch_reserve", "mi355ndt_batch_set_target", "mi355ndt_batch_set_source", "mi355ndt_batch_set_clouds", "mi355ndt_batch_bind_device",
     "mi355ndt_batch_build_targets", "mi355ndt_batch_align", "mi355ndt_batch_size", "mi355ndt_batch_pose_records",
@@ -228,6 +229,10 @@ class Engine:
     def set_target(self, cloud):
         a = _as_points(cloud)
         self._chk(self.lib.mi355ndt_set_target(self.h, a.ctypes.data_as(C.c_void_p), a.shape[0], a.strides[0]), "set_target")
+
+    def promote_source_to_target(self):
+        """the cloud last set as source becomes the target, device to device (the nodelet's keyframe switch, scan_matching_odom_nodelet.cpp:240-243)"""
+        self._chk(self.lib.mi355ndt_promote_source_to_target(self.h), "promote_source_to_target")
 
     def set_source(self, cloud):
         a = _as_points(cloud)

@@ -27,7 +27,56 @@ static pcl::PointCloud<PointT>::Ptr load(const char* path, size_t n) {
 
 static int g_vis_calls = 0;
 
+// adaptor_main seq <frames.f32> <n_frames> <n_points> : the per-frame call sequence of matching_s2k (scan_matching_odom_nodelet.cpp:192-261) on n_frames
+// clouds of n_points points -- frame 0 becomes the keyframe (setInputTarget), every later frame is setInputSource + align (frame 1 twice, :223-227),
+// every third frame is promoted to keyframe afterwards (`key = filtered; setInputTarget(key)`, :240-243) -- then prints the engine's cloud counters
+// (uploads, promotions) and every frame's final pose: ONE trip over PCIe per frame is the drop-in's budget.
+static int run_sequence(int argc, char** argv) {
+  if (argc < 5) return 2;
+  const size_t nf = strtoul(argv[3], 0, 10), np = strtoul(argv[4], 0, 10);
+  FILE* f = fopen(argv[2], "rb");
+  if (!f) { perror(argv[2]); return 2; }
+  std::vector<pcl::PointCloud<PointT>::Ptr> frames;
+  for (size_t k = 0; k < nf; k++) {
+    pcl::PointCloud<PointT>::Ptr c(new pcl::PointCloud<PointT>());
+    c->points.resize(np);
+    for (size_t i = 0; i < np; i++) {
+      float v[3];
+      if (fread(v, sizeof(float), 3, f) != 3) { fprintf(stderr, "short read\n"); return 2; }
+      c->points[i].x = v[0]; c->points[i].y = v[1]; c->points[i].z = v[2]; c->points[i].data[3] = 1.f; c->points[i].intensity = 0.f;
+    }
+    c->width = (unsigned)np;
+    frames.push_back(c);
+  }
+  fclose(f);
+  mi355ndt::NormalDistributionsTransform<PointT, PointT> reg(MI355NDT_VARIANT_PCA);
+  reg.setNumThreads(4);
+  reg.setTransformationEpsilon(0.01);
+  reg.setMaximumIterations(64);
+  reg.setResolution(1.0f);
+  reg.setNeighborhoodSearchMethod(mi355ndt::DIRECT1);
+  pcl::PointCloud<PointT>::ConstPtr key = frames[0];
+  reg.setInputTarget(key);
+  Eigen::Matrix4f guess = Eigen::Matrix4f::Identity();
+  guess(0, 3) = 1.0f;
+  std::vector<Eigen::Matrix4f> poses;
+  for (size_t k = 1; k < nf; k++) {
+    pcl::PointCloud<PointT> out;
+    reg.setInputSource(frames[k]);
+    reg.align(out, guess);
+    if (k == 1) reg.align(out, reg.getFinalTransformation());      // :223-227
+    poses.push_back(reg.getFinalTransformation());
+    if (k % 3 == 0) { key = frames[k]; reg.setInputTarget(key); }  // :240-243
+  }
+  mi355ndt_profile P;
+  mi355ndt_profile_get(reg.handle(), &P);
+  printf("%lld %lld %lld\n", P.cloud_uploads, P.cloud_promotions, P.cloud_upload_bytes);
+  for (size_t k = 0; k < poses.size(); k++) { for (int i = 0; i < 16; i++) printf("%.9g ", poses[k].data()[i]); printf("\n"); }
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 2 && !strcmp(argv[1], "seq")) return run_sequence(argc, argv);
   if (argc < 8) return 2;
   const size_t nt = strtoul(argv[3], 0, 10), ns = strtoul(argv[4], 0, 10);
   pcl::PointCloud<PointT>::Ptr tgt = load(argv[1], nt), src = load(argv[2], ns);

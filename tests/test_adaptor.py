@@ -28,7 +28,7 @@ def test_adaptor_compiles_and_links_against_pcl_stub():
     und = subprocess.check_output(["nm", "-u", exe], text=True)
     for sym in ["mi355ndt_create", "mi355ndt_set_target", "mi355ndt_set_source", "mi355ndt_align", "mi355ndt_get_aligned",
                 "mi355ndt_get_incremental", "mi355ndt_set_params", "mi355ndt_get_fitness_score", "mi355ndt_get_voxels", "mi355ndt_set_latency_mode",
-                "mi355ndt_calculate_score", "mi355ndt_convert_transform"]:
+                "mi355ndt_calculate_score", "mi355ndt_convert_transform", "mi355ndt_promote_source_to_target", "mi355ndt_profile_get"]:
         assert sym in und, sym
 
 
@@ -82,3 +82,41 @@ def test_adaptor_end_to_end(tmp_path, variant, mode, res, lat):
     assert float(w[0]) == eng.calculate_score(a)
     assert np.array_equal(np.array(w[1:17], np.float32).reshape(4, 4).T, full.convertTransform([1.0, 2.0, 3.0, 0.1, 0.2, 0.3])) and int(w[17]) == 1
     full.engine.close()
+
+
+@pytest.mark.gpu
+def test_adaptor_sends_every_frame_over_pcie_once(tmp_path):
+    """The nodelet's call sequence (scan_matching_odom_nodelet.cpp:192-261) through the adaptor: frame 0 is uploaded as the first keyframe, every later frame
+    ONCE as the source (setInputSource hands it over; neither align() -- frame 1 runs two -- nor the keyframe switch `key = filtered; setInputTarget(key)`
+    sends it again: the switch is a device-to-device promotion).  Poses equal those of the plain C-ABI sequence set_target / set_source / align."""
+    from lv_slam_amd import ndt, synth
+    exe = build_adaptor()
+    nf, naz = 8, 256
+    scans, _ = synth.make_sequence(nf, naz, n_beams=32)
+    frames = np.stack([sc.numpy().astype(np.float32) for sc in scans])
+    n = frames.shape[1]
+    frames.tofile(tmp_path / "frames.f32")
+    out = subprocess.check_output([exe, "seq", str(tmp_path / "frames.f32"), str(nf), str(n)], text=True, timeout=300).strip().splitlines()
+    uploads, promotions, nbytes = (int(x) for x in out[0].split())
+    assert uploads == nf, out[0]                          # one per frame: the first as target, the others as source
+    assert promotions == (nf - 1) // 3 and nbytes == nf * n * 12
+    # the same sequence through the C-ABI with an upload for everything
+    eng = ndt.Engine(ndt.default_params(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=ndt.DIRECT1, variant=1))
+    eng.set_target(frames[0])
+    G = synth.default_guess()
+    for k in range(1, nf):
+        eng.set_source(frames[k])
+        r = eng.align(G)
+        if k == 1:
+            r = eng.align(r["final"])
+        assert np.array_equal(np.array(out[k].split(), np.float32).reshape(4, 4).T, r["final"]), k
+        if k % 3 == 0:
+            eng.set_target(frames[k])
+    assert eng.profile_get()["cloud_uploads"] == nf + (nf - 1) // 3      # (this sequence sent every keyframe twice)
+    # ... and the promotion on its own: the grid it leaves is the grid set_target builds from the same cloud
+    v_up = eng.get_voxels(0)
+    eng.set_source(frames[6])
+    eng.promote_source_to_target()
+    v_pr = eng.get_voxels(0)
+    assert v_up.tobytes() == v_pr.tobytes() and eng.profile_get()["cloud_promotions"] == 1
+    eng.close()

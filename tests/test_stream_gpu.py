@@ -186,6 +186,36 @@ def test_one_launch_align_that_gives_up_is_rerun_by_the_rounds():
     assert pr["async_fallbacks"] >= 1 and pr["stream_redone"] >= 1
 
 
+def test_one_aborted_launch_is_recovered_once():
+    """ONE launch of a stream gives up (the hook is armed for the third submit only) while earlier batches still have pairs riding in it and later batches
+    follow: the recovery runs once -- one fallback counted, only the batches that were unfinished at that moment re-run, the batches submitted afterwards
+    stream normally -- and every result word still equals the synchronous align's.  (A recovery per collect that walked past the aborted launch's status
+    slot used to mark healthy later batches for a synchronous re-run as well.)"""
+    kw = dict(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=ndt.DIRECT7, variant=0)
+    batches, n = make_batches(3100, [40, 40, 40, 40, 40, 40, 40], 512)
+    ref = sync_results(batches, n, kw)
+    eng = ndt.Engine(ndt.default_params(**kw))
+    eng.set_option(ndt.OPT_STREAM_THRESHOLD, 16)             # pairs of batches 0 and 1 are carried into the launches behind them
+    eng.profile_enable(True)
+    eng.stream_begin(4, 40, n, n)
+    ids, got = [], []
+    for k, (T, S, cnt, G) in enumerate(batches):
+        if len(ids) - len(got) >= 4:
+            got.append(eng.stream_collect(ids[len(got)], 40))
+        eng.set_option(ndt.OPT_DEBUG_ASYNC_ABORT, 40 if k == 2 else -1)
+        ids.append(eng.stream_submit(T.data_ptr(), [n] * 40, n, S.data_ptr(), cnt, n, colmajor(G)))
+    while len(got) < len(ids):
+        got.append(eng.stream_collect(ids[len(got)], 40))
+    pr = eng.profile_get()
+    eng.stream_end()
+    eng.close()
+    for bi, (r, g) in enumerate(zip(ref, got)):
+        for k, (x, y) in enumerate(zip(r, g)):
+            assert same(x, y), (bi, k)
+    assert pr["async_fallbacks"] == 1, pr
+    assert 1 <= pr["stream_redone"] <= 4, pr                 # at most the batches resident when the launch gave up
+
+
 @pytest.mark.parametrize("mask", [0x0F, 0xA5, 0x01])
 def test_rings_without_workgroups_of_their_own_are_served_by_the_others(mask):
     """Tickets go round the eight rings and a ring is served by the workgroups of one XCD; nothing guarantees that every XCD holds workgroups
