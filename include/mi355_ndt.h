@@ -100,6 +100,7 @@ typedef struct mi355ndt_profile {
   long long stream_redone;   /* stream mode: batches re-run synchronously (build plan exceeded, or a launch gave up) */
   long long cloud_uploads;   /* host clouds staged and sent over PCIe (set_target / set_source / batch_set_* / calculate_score / prefilter), counted always */
   long long cloud_upload_bytes;
+  long long cloud_transfers;  /* host-to-device transfers those clouds travelled in (mi355ndt_batch_set_clouds / stream_submit_host send up to eight clouds per transfer) */
   long long cloud_promotions; /* mi355ndt_promote_source_to_target calls (device-to-device instead of an upload) */
 } mi355ndt_profile;
 
@@ -300,6 +301,13 @@ int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts /* 2..4 */, int max
 int mi355ndt_stream_submit(mi355ndt_handle* h, int n_pairs, const float* d_targets, const int* target_counts, size_t target_pitch,
                            const float* d_sources, const int* source_counts, size_t source_pitch, const float* guesses_colmajor,
                            long long* batch_id);
+/* The same for HOST clouds -- what the node has (scan_matching_odom_nodelet.cpp:144-183: pcl::PointCloud records arriving one callback at a time): arrays of
+ * n_pairs pointers to the targets' / sources' records (x, y, z as the first three floats of every `stride_bytes`-long record, as mi355ndt_set_target takes
+ * them) and their point counts.  The clouds are staged by `n_threads` threads of the engine (0 = 8) into the batch context's pinned slots, cross PCIe and land in
+ * the context's own device buffers while the launches of earlier batches run; returns as soon as the caller's memory is no longer needed.  Counts must not
+ * exceed what mi355ndt_stream_begin was told.  Results: word for word those of mi355ndt_batch_set_clouds + batch_build_targets + batch_align. */
+int mi355ndt_stream_submit_host(mi355ndt_handle* h, int n_pairs, const void* const* targets, const size_t* target_counts, const void* const* sources,
+                                const size_t* source_counts, size_t stride_bytes, const float* guesses_colmajor, int n_threads, long long* batch_id);
 int mi355ndt_stream_collect(mi355ndt_handle* h, long long batch_id, mi355ndt_result* out);
 /* Pose records for the multi-GPU gather (the 96-byte layout of mi355ndt_batch_pose_records) of the NEXT batch submitted: `d_records` is a
  * caller-owned DEVICE buffer of `capacity` records (>= that batch's pairs); record b is written by the device -- by the very wave that

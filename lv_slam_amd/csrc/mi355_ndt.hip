@@ -144,7 +144,7 @@ struct mi355ndt_handle {
   // records are compacted to x,y,z into a slot (the only CPU work), the slot goes over PCIe asynchronously and a small kernel
   // spreads it into the SoA rows; the next call stages the next cloud while this one is still in flight.
   struct UpSlot { float* h = nullptr; float* d = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false, filling = false; };
-  static constexpr int UP_SLOTS = 16;
+  static constexpr int UP_SLOTS = 12;             // (a slot grows to the largest transfer it has carried: up to UP_GROUP_MAX clouds = 12.6 MB of 65,536-point clouds)
   UpSlot up[UP_SLOTS];
   int up_next = 0;
   static constexpr int UP_STREAMS = 4;            // an upload rides copy stream (pair + 2 * side) % UP_STREAMS: per-transfer latencies of the SDMA queues
@@ -186,6 +186,7 @@ struct mi355ndt_handle {
   };
   bool stream_on = false, s_sync_only = false, s_drop_carry = true;
   int s_nctx = 0, s_max_pairs = 0, s_items = 0, s_ring_cap = 0, s_thresh = 0;
+  size_t s_max_tgt = 0, s_max_src = 0;            // what mi355ndt_stream_begin was told (mi355ndt_stream_submit_host sizes the contexts' own cloud buffers with it)
   int s_thresh_opt = -1;                          // MI355NDT_OPT_STREAM_THRESHOLD
   int s_reserve_opt = -1;                         // MI355NDT_OPT_STREAM_RESERVE
   int s_plan_cb = 0; size_t s_plan_words = 0;
@@ -225,6 +226,11 @@ struct mi355ndt_handle {
 
 // several kernels carry the pair index in grid.y (HIP limit 65535)
 #define MAX_PAIRS 65535
+#ifndef UP_GROUP_PAIRS
+#define UP_GROUP_PAIRS 8          // pair slots per upload group of mi355ndt_batch_set_clouds: their targets and sources travel as ONE transfer (measured, 271-pair
+#endif                            // batches of 32-byte records streamed: 2 / 4 / 8 pairs per transfer = 20.2 / 21.4 / 22.2 k registrations/s; one cloud per transfer: 15.4 k)
+#define UP_GROUP_MAX   (2 * UP_GROUP_PAIRS)
+static_assert(UP_GROUP_MAX <= (int)(sizeof(DeintTab::e) / sizeof(DeintTab::e[0])), "k_deinterleave_multi's table");
 // between mi355ndt_stream_begin and mi355ndt_stream_end the handle's batches belong to the stream: the other entry points refuse
 #define NOT_IN_STREAM(h) do { if ((h)->stream_on) { (h)->err = "the handle is in stream mode (mi355ndt_stream_begin): call mi355ndt_stream_end first"; return MI355NDT_ERR_STATE; } } while (0)
 static inline void cpu_relax() {
@@ -582,11 +588,20 @@ static int compute_enqueued(mi355ndt_handle* h) {       // call after enqueueing
   return MI355NDT_OK;
 }
 
-// One host cloud -> SoA rows of pair slot `pair` in d_base, asynchronously.  Returns as soon as the caller's memory is no longer
-// needed (the records are compacted into a pinned ring slot; nothing of the caller's buffer is referenced afterwards).
-static int upload_cloud(mi355ndt_handle* h, float* d_base, size_t pitch, int pair, const void* pts, size_t n, size_t stride) {
-  if (!pts && n) return MI355NDT_ERR_BAD_ARG;
-  if ((n && stride < 12) || n > pitch) return MI355NDT_ERR_BAD_ARG;
+// Host clouds -> SoA rows of their pair slots, asynchronously, SEVERAL CLOUDS PER TRANSFER.  Returns as soon as the caller's memory is no longer
+// needed (the records are compacted into a pinned ring slot; nothing of the caller's buffers is referenced afterwards).  One transfer = one
+// hipMemcpyAsync + one k_deinterleave_multi launch + one event, whatever the number of clouds in it: with one cloud per transfer the ~50 us of
+// HIP calls per cloud, serialised under the engine's lock, held the staging of a 271-pair batch to 60 GB/s of records read whatever the number
+// of staging threads (round 6, tools/host_stage_probe.cpp: the same compaction alone reaches 180-195 GB/s at eight threads on the same host).
+struct UpItem { float* d_base; size_t pitch; int pair; const void* pts; size_t n, stride; };
+static int upload_items(mi355ndt_handle* h, const UpItem* it, int cnt) {
+  if (cnt < 1 || cnt > UP_GROUP_MAX) return MI355NDT_ERR_BAD_ARG;
+  size_t total = 0;
+  for (int k = 0; k < cnt; k++) {
+    if (!it[k].pts && it[k].n) return MI355NDT_ERR_BAD_ARG;
+    if ((it[k].n && it[k].stride < 12) || it[k].n > it[k].pitch) return MI355NDT_ERR_BAD_ARG;
+    total += it[k].n;
+  }
   mi355ndt_handle::UpSlot* u = nullptr;
   for (;;) {                                      // a slot no other thread is filling right now
     {
@@ -602,11 +617,11 @@ static int upload_cloud(mi355ndt_handle* h, float* d_base, size_t pitch, int pai
   hipError_t e = hipSuccess;
   if (!u->ev) e = hipEventCreateWithFlags(&u->ev, hipEventDisableTiming);
   if (e == hipSuccess && u->used) e = hipEventSynchronize(u->ev);      // the slot's previous transfer has to be out of the pinned buffer
-  if (e == hipSuccess && n > u->cap) {
+  if (e == hipSuccess && total > u->cap) {
     if (u->h) { (void)hipHostFree(u->h); u->h = nullptr; }
     if (u->d) { (void)hipFree(u->d); u->d = nullptr; }
     u->cap = 0; u->used = false;
-    const size_t cap = std::max(n, (size_t)65536);
+    const size_t cap = std::max(total, (size_t)65536);
     e = hipHostMalloc((void**)&u->h, cap * 3 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&u->d, cap * 3 * sizeof(float));
     if (e == hipSuccess) u->cap = cap;
@@ -617,28 +632,44 @@ static int upload_cloud(mi355ndt_handle* h, float* d_base, size_t pitch, int pai
     u->filling = false;
     return MI355NDT_ERR_HIP;
   }
-  // the CPU part, outside the lock: x,y,z of every record into the pinned slot
-  const unsigned char* p = (const unsigned char*)pts;
-  if (stride == 12) memcpy(u->h, p, n * 12);
-  else for (size_t i = 0; i < n; i++) memcpy(u->h + 3 * i, p + i * stride, 12);
+  // the CPU part, outside the lock: x,y,z of every record into the pinned slot, cloud after cloud
+  DeintTab tab;
+  tab.cnt = cnt;
+  size_t off = 0, max_pitch = 0;
+  for (int k = 0; k < cnt; k++) {
+    const unsigned char* p = (const unsigned char*)it[k].pts;
+    float* dst = u->h + 3 * off;
+    const size_t n = it[k].n, stride = it[k].stride;
+    if (stride == 12) { if (n) memcpy(dst, p, n * 12); }
+    else for (size_t i = 0; i < n; i++) memcpy(dst + 3 * i, p + i * stride, 12);
+    tab.e[k].src_off = 3 * off; tab.e[k].n = (int)n; tab.e[k].rows = it[k].d_base + (size_t)it[k].pair * 3 * it[k].pitch; tab.e[k].pitch = it[k].pitch;
+    off += n;
+    max_pitch = std::max(max_pitch, it[k].pitch);
+  }
   {
     std::lock_guard<std::mutex> lk(h->up_mtx);
-    // the copy stream is chosen by DESTINATION (pair slot and side), not by staging slot: two uploads into the same rows -- set_source(A)
-    // then set_source(B) with no build / align in between -- ride one stream and land in call order
-    hipStream_t cs = h->copy_stream[(pair + (d_base == h->d_src_own ? 2 : 0)) % mi355ndt_handle::UP_STREAMS];   // (one-sided batches use all four streams)
-    if (n) e = hipMemcpyAsync(u->d, u->h, n * 3 * sizeof(float), hipMemcpyHostToDevice, cs);
+    // the copy stream is chosen by DESTINATION (the pair slot's group), not by staging slot: two uploads into the same rows -- set_source(A)
+    // then set_source(B) with no build / align in between -- ride one stream and land in call order (a group never spans two stream classes:
+    // mi355ndt_batch_set_clouds groups pairs by pair / UP_GROUP_PAIRS)
+    hipStream_t cs = h->copy_stream[(it[0].pair / UP_GROUP_PAIRS) % mi355ndt_handle::UP_STREAMS];
+    if (total) e = hipMemcpyAsync(u->d, u->h, total * 3 * sizeof(float), hipMemcpyHostToDevice, cs);
     if (e == hipSuccess) {
-      k_deinterleave<<<(unsigned)((pitch + 255) / 256), 256, 0, cs>>>(u->d, (int)n, d_base + (size_t)pair * 3 * pitch, pitch);
+      k_deinterleave_multi<<<dim3((unsigned)((max_pitch + 255) / 256), (unsigned)cnt), 256, 0, cs>>>(u->d, tab);
       e = hipEventRecord(u->ev, cs);
     }
     u->used = e == hipSuccess;
     u->filling = false;
     h->uploads_pending = true;
-    h->P.cloud_uploads++;                          // (counted whether or not event profiling is on: tests/test_adaptor.py holds the drop-in to one per frame)
-    h->P.cloud_upload_bytes += (long long)(n * 3 * sizeof(float));
+    h->P.cloud_uploads += cnt;                     // (counted whether or not event profiling is on: tests/test_adaptor.py holds the drop-in to one per frame)
+    h->P.cloud_upload_bytes += (long long)(total * 3 * sizeof(float));
+    h->P.cloud_transfers++;
     if (e != hipSuccess) { h->err = std::string("upload: ") + hipGetErrorString(e); return MI355NDT_ERR_HIP; }
   }
   return MI355NDT_OK;
+}
+static int upload_cloud(mi355ndt_handle* h, float* d_base, size_t pitch, int pair, const void* pts, size_t n, size_t stride) {
+  const UpItem it = {d_base, pitch, pair, pts, n, stride};
+  return upload_items(h, &it, 1);
 }
 
 int mi355ndt_batch_set_target(mi355ndt_handle* h, int pair, const void* pts, size_t n, size_t stride) {
@@ -685,14 +716,23 @@ int mi355ndt_batch_set_clouds(mi355ndt_handle* h, int first_pair, int n, const v
     CPU_AND(&near, &near, &mine);
     pin = CPU_COUNT(&near) > 0;
   } else pin = false;
-  std::atomic<int> next_pair{0};                 // pairs are taken one by one: a thread that runs slowly (the caller's, t = 0, may
-  auto work = [&](int t) {                       // sit on a narrowed CPU set) simply takes fewer of them
+  // pairs are taken in GROUPS of UP_GROUP_PAIRS consecutive pair slots (aligned to the slot index, so that a slot's uploads always ride the same
+  // copy stream): one transfer per group -- both clouds of up to four pairs -- instead of one per cloud (upload_items); a thread that runs slowly
+  // (the caller's, t = 0, may sit on a narrowed CPU set) simply takes fewer groups
+  const int g_first = first_pair / UP_GROUP_PAIRS, g_last = (first_pair + n - 1) / UP_GROUP_PAIRS;
+  std::atomic<int> next_group{g_first};
+  auto work = [&](int t) {
     (void)hipSetDevice(h->device);
     if (pin && t > 0) (void)sched_setaffinity(0, sizeof near, &near);   // (t = 0 is the caller's thread: left alone)
-    for (int k = next_pair.fetch_add(1); k < n; k = next_pair.fetch_add(1)) {
-      int rc = MI355NDT_OK;
-      if (targets) rc = mi355ndt_batch_set_target(h, first_pair + k, targets[k], target_counts[k], stride);
-      if (rc == MI355NDT_OK && sources) rc = mi355ndt_batch_set_source(h, first_pair + k, sources[k], source_counts[k], stride);
+    for (int g = next_group.fetch_add(1); g <= g_last; g = next_group.fetch_add(1)) {
+      UpItem it[UP_GROUP_MAX];
+      int cnt = 0;
+      for (int pr = std::max(first_pair, g * UP_GROUP_PAIRS); pr < std::min(first_pair + n, (g + 1) * UP_GROUP_PAIRS); pr++) {
+        const int k = pr - first_pair;
+        if (targets) it[cnt++] = UpItem{h->d_tgt_own, h->tgt_pitch, pr, targets[k], target_counts[k], stride};
+        if (sources) it[cnt++] = UpItem{h->d_src_own, h->src_pitch, pr, sources[k], source_counts[k], stride};
+      }
+      const int rc = upload_items(h, it, cnt);
       if (rc != MI355NDT_OK) { rcs[(size_t)t] = rc; return; }
     }
   };
@@ -704,6 +744,15 @@ int mi355ndt_batch_set_clouds(mi355ndt_handle* h, int first_pair, int n, const v
   work(0);
   for (auto& x : th) x.join();
   for (int rc : rcs) if (rc != MI355NDT_OK) return rc;
+  {
+    std::lock_guard<std::mutex> lk(h->up_mtx);
+    for (int k = 0; k < n; k++) {
+      if (targets) h->h_tgt_cnt[(size_t)(first_pair + k)] = (int)target_counts[k];
+      if (sources) h->h_src_cnt[(size_t)(first_pair + k)] = (int)source_counts[k];
+    }
+    if (targets) { h->targets_built = false; h->have_target = true; }
+    if (sources) h->have_source = true;
+  }
   return MI355NDT_OK;
 }
 
@@ -806,6 +855,9 @@ int mi355ndt_profile_get(mi355ndt_handle* h, mi355ndt_profile* out) {
     ev_collect(e, e->ev_update, h->P.update_ms, h->P.update_launches);
     ev_collect(e, e->ev_build, h->P.build_ms, h->P.build_launches);
     h->P.build_alg_bytes += e->P.build_alg_bytes; e->P.build_alg_bytes = 0;
+    { std::lock_guard<std::mutex> lk(e->up_mtx);   // (mi355ndt_stream_submit_host stages into the contexts' engines)
+      h->P.cloud_uploads += e->P.cloud_uploads; e->P.cloud_uploads = 0; h->P.cloud_upload_bytes += e->P.cloud_upload_bytes; e->P.cloud_upload_bytes = 0;
+      h->P.cloud_transfers += e->P.cloud_transfers; e->P.cloud_transfers = 0; }
   }
   unsigned long long hh = 0;                      // (point, voxel) evaluations since the last reset, summed on the device
   HIPCHK(h, hipMemcpy(&hh, h->d_hits, sizeof hh, hipMemcpyDeviceToHost));
@@ -2045,7 +2097,7 @@ int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts, int max_pairs, siz
   if (h->stream_on) return MI355NDT_ERR_STATE;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  h->s_nctx = n_contexts; h->s_max_pairs = max_pairs;
+  h->s_nctx = n_contexts; h->s_max_pairs = max_pairs; h->s_max_tgt = max_tgt; h->s_max_src = max_src;
   h->s_items = std::max(1, (int)((max_src + CHUNK_PTS - 1) / CHUNK_PTS)) * QUARTERS;
   h->s_sync_only = !stream_async_ok(h);
   h->s_next_id = 0; h->s_launches = 0; h->s_counted = 0; h->s_drop_carry = true; h->s_recovered_upto = -1;
@@ -2282,6 +2334,37 @@ int mi355ndt_stream_submit(mi355ndt_handle* h, int n_pairs, const float* d_t, co
   e->aligned_once = true;
   *batch_id = id; h->s_next_id++;
   return MI355NDT_OK;
+}
+
+// The stream for the caller the reference actually has: HOST clouds (scan_matching_odom_nodelet.cpp:144-183 receives pcl::PointCloud records, one
+// callback at a time).  The batch's clouds are staged by the engine's own threads into the pinned slots of the context this batch lives in,
+// cross PCIe on that context's copy streams and land in ITS device buffers -- while the launches of the batches submitted before keep the GPU
+// busy -- and then the batch goes the way of mi355ndt_stream_submit.  Returns when the caller's memory is no longer needed.
+int mi355ndt_stream_submit_host(mi355ndt_handle* h, int n_pairs, const void* const* targets, const size_t* target_counts, const void* const* sources,
+                                const size_t* source_counts, size_t stride, const float* guesses, int n_threads, long long* batch_id) {
+  if (!h) return MI355NDT_ERR_BAD_HANDLE;
+  if (!h->stream_on) return MI355NDT_ERR_STATE;
+  if (n_pairs < 1 || n_pairs > h->s_max_pairs || !targets || !target_counts || !sources || !source_counts || stride < 12 || !guesses || !batch_id) return MI355NDT_ERR_BAD_ARG;
+  for (int b = 0; b < n_pairs; b++)
+    if (target_counts[b] > h->s_max_tgt || source_counts[b] > h->s_max_src || (!targets[b] && target_counts[b]) || (!sources[b] && source_counts[b])) return MI355NDT_ERR_BAD_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  const int ci = (int)(h->s_next_id % h->s_nctx);
+  mi355ndt_handle::StreamCtx& S = h->sctx[ci];
+  if (S.busy) { h->err = "stream_submit_host: collect batch " + std::to_string(S.batch_id) + " first (its context is the one this batch needs)"; return MI355NDT_ERR_STATE; }
+  mi355ndt_handle* e = S.e;
+  const size_t tp = (h->s_max_tgt + 63) & ~(size_t)63, sp = (h->s_max_src + 63) & ~(size_t)63;
+  if (!e->d_tgt_own || !e->d_src_own || e->own_tgt_pairs < h->s_max_pairs || e->own_src_pairs < h->s_max_pairs || e->own_tgt_pitch != tp || e->own_src_pitch != sp) {
+    int rc = mi355ndt_batch_reserve(e, h->s_max_pairs, h->s_max_tgt, h->s_max_src);      // (once per context: the stream's sizes never change)
+    if (rc) { h->err = e->err; return rc; }
+  }
+  // (the context's previous batch has been collected -- S.busy is false --, so no kernel still reads these rows)
+  e->n_pairs = h->s_max_pairs; e->d_tgt = e->d_tgt_own; e->d_src = e->d_src_own; e->tgt_pitch = tp; e->src_pitch = sp;
+  int rc = mi355ndt_batch_set_clouds(e, 0, n_pairs, targets, target_counts, sources, source_counts, stride, n_threads);
+  if (rc) { h->err = e->err; return rc; }
+  std::vector<int> tc((size_t)n_pairs), sc((size_t)n_pairs);
+  for (int b = 0; b < n_pairs; b++) { tc[(size_t)b] = (int)target_counts[b]; sc[(size_t)b] = (int)source_counts[b]; }
+  // (the build that mi355ndt_stream_submit enqueues first waits for these uploads: uploads_before_compute of the context's engine)
+  return mi355ndt_stream_submit(h, n_pairs, e->d_tgt_own, tc.data(), tp, e->d_src_own, sc.data(), sp, guesses, batch_id);
 }
 
 int mi355ndt_stream_pose_records(mi355ndt_handle* h, void* d_records, size_t capacity, int id_base, int id_stride) {

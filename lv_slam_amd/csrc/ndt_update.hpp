@@ -507,6 +507,20 @@ NDT_KERNEL void __launch_bounds__(256) k_deinterleave(const float* __restrict__ 
 }
 
 
+// ... and several clouds of one transfer at once (grid.y = cloud): mi355_ndt.hip, upload_items
+struct DeintTab { int cnt, pad_; struct { unsigned long long src_off; float* rows; unsigned long long pitch; int n, pad_; } e[16]; };
+NDT_KERNEL void __launch_bounds__(256) k_deinterleave_multi(const float* __restrict__ packed, const DeintTab tab) {
+  const int c = blockIdx.y;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t pitch = tab.e[c].pitch;
+  if (i >= pitch) return;
+  const float* xyz = packed + tab.e[c].src_off;
+  float x = 0.f, y = 0.f, z = 0.f;
+  if (i < (size_t)tab.e[c].n) { x = xyz[3 * i]; y = xyz[3 * i + 1]; z = xyz[3 * i + 2]; }
+  float* rows = tab.e[c].rows;
+  rows[i] = x; rows[pitch + i] = y; rows[2 * pitch + i] = z;
+}
+
 // Pose records for the multi-GPU gather: 96 bytes = {float final[16] column-major; float score; int iterations;
 // int converged; int pair_id; int pad[4]} per pair, packed on the device straight from the results of the last batch align.
 // Rows past the batch (a rank that owns one pair fewer than its neighbours) carry pair_id = -1.

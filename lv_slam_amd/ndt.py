@@ -56,7 +56,7 @@ class Profile(C.Structure):
                 ("build_launches", C.c_longlong), ("build_alg_bytes", C.c_double), ("update_ms", C.c_double),
                 ("update_launches", C.c_longlong), ("async_fallbacks", C.c_longlong), ("stream_launches", C.c_longlong),
                 ("stream_carried", C.c_longlong), ("stream_redone", C.c_longlong), ("cloud_uploads", C.c_longlong), ("cloud_upload_bytes", C.c_longlong),
-                ("cloud_promotions", C.c_longlong)]
+                ("cloud_transfers", C.c_longlong), ("cloud_promotions", C.c_longlong)]
 
 
 class SeqParams(C.Structure):
@@ -85,7 +85,7 @@ SYMBOLS = [
     "mi355ndt_profile_enable", "mi355ndt_profile_reset", "mi355ndt_profile_get", "mi355ndt_synchronize",
     "mi355ndt_set_latency_mode", "mi355ndt_sequence_run",
     "mi355ndt_calculate_score", "mi355ndt_convert_transform", "mi355ndt_set_option", "mi355ndt_get_option",
-    "mi355ndt_stream_begin", "mi355ndt_stream_submit", "mi355ndt_stream_collect", "mi355ndt_stream_end", "mi355ndt_stream_pose_records", "mi355ndt_pack_pose_records",
+    "mi355ndt_stream_begin", "mi355ndt_stream_submit", "mi355ndt_stream_submit_host", "mi355ndt_stream_collect", "mi355ndt_stream_end", "mi355ndt_stream_pose_records", "mi355ndt_pack_pose_records",
 ]
 OPT_ASYNC_ALIGN = 2            # mi355ndt_option: 1 (default) = one persistent launch per batch align, 0 = lockstep (update, sweep) rounds; same bits
 OPT_DEBUG_ASYNC_ABORT = 3      # mi355ndt_option (test hook): the wave that claims this position of ring 0 gives up -> the batch is re-run in rounds
@@ -120,6 +120,7 @@ def load_library(path: str = LIB_PATH):
     L.mi355ndt_set_stream.argtypes = [vp, vp]
     L.mi355ndt_set_target.argtypes = [vp, vp, sz, sz]
     L.mi355ndt_set_source.argtypes = [vp, vp, sz, sz]
+    L.mi355ndt_promote_source_to_target.argtypes = [vp]
     L.mi355ndt_align.argtypes = [vp, vp, C.POINTER(Result)]
     L.mi355ndt_get_aligned.argtypes = [vp, vp, sz]
     L.mi355ndt_get_incremental.argtypes = [vp, i, vp, vp]
@@ -153,6 +154,7 @@ def load_library(path: str = LIB_PATH):
     L.mi355ndt_get_option.argtypes = [vp, i, C.POINTER(i)]
     L.mi355ndt_stream_begin.argtypes = [vp, i, i, sz, sz]
     L.mi355ndt_stream_submit.argtypes = [vp, i, vp, vp, sz, vp, vp, sz, vp, C.POINTER(C.c_longlong)]
+    L.mi355ndt_stream_submit_host.argtypes = [vp, i, vp, vp, vp, vp, sz, vp, i, C.POINTER(C.c_longlong)]
     L.mi355ndt_stream_collect.argtypes = [vp, C.c_longlong, vp]
     L.mi355ndt_stream_end.argtypes = [vp]
     L.mi355ndt_stream_pose_records.argtypes = [vp, vp, sz, i, i]
@@ -419,6 +421,18 @@ class Engine:
         self._chk(self.lib.mi355ndt_stream_submit(self.h, len(tc), C.c_void_p(d_targets_ptr), tc.ctypes.data_as(C.c_void_p), target_pitch,
                                                   C.c_void_p(d_sources_ptr), sc.ctypes.data_as(C.c_void_p), source_pitch,
                                                   g.ctypes.data_as(C.c_void_p), C.byref(bid)), "stream_submit")
+        return bid.value
+
+    def stream_submit_host_raw(self, tgt_ptrs, tgt_counts, src_ptrs, src_counts, stride: int, guesses_colmajor: np.ndarray, threads: int = 8) -> int:
+        """Enqueue one batch of HOST clouds (arrays of record pointers and point counts, as batch_set_clouds_raw takes them); returns the batch id
+        as soon as the caller's memory is no longer needed."""
+        tp = np.ascontiguousarray(tgt_ptrs, np.uint64); sp = np.ascontiguousarray(src_ptrs, np.uint64)
+        tc = np.ascontiguousarray(tgt_counts, np.uint64); sc = np.ascontiguousarray(src_counts, np.uint64)
+        g = np.ascontiguousarray(guesses_colmajor, np.float32)
+        assert len(tp) == len(sp) == len(tc) == len(sc) and g.size == 16 * len(tp)
+        bid = C.c_longlong(-1)
+        self._chk(self.lib.mi355ndt_stream_submit_host(self.h, len(tp), tp.ctypes.data_as(C.c_void_p), tc.ctypes.data_as(C.c_void_p), sp.ctypes.data_as(C.c_void_p),
+                                                       sc.ctypes.data_as(C.c_void_p), C.c_size_t(stride), g.ctypes.data_as(C.c_void_p), int(threads), C.byref(bid)), "stream_submit_host")
         return bid.value
 
     def stream_pose_records(self, d_records_ptr: int, capacity: int, id_base: int, id_stride: int):

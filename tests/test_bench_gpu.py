@@ -126,6 +126,9 @@ def test_eight_ranks_on_one_device_gloo():
     g4 = c4["gather_check"]
     assert g4["pairs_gathered"] == 13 and g4["records_per_rank"] == 2 and g4["permutation_of_all_pair_ids"] and g4["own_records_bit_identical_on_every_rank"]
     assert d["config"]["stream"]["bit_identical_to_synchronous"] is True and d["value_synchronous"] > 0
+    # every rank reports how long its inputs took (the ranks of a node share the host's CPUs): eight values, none out of line
+    g = d["config"]["input_generation_s_per_rank"]
+    assert len(g) == 8 and d["config"]["input_generation_s"] == max(g) and max(g) < 60.0, g
 
 
 def test_streamed_headline_carries_both_rates():

@@ -336,3 +336,56 @@ def test_stream_pose_records_are_written_by_the_device():
         assert sorted(rec) == [3 + k + 8 * b for b in range(B)] and rec[3 + k]["iterations"] == res[0].iterations
     eng.stream_end()
     eng.close()
+
+
+@pytest.mark.parametrize("rec_floats,nctx", [(8, 3), (4, 2)])
+def test_stream_submit_host_equals_the_synchronous_host_path(rec_floats, nctx):
+    """HOST clouds through the stream (mi355ndt_stream_submit_host: staged into the batch context's pinned slots, over PCIe under the launches of earlier
+    batches) against the same clouds through the synchronous drop-in calls (batch_set_clouds + build + align) and against the device-resident synchronous
+    align: every result word equal.  Ragged clouds, 32-byte pcl::PointXYZI and 16-byte pcl::PointXYZ records, five batches through two / three contexts."""
+    kw = dict(resolution=1.0, trans_epsilon=0.01, max_iterations=64, neighbor_mode=ndt.DIRECT1, variant=1)
+    batches, n = make_batches(3300, [24, 17, 24, 9, 24], 256)
+    ref = sync_results(batches, n, kw)
+    stride = rec_floats * 4
+    host = []
+    for T, S, cnt, G in batches:
+        B = len(cnt)
+        tg = np.zeros((B, n, rec_floats), np.float32); sr = np.zeros((B, n, rec_floats), np.float32)
+        tg[:, :, :3] = T.permute(0, 2, 1).cpu().numpy(); sr[:, :, :3] = S.permute(0, 2, 1).cpu().numpy()
+        tg[:, :, 3] = 1.0; sr[:, :, 3] = 1.0
+        host.append((tg, sr))
+    ptrs = lambda a: np.uint64(a.ctypes.data) + np.arange(a.shape[0], dtype=np.uint64) * np.uint64(a.shape[1] * stride)
+    # the synchronous drop-in path
+    eng = ndt.Engine(ndt.default_params(**kw))
+    for (T, S, cnt, G), (tg, sr), r in zip(batches, host, ref):
+        B = len(cnt)
+        eng.batch_reserve(B, n, n)
+        eng.batch_set_clouds_raw(0, ptrs(tg), np.full(B, n, np.uint64), ptrs(sr), np.asarray(cnt, np.uint64), stride, 4)
+        eng.batch_build_targets()
+        got = eng.batch_align(G)
+        for k, (x, y) in enumerate(zip(r, got)):
+            assert same(x, y), k
+    # ... and streamed
+    eng.profile_reset()
+    eng.stream_begin(nctx, 24, n, n)
+    ids, got = [], []
+    for bi, ((T, S, cnt, G), (tg, sr)) in enumerate(zip(batches, host)):
+        if len(ids) - len(got) >= nctx:
+            got.append(eng.stream_collect(ids[len(got)], len(batches[len(got)][2])))
+        B = len(cnt)
+        ids.append(eng.stream_submit_host_raw(ptrs(tg), np.full(B, n, np.uint64), ptrs(sr), np.asarray(cnt, np.uint64), stride, colmajor(G), 4))
+        tg[:] = np.nan; sr[:] = np.nan                   # the call has returned: the caller's memory is the caller's again
+    while len(got) < len(ids):
+        got.append(eng.stream_collect(ids[len(got)], len(batches[len(got)][2])))
+    pr = eng.profile_get()
+    # a batch whose counts exceed what stream_begin was told is refused, not truncated
+    with pytest.raises(ndt.NDTError):
+        big = np.zeros((1, 2 * n, rec_floats), np.float32)
+        eng.stream_submit_host_raw(ptrs(big), np.array([2 * n], np.uint64), ptrs(big), np.array([n], np.uint64), stride, colmajor(batches[0][3][:1]), 2)
+    eng.stream_end()
+    eng.close()
+    for bi, (r, g) in enumerate(zip(ref, got)):
+        assert len(r) == len(g)
+        for k, (x, y) in enumerate(zip(r, g)):
+            assert same(x, y), (bi, k)
+    assert pr["cloud_uploads"] == 2 * sum(len(b[2]) for b in batches) and pr["async_fallbacks"] == 0
