@@ -127,6 +127,7 @@ def ora_align(grid, src, G):
     return O.align(grid, src, G)
 
 
+ARITH = 0
 STATS = {"aligns": 0, "iterations": 0, "zero_hit_aligns": 0, "not_converged": 0, "hit_iteration_cap": 0, "paths": {}, "modes": {}, "mt_live": 0,
          "voxel_checks": 0, "sweep_checks": 0, "searchable_leaves": 0}
 
@@ -364,14 +365,20 @@ def run_case(case, seed, fails, oracle_only=False):
                 compare(eng.align(G), oracle_res[0], "align (no grid)", fails, ctx)
                 return
             try:
-                STATS["voxel_checks"] += 1
-                STATS["searchable_leaves"] += int(check_voxels(eng, grids[0]) or 0)
+                if not ARITH:                     # (tolerance arithmetic: tree leaf sums -- same leaves, sums to 1e-16, not bit for bit: tests/test_tolerance_mode.py)
+                    STATS["voxel_checks"] += 1
+                    STATS["searchable_leaves"] += int(check_voxels(eng, grids[0]) or 0)
             except AssertionError as e:
                 fails.append(dict(ctx, what="voxels", detail=str(e)[:200]))
             p = O.se3_log(G.astype(np.float64)) + np.concatenate([rng.normal(0, 0.05, 3), rng.normal(0, 0.01, 3)])
             try:
                 STATS["sweep_checks"] += 1
-                check_sweep(eng.derivatives(p), O.derivatives_at(grids[0], src, p))
+                if ARITH:                         # the tolerance arithmetic's bar for one sweep: 1e-5 of the largest entry, the same hits
+                    (s1, g1, H1, h1), (s0, g0, H0, h0) = eng.derivatives(p), O.derivatives_at(grids[0], src, p)
+                    assert h1 == h0 and abs(s1 - s0) <= 1e-5 * max(abs(s0), 1e-300), ("score", s1, s0, h1, h0)
+                    assert np.max(np.abs(g1 - g0)) <= 1e-5 * max(np.max(np.abs(g0)), 1e-300) and np.max(np.abs(H1 - H0)) <= 1e-5 * max(np.max(np.abs(H0)), 1e-300), "g / H"
+                else:
+                    check_sweep(eng.derivatives(p), O.derivatives_at(grids[0], src, p))
             except AssertionError as e:
                 fails.append(dict(ctx, what="sweep", detail=str(e)[:200]))
             compare(eng.align(G), oracle_res[0], "align", fails, ctx, lambda: ora_align(grids[0], src, G))
@@ -430,12 +437,17 @@ def main():
     ap.add_argument("--oracle-only", action="store_true", help="CPU dry run: scenes + oracle only")
     ap.add_argument("--aux", type=float, default=None, help="probability of the prefilter / fitness / output-cloud checks per case (default 0.15)")
     ap.add_argument("--seconds", type=float, default=1e9, help="stop after this much wall time")
+    ap.add_argument("--arith", type=int, default=0, choices=[0, 1], help="1: every engine in the tolerance arithmetic (MI355NDT_OPT_ARITH); aligns are held to the same bar "
+                                                                             "(the oracle's iteration count, 1e-4 m / 1e-5 rad), voxels and sweeps to the mode's own (see the code)")
     ap.add_argument("--stream", type=float, default=0.0, help="probability that a case goes through mi355ndt_stream_* (three ragged batches, 2..4 contexts)")
     a = ap.parse_args()
     if a.summarize:
         return summarize(a.summarize, a.out)
-    global AUX_P, STREAM_P
+    global AUX_P, STREAM_P, ARITH
     STREAM_P = a.stream
+    ARITH = a.arith
+    if ARITH:
+        os.environ["MI355NDT_ARITH"] = "1"      # (read by mi355ndt_create: every engine of the run)
     if a.aux is not None:
         AUX_P = a.aux
     fails, errors, done = [], [], 0
@@ -448,7 +460,7 @@ def main():
         except ndt.NDTError as e:                # an error code is a legitimate outcome only if the oracle agrees there is nothing to align
             errors.append(dict(case=case, error=str(e)[:200]))
         done += 1
-    out = dict(seed=a.seed, first=a.first, cases_run=done, seconds=round(time.time() - t0, 1), failures=fails, errors=errors, stats=STATS)
+    out = dict(seed=a.seed, first=a.first, arith=a.arith, cases_run=done, seconds=round(time.time() - t0, 1), failures=fails, errors=errors, stats=STATS)
     od = os.path.join(ROOT, "gpurun_out", "fuzz")
     os.makedirs(od, exist_ok=True)
     json.dump(out, open(os.path.join(od, f"fuzz_{a.seed}_{a.first}.json"), "w"), indent=1)
