@@ -74,7 +74,7 @@ def parse():
     ap.add_argument("--f32-sum-order", type=int, default=0, choices=[0, 1],
                     help="MI355NDT_OPT_F32_SUM_ORDER of every engine of the run: 0 = (t0 + t1) + t2, the canonical order of the fixtures; 1 = (t0 + t2) + t1, "
                          "the lane pairing of Eigen 3.3's SSE predux -- the parity legs then check against the oracle's matching variant (ORA_VAR_SUM3_02_1)")
-    ap.add_argument("--arith", type=int, default=0, choices=[0, 1],
+    ap.add_argument("--arith", type=int, default=int(os.environ.get("MI355NDT_ARITH", "0") == "1"), choices=[0, 1],
                     help="MI355NDT_OPT_ARITH of every engine of the run: 0 = the exact arithmetic (results equal the oracle's bit for bit; what `value` is measured in), "
                          "1 = tolerance arithmetic for the whole line (the default line already carries it as the `tolerance_mode` block beside the exact `value`)")
     ap.add_argument("--no-tolerance-mode", action="store_true", help="skip the `tolerance_mode` blocks (the same jobs again under MI355NDT_OPT_ARITH = 1, compared pair by pair with the exact results)")
@@ -572,8 +572,11 @@ def prefiltered_row(a, ndt, synth, dev, dev_index):
         one(k, False)
     eng.profile_enable(True)
     eng.profile_reset()
+    gc.collect()
+    gc.disable()                                  # (as in timed_job: a generation-2 collection costs ~15 ms and lands in whichever phase it interrupts)
     for k in range(n_pairs):
         one(k, True)
+    gc.enable()
     prof = eng.profile_get()
     eng.profile_enable(False)
     for k in range(min(n_pairs, 8)):                            # leaf statistics of the conditioned targets

@@ -399,6 +399,9 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum(const float* __restri
 // leaf instead of a chain per point.  Same terms, f64 throughout, another order: sums agree with the ordered ones to ~1e-16 relative
 // (north_star's tolerance is 1e-4 m on the pose; BASELINE.md 5: no f64-only choice ever moved a pose bit), never bit for bit -- so never
 // under the default arithmetic.  cov_'s Identity seed (voxel_grid_covariance_omp.h:101) goes in at the end.
+#ifndef LS_TREE_LEAVES
+#define LS_TREE_LEAVES 1       // leaves a wave works on side by side (their key / id loads, then their row gathers, go out together).  Measured, build of 271
+#endif                         // targets: 1 / 2 / 4 leaves = 0.68 / 0.71 / 0.90 ms -- the kernel is bound by what its gathers cost the vector L1, not by round trips
 __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum_tree(const float* __restrict__ tgt, size_t pitch, const unsigned* __restrict__ keys, const unsigned* __restrict__ vals,
                                                                 const GridDesc* __restrict__ gd, const unsigned* __restrict__ seg_start,
                                                                 double* sums, int* vox_idx, int* vox_n, int cb, int nx, int n_targets) {
@@ -409,62 +412,94 @@ __global__ void __launch_bounds__(64 * LS_WAVES) k_leafsum_tree(const float* __r
   const unsigned* K = keys + (size_t)b * pitch;
   const unsigned* V = vals + (size_t)b * pitch;
   const float* X = tgt + (size_t)b * 3 * pitch;
+  constexpr int NL = LS_TREE_LEAVES;
   const int id0 = bx * LS_WAVES + wv, idstep = nx * LS_WAVES;
-  size_t start_next = id0 < g.n_voxels ? seg_start[g.rec_off + id0] : 0;
-  for (int id = id0; id < g.n_voxels; id += idstep) {
-    const size_t start = start_next;
-    if (id + idstep < g.n_voxels) start_next = seg_start[g.rec_off + id + idstep];
-    double a[9];
+  const int nv = g.n_voxels;
+  for (int idb = id0; idb < nv; idb += NL * idstep) {
+    size_t start[NL];
+    bool have[NL];
 #pragma unroll
-    for (int k = 0; k < 9; k++) a[k] = 0.0;
-    int cnt = 0;
-    unsigned key = 0;
-    for (size_t j0 = start;; j0 += 64) {
-      const size_t j = j0 + lane;
-      const bool inb = j < pitch;
-      const unsigned kj = inb ? K[j] : 0u;
-      const unsigned pi = inb ? V[j] : 0u;
-      if (j0 == start) key = __shfl(kj, 0);
-      const bool in = inb && kj == key;
-      const int m = (int)__popcll(__ballot(in));
-      if (in) {
-        const double x = (double)X[pi], y = (double)X[pitch + pi], z = (double)X[2 * pitch + pi];
-        a[0] += x; a[1] += y; a[2] += z;
-        a[3] += x * x; a[4] += x * y; a[5] += x * z; a[6] += y * y; a[7] += y * z; a[8] += z * z;
+    for (int u = 0; u < NL; u++) { const int id = idb + u * idstep; have[u] = id < nv; start[u] = have[u] ? seg_start[g.rec_off + id] : 0; }
+    double a[NL][9];
+    int cnt[NL];
+    unsigned key[NL];
+    bool more[NL];
+#pragma unroll
+    for (int u = 0; u < NL; u++) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) a[u][k] = 0.0;
+      cnt[u] = 0; key[u] = 0u; more[u] = have[u];
+    }
+    for (int chunk = 0;; chunk++) {                 // chunk c of every leaf that still has one, side by side
+      bool any = false;
+#pragma unroll
+      for (int u = 0; u < NL; u++) any = any || more[u];
+      if (!any) break;
+      unsigned kj[NL], pi[NL];
+      bool inb[NL];
+#pragma unroll
+      for (int u = 0; u < NL; u++) {
+        const size_t j = start[u] + (size_t)chunk * 64 + lane;
+        inb[u] = more[u] && j < pitch;
+        kj[u] = inb[u] ? K[j] : 0u;
+        pi[u] = inb[u] ? V[j] : 0u;
       }
-      cnt += m;
-      if (m < 64) break;
+      float fx[NL], fy[NL], fz[NL];
+      bool in[NL];
+#pragma unroll
+      for (int u = 0; u < NL; u++) {
+        if (chunk == 0) key[u] = __shfl(kj[u], 0);
+        in[u] = inb[u] && kj[u] == key[u];
+        fx[u] = fy[u] = fz[u] = 0.f;
+        if (in[u]) { fx[u] = X[pi[u]]; fy[u] = X[pitch + pi[u]]; fz[u] = X[2 * pitch + pi[u]]; }
+      }
+#pragma unroll
+      for (int u = 0; u < NL; u++) {
+        const int m = (int)__popcll(__ballot(in[u]));
+        if (in[u]) {
+          const double x = (double)fx[u], y = (double)fy[u], z = (double)fz[u];
+          a[u][0] += x; a[u][1] += y; a[u][2] += z;
+          a[u][3] += x * x; a[u][4] += x * y; a[u][5] += x * z; a[u][6] += y * y; a[u][7] += y * z; a[u][8] += z * z;
+        }
+        cnt[u] += m;
+        more[u] = more[u] && m == 64;
+      }
     }
     // wave sum as a reduce-scatter (the sweep's scheme, ndt_sweep.hpp): 9 -> 5 values across the lane halves, 5 -> 3 across row pairs, then rows
     typedef unsigned int u2v __attribute__((ext_vector_type(2)));
-    double p1[5], p2[3];
 #pragma unroll
-    for (int i = 0; i < 5; i++) {
-      const double u = a[i], v = (i + 5 < 9) ? a[i + 5] : 0.0;
-      const u2v lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(u), (unsigned)__double2loint(v), false, false);
-      const u2v hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(u), (unsigned)__double2hiint(v), false, false);
-      p1[i] = __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);   // lanes 0..31: sum i, lanes 32..63: sum i + 5
-    }
+    for (int u = 0; u < NL; u++) {
+      if (!have[u]) continue;                      // (wave-uniform)
+      const int id = idb + u * idstep;
+      double p1[5], p2[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-      const double u = p1[i], v = (i + 3 < 5) ? p1[i + 3] : 0.0;
-      const u2v lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(u), (unsigned)__double2loint(v), false, false);
-      const u2v hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(u), (unsigned)__double2hiint(v), false, false);
-      double w = __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);   // even rows: p1[i], odd rows: p1[i + 3]
+      for (int i = 0; i < 5; i++) {
+        const double x = a[u][i], v = (i + 5 < 9) ? a[u][i + 5] : 0.0;
+        const u2v lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(v), false, false);
+        const u2v hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(v), false, false);
+        p1[i] = __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);   // lanes 0..31: sum i, lanes 32..63: sum i + 5
+      }
 #pragma unroll
-      for (int o = 8; o > 0; o >>= 1) w += __shfl_xor(w, o);
-      p2[i] = w;
-    }
-    if ((lane & 15) == 0) {
-      // row 0 (lane 0): sums 0 1 2, row 1 (lane 16): 3 4, row 2 (lane 32): 5 6 7, row 3 (lane 48): 8 -- S0 S1 S2 C00 C01 C02 C11 C12 C22
-      const int row = lane >> 4, base = 3 * (row & 1) + 5 * (row >> 1), nrow = (row & 1) ? ((row >> 1) ? 1 : 2) : 3;
-      double* o = sums + (size_t)(g.rec_off + id) * 9;
+      for (int i = 0; i < 3; i++) {
+        const double x = p1[i], v = (i + 3 < 5) ? p1[i + 3] : 0.0;
+        const u2v lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(v), false, false);
+        const u2v hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(v), false, false);
+        double w = __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);   // even rows: p1[i], odd rows: p1[i + 3]
 #pragma unroll
-      for (int i = 0; i < 3; i++) if (i < nrow) { const int k = base + i; o[k] = p2[i] + ((k == 3 || k == 6 || k == 8) ? 1.0 : 0.0); }
-    }
-    if (lane == 0) {
-      vox_idx[g.rec_off + id] = (int)(key & ((1u << cb) - 1u));
-      vox_n[g.rec_off + id] = cnt;
+        for (int o = 8; o > 0; o >>= 1) w += __shfl_xor(w, o);
+        p2[i] = w;
+      }
+      if ((lane & 15) == 0) {
+        // row 0 (lane 0): sums 0 1 2, row 1 (lane 16): 3 4, row 2 (lane 32): 5 6 7, row 3 (lane 48): 8 -- S0 S1 S2 C00 C01 C02 C11 C12 C22
+        const int row = lane >> 4, base = 3 * (row & 1) + 5 * (row >> 1), nrow = (row & 1) ? ((row >> 1) ? 1 : 2) : 3;
+        double* o = sums + (size_t)(g.rec_off + id) * 9;
+#pragma unroll
+        for (int i = 0; i < 3; i++) if (i < nrow) { const int k = base + i; o[k] = p2[i] + ((k == 3 || k == 6 || k == 8) ? 1.0 : 0.0); }
+      }
+      if (lane == 0) {
+        vox_idx[g.rec_off + id] = (int)(key[u] & ((1u << cb) - 1u));
+        vox_n[g.rec_off + id] = cnt[u];
+      }
     }
   }
 }

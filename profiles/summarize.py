@@ -82,37 +82,59 @@ def sec2():
 
 section(sec2)
 
+TRAFFIC_CFGS = (("cfg3", "271x65536:omp:direct7:1.0", "bench.py defaults (271 pairs x 65536 pts, ndt_omp, 1.0 m, DIRECT7)", "{TAG}_traffic.json"),
+                ("pca_direct1", "271x65536:pca:direct1:1.0", "the nodelet's registration (271 pairs x 65536 pts, ndt_pca, 1.0 m, DIRECT1)", "{TAG}_traffic_pca_direct1.json"),
+                ("cfg5_d7", "128x131072:pca:direct7:0.5", "BASELINE config 5's per-GPU share (128 pairs x 131072 pts, ndt_pca, 0.5 m, DIRECT7)", "{TAG}_traffic_cfg5_d7.json"),
+                ("cfg5_d1", "128x131072:pca:direct1:0.5", "BASELINE config 5's per-GPU share with DIRECT1 (128 pairs x 131072 pts, ndt_pca, 0.5 m)", "{TAG}_traffic_cfg5_d1.json"))
+TRAFFIC = {}
+
+
 def sec3():
     global traffic, fe, wr, sw, kmax, bench
-    # ---- PMC passes: FETCH_SIZE / WRITE_SIZE per sweep dispatch (rocprofv3 reports them in KB)
+    # ---- PMC passes: FETCH_SIZE / WRITE_SIZE per sweep dispatch (rocprofv3 reports them in KB), every timed configuration, both arithmetics
     def counter(dirname, name):
         rows = list(csv.DictReader(open(one(f"{dirname}/**/*_counter_collection.csv"))))
         rows = [r for r in rows if r["Counter_Name"] == name and ("k_sweep" in r["Kernel_Name"] or "k_align_async" in r["Kernel_Name"])]
         rows.sort(key=lambda r: int(r["Dispatch_Id"]))
         return [float(r["Counter_Value"]) for r in rows]
 
-
-    fe, wr = counter("fetch", "FETCH_SIZE"), counter("write", "WRITE_SIZE")
-    n = min(len(fe), len(wr))
-    with open(os.path.join(OUT, f"{TAG}_final_pmc_sweep.csv"), "w") as f:
-        f.write("dispatch,FETCH_SIZE_KB,WRITE_SIZE_KB\n")
-        for k in range(n):
-            f.write(f"{k},{fe[k]},{wr[k]}\n")
-    fe_avg, wr_avg = sum(fe[:n]) / n, sum(wr[:n]) / n
-    kmax = max(range(n), key=lambda k: fe[k])
+    for sfx, arith in (("", 0), ("_tol", 1)):
+        for tag, key, wl, outname in TRAFFIC_CFGS:
+            try:
+                f_, w_ = counter(f"fetch_{tag}{sfx}", "FETCH_SIZE"), counter(f"write_{tag}{sfx}", "WRITE_SIZE")
+            except AssertionError:
+                continue
+            n = min(len(f_), len(w_))
+            if n == 0:
+                continue
+            b = load_line(os.path.join(SRC, f"traffic_bench_{tag}{sfx}.json"))
+            rs = b.get("roofline_synchronous") or b["roofline"]
+            fe_avg, wr_avg = sum(f_[:n]) / n, sum(w_[:n]) / n
+            k = max(range(n), key=lambda i: f_[i])
+            t = {"kernel": "k_align_async (one launch per batch align: derivative sweeps + Newton updates)", "workload": wl, "workload_key": key, "arith": arith,
+                 "launches_counted": n, "fetch_size_kb_avg_per_launch": fe_avg, "write_size_kb_avg_per_launch": wr_avg, "fetch_correction": 2.0,
+                 "traffic_bytes_per_launch": (2.0 * fe_avg + wr_avg) * 1024, "traffic_bytes_per_launch_uncorrected": (fe_avg + wr_avg) * 1024,
+                 "full_launch": {"fetch_kb": f_[k], "write_kb": w_[k]},
+                 "algorithmic_bytes_per_launch": rs["alg_bytes_per_launch"], "avg_launch_us_of_that_run": rs["avg_launch_us"],
+                 "physical_hbm_gbs": round((2.0 * fe_avg + wr_avg) * 1024 / (rs["avg_launch_us"] * 1e-6) / 1e9, 1),
+                 "physical_hbm_frac_of_peak": round((2.0 * fe_avg + wr_avg) * 1024 / (rs["avg_launch_us"] * 1e-6) / 8.0e12, 4),
+                 "physical_over_algorithmic": round((2.0 * fe_avg + wr_avg) * 1024 / rs["alg_bytes_per_launch"], 4),
+                 "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --cpu-seconds 0 --no-stream --steps 4 --warmup 1 <config>`, "
+                           "--kernel-include-regex 'k_sweep|k_align_async', no trace domains; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE x2 is the gfx950 "
+                           "half-counting correction of MI355X_MICROARCH.md (HBM section).  One launch = one whole batch align (every sweep of every pair); the launch time is "
+                           "the same run's (HIP events inside the engine, under the counter pass)."}
+            TRAFFIC[(tag, arith)] = t
+            name = outname.replace("{TAG}", TAG)
+            if arith:
+                name = name.replace("_traffic", "_traffic_tol")
+            json.dump(t, open(os.path.join(OUT, name), "w"), indent=1)
+            if tag == "cfg3" and arith == 0:
+                traffic, fe, wr, kmax = t, f_, w_, k
+                with open(os.path.join(OUT, f"{TAG}_final_pmc_sweep.csv"), "w") as f:
+                    f.write("dispatch,FETCH_SIZE_KB,WRITE_SIZE_KB\n")
+                    for i in range(n):
+                        f.write(f"{i},{f_[i]},{w_[i]}\n")
     bench = load_line(os.path.join(SRC, "kt_bench.json"))
-    traffic = {
-        "kernel": "k_align_async (one launch per batch align: derivative sweeps + Newton updates)", "workload": "bench.py defaults (271 pairs x 65536 pts, ndt_omp, 1.0 m, DIRECT7)", "workload_key": "271x65536:omp:direct7:1.0",
-        "launches_counted": n, "fetch_size_kb_avg_per_launch": fe_avg, "write_size_kb_avg_per_launch": wr_avg, "fetch_correction": 2.0,
-        "traffic_bytes_per_launch": (2.0 * fe_avg + wr_avg) * 1024, "traffic_bytes_per_launch_uncorrected": (fe_avg + wr_avg) * 1024,
-        "full_launch": {"fetch_kb": fe[kmax], "write_kb": wr[kmax]},
-        "algorithmic_bytes_per_launch": (bench.get("roofline_synchronous") or bench["roofline"])["alg_bytes_per_launch"],
-        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --cpu-seconds 0 --steps 4 --warmup 1`, "
-                  "--kernel-include-regex 'k_sweep|k_align_async', no trace domains; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE x2 is the gfx950 "
-                  "half-counting correction of MI355X_MICROARCH.md (HBM section), calibrated on the compulsory traffic of a full launch "
-                  "(source points 213 MB + records ~25 MB + bitmap ~11 MB).  One launch = one whole batch align (every sweep of every pair).",
-    }
-    json.dump(traffic, open(os.path.join(OUT, f"{TAG}_traffic.json"), "w"), indent=1)
 
 
 section(sec3)
@@ -176,7 +198,8 @@ def sec4():
             "tcp_busy_frac": round(c.get("TCP_GATE_EN1_sum", 0.0) / (256.0 * cycles), 3),
             "tcp_line_accesses_per_dispatch": c.get("TCP_TOTAL_CACHE_ACCESSES_sum"),
             "l2_hit_frac": round(c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3) if "TCC_HIT_sum" in c else None,
-            "physical_hbm_frac_of_peak": round(traffic["traffic_bytes_per_launch"] / (cycles / 2.4e9) / 8.0e12, 4) if tag == "sq_direct7" else None,
+            "physical_hbm_frac_of_peak": (TRAFFIC.get(({"sq_direct7": "cfg3", "sq_pca_direct1": "pca_direct1", "sq_cfg5_d1": "cfg5_d1", "sq_cfg5_d7": "cfg5_d7"}[tag], 0)) or {}).get("physical_hbm_frac_of_peak"),
+            "physical_hbm_source": "profiles/" + {"sq_direct7": f"{TAG}_traffic.json", "sq_pca_direct1": f"{TAG}_traffic_pca_direct1.json", "sq_cfg5_d1": f"{TAG}_traffic_cfg5_d1.json", "sq_cfg5_d7": f"{TAG}_traffic_cfg5_d7.json"}[tag],
             "note": "mean over the k_align_async dispatches of a short bench run (one dispatch = one batch align: every sweep and every Newton update of every pair); GRBM_GUI_ACTIVE / 8 as elapsed cycles",
         }
         json.dump(valu, open(os.path.join(OUT, outname), "w"), indent=1)
@@ -216,4 +239,49 @@ def sec5():
 
 
 section(sec5)
+
+
+def sec6():
+    # ---- the tolerance arithmetic (MI355NDT_ARITH=1): counters of its launches for the same four configurations, its build, its kernel times
+    import subprocess
+    for tag, key, tcfg in (("sq_tol_direct7", "271x65536:omp:direct7:1.0", "cfg3"), ("sq_tol_pca_direct1", "271x65536:pca:direct1:1.0", "pca_direct1"),
+                           ("sq_tol_cfg5_d1", "128x131072:pca:direct1:0.5", "cfg5_d1"), ("sq_tol_cfg5_d7", "128x131072:pca:direct7:0.5", "cfg5_d7")):
+        pth = os.path.join(SRC, f"pmc_{tag}.txt")
+        if not os.path.exists(pth) or os.path.getsize(pth) < 100:
+            continue
+        open(os.path.join(OUT, f"{TAG}_pmc_{tag}.txt"), "w").write(open(pth).read())
+        red = json.loads(subprocess.run([sys.executable, os.path.join(HERE, "reduce_pmc.py"), pth], capture_output=True, text=True).stdout or "{}")
+        r = next(iter(red.values()), None)
+        if not r:
+            continue
+        t = TRAFFIC.get((tcfg, 1))
+        r.update({"workload_key": key, "arith": 1, "kernel": "k_align_async<., ., 2> (tolerance arithmetic)",
+                  "valu_busy_frac_what": "4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x cycles): VALU-busy share of the launch (1.0 = the vector ALUs never idle)",
+                  "valu_wave_insts_per_64_hits": round(64.0 * r["valu_wave_insts"] / (t["algorithmic_bytes_per_launch"] / 1.0), 6) if False else None,
+                  "physical_hbm_frac_of_peak": t["physical_hbm_frac_of_peak"] if t else None, "physical_over_algorithmic": t["physical_over_algorithmic"] if t else None})
+        if t:
+            K = 7 if "direct7" in key else 1
+            b = load_line(os.path.join(SRC, f"traffic_bench_{tcfg}_tol.json"))
+            hpp = b["roofline"]["hits_per_point"]
+            hits = hpp * t["algorithmic_bytes_per_launch"] / (12 + 4 * K + 64 * hpp)
+            r["valu_wave_insts_per_64_hits"] = round(64.0 * r["valu_wave_insts"] / hits, 1)
+        json.dump(r, open(os.path.join(OUT, f"{TAG}_valu_tol_{tcfg}.json"), "w"), indent=1)
+    pth = os.path.join(SRC, "pmc_tol_build.txt")
+    if os.path.exists(pth) and os.path.getsize(pth) > 100:
+        open(os.path.join(OUT, f"{TAG}_pmc_tol_build.txt"), "w").write(open(pth).read())
+        open(os.path.join(OUT, f"{TAG}_tol_build_counters.json"), "w").write(subprocess.run([sys.executable, os.path.join(HERE, "reduce_pmc.py"), pth], capture_output=True, text=True).stdout)
+    pth = os.path.join(SRC, "kernel_stats_tol.csv")
+    if os.path.exists(pth):
+        rows = list(csv.DictReader(open(pth)))
+        with open(os.path.join(OUT, f"{TAG}_final_kernel_stats_tol.csv"), "w") as f:
+            f.write("kernel,calls,total_us,avg_us,min_us,max_us\n")
+            for r in rows:
+                if any(k in r["Name"] for k in ("k_align_async", "k_sweep", "k_async_prepare", "k_stream_", "k_leafsum", "k_rs_", "k_mark", "k_minmax", "k_voxels", "k_rank", "k_griddesc", "k_word_offsets", "k_build_check", "k_update")):
+                    f.write(f"\"{r['Name'][:110]}\",{r['Calls']},{float(r['TotalDurationNs']) / 1e3:.1f},{float(r['AverageNs']) / 1e3:.3f},{float(r['MinNs']) / 1e3:.2f},{float(r['MaxNs']) / 1e3:.2f}\n")
+    p = os.path.join(SRC, "kt_tol_bench.json")
+    if os.path.exists(p) and os.path.getsize(p) > 10:
+        json.dump(load_line(p), open(os.path.join(OUT, f"{TAG}_bench_tol_under_rocprof.json"), "w"), indent=1)
+
+
+section(sec6)
 

@@ -6,7 +6,7 @@ TAG=$1; shift
 O=$R/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py --cpu-seconds 0 --config4-pairs 0 --seq-frames 0 --no-other-configs "$@" > $O/bench.json 2> $O/kt.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python $R/bench.py --cpu-seconds 0 --config4-pairs 0 --seq-frames 0 --no-other-configs --no-tolerance-mode "$@" > $O/bench.json 2> $O/kt.log
 python - <<PY > $O/kstats.txt
 import csv, glob
 f = glob.glob("$O/kt/**/*_kernel_stats.csv", recursive=True)
