@@ -41,6 +41,13 @@ extern "C" {
                                           (voxel_grid_covariance_omp_impl.hpp:75-84) or engine cell cap */
 #define MI355NDT_ERR_NO_DEVICE   (-5)
 #define MI355NDT_ERR_UNSUPPORTED (-6)  /* reserved: every configuration of the reference classes is served at present */
+/* Positive: a warning that rides in mi355ndt_result.status, never a return code.  Set only under MI355NDT_OPT_ARITH = 1: the registration is of a kind the
+ * tolerance arithmetic is not meant for -- fewer than MI355NDT_TOLERANCE_MIN_HITS (point, voxel) hits at the final pose (the Hessian of a handful of points:
+ * ~1e-7 per f32 term times its condition number is no tolerance-level perturbation any more) or a run that stopped at the iteration cap (an oscillating run
+ * amplifies any rounding difference).  The result stands; a caller that needs the default arithmetic's robustness re-runs that pair with the option off (the
+ * pcl adaptor and the python mirror do so by themselves). */
+#define MI355NDT_WARN_TOLERANCE_ARITH 1
+#define MI355NDT_TOLERANCE_MIN_HITS   4096
 #define MI355NDT_ERR_STATE       (-7)  /* align/derivatives before target+source were set */
 
 /* pclomp::NeighborSearchMethod, include/ndt_omp/ndt_omp.h:51-56 (same enum order) */
@@ -68,7 +75,7 @@ typedef struct mi355ndt_result {
   int       converged;            /* hasConverged()                    (converged_) */
   int       sweeps;               /* computeDerivatives passes (1 + steps taken); live More-Thuente case: the count the
                                      reference makes -- repeated evaluations of an unchanged pose are reused, not re-run */
-  int       status;               /* per-pair status: MI355NDT_OK or MI355NDT_ERR_GRID */
+  int       status;               /* per-pair status: MI355NDT_OK, MI355NDT_ERR_GRID, or MI355NDT_WARN_TOLERANCE_ARITH (> 0: a result, with a caveat) */
   long long hits_last;            /* (point,voxel) evaluations in the last sweep */
 } mi355ndt_result;
 

@@ -52,6 +52,7 @@ NDT_FAST_KERNELS(NDT_DECLARE)
 
 
 // ------------------------------------------------------------------------------------ host side
+struct mi355ndt_handle;
 struct mi355ndt_handle {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -284,6 +285,11 @@ static int check_params(const mi355ndt_params& p) {
 
 // impl2:888: the More-Thuente loop (and computeHessian after it) runs iff !(step_max - step_min > 0), step_min = eps/2
 static bool mt_is_live(const mi355ndt_params& p) { return !((p.step_size - p.trans_epsilon / 2) > 0); }
+// MI355NDT_OPT_ARITH = 1 is served for DIRECT1 / DIRECT7 with the dead More-Thuente loop (every configuration lv_slam ships); every other configuration
+// ignores the option altogether: exact kernels, ordered leaf sums, the exact records alone
+static bool fast_served(const mi355ndt_handle* h) {
+  return h->arith == 1 && (h->prm.neighbor_mode == MI355NDT_DIRECT1 || h->prm.neighbor_mode == MI355NDT_DIRECT7) && !mt_is_live(h->prm);
+}
 
 extern "C" {
 
@@ -953,9 +959,11 @@ static int build_targets_impl(mi355ndt_handle* h) {
   h->cent_built = want_cent;
   h->icov64_built = mt_live;
   if (mt_live) HIPCHK(h, grow(h->d_icov64, h->icov64_cap, h->recs_cap * 9));
-  const bool want_fast = h->arith == 1;
-  if (want_fast) HIPCHK(h, grow(h->d_recs_fast, h->recs_fast_cap, h->recs_cap));
-  h->recs_fast_built = want_fast;
+  // the tolerance arithmetic's records and tree leaf sums only where its sweeps are served (DIRECT1 / DIRECT7, dead More-Thuente loop): every other
+  // configuration ignores the option altogether -- ordered sums, the exact records alone, results word for word those of the option off
+  const bool want_fast_recs = fast_served(h);
+  if (want_fast_recs) HIPCHK(h, grow(h->d_recs_fast, h->recs_fast_cap, h->recs_cap));
+  h->recs_fast_built = want_fast_recs;
   const bool want_kdw = h->prm.neighbor_mode == MI355NDT_KDTREE && h->prm.variant == MI355NDT_VARIANT_PCA;
   h->kdw_built = want_kdw;
   if (want_kdw) HIPCHK(h, grow(h->d_kdw, h->kdw_cap, h->recs_cap));
@@ -991,7 +999,7 @@ static int build_targets_impl(mi355ndt_handle* h) {
     k_rank<<<B, 1024, 0, s>>>(h->d_grid, h->d_words, h->d_heads, h->d_head_cnt, nsl, scap, h->d_seg_start);
     // leaf-sum workgroups per target: 64 keeps ~4 targets (3 MB of points) in flight per XCD, inside its 4 MB L2
     const int lb = std::max(1, std::min((int)((rpp + LS_WAVES - 1) / LS_WAVES), 64));
-    if (h->arith == 1 && !want_cent && !h->leaf_sorted) {       // tolerance arithmetic: the leaf sums as a tree (ndt_build.hpp)
+    if (want_fast_recs && !want_cent && !h->leaf_sorted) {      // tolerance arithmetic: the leaf sums as a tree (ndt_build.hpp)
       k_leafsum_tree<<<xcd_grid(lb, B), 64 * LS_WAVES, 0, s>>>(h->d_tgt, pitch, kb, h->d_vals_b, h->d_grid, h->d_seg_start, h->d_sums, h->d_vox_idx, h->d_vox_n, cb, lb, B);
     } else if (h->leaf_sorted) {
       // the sorted order as 16-byte points first (one streaming gather), then leaf sums that read them contiguously
@@ -1010,7 +1018,7 @@ static int build_targets_impl(mi355ndt_handle* h) {
   }
   k_voxels<<<dim3((unsigned)((rpp + 255) / 256), B), 256, 0, s>>>(h->d_grid, h->d_sums, h->d_recs, h->d_vox_n,
                                                                   h->prm.min_covar_eigvalue_mult, h->prm.variant == MI355NDT_VARIANT_PCA,
-                                                                  mt_live ? h->d_icov64 : nullptr, want_kdw ? h->d_kdw : nullptr, want_fast ? h->d_recs_fast : nullptr);
+                                                                  mt_live ? h->d_icov64 : nullptr, want_kdw ? h->d_kdw : nullptr, want_fast_recs ? h->d_recs_fast : nullptr);
   HIPCHK(h, hipGetLastError());
   if (h->prof) {
     if (build_events) HIPCHK(h, ev_end(h, h->ev_build));
@@ -1082,7 +1090,7 @@ static void make_sweep_const(const mi355ndt_handle* h, SweepConst& sc) {
 
 // The arithmetic a sweep runs in: 2 = tolerance arithmetic (MI355NDT_OPT_ARITH = 1; instantiated for DIRECT1 / DIRECT7 with the dead More-Thuente
 // loop -- every configuration lv_slam ships; the other searches and the live line search keep the exact kernels), else the f32 sum order.
-static bool want_fast(const mi355ndt_handle* h, const SweepConst& sc) { return h->arith == 1 && (sc.K == 1 || sc.K == 7) && !mt_is_live(h->prm); }
+static bool want_fast(const mi355ndt_handle* h, const SweepConst& sc) { (void)sc; return fast_served(h); }
 static int sweep_ord(const mi355ndt_handle* h, const SweepConst& sc) {
   // (a stream's parent handle owns no grids: its contexts' engines build them, with the option as it stood at mi355ndt_stream_begin)
   if (want_fast(h, sc) && (h->recs_fast_built || h->stream_on)) return 2;
@@ -1140,11 +1148,22 @@ static void launch_hessian(mi355ndt_handle* h, const SweepConst& sc) {
       gc[0], gc[1], sc.kd_r2, sc.leaf_pow2, sc.inv_leaf);
 }
 
+// MI355NDT_OPT_ARITH = 1: results of registrations the tolerance arithmetic is not meant for carry a warning (include/mi355_ndt.h).  A property of the
+// pair alone (its hits at the final pose, its iteration count), applied to the host copy of the results by every path that hands results out.
+static void tolerance_warnings(const mi355ndt_handle* h, mi355ndt_result* out, int n) {
+  SweepConst sc;
+  make_sweep_const(h, sc);
+  if (!want_fast(h, sc)) return;
+  for (int b = 0; b < n; b++)
+    if (out[b].status == MI355NDT_OK && (out[b].hits_last < MI355NDT_TOLERANCE_MIN_HITS || out[b].iterations >= h->prm.max_iterations + 2))
+      out[b].status = MI355NDT_WARN_TOLERANCE_ARITH;
+}
 static int batch_align_impl(mi355ndt_handle* h, const float* guesses, mi355ndt_result* out);
 int mi355ndt_batch_align(mi355ndt_handle* h, const float* guesses, mi355ndt_result* out) {
   if (!h) return MI355NDT_ERR_BAD_HANDLE;
   NOT_IN_STREAM(h);
   const int rc = batch_align_impl(h, guesses, out);
+  if (rc == MI355NDT_OK) tolerance_warnings(h, out, h->n_pairs);
   if (rc != MI355NDT_OK) {
     // an error exit may leave (update, sweep) rounds queued: drain them, so that no sweep of THIS align can post its progress words
     // into the flags the next align resets (the latency-mode pump restarts its sequence numbers at 1)
@@ -1326,7 +1345,7 @@ static int batch_align_impl(mi355ndt_handle* h, const float* guesses, mi355ndt_r
   { int rcu = uploads_before_compute(h); if (rcu) return rcu; }
   const bool mt_live = mt_is_live(h->prm);                       // impl2:888: More-Thuente loop + computeHessian are live
   const bool pca_kd = h->prm.neighbor_mode == MI355NDT_KDTREE && h->prm.variant == MI355NDT_VARIANT_PCA;
-  if (!h->targets_built || (mt_live && !h->icov64_built) || (pca_kd && !h->kdw_built) || (h->arith == 1 && !h->recs_fast_built)) { int rc = mi355ndt_batch_build_targets(h); if (rc) return rc; }
+  if (!h->targets_built || (mt_live && !h->icov64_built) || (pca_kd && !h->kdw_built) || (fast_served(h) && !h->recs_fast_built)) { int rc = mi355ndt_batch_build_targets(h); if (rc) return rc; }
   int rc = prep_align_ws(h);
   if (rc) return rc;
   const int B = h->n_pairs;
@@ -1597,7 +1616,7 @@ static int hook_ready(mi355ndt_handle* h) {
   HIPCHK(h, hipSetDevice(h->device));
   { int rcu = uploads_before_compute(h); if (rcu) return rcu; }
   const bool pca_kd = h->prm.neighbor_mode == MI355NDT_KDTREE && h->prm.variant == MI355NDT_VARIANT_PCA;
-  if (!h->targets_built || (pca_kd && !h->kdw_built) || (h->arith == 1 && !h->recs_fast_built)) { int rc = mi355ndt_batch_build_targets(h); if (rc) return rc; }
+  if (!h->targets_built || (pca_kd && !h->kdw_built) || (fast_served(h) && !h->recs_fast_built)) { int rc = mi355ndt_batch_build_targets(h); if (rc) return rc; }
   return prep_align_ws(h);
 }
 
@@ -2440,6 +2459,7 @@ int mi355ndt_stream_collect(mi355ndt_handle* h, long long batch_id, mi355ndt_res
     if (rc) { h->err = e->err; return rc; }
   }
   memcpy(out, S.h_res, (size_t)S.n_pairs * sizeof(mi355ndt_result));
+  tolerance_warnings(h, out, S.n_pairs);         // (a synchronously re-run batch has them already: idempotent)
   if (h->prof) {
     const int K = h->prm.neighbor_mode == MI355NDT_DIRECT1 ? 1 : h->prm.neighbor_mode == MI355NDT_DIRECT7 ? 7 : h->prm.neighbor_mode == MI355NDT_DIRECT26 ? 26 : 27;
     for (int b = 0; b < S.n_pairs; b++) {

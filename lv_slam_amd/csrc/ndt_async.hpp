@@ -99,7 +99,9 @@ struct AsyncCtl {
 #endif
 #define ASYNC_HELP_AFTER 64u         // polls (~1 us each) a wave waits for its own ticket before it looks at other rings: the help is for a launch
                                      // that would otherwise not finish, and costs a launch that needs none 0.3-1.4 % when it starts at once (measured)
-#define ASYNC_SPIN_LIMIT (1u << 23)      // polls of ~1 us: a device that stopped making progress ends the launch after seconds, not never
+#define ASYNC_SPIN_LIMIT (1u << 18)      // polls of ~1-2.5 us: a wave that has seen no ticket for ~0.3-0.6 s ends the launch (the caller re-runs the batch in rounds).  Legitimate
+                                         // waits are the tail of a launch -- a claimed position at most ~16 tickets ahead of the last pair's: ~1 ms --, two to three orders of
+                                         // magnitude below; round 5's 2^23 left a starved launch spinning for ~10 s before it fell back
 
 // Everything the launch reads before it has written it, set by ONE kernel on the stream in front of it (never inside the launch): the
 // context table, the NEW pairs' initial states (k_init_state's job) and arrival counters, the first tickets -- the pairs the previous

@@ -92,6 +92,7 @@ OPT_DEBUG_ASYNC_ABORT = 3      # mi355ndt_option (test hook): the wave that clai
 OPT_DEBUG_ASYNC_RINGS = 6      # mi355ndt_option (test hook): bit x clear -> ring x of a one-launch align has no workgroups of its own
 OPT_STREAM_RESERVE = 5         # mi355ndt_option: workgroup slots the stream's launches leave free for the next batch's build (0 = off)
 OPT_STREAM_THRESHOLD = 4       # mi355ndt_option: pairs a stream launch hands over to the next one (-1 = auto, 0 = none)
+WARN_TOLERANCE_ARITH = 1       # mi355ndt_result.status under OPT_ARITH = 1: fewer than 4,096 hits at the final pose, or stopped at the iteration cap
 OPT_ARITH = 7                  # mi355ndt_option: 0 = the reference recipe's arithmetic, one rounding per operation (default), 1 = tolerance arithmetic (held to 1e-4 m / 1e-5 rad, not to bits)
 OPT_F32_SUM_ORDER = 1          # mi355ndt_option: 0 = (t0 + t1) + t2 (canonical), 1 = (t0 + t2) + t1 (Eigen 3.3 SSE predux pairing)
 
@@ -584,6 +585,12 @@ class NormalDistributionsTransform:
             return np.zeros((0, 3), np.float32)
         G = np.eye(4, dtype=np.float32) if guess is None else np.asarray(guess, np.float32)
         r = self._eng.align(G)
+        if r["status"] == WARN_TOLERANCE_ARITH:      # the tolerance arithmetic on a registration it is not meant for: once more in the default arithmetic
+            self._eng.set_option(OPT_ARITH, 0)
+            try:
+                r = self._eng.align(G)
+            finally:
+                self._eng.set_option(OPT_ARITH, 1)
         self._last = r
         self._final = r["final"]
         self._converged = r["converged"]

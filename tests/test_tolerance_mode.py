@@ -213,3 +213,51 @@ def test_latency_mode_in_tolerance_arithmetic_vs_oracle():
     dt, dr = se3_err(ro["final"], r["final"])
     assert dt < 1e-4 and dr < 1e-5, (dt, dr)
     eng.close()
+
+
+def test_a_registration_the_mode_is_not_meant_for_is_flagged_and_the_mirror_reruns_it():
+    """Fewer than MI355NDT_TOLERANCE_MIN_HITS hits at the final pose (a source of a few hundred points: the Hessian of a handful of leaves) or a stop at the
+    iteration cap: the result carries MI355NDT_WARN_TOLERANCE_ARITH in its status -- under the tolerance arithmetic only, for the pair alone, by every path --
+    and the reference-shaped mirror (like the pcl adaptor) answers with the default arithmetic's result instead."""
+    naz, kw = CONFIGS["nodelet"]
+    tgt, src, _ = synth.make_pair(4, naz)
+    tgt, src = tgt.numpy(), src.numpy()
+    few = np.ascontiguousarray(src[::211])            # ~310 points
+    G = synth.default_guess()
+    res = {}
+    for arith in (0, 1):
+        eng = engine(kw, arith)
+        eng.set_target(tgt)
+        eng.set_source(few)
+        res[arith] = eng.align(G)
+        eng.set_source(src)
+        assert eng.align(G)["status"] == 0            # a full scan: no caveat in either arithmetic
+        # the same two pairs as a batch: the flag is the pair's, not the batch's
+        eng.batch_reserve(2, len(tgt), len(src))
+        for b, s in enumerate((few, src)):
+            eng.batch_set_target(b, tgt); eng.batch_set_source(b, s)
+        eng.batch_build_targets()
+        rb = eng.batch_align(G)
+        assert [r["status"] for r in rb] == [arith, 0] and words([rb[0]]) == words([res[arith]])
+        eng.close()
+    assert res[0]["status"] == 0 and res[1]["status"] == ndt.WARN_TOLERANCE_ARITH and res[1]["hits_last"] < 4096
+    # a run that stops at the iteration cap
+    eng = engine(dict(kw, max_iterations=1), 1)
+    eng.set_target(tgt); eng.set_source(src)
+    r = eng.align(G)
+    assert r["iterations"] == 3 and r["status"] == ndt.WARN_TOLERANCE_ARITH
+    eng.close()
+    # the mirror: setArithmetic(1), few-hit source -> the default arithmetic's words
+    reg = ndt.NormalDistributionsTransform(variant=ndt.VARIANT_PCA)
+    reg.setResolution(1.0); reg.setNeighborhoodSearchMethod(ndt.DIRECT1); reg.setTransformationEpsilon(0.01); reg.setMaximumIterations(64)
+    reg.setArithmetic(1)
+    reg.setInputTarget(tgt); reg.setInputSource(few)
+    reg.align(G)
+    assert np.array_equal(reg.getFinalTransformation(), res[0]["final"]) and reg.getFinalNumIteration() == res[0]["iterations"]
+    assert reg.engine.get_option(ndt.OPT_ARITH) == 1
+    reg.setInputSource(src)
+    reg.align(G)                                       # ... and a full scan stays in the tolerance arithmetic
+    eng = engine(kw, 1)
+    eng.set_target(tgt); eng.set_source(src)
+    assert np.array_equal(reg.getFinalTransformation(), eng.align(G)["final"])
+    eng.close(); reg.engine.close()
