@@ -1026,8 +1026,10 @@ def pose_deltas(res_a, res_b):
     d = np.array([se3_err(res_a["final"][k].reshape(4, 4).T, res_b["final"][k].reshape(4, 4).T) for k in range(n)], dtype=np.float64).reshape(n, 2)
     flips = res_a["it"] != res_b["it"]
     beyond = (d[:, 0] >= 1e-4) | (d[:, 1] >= 1e-5)
+    flagged = res_b["status"] == 1                 # MI355NDT_WARN_TOLERANCE_ARITH: the engine's own caveat (few hits / iteration cap); the drop-in re-runs those in the default arithmetic
     return {"pairs": n, "iteration_flips": int(flips.sum()), "converged_flag_flips": int((res_a["conv"] != res_b["conv"]).sum()),
             "pairs_beyond_tolerance": int(beyond.sum()), "pairs_beyond_tolerance_slots": [int(k) for k in np.nonzero(beyond)[0][:16]],
+            "pairs_flagged_by_the_engine": int(flagged.sum()), "pairs_beyond_tolerance_and_not_flagged": int((beyond & ~flagged).sum()),
             "max_dtrans_m": float(d[:, 0].max()), "max_drot_rad": float(d[:, 1].max()), "median_dtrans_m": float(np.median(d[:, 0])),
             "p99_dtrans_m": float(np.percentile(d[:, 0], 99)), "tolerance": "trans<1e-4 m, rot<1e-5 rad"}
 

@@ -47,7 +47,7 @@ for first in range(0, a.pairs, a.chunk):
         R[name] = np.frombuffer(np.frombuffer(res, dtype=np.uint8).copy(), dtype=bench.RES_DT)
     for k in range(nb):
         fe, ft = R["exact"]["final"][k].reshape(4, 4).T, R["tolerance"]["final"][k].reshape(4, 4).T
-        rows["tolerance_vs_exact"].append(bench.se3_err(fe, ft) + (int(R["exact"]["it"][k] != R["tolerance"]["it"][k]), int(R["exact"]["conv"][k] != R["tolerance"]["conv"][k])))
+        rows["tolerance_vs_exact"].append(bench.se3_err(fe, ft) + (int(R["exact"]["it"][k] != R["tolerance"]["it"][k]), int(R["exact"]["conv"][k] != R["tolerance"]["conv"][k]), int(R["tolerance"]["status"][k] == 1)))
         its["exact"].append(int(R["exact"]["it"][k])); its["tolerance"].append(int(R["tolerance"]["it"][k]))
         if not a.no_oracle:
             c0 = time.perf_counter()
@@ -55,7 +55,7 @@ for first in range(0, a.pairs, a.chunk):
             t_cpu += time.perf_counter() - c0
             its["oracle"].append(int(ro["iterations"]))
             for nm, f, r in (("tolerance_vs_oracle", ft, R["tolerance"]), ("exact_vs_oracle", fe, R["exact"])):
-                rows[nm].append(bench.se3_err(ro["final"], f) + (int(ro["iterations"] != int(r["it"][k])), int(bool(ro["converged"]) != bool(r["conv"][k]))))
+                rows[nm].append(bench.se3_err(ro["final"], f) + (int(ro["iterations"] != int(r["it"][k])), int(bool(ro["converged"]) != bool(r["conv"][k])), int(r["status"][k] == 1)))
     del W
     print(f"pairs {first}..{first + nb - 1} done, {time.perf_counter() - t0:.0f} s", file=sys.stderr, flush=True)
 
@@ -67,6 +67,8 @@ def summary(v):
     worst = int(np.argmax(v[:, 0]))
     return {"pairs": len(v), "iteration_flips": int(v[:, 2].sum()), "converged_flag_flips": int(v[:, 3].sum()), "pairs_beyond_tolerance": int(beyond.sum()),
             "pairs_beyond_tolerance_without_an_iteration_flip": int((beyond & (v[:, 2] == 0)).sum()),
+            "pairs_flagged_by_the_engine": int(v[:, 4].sum()), "pairs_beyond_tolerance_and_not_flagged": int((beyond & (v[:, 4] == 0)).sum()),
+            "pairs_beyond_tolerance_list": [int(k) for k in np.nonzero(beyond)[0][:16]],
             "max_dtrans_m": float(v[:, 0].max()), "max_drot_rad": float(v[:, 1].max()), "pair_of_max_dtrans": worst,
             "median_dtrans_m": float(np.median(v[:, 0])), "p99_dtrans_m": float(np.percentile(v[:, 0], 99)), "p999_dtrans_m": float(np.percentile(v[:, 0], 99.9)),
             "median_drot_rad": float(np.median(v[:, 1])), "p99_drot_rad": float(np.percentile(v[:, 1], 99)),
