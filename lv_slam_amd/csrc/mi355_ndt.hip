@@ -2136,8 +2136,11 @@ int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts, int max_pairs, siz
     h->s_thresh = std::max(0, std::min(t, ASYNC_MAX_CARRY));
   }
   {
-    // MI355NDT_STREAM_RESERVE (workgroups, rounded to a multiple of 8; default 0 = the build runs between the launches, on the same stream)
-    int r = 0;
+    // MI355NDT_STREAM_RESERVE (workgroups, rounded to a multiple of 8; 0 = the build runs between the launches, on the same stream).  Default: 0 -- except
+    // for DIRECT1, whose launches wait for their point stream more than they compute (VALU busy 0.4-0.6) and are short enough for the build to be 30 % of a
+    // step: the next batch's build beside the launch is worth +5 % there (round 6: 117.0 -> 123.3 k registrations/s at 1 m, 42.3 -> 43.1 k at 0.5 m; DIRECT7
+    // launches are VALU-bound and the build's CU-time is work: +-0, and -32 % for ndt_pca / DIRECT7, whose workgroups fill a CU's LDS)
+    int r = sc.K == 1 ? 96 : 0;
     if (const char* e = std::getenv("MI355NDT_STREAM_RESERVE")) r = std::atoi(e);
     if (h->s_reserve_opt >= 0) r = h->s_reserve_opt;
     r = std::max(0, std::min(r, h->n_cu * sweep_wpe(sc.pca != 0, sc.K, want_fast(h, sc)) / 2)) & ~7;

@@ -95,3 +95,27 @@ def test_mirror_has_reference_method_names():
     # enum order of ndt_omp.h:51-56
     assert (ndt.KDTREE, ndt.DIRECT26, ndt.DIRECT7, ndt.DIRECT1) == (0, 1, 2, 3)
 
+
+
+def test_option_and_warning_constants_match_header(lib, tmp_path):
+    """the engine options and the one positive status value, as the header spells them, are what the python binding uses; the profile's cloud counters sit
+    where the header puts them"""
+    import subprocess
+    src = tmp_path / "opt.c"
+    src.write_text('''
+#include <stdio.h>
+#include <stddef.h>
+#include "mi355_ndt.h"
+int main(void) {
+  printf("%d %d %d %d %d %d %d %d %d ", MI355NDT_OPT_F32_SUM_ORDER, MI355NDT_OPT_ASYNC_ALIGN, MI355NDT_OPT_DEBUG_ASYNC_ABORT, MI355NDT_OPT_STREAM_THRESHOLD,
+         MI355NDT_OPT_STREAM_RESERVE, MI355NDT_OPT_DEBUG_ASYNC_RINGS, MI355NDT_OPT_ARITH, MI355NDT_WARN_TOLERANCE_ARITH, MI355NDT_TOLERANCE_MIN_HITS);
+  printf("%zu %zu %zu\\n", offsetof(mi355ndt_profile, cloud_uploads), offsetof(mi355ndt_profile, cloud_transfers), offsetof(mi355ndt_profile, cloud_promotions));
+  return 0;
+}''')
+    exe = tmp_path / "opt"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got == [ndt.OPT_F32_SUM_ORDER, ndt.OPT_ASYNC_ALIGN, ndt.OPT_DEBUG_ASYNC_ABORT, ndt.OPT_STREAM_THRESHOLD, ndt.OPT_STREAM_RESERVE, ndt.OPT_DEBUG_ASYNC_RINGS,
+                   ndt.OPT_ARITH, ndt.WARN_TOLERANCE_ARITH, 4096,
+                   ndt.Profile.cloud_uploads.offset, ndt.Profile.cloud_transfers.offset, ndt.Profile.cloud_promotions.offset]
+    assert ndt.WARN_TOLERANCE_ARITH > 0      # a caveat on a result, never an error code
