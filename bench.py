@@ -695,6 +695,7 @@ def generate_synthetic(ctx, synth, ids, azimuth):
     looks up the cached street primitives; eight ranks of a node therefore do not queue on the host's CPU quota."""
     N = azimuth * 64
     t0 = time.perf_counter()
+    apply_affinity()                                             # (the thread that issues the device work: not on the one CPU libgomp bound it to)
     T = torch.empty(len(ids), 3, N, device=ctx.dev, dtype=torch.float32)
     S = torch.empty(len(ids), 3, N, device=ctx.dev, dtype=torch.float32)
     quota = cpu_quota() or os.cpu_count() or 8
@@ -702,24 +703,59 @@ def generate_synthetic(ctx, synth, ids, azimuth):
     # only throttle each other: keep torch's pool within the quota
     torch.set_num_threads(max(1, min(torch.get_num_threads(), quota // 2)))
 
-    def gen(k):
-        apply_affinity()
-        torch.cuda.set_device(ctx.local)
-        t, s, _ = synth.make_pair(ids[k], azimuth, device=ctx.dev)
-        T[k] = t.T
-        S[k] = s.T
+    # The seeded draws of a pair (2 x N f64 normals + 2 x N uniforms from torch's CPU generator, GIL released) come from four threads (more
+    # only take the CPU from the thread that issues the device work: 12 threads 9.0 s, 4 threads 6.5 s for 4,541 pairs), three batches ahead
+    # of the device, straight into pinned staging buffers (one asynchronous copy per batch); the ray casting of a batch of pairs
+    # is ONE pass of batched device operations (synth.make_pairs: the same arithmetic as synth.make_pair scan by scan, bit for bit --
+    # tests/test_synth.py -- without ~150 kernel launches from Python per pair, which is what the 29 s of rounds 3-5 were).
+    per = max(1, min(16, (16 * 65536) // N))
+    ahead = int(os.environ.get("BENCH_GEN_AHEAD", "3"))
+    on_gpu = ctx.dev.type == "cuda"
+    ring_bufs = [(torch.empty(per, 2, N, dtype=torch.float64, pin_memory=on_gpu), torch.empty(per, 2, N, dtype=torch.float64, pin_memory=on_gpu))
+                 for _ in range(ahead + 1)]
+    copied = [None] * (ahead + 1)                                # the event behind the last copy out of each staging slot
 
-    if len(ids) > 8:
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=max(2, min(8, quota // 2))) as pool:
-            list(pool.map(gen, range(len(ids))))
-    else:
-        for k in range(len(ids)):
-            gen(k)
-    torch.cuda.synchronize()
+    def draw(k, slot, j):
+        apply_affinity()
+        synth.pair_noise(ids[k], N, noise_sigma=None, out=(ring_bufs[slot][0][j], ring_bufs[slot][1][j]))
+
+    from concurrent.futures import ThreadPoolExecutor
+    batches = [list(range(b, min(b + per, len(ids)))) for b in range(0, len(ids), per)]
+    with ThreadPoolExecutor(max_workers=int(os.environ.get("BENCH_GEN_THREADS", max(2, min(4, quota // 4))))) as pool:
+        futs, waited = {}, 0.0
+
+        def submit(bi):
+            slot = bi % (ahead + 1)
+            if copied[slot] is not None:
+                copied[slot].synchronize()
+            futs[bi] = [pool.submit(draw, k, slot, j) for j, k in enumerate(batches[bi])]
+        for bi in range(min(ahead, len(batches))):
+            submit(bi)
+        for bi, ks in enumerate(batches):
+            if bi + ahead < len(batches):
+                submit(bi + ahead)
+            tw = time.perf_counter()
+            for f in futs.pop(bi):
+                f.result()
+            waited += time.perf_counter() - tw
+            slot = bi % (ahead + 1)
+            noise = ring_bufs[slot][0][:len(ks)].to(ctx.dev, non_blocking=True)
+            ring = ring_bufs[slot][1][:len(ks)].to(ctx.dev, non_blocking=True)
+            if on_gpu:
+                copied[slot] = torch.cuda.Event()
+                copied[slot].record()
+            t, s_, _ = synth.make_pairs([ids[k] for k in ks], azimuth, device=ctx.dev, draws=(noise, ring), unit_noise=True)
+            T[ks[0]:ks[-1] + 1] = t.permute(0, 2, 1)
+            S[ks[0]:ks[-1] + 1] = s_.permute(0, 2, 1)
+            del t, s_, noise, ring
+    if on_gpu:
+        torch.cuda.synchronize()
+    if os.environ.get("BENCH_GEN_DEBUG"):
+        print(f"[generate_synthetic] {len(ids)} pairs: {time.perf_counter() - t0:.2f} s, of which waiting for the draws {waited:.2f} s "
+              f"({per} pairs per pass, {ahead} batches ahead)", file=sys.stderr)
     cnt = [N] * len(ids)
     return {"T": T, "S": S, "tcnt": cnt, "scnt": list(cnt), "pitch": N, "ids": list(ids), "data": "synthetic", "max_points": N,
-            "generated_on": f"cuda:{ctx.local} (ray casting in torch on the device; per-pair noise drawn on the CPU)"}, time.perf_counter() - t0
+            "generated_on": f"cuda:{ctx.local} (ray casting in torch on the device, {per} pairs per pass; per-pair noise drawn on the CPU)"}, time.perf_counter() - t0
 
 
 def load_kitti(ctx, a, ndt, ids):

@@ -51,7 +51,9 @@ def test_single_gpu_line_contract():
     assert p["pairs_checked"] >= 3 and p["iterations_equal"] == p["pairs_checked"] and p["max_dtrans_m"] < 1e-4 and p["max_drot_rad"] < 1e-5
     # the drop-in path's leg (host AoS clouds in, PCIe inclusive) is part of the default single-GPU line, and never `value`
     h = d["host_clouds"]
-    assert d["value_host_clouds"] == h["registrations_per_s"] > 0 and h["bit_identical_to_device_resident_run"] is True
+    assert d["value_host_clouds"] == max(h["registrations_per_s"], h["streamed"]["registrations_per_s"]) > 0 and h["registrations_per_s"] > 0
+    assert ("streamed" in d["value_host_clouds_mode"]) == (h["streamed"]["registrations_per_s"] >= h["registrations_per_s"])
+    assert h["bit_identical_to_device_resident_run"] is True and h["streamed"]["bit_identical_to_device_resident_run"] is True
     assert h["pairs_per_batch"] == 6 and h["record_bytes"] == 32
     # BASELINE config 4 rides along (here shrunk to 9 pairs): a strong-scaling block with its own parity sample
     c4 = d["config4"]
@@ -73,7 +75,7 @@ def test_single_gpu_line_contract():
     oc = d["other_configs"]["configs"]
     assert set(oc) == {"ndt_pca_direct1", "config5_direct7", "config5_direct1"}
     for name, c in oc.items():
-        assert c["value"] > 0 and c["ms_per_step"] > 0 and c["steps"] >= 5 and c["timed_s"] >= 0.3, name
+        assert c["value"] > 0 and c["ms_per_step"] > 0 and c["steps"] >= 5 and c["timed_s"] >= 0.2, name       # (the step count is fixed from the synchronous leg: the faster leg fills a little less than --other-seconds)
         rr = c["roofline"]
         assert rr["bound"] == "hbm" and 0 < rr["frac"] < 1.2 and rr["avg_launch_us"] > 0 and abs(rr["frac"] - rr["achieved"] / 8000.0) < 1e-3, name
         pp = c["parity"]
@@ -128,7 +130,7 @@ def test_eight_ranks_on_one_device_gloo():
     assert d["config"]["stream"]["bit_identical_to_synchronous"] is True and d["value_synchronous"] > 0
     # every rank reports how long its inputs took (the ranks of a node share the host's CPUs): eight values, none out of line
     g = d["config"]["input_generation_s_per_rank"]
-    assert len(g) == 8 and d["config"]["input_generation_s"] == max(g) and max(g) < 60.0, g
+    assert len(g) == 8 and d["config"]["input_generation_s"] == max(g) and max(g) < 20.0, g
 
 
 def test_streamed_headline_carries_both_rates():
