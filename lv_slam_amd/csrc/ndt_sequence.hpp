@@ -159,6 +159,42 @@ k_seq_update(SeqState* seq, PairState* st, const double* __restrict__ partials, 
   unsigned long long tl_last = __builtin_readcyclecounter();
 #endif
   if (threadIdx.x == 0) sol[6] = 0.0;
+#if defined(NDT_TIMELINE) && defined(SEQ_UPDATE_REPEAT)
+  // ---- analysis build only (tools/seq_run.py, docs/experiments.md 10e): "what would the update cost if its code were resident?"  The body up to
+  // the Newton step runs SEQ_UPDATE_REPEAT times on the same inputs -- state and rows re-read with agent-scope loads (L2, as a resident updater would
+  // have to), nothing written back in between -- and only the LAST pass is stamped: same instructions, instruction cache warm.
+  {
+    static_assert(sizeof(PairState) % 8 == 0, "PairState travels as 8-byte words");
+    constexpr int NWr = (int)(sizeof(PairState) / 8);
+    if (Q.done == 0) {
+      const int cur_r = Q.cur, n_r = Q.cur_n;
+      const int nch = (n_r + pts_per_chunk - 1) / pts_per_chunk;
+      const gu64* sgr = (const gu64*)reinterpret_cast<const unsigned long long*>(&st[cur_r]);
+      unsigned long long* slr = reinterpret_cast<unsigned long long*>(&Ssh);
+      for (int rep = 0; rep < SEQ_UPDATE_REPEAT - 1; rep++) {
+        for (int i = threadIdx.x; i < NWr; i += UPD_THREADS) slr[i] = __hip_atomic_load(sgr + i, RLX_AGENT);
+        const double vr = reduce_pair_rows<true>(partials + (size_t)cur_r * rows_per_pair * NACC, nch, true, sm, true);
+        const int ln = threadIdx.x & 63;
+        if (threadIdx.x < NACC) {
+          if (ln == 0) Ssh.score = vr;
+          else if (ln < 7) Ssh.g[ln - 1] = vr;
+          else if (ln < 43) Ssh.H[ln - 7] = vr;
+          else Ssh.hits = (long long)vr;
+        }
+        __syncthreads();
+        if (threadIdx.x >= 64 && threadIdx.x < 128) newton_solve_side(Ssh, sol);
+        if (threadIdx.x < 64) {
+          const bool reb = Ssh.phase == PH_STEP && Ssh.reb_tag == (long long)Ssh.sweeps;
+          (void)newton_update(Ssh, &results[cur_r], step_max, eps, max_iterations, 0, sol, reb);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) sol[6] = 0.0;
+        __syncthreads();
+      }
+    }
+    tl_last = __builtin_readcyclecounter();
+  }
+#endif
   const int done = Q.done, cur = Q.cur, n_src = Q.cur_n;                         // (block-uniform)
   if (threadIdx.x == 0) { const int l = Q.launches + 1; Q.launches = l; host_flags[1] = l; }   // launches executed (the host bounds its queue depth with it)
   if (done) return;                                                              // (the pump's overshoot)
