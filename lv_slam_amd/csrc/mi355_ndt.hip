@@ -2136,11 +2136,19 @@ int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts, int max_pairs, siz
     h->s_thresh = std::max(0, std::min(t, ASYNC_MAX_CARRY));
   }
   {
-    // MI355NDT_STREAM_RESERVE (workgroups, rounded to a multiple of 8; 0 = the build runs between the launches, on the same stream).  Default: 0 -- except
-    // for DIRECT1, whose launches wait for their point stream more than they compute (VALU busy 0.4-0.6) and are short enough for the build to be 30 % of a
-    // step: the next batch's build beside the launch is worth +5 % there (round 6: 117.0 -> 123.3 k registrations/s at 1 m, 42.3 -> 43.1 k at 0.5 m; DIRECT7
-    // launches are VALU-bound and the build's CU-time is work: +-0, and -32 % for ndt_pca / DIRECT7, whose workgroups fill a CU's LDS)
-    int r = sc.K == 1 ? 96 : 0;
+    // MI355NDT_STREAM_RESERVE (workgroups, rounded to a multiple of 8; 0 = the build runs between the launches, on the same stream).  Defaults
+    // (tools/reserve_sweep_d1.sh, tools/reserve_sweep_d7.sh; the launch's time grows with the slots it gives away, 512 / (512 - r)):
+    //  * DIRECT1: 96.  Its launches wait for their point stream more than they compute (VALU busy 0.4-0.6) and are short enough for the build to be 30 %
+    //    of a step: 112 -> 120-123 k registrations/s at 1 m (r = 0 / 64 / 96 / 128 / 160: 112.1 / 117.3 / 119.9 / 123.0 / 115.7 k), 42.3 -> 44.5 k at 0.5 m.
+    //  * ndt_omp / DIRECT7 (the headline's configuration): 64 = eight slots per XCD.  The launch is VALU-bound, so the slots are paid for in full
+    //    (3.95 -> 4.41 ms) -- but the whole 0.70 ms build disappears under it: 57.3 -> 59.7 k and 55.7 -> 59.2 k on two boxes (r = 0 / 16 / 32 / 48 /
+    //    64 / 80 / 96: 55.7 / 56.3 / 57.4 / 56.9 / 59.2 / 57.9 / 56.1 k); the tolerance arithmetic +2 % (90.3 -> 92.3 k).
+    //    The smaller the batch, the more it is worth (a small build is a chain of short kernels, not throughput): 64 pairs 41.3 -> 50.6 k (DIRECT1:
+    //    65.4 -> 93.1 k); at 1,536 pairs per batch the build no longer fits under its launch: exact +-0, tolerance arithmetic -6 % (DIRECT1 still +4 %)
+    //    -- so only for batches up to 768 x 65,536 target points (tools/reserve_matrix.sh).
+    //  * ndt_pca / DIRECT7: 0 (its workgroups fill a CU's LDS: -32 % with the build beside them).  Everything else: 0.
+    const bool small_batch = (unsigned long long)max_pairs * (unsigned long long)max_tgt <= 768ull * 65536ull;
+    int r = sc.K == 1 ? 96 : ((sc.K == 7 && !sc.pca && small_batch) ? 64 : 0);
     if (const char* e = std::getenv("MI355NDT_STREAM_RESERVE")) r = std::atoi(e);
     if (h->s_reserve_opt >= 0) r = h->s_reserve_opt;
     r = std::max(0, std::min(r, h->n_cu * sweep_wpe(sc.pca != 0, sc.K, want_fast(h, sc)) / 2)) & ~7;
