@@ -1041,6 +1041,12 @@ def sweep_roofline(J):
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4),
             "frac_of_achievable_6290": round(ach / 6290.0, 4),     # MI355X_MICROARCH.md: measured-achievable HBM rate
+            # stream mode with the next batch's build beside the launch (MI355NDT_OPT_STREAM_RESERVE): the launch runs on launch_slots of the GPU's
+            # launch_slots + reserved_slots workgroup slots and shares caches and HBM with the build for as long as that runs -- its duration, hence `frac`,
+            # includes what it gave away; `frac_of_its_slots` = frac / (launch_slots / all slots); `roofline_synchronous` is the launch with the GPU to itself
+            **({"launch_slots": int(prof["stream_launch_slots"]), "reserved_slots_for_the_next_build": int(prof["stream_reserved_slots"]),
+                "frac_of_its_slots": round(ach / HBM_PEAK_GBS * (prof["stream_launch_slots"] + prof["stream_reserved_slots"]) / prof["stream_launch_slots"], 4)}
+               if prof.get("stream_reserved_slots", 0) > 0 else {}),
             "launches": prof["sweep_launches"], "avg_launch_us": round(1e3 * prof["sweep_ms"] / max(1, prof["sweep_launches"]), 2),
             "alg_bytes_per_launch": round(prof["sweep_alg_bytes"] / max(1, prof["sweep_launches"])),
             "hits_per_point": round(prof["sweep_hits"] / max(1, prof["sweep_points"]), 3),

@@ -109,6 +109,8 @@ typedef struct mi355ndt_profile {
   long long cloud_upload_bytes;
   long long cloud_transfers;  /* host-to-device transfers those clouds travelled in (mi355ndt_batch_set_clouds / stream_submit_host send up to eight clouds per transfer) */
   long long cloud_promotions; /* mi355ndt_promote_source_to_target calls (device-to-device instead of an upload) */
+  long long stream_reserved_slots; /* stream mode: workgroup slots the persistent launches leave to the next batch's build (the effective MI355NDT_OPT_STREAM_RESERVE; 0 = the build runs between the launches) */
+  long long stream_launch_slots;   /* stream mode: workgroups of one persistent launch (CUs x workgroups per CU - the reserved slots) */
 } mi355ndt_profile;
 
 typedef struct mi355ndt_handle mi355ndt_handle;

@@ -201,7 +201,7 @@ struct mi355ndt_handle {
   static constexpr int S_EV = 16;
   // Build under the launch: with s_reserve_wg > 0 the contexts' engines run their builds on s_build_stream, the persistent launches leave
   // that many workgroup slots free, and events order  launch j-2 done -> build of batch j -> launch j
-  hipStream_t s_build_stream = nullptr; int s_reserve_wg = 0;
+  hipStream_t s_build_stream = nullptr; int s_reserve_wg = 0, s_launch_slots = 0;
   hipEvent_t s_ev_built[ASYNC_MAX_CTX] = {}; hipEvent_t s_ev_launched[S_EV] = {};
   volatile StreamStatus* h_sstatus = nullptr; StreamStatus* d_sstatus = nullptr;   // mapped ring of per-launch status slots (k_stream_status)
 
@@ -868,6 +868,7 @@ int mi355ndt_profile_get(mi355ndt_handle* h, mi355ndt_profile* out) {
   unsigned long long hh = 0;                      // (point, voxel) evaluations since the last reset, summed on the device
   HIPCHK(h, hipMemcpy(&hh, h->d_hits, sizeof hh, hipMemcpyDeviceToHost));
   *out = h->P;
+  if (h->stream_on) { out->stream_reserved_slots = h->s_reserve_wg; out->stream_launch_slots = h->s_launch_slots; }
   out->sweep_hits += (long long)hh;
   out->sweep_alg_bytes += 64.0 * (double)hh;
   return MI355NDT_OK;
@@ -2154,6 +2155,7 @@ int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts, int max_pairs, siz
     r = std::max(0, std::min(r, h->n_cu * sweep_wpe(sc.pca != 0, sc.K, want_fast(h, sc)) / 2)) & ~7;
     if (n_contexts < 3) r = 0;                       // (the overlapped build needs its context free one launch earlier: at least three contexts)
     h->s_reserve_wg = r;
+    h->s_launch_slots = std::max(8, h->n_cu * sweep_wpe(sc.pca != 0, sc.K, want_fast(h, sc)) - r);
   }
   h->s_ring_cap = async_ring_cap(h, (long long)max_pairs + ASYNC_MAX_CARRY);
   if (h->s_ring_cap == 0) h->s_sync_only = true;

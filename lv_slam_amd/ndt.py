@@ -56,7 +56,8 @@ class Profile(C.Structure):
                 ("build_launches", C.c_longlong), ("build_alg_bytes", C.c_double), ("update_ms", C.c_double),
                 ("update_launches", C.c_longlong), ("async_fallbacks", C.c_longlong), ("stream_launches", C.c_longlong),
                 ("stream_carried", C.c_longlong), ("stream_redone", C.c_longlong), ("cloud_uploads", C.c_longlong), ("cloud_upload_bytes", C.c_longlong),
-                ("cloud_transfers", C.c_longlong), ("cloud_promotions", C.c_longlong)]
+                ("cloud_transfers", C.c_longlong), ("cloud_promotions", C.c_longlong),
+                ("stream_reserved_slots", C.c_longlong), ("stream_launch_slots", C.c_longlong)]
 
 
 class SeqParams(C.Structure):

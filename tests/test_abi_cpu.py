@@ -109,7 +109,8 @@ def test_option_and_warning_constants_match_header(lib, tmp_path):
 int main(void) {
   printf("%d %d %d %d %d %d %d %d %d ", MI355NDT_OPT_F32_SUM_ORDER, MI355NDT_OPT_ASYNC_ALIGN, MI355NDT_OPT_DEBUG_ASYNC_ABORT, MI355NDT_OPT_STREAM_THRESHOLD,
          MI355NDT_OPT_STREAM_RESERVE, MI355NDT_OPT_DEBUG_ASYNC_RINGS, MI355NDT_OPT_ARITH, MI355NDT_WARN_TOLERANCE_ARITH, MI355NDT_TOLERANCE_MIN_HITS);
-  printf("%zu %zu %zu\\n", offsetof(mi355ndt_profile, cloud_uploads), offsetof(mi355ndt_profile, cloud_transfers), offsetof(mi355ndt_profile, cloud_promotions));
+  printf("%zu %zu %zu %zu %zu\\n", offsetof(mi355ndt_profile, cloud_uploads), offsetof(mi355ndt_profile, cloud_transfers), offsetof(mi355ndt_profile, cloud_promotions),
+         offsetof(mi355ndt_profile, stream_launch_slots), sizeof(mi355ndt_profile));
   return 0;
 }''')
     exe = tmp_path / "opt"
@@ -117,5 +118,6 @@ int main(void) {
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     assert got == [ndt.OPT_F32_SUM_ORDER, ndt.OPT_ASYNC_ALIGN, ndt.OPT_DEBUG_ASYNC_ABORT, ndt.OPT_STREAM_THRESHOLD, ndt.OPT_STREAM_RESERVE, ndt.OPT_DEBUG_ASYNC_RINGS,
                    ndt.OPT_ARITH, ndt.WARN_TOLERANCE_ARITH, 4096,
-                   ndt.Profile.cloud_uploads.offset, ndt.Profile.cloud_transfers.offset, ndt.Profile.cloud_promotions.offset]
+                   ndt.Profile.cloud_uploads.offset, ndt.Profile.cloud_transfers.offset, ndt.Profile.cloud_promotions.offset,
+                   ndt.Profile.stream_launch_slots.offset, C.sizeof(ndt.Profile)]
     assert ndt.WARN_TOLERANCE_ARITH > 0      # a caveat on a result, never an error code
