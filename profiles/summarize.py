@@ -78,6 +78,18 @@ def sec2():
         for k, r in enumerate(sw):
             f.write(f"{k},{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:.2f},{r.get('Grid_Size', r.get('Grid_Size_X', ''))},"
                     f"{r.get('VGPR_Count', '')},{r.get('SGPR_Count', '')},{r.get('LDS_Block_Size', '')},{r.get('Scratch_Size', '')}\n")
+    # the same dispatches by launch size: the streamed job's launches leave workgroup slots to the next batch's build (a smaller grid) and run beside
+    # it; the synchronous job's (and a stream's flushes) have the GPU to themselves -- bench.py's `roofline` is the first kind, `roofline_synchronous` the second
+    kinds = {}
+    for r in sw:
+        kinds.setdefault(str(r.get('Grid_Size', r.get('Grid_Size_X', ''))), []).append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    with open(os.path.join(OUT, f"{TAG}_final_sweep_launch_kinds.csv"), "w") as f:
+        f.write("grid_size_threads,dispatches,median_us,full_launches,avg_us_of_full_launches\n")
+        for g, d in sorted(kinds.items(), key=lambda kv: -len(kv[1])):
+            d.sort()
+            med = d[len(d) // 2]
+            full = [x for x in d if x >= 0.5 * med]
+            f.write(f"{g},{len(d)},{med:.2f},{len(full)},{sum(full) / len(full):.2f}\n")
 
 
 section(sec2)
