@@ -202,7 +202,7 @@ struct mi355ndt_handle {
   // Build under the launch: with s_reserve_wg > 0 the contexts' engines run their builds on s_build_stream, the persistent launches leave
   // that many workgroup slots free, and events order  launch j-2 done -> build of batch j -> launch j
   hipStream_t s_build_stream = nullptr; int s_reserve_wg = 0, s_launch_slots = 0;
-  hipEvent_t s_ev_built[ASYNC_MAX_CTX] = {}; hipEvent_t s_ev_launched[S_EV] = {};
+  hipEvent_t s_ev_built[ASYNC_MAX_CTX] = {}; hipEvent_t s_ev_launched[S_EV] = {}; hipEvent_t s_ev_prepared[S_EV] = {}; bool s_prep_first = true;
   volatile StreamStatus* h_sstatus = nullptr; StreamStatus* d_sstatus = nullptr;   // mapped ring of per-launch status slots (k_stream_status)
 
   // profiling
@@ -1236,6 +1236,7 @@ struct AsyncLaunch {
   unsigned long long* stamp_end = nullptr;       // stream mode + profiling: where k_async_prepare stamps the end of the build in front of it
   int claim_items = 1;                           // DIRECT7 items per claimed position (DIRECT1: always ASYNC_CLAIM(1) = 2; ndt_async.hpp)
   int reserve_wg = 0;
+  hipEvent_t ev_prepared = nullptr;              // stream mode, build beside the launch: recorded between the prepare kernel and the persistent launch
 };
 #define NDT_CTX_ARGS(i) L.tab.c[i].src, L.tab.c[i].pitch, L.tab.c[i].st, L.tab.c[i].gd, L.tab.c[i].words, L.tab.c[i].recs, L.tab.c[i].partials, L.tab.c[i].src_cnt, \
                         L.tab.c[i].arrived, L.tab.c[i].cent
@@ -1276,6 +1277,7 @@ static int launch_async(mi355ndt_handle* h, const SweepConst& sc, const AsyncLau
     const size_t n = std::max(std::max(std::max((size_t)8 * L.ring_cap, (size_t)L.n_new * ASYNC_ARR_STRIDE), sizeof(AsyncCtl) / sizeof(unsigned)), (size_t)L.pose_cap);
     k_async_prepare<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(L.tab, L.tab_dev, L.new_ci, L.n_new, L.st_new, L.guess_new, L.src_cnt_new, L.gd_new, L.arrived_new,
                                                                L.active_list, L.sweep_ctl, L.ring, L.ring_cap, L.ctl, L.prev, L.done_new, L.pose_new, L.pose_cap, L.stamp_end);
+    if (L.ev_prepared) HIPCHK(h, hipEventRecord(L.ev_prepared, s));
   }
   if (h->prof) HIPCHK(h, ev_begin(h, h->ev_sweep));
   int rc;
@@ -2083,6 +2085,7 @@ static int stream_free(mi355ndt_handle* h) {
   }
   for (auto& e : h->s_ev_built) if (e) { (void)hipEventDestroy(e); e = nullptr; }
   for (auto& e : h->s_ev_launched) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  for (auto& e : h->s_ev_prepared) if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (h->s_build_stream) { (void)hipStreamSynchronize(h->s_build_stream); (void)hipStreamDestroy(h->s_build_stream); h->s_build_stream = nullptr; }
   if (h->d_sctl) { (void)hipFree(h->d_sctl); h->d_sctl = nullptr; }
   if (h->d_sring) { (void)hipFree(h->d_sring); h->d_sring = nullptr; }
@@ -2171,6 +2174,8 @@ int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts, int max_pairs, siz
       if (hipStreamCreateWithFlags(&h->s_build_stream, hipStreamNonBlocking) != hipSuccess) return fail(MI355NDT_ERR_HIP);
       for (auto& ev : h->s_ev_built) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(MI355NDT_ERR_HIP);
       for (auto& ev : h->s_ev_launched) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(MI355NDT_ERR_HIP);
+      for (auto& ev : h->s_ev_prepared) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(MI355NDT_ERR_HIP);
+      if (const char* pf = std::getenv("MI355NDT_STREAM_PREP_FIRST")) h->s_prep_first = std::atoi(pf) != 0;
     }
     rc = mi355ndt_set_stream(e, h->s_reserve_wg > 0 ? h->s_build_stream : h->stream);
     if (rc) return fail(rc);
@@ -2246,6 +2251,7 @@ static int stream_launch(mi355ndt_handle* h, int new_ci, int n_new) {
   const bool thresh_given = h->s_thresh_opt >= 0 || std::getenv("MI355NDT_STREAM_THRESH");
   L.items_per_pair = h->s_items; L.stop_thresh = flush ? 0 : (thresh_given ? h->s_thresh : std::min(h->s_thresh, n_new / 4)); L.debug_abort_pos = h->debug_abort_pos; L.debug_ring_mask = h->debug_ring_mask;
   L.reserve_wg = flush ? 0 : h->s_reserve_wg;
+  L.ev_prepared = (h->s_reserve_wg > 0 && h->s_prep_first) ? h->s_ev_prepared[j % mi355ndt_handle::S_EV] : nullptr;
   // two DIRECT7 items per claim halve the hand-overs between items (+1.4-2 %); the coarser positions lengthen a launch's own tail, so only
   // where the tail is handed on (docs/experiments.md 10d)
   L.claim_items = (sc.K == 7 && L.stop_thresh > 0) ? 2 : 1;
@@ -2325,7 +2331,12 @@ int mi355ndt_stream_submit(mi355ndt_handle* h, int n_pairs, const float* d_t, co
   memcpy(S.h_in, tc, (size_t)n_pairs * sizeof(int));
   memcpy(S.h_in + h->s_max_pairs, scnt, (size_t)n_pairs * sizeof(int));
   memcpy(S.h_in + 2 * (size_t)h->s_max_pairs, guesses, (size_t)n_pairs * 16 * sizeof(float));
-  if (h->s_reserve_wg > 0 && h->s_launches >= 2)     // this context's previous batch was finished by the launch before the last one (must_finish)
+  // this context's previous batch was finished by the launch before the last one (must_finish): the build may start when that launch has ended -- and
+  // a moment later still, when the LAST launch's prepare kernel is through (it follows that end on the stream): the build's first kernels stream the
+  // whole batch through HBM and would otherwise run against the one short kernel every launch waits for (k_async_prepare: 50 us beside k_minmax, 17 alone)
+  if (h->s_reserve_wg > 0 && h->s_prep_first && h->s_launches >= 1)
+    HIPCHK(h, hipStreamWaitEvent(e->stream, h->s_ev_prepared[(h->s_launches - 1) % mi355ndt_handle::S_EV], 0));
+  else if (h->s_reserve_wg > 0 && h->s_launches >= 2)
     HIPCHK(h, hipStreamWaitEvent(e->stream, h->s_ev_launched[(h->s_launches - 2) % mi355ndt_handle::S_EV], 0));
   // (one workgroup reads the block from mapped host memory and clears the build's word block: no copy, no fill -- k_stream_inputs)
   k_stream_inputs<<<1, 1024, 0, e->stream>>>(S.h_in_dev, reinterpret_cast<unsigned*>(S.d_in), (unsigned)(2 * (size_t)h->s_max_pairs + (size_t)n_pairs * 16),
