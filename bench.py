@@ -1371,6 +1371,10 @@ def main():
     # launch time, and the unit the sweep is limited by is the vector ALU (`roofline_valu`)
     roof["what"] = ("achieved = algorithmic bytes (SURVEY 8(d): 12 + 4*neighbours + 64*hits per point) / launch time: a cache-resident working set priced "
                     "against HBM, not HBM traffic; physical_hbm_frac is the measured HBM share; the binding unit is VALU issue (roofline_valu.active_frac)")
+    if roof.get("reserved_slots_for_the_next_build"):
+        roof["what"] += (f"; THIS launch runs on {roof['launch_slots']} of {roof['launch_slots'] + roof['reserved_slots_for_the_next_build']} workgroup slots with the next batch's "
+                         "target build beside it on the others (stream mode, MI355NDT_OPT_STREAM_RESERVE): it is slower by the slots it gives away and the step is shorter "
+                         "by the whole build -- frac_of_its_slots is the same rate per slot it had, roofline_synchronous.frac the same kernel with the GPU to itself")
 
     cpu, parity = (None, None)
     if a.cpu_seconds > 0 and world == 1:          # the CPU leg runs on rank 0 of the single-GPU run only
