@@ -1164,7 +1164,8 @@ def other_configs_block(ctx, a, synth, W_head):
                      "stream": None if JS is None else {k: JS[k] for k in ("n_batches", "n_contexts", "bit_identical_to_synchronous", "launches", "pairs_handed_over", "batches_rerun", "launches_that_gave_up")},
                      "mean_iterations": round(float(res_np["it"].mean()), 2), "converged": int(res_np["conv"].sum()),
                      "roofline": {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us", "alg_bytes_per_launch",
-                                                   "hits_per_point", "flops", "build_ms_per_step", "update_ms_per_step", "sweep_ms_per_step", "build_frac")},
+                                                   "hits_per_point", "flops", "build_ms_per_step", "update_ms_per_step", "sweep_ms_per_step", "build_frac",
+                                                   "launch_slots", "reserved_slots_for_the_next_build", "frac_of_its_slots") if k in r},
                      "roofline_valu": valu_roofline(f"{nb}x{N}:{b.variant}:{b.mode}:{b.resolution}"),
                      "parity": parity}
         attach_traffic(out[name]["roofline"], f"{nb}x{N}:{b.variant}:{b.mode}:{b.resolution}", r_sync["avg_launch_us"], None)

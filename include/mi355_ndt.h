@@ -218,9 +218,9 @@ enum mi355ndt_option {
   /* Stream mode, read by mi355ndt_stream_begin: the persistent launches leave `value` workgroup slots free (rounded down to a multiple of 8)
    * and the NEXT batch's target build runs on a stream of its own beside the launch instead of between two launches -- the build streams
    * through HBM, the launch saturates the vector ALUs.  Needs >= 3 contexts (a context is rebuilt one launch earlier, so its pairs are carried
-   * through one launch less).  -1 (default): the environment variable MI355NDT_STREAM_RESERVE, else 96 for DIRECT1 (launches that wait for their
-   * point stream leave the vector ALUs to the build: +5-8 %), 64 for ndt_omp / DIRECT7 with batches of up to 768 x 65,536 target points (the launch pays for the slots in full, the
-   * whole build disappears under it: +4-6 % at 271 pairs, +22 % at 64) and 0 = off for every other search (ndt_pca / DIRECT7 fills a CU's LDS: -32 %).  No result bit depends on it. */
+   * through one launch less).  -1 (default): the environment variable MI355NDT_STREAM_RESERVE, else for DIRECT1 128 with clouds of up to 98,304 points and 96 beyond (launches that
+   * wait for their point stream leave the vector ALUs to the build: +5-10 %), for DIRECT7 with batches of up to 768 x 65,536 target points 64 (ndt_omp) / 32 (ndt_pca)
+   * (the launch pays for the slots in full, the whole build disappears under it: +4-6 % at 271 pairs, +22 % at 64) and 0 = off for every other search.  No result bit depends on it. */
   MI355NDT_OPT_STREAM_RESERVE = 5,
   /* Test hook, default 0xFF (off).  Bit x clear: the workgroups of a one-launch align that serve ring x leave at once, as if XCD x held no
    * workgroup of this launch (another engine's launch filling it).  The launch must still finish every pair -- waiting waves serve the

@@ -2141,18 +2141,23 @@ int mi355ndt_stream_begin(mi355ndt_handle* h, int n_contexts, int max_pairs, siz
   }
   {
     // MI355NDT_STREAM_RESERVE (workgroups, rounded to a multiple of 8; 0 = the build runs between the launches, on the same stream).  Defaults
-    // (tools/reserve_sweep_d1.sh, tools/reserve_sweep_d7.sh; the launch's time grows with the slots it gives away, 512 / (512 - r)):
-    //  * DIRECT1: 96.  Its launches wait for their point stream more than they compute (VALU busy 0.4-0.6) and are short enough for the build to be 30 %
-    //    of a step: 112 -> 120-123 k registrations/s at 1 m (r = 0 / 64 / 96 / 128 / 160: 112.1 / 117.3 / 119.9 / 123.0 / 115.7 k), 42.3 -> 44.5 k at 0.5 m.
+    // (tools/reserve_sweep_*.sh, reserve_matrix.sh, reserve_resweep*.sh; a launch's time grows with the slots it gives away, 512 / (512 - r), in every search:
+    // what is won is the build's time):
+    //  * DIRECT1: 128 for clouds of up to 98,304 points, 96 beyond.  Its launches wait for their point stream more than they compute (VALU busy 0.4-0.6) and
+    //    are short enough for the build to be 30 % of a step: nodelet configuration (1 m, 65,536 points) r = 0 / 64 / 96 / 112 / 128 / 160: 112.1 / 117.3 /
+    //    122.1 / 120.1 / 124.7 / 116.8 k registrations/s; config 5's clouds (0.5 m, 131,072 points) 42.3 / - / 44.5 / - / 43.0 k; 64-pair batches 65.4 -> 96.6 k.
     //  * ndt_omp / DIRECT7 (the headline's configuration): 64 = eight slots per XCD.  The launch is VALU-bound, so the slots are paid for in full
     //    (3.95 -> 4.41 ms) -- but the whole 0.70 ms build disappears under it: 57.3 -> 59.7 k and 55.7 -> 59.2 k on two boxes (r = 0 / 16 / 32 / 48 /
-    //    64 / 80 / 96: 55.7 / 56.3 / 57.4 / 56.9 / 59.2 / 57.9 / 56.1 k); the tolerance arithmetic +2 % (90.3 -> 92.3 k).
-    //    The smaller the batch, the more it is worth (a small build is a chain of short kernels, not throughput): 64 pairs 41.3 -> 50.6 k (DIRECT1:
-    //    65.4 -> 93.1 k); at 1,536 pairs per batch the build no longer fits under its launch: exact +-0, tolerance arithmetic -6 % (DIRECT1 still +4 %)
-    //    -- so only for batches up to 768 x 65,536 target points (tools/reserve_matrix.sh).
-    //  * ndt_pca / DIRECT7: 0 (its workgroups fill a CU's LDS: -32 % with the build beside them).  Everything else: 0.
+    //    64 / 80 / 96 / 128: 55.7 / 56.3 / 57.4 / 56.9 / 59.2 / 57.9 / 56.1 / 53.4 k); the tolerance arithmetic +2 % (90.3 -> 92.3 k).
+    //    The smaller the batch, the more it is worth (a small build is a chain of short kernels, not throughput): 64 pairs 41.3 -> 50.6 k; at 1,536 pairs
+    //    per batch the build no longer fits under its launch: exact +-0, tolerance arithmetic -6 % (DIRECT1 still +4 %) -- so only for batches up to
+    //    768 x 65,536 target points.
+    //  * ndt_pca / DIRECT7: 32 (same bound on the batch).  Until the build was made to start BEHIND the launch's prepare kernel (stream_submit) its first kernels
+    //    raced the launch's own start and r >= 64 cost a third of the rate; since then config 5 (0.5 m, 128 x 131,072) r = 0 / 16 / 32 / 48 / 64 / 96: 19.1 /
+    //    19.3 / 20.0 / 19.6 / 19.8 / 18.8 k, 271 x 65,536 at 1 m 34.9 -> 35.3 k, 64-pair batches 31.7 -> 35.3 k.
+    //  * Everything else (DIRECT26, KDTREE): 0.
     const bool small_batch = (unsigned long long)max_pairs * (unsigned long long)max_tgt <= 768ull * 65536ull;
-    int r = sc.K == 1 ? 96 : ((sc.K == 7 && !sc.pca && small_batch) ? 64 : 0);
+    int r = sc.K == 1 ? (max_tgt <= 98304 ? 128 : 96) : ((sc.K == 7 && small_batch) ? (sc.pca ? 32 : 64) : 0);
     if (const char* e = std::getenv("MI355NDT_STREAM_RESERVE")) r = std::atoi(e);
     if (h->s_reserve_opt >= 0) r = h->s_reserve_opt;
     r = std::max(0, std::min(r, h->n_cu * sweep_wpe(sc.pca != 0, sc.K, want_fast(h, sc)) / 2)) & ~7;

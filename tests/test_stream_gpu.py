@@ -393,8 +393,8 @@ def test_stream_submit_host_equals_the_synchronous_host_path(rec_floats, nctx):
 
 def test_stream_reserve_defaults_follow_the_search_and_the_batch_size():
     """MI355NDT_OPT_STREAM_RESERVE left at its default: the next batch's build runs beside the launch (profile.stream_reserved_slots > 0) for DIRECT1
-    (96 workgroup slots) and for ndt_omp / DIRECT7 with batches of up to 768 x 65,536 target points (64 = eight per XCD), and between the launches
-    (0) for ndt_pca / DIRECT7, for large batches, with fewer than three contexts and for every other search; an explicit value wins.  (No result bit
+    (128 workgroup slots, 96 for clouds beyond 98,304 points) and for DIRECT7 with batches of up to 768 x 65,536 target points (ndt_omp 64 = eight per XCD,
+    ndt_pca 32), and between the launches (0) for large DIRECT7 batches, with fewer than three contexts and for every other search; an explicit value wins.  (No result bit
     depends on it: test_stream_equals_the_synchronous_batches, and bench.py compares every streamed batch with the synchronous results.)"""
     def slots(kw, nctx, max_pairs, pts, opts=()):
         eng = ndt.Engine(ndt.default_params(resolution=1.0, trans_epsilon=0.01, max_iterations=64, **kw))
@@ -412,8 +412,8 @@ def test_stream_reserve_defaults_follow_the_search_and_the_batch_size():
     assert slots(omp7, 2, 271, 65536) == (0, all_slots)                       # two contexts: the build has nowhere to run ahead
     assert slots(omp7, 3, 768, 65536)[0] == 64 and slots(omp7, 3, 769, 65536)[0] == 0
     assert slots(omp7, 4, 128, 131072)[0] == 64
-    assert slots(pca7, 3, 128, 131072) == (0, all_slots)
-    assert slots(pca1, 3, 271, 65536) == (96, all_slots - 96) and slots(pca1, 3, 1536, 65536)[0] == 96
+    assert slots(pca7, 3, 128, 131072) == (32, all_slots - 32) and slots(pca7, 3, 1536, 65536)[0] == 0
+    assert slots(pca1, 3, 271, 65536) == (128, all_slots - 128) and slots(pca1, 3, 1536, 65536)[0] == 128 and slots(pca1, 3, 128, 131072)[0] == 96
     assert slots(dict(neighbor_mode=ndt.KDTREE, variant=0), 3, 64, 65536)[0] == 0
     assert slots(omp7, 3, 271, 65536, opts=((ndt.OPT_STREAM_RESERVE, 32),)) == (32, all_slots - 32)
     assert slots(pca1, 3, 271, 65536, opts=((ndt.OPT_STREAM_RESERVE, 0),)) == (0, all_slots)
